@@ -1,0 +1,330 @@
+"""numpy restatement of the BERT bi-encoder forward/backward and the two
+training losses on the COCO-DR hot path.  TEST INFRASTRUCTURE ONLY (see
+oracle/__init__.py).
+
+Every function cites the reference line it follows (paths relative to
+/root/reference; ``hf:`` = transformers/models/bert/modeling_bert.py of the
+installed transformers 5.15.0, the third-party package the reference calls).
+
+All arithmetic is done in the dtype of the parameters handed in (float32 to
+mirror the reference CPU path, float64 for a tighter checker).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+from scipy.special import erf
+
+__all__ = [
+    "OracleConfig", "make_params", "layer_names", "embeddings_fwd", "encoder_fwd",
+    "encoder_bwd", "cls_embedding", "co_target", "contrastive_loss",
+    "contrastive_loss_grad", "contrastive_local_grad", "triplet_nll",
+    "triplet_nll_grad", "gelu", "layer_norm_fwd",
+]
+
+LN_EPS = 1e-12  # BertConfig.layer_norm_eps default (hf: BertEmbeddings / BertSelfOutput)
+
+
+@dataclass
+class OracleConfig:
+    vocab_size: int = 30522
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+
+def layer_names(i: int) -> Dict[str, str]:
+    p = f"encoder.layer.{i}."
+    return dict(
+        wq=p + "attention.self.query.weight", bq=p + "attention.self.query.bias",
+        wk=p + "attention.self.key.weight", bk=p + "attention.self.key.bias",
+        wv=p + "attention.self.value.weight", bv=p + "attention.self.value.bias",
+        wo=p + "attention.output.dense.weight", bo=p + "attention.output.dense.bias",
+        g1=p + "attention.output.LayerNorm.weight", b1=p + "attention.output.LayerNorm.bias",
+        w1=p + "intermediate.dense.weight", bi=p + "intermediate.dense.bias",
+        w2=p + "output.dense.weight", b2=p + "output.dense.bias",
+        g2=p + "output.LayerNorm.weight", be2=p + "output.LayerNorm.bias",
+    )
+
+
+def make_params(cfg: OracleConfig, seed: int = 0, dtype=np.float32, std: float = 0.02,
+                perturb_ln: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded random-init parameters under HF BertModel state-dict names.
+
+    HF ``_init_weights`` is normal(0, 0.02) for Linear/Embedding, ones/zeros for
+    LayerNorm (ANCE/model/models.py:54-60 restates the same rule).  With
+    ``perturb_ln`` the LayerNorm gains/biases and all Linear biases get small
+    random values so that parity tests exercise them.
+    numpy's PCG64 stream is stable across versions, so fixtures only store the seed.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    P: Dict[str, np.ndarray] = {}
+
+    def nrm(*shape):
+        return (rng.standard_normal(shape) * std).astype(dtype)
+
+    def ln(name):
+        if perturb_ln:
+            P[name + ".weight"] = (1.0 + 0.1 * rng.standard_normal(H)).astype(dtype)
+            P[name + ".bias"] = (0.05 * rng.standard_normal(H)).astype(dtype)
+        else:
+            P[name + ".weight"] = np.ones(H, dtype)
+            P[name + ".bias"] = np.zeros(H, dtype)
+
+    def bias(n):
+        return (0.02 * rng.standard_normal(n)).astype(dtype) if perturb_ln else np.zeros(n, dtype)
+
+    P["embeddings.word_embeddings.weight"] = nrm(cfg.vocab_size, H)
+    P["embeddings.position_embeddings.weight"] = nrm(cfg.max_position_embeddings, H)
+    P["embeddings.token_type_embeddings.weight"] = nrm(cfg.type_vocab_size, H)
+    ln("embeddings.LayerNorm")
+    for i in range(cfg.num_hidden_layers):
+        n = layer_names(i)
+        for w, b, shape in (("wq", "bq", (H, H)), ("wk", "bk", (H, H)), ("wv", "bv", (H, H)),
+                            ("wo", "bo", (H, H))):
+            P[n[w]] = nrm(*shape)
+            P[n[b]] = bias(shape[0])
+        ln(n["g1"][: -len(".weight")])
+        P[n["w1"]] = nrm(I, H)
+        P[n["bi"]] = bias(I)
+        P[n["w2"]] = nrm(H, I)
+        P[n["b2"]] = bias(H)
+        ln(n["g2"][: -len(".weight")])
+    return P
+
+
+# --------------------------------------------------------------------------- primitives
+def gelu(x: np.ndarray) -> np.ndarray:
+    """Exact erf GELU - ``hidden_act="gelu"`` (hf: BertIntermediate)."""
+    return (0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))).astype(x.dtype)
+
+
+def gelu_grad(x: np.ndarray) -> np.ndarray:
+    cdf = 0.5 * (1.0 + erf(x / np.sqrt(2.0)))
+    pdf = np.exp(-0.5 * x * x) / np.sqrt(2.0 * np.pi)
+    return (cdf + x * pdf).astype(x.dtype)
+
+
+def layer_norm_fwd(y: np.ndarray, g: np.ndarray, b: np.ndarray, eps: float = LN_EPS):
+    """torch.nn.LayerNorm over the last axis, biased variance (hf: BertSelfOutput.LayerNorm)."""
+    mu = y.mean(-1, keepdims=True)
+    var = ((y - mu) ** 2).mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (y - mu) * rstd
+    return (xhat * g + b).astype(y.dtype), xhat.astype(y.dtype), rstd.astype(y.dtype)
+
+
+def layer_norm_bwd(dout: np.ndarray, xhat: np.ndarray, rstd: np.ndarray, g: np.ndarray):
+    dg = (dout * xhat).reshape(-1, xhat.shape[-1]).sum(0)
+    db = dout.reshape(-1, xhat.shape[-1]).sum(0)
+    dxhat = dout * g
+    dy = rstd * (dxhat - dxhat.mean(-1, keepdims=True) - xhat * (dxhat * xhat).mean(-1, keepdims=True))
+    return dy, dg, db
+
+
+# --------------------------------------------------------------------------- encoder
+def embeddings_fwd(P, input_ids: np.ndarray, cache: Optional[dict] = None) -> np.ndarray:
+    """hf: BertEmbeddings.forward - LN(word[ids] + type[0] + pos[0..L-1]).
+
+    The reference never passes token_type_ids or position_ids
+    (COCO/data.py:140 ``return_token_type_ids=False``; ANCE/model/models.py:226-227
+    passes only ids+mask) so segment row 0 and positions 0..L-1 are used always.
+    """
+    B, L = input_ids.shape
+    we = P["embeddings.word_embeddings.weight"]
+    pe = P["embeddings.position_embeddings.weight"]
+    te = P["embeddings.token_type_embeddings.weight"]
+    y = we[input_ids] + pe[None, :L] + te[0][None, None]
+    out, xhat, rstd = layer_norm_fwd(y, P["embeddings.LayerNorm.weight"], P["embeddings.LayerNorm.bias"])
+    if cache is not None:
+        cache["emb"] = dict(xhat=xhat, rstd=rstd, ids=input_ids)
+    return out
+
+
+def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optional[dict]):
+    """One BertLayer: hf BertSelfAttention (eager) + BertSelfOutput + BertIntermediate + BertOutput."""
+    n = layer_names(i)
+    B, L, H = x.shape
+    d = H // nh
+    q = x @ P[n["wq"]].T + P[n["bq"]]
+    k = x @ P[n["wk"]].T + P[n["bk"]]
+    v = x @ P[n["wv"]].T + P[n["bv"]]
+
+    def heads(t):
+        return t.reshape(B, L, nh, d).transpose(0, 2, 1, 3)  # [B,nh,L,d]
+
+    qh, kh, vh = heads(q), heads(k), heads(v)
+    s = (qh @ kh.transpose(0, 1, 3, 2)) * x.dtype.type(1.0 / np.sqrt(d))
+    # key-padding mask: additive 0 / finfo.min in hf 5.x (-10000 in <=4.x); both give exactly 0
+    # probability after the fp32 softmax whenever >=1 key is unmasked.
+    s = np.where(mask[:, None, None, :] != 0, s, -np.inf)
+    s = s - s.max(-1, keepdims=True)
+    e = np.exp(s)
+    p = (e / e.sum(-1, keepdims=True)).astype(x.dtype)
+    ctx = (p @ vh).transpose(0, 2, 1, 3).reshape(B, L, H)
+    a = ctx @ P[n["wo"]].T + P[n["bo"]]
+    x1, xhat1, rstd1 = layer_norm_fwd(a + x, P[n["g1"]], P[n["b1"]])
+    u = x1 @ P[n["w1"]].T + P[n["bi"]]
+    h = gelu(u)
+    f = h @ P[n["w2"]].T + P[n["b2"]]
+    x2, xhat2, rstd2 = layer_norm_fwd(f + x1, P[n["g2"]], P[n["be2"]])
+    if cache is not None:
+        cache[i] = dict(x=x, qh=qh, kh=kh, vh=vh, p=p, ctx=ctx, xhat1=xhat1, rstd1=rstd1, x1=x1,
+                        u=u, h=h, xhat2=xhat2, rstd2=rstd2)
+    return x2
+
+
+def encoder_fwd(P, cfg: OracleConfig, input_ids: np.ndarray, attention_mask: np.ndarray,
+                keep_cache: bool = False):
+    """BertModel forward -> list of N+1 hidden states (``output_hidden_states=True``,
+    COCO/modeling.py:199-204) and the cache the backward needs."""
+    cache = {} if keep_cache else None
+    x = embeddings_fwd(P, input_ids, cache)
+    hs = [x]
+    for i in range(cfg.num_hidden_layers):
+        x = _layer_fwd(P, i, x, attention_mask, cfg.num_attention_heads, cache)
+        hs.append(x)
+    if keep_cache:
+        cache["mask"] = attention_mask
+    return hs, cache
+
+
+def cls_embedding(last_hidden: np.ndarray) -> np.ndarray:
+    """Raw last-layer [CLS], no pooler/projection/norm.
+    ANCE/model/models.py:225-229 ``outputs1[0][:, 0]``; COCO/modeling.py:206 ``hidden_states[-1][:, :1]``."""
+    return last_hidden[:, 0]
+
+
+def encoder_bwd(P, cfg: OracleConfig, cache: dict, d_last: np.ndarray) -> Dict[str, np.ndarray]:
+    """Reverse-mode gradient of ``encoder_fwd`` w.r.t. every parameter given dL/d(hidden_states[-1])."""
+    G: Dict[str, np.ndarray] = {}
+    nh = cfg.num_attention_heads
+    dx = d_last
+    for i in reversed(range(cfg.num_hidden_layers)):
+        n = layer_names(i)
+        c = cache[i]
+        B, L, H = c["x"].shape
+        d = H // nh
+        dy2, G[n["g2"]], G[n["be2"]] = layer_norm_bwd(dx, c["xhat2"], c["rstd2"], P[n["g2"]])
+        G[n["w2"]] = dy2.reshape(-1, H).T @ c["h"].reshape(-1, c["h"].shape[-1])
+        G[n["b2"]] = dy2.reshape(-1, H).sum(0)
+        dh = dy2 @ P[n["w2"]]
+        du = dh * gelu_grad(c["u"])
+        G[n["w1"]] = du.reshape(-1, du.shape[-1]).T @ c["x1"].reshape(-1, H)
+        G[n["bi"]] = du.reshape(-1, du.shape[-1]).sum(0)
+        dx1 = du @ P[n["w1"]] + dy2
+        dy1, G[n["g1"]], G[n["b1"]] = layer_norm_bwd(dx1, c["xhat1"], c["rstd1"], P[n["g1"]])
+        G[n["wo"]] = dy1.reshape(-1, H).T @ c["ctx"].reshape(-1, H)
+        G[n["bo"]] = dy1.reshape(-1, H).sum(0)
+        dctx = (dy1 @ P[n["wo"]]).reshape(B, L, nh, d).transpose(0, 2, 1, 3)
+        p = c["p"]
+        dv = p.transpose(0, 1, 3, 2) @ dctx
+        dp = dctx @ c["vh"].transpose(0, 1, 3, 2)
+        ds = p * (dp - (dp * p).sum(-1, keepdims=True))
+        scale = p.dtype.type(1.0 / np.sqrt(d))
+        dq = (ds @ c["kh"]) * scale
+        dk = (ds.transpose(0, 1, 3, 2) @ c["qh"]) * scale
+
+        def merge(t):
+            return t.transpose(0, 2, 1, 3).reshape(B, L, H)
+
+        dq, dk, dv = merge(dq), merge(dk), merge(dv)
+        xf = c["x"].reshape(-1, H)
+        G[n["wq"]] = dq.reshape(-1, H).T @ xf
+        G[n["wk"]] = dk.reshape(-1, H).T @ xf
+        G[n["wv"]] = dv.reshape(-1, H).T @ xf
+        G[n["bq"]] = dq.reshape(-1, H).sum(0)
+        G[n["bk"]] = dk.reshape(-1, H).sum(0)
+        G[n["bv"]] = dv.reshape(-1, H).sum(0)
+        dx = dq @ P[n["wq"]] + dk @ P[n["wk"]] + dv @ P[n["wv"]] + dy1
+    e = cache["emb"]
+    dy, G["embeddings.LayerNorm.weight"], G["embeddings.LayerNorm.bias"] = layer_norm_bwd(
+        dx, e["xhat"], e["rstd"], P["embeddings.LayerNorm.weight"])
+    B, L, H = dy.shape
+    gw = np.zeros_like(P["embeddings.word_embeddings.weight"])
+    np.add.at(gw, e["ids"].reshape(-1), dy.reshape(-1, H))
+    G["embeddings.word_embeddings.weight"] = gw
+    gp = np.zeros_like(P["embeddings.position_embeddings.weight"])
+    gp[:L] = dy.sum(0)
+    G["embeddings.position_embeddings.weight"] = gp
+    gt = np.zeros_like(P["embeddings.token_type_embeddings.weight"])
+    gt[0] = dy.sum((0, 1))
+    G["embeddings.token_type_embeddings.weight"] = gt
+    return G
+
+
+# --------------------------------------------------------------------------- losses
+def co_target(m: int) -> np.ndarray:
+    """COCO/modeling.py:172-177 - ``arange(m).view(-1,2).flip([1]).flatten()`` = [1,0,3,2,...]."""
+    return np.arange(m, dtype=np.int64).reshape(-1, 2)[:, ::-1].reshape(-1).copy()
+
+
+def _log_softmax_rows(S: np.ndarray) -> np.ndarray:
+    mx = S.max(-1, keepdims=True)
+    return S - mx - np.log(np.exp(S - mx).sum(-1, keepdims=True))
+
+
+def contrastive_loss(E: np.ndarray, world_size: int = 1) -> np.ndarray:
+    """COCO/modeling.py:244-248 - S = E.E^T, diagonal = -inf, CE(S, co_target, 'none') * world.
+    Returns the per-row loss [M]; the caller takes ``.mean()`` (COCO/modeling.py:229)."""
+    M = E.shape[0]
+    S = E @ E.T
+    S[np.arange(M), np.arange(M)] = -np.inf
+    ls = _log_softmax_rows(S)
+    return (-ls[np.arange(M), co_target(M)] * world_size).astype(E.dtype)
+
+
+def contrastive_loss_grad(E: np.ndarray, world_size: int = 1) -> Tuple[float, np.ndarray]:
+    """loss = mean(contrastive_loss(E)) and dloss/dE for ALL rows (single-process autograd result)."""
+    M = E.shape[0]
+    S = E @ E.T
+    S[np.arange(M), np.arange(M)] = -np.inf
+    ls = _log_softmax_rows(S)
+    t = co_target(M)
+    loss = float((-ls[np.arange(M), t]).mean() * world_size)
+    G = np.exp(ls)
+    G[np.arange(M), t] -= 1.0
+    G *= world_size / M
+    dE = G @ E + G.T @ E
+    return loss, dE.astype(E.dtype)
+
+
+def contrastive_local_grad(E: np.ndarray, world_size: int, rank: int) -> np.ndarray:
+    """Gradient that reaches rank ``rank``'s own rows under the reference's gather
+    (COCO/modeling.py:182-186: only slot ``local_rank`` carries autograd history).
+    Equals rows [rank*m:(rank+1)*m] of (W/M)(G E + G^T E) - SURVEY 8(e)."""
+    _, dE = contrastive_loss_grad(E, world_size)
+    m = E.shape[0] // world_size
+    return dE[rank * m:(rank + 1) * m]
+
+
+def triplet_nll(q: np.ndarray, a: np.ndarray, b: np.ndarray):
+    """ANCE/model/models.py:97-106 - logits = [sum(q*a), sum(q*b)]; loss = -log_softmax(logits)[:,0]."""
+    logits = np.stack([(q * a).sum(-1), (q * b).sum(-1)], 1)
+    ls = _log_softmax_rows(logits)
+    return (-ls[:, 0]).astype(q.dtype), logits.astype(q.dtype)
+
+
+def triplet_nll_grad(q, a, b, weights: Optional[np.ndarray] = None):
+    """``(loss*weights).mean()`` (ANCE/model/models.py:260-261) and its gradient w.r.t. q, a, b."""
+    B = q.shape[0]
+    loss, logits = triplet_nll(q, a, b)
+    w = np.ones(B, q.dtype) if weights is None else weights.astype(q.dtype)
+    p = np.exp(_log_softmax_rows(logits))
+    dl = p.copy()
+    dl[:, 0] -= 1.0
+    dl *= (w / B)[:, None]
+    dq = dl[:, :1] * a + dl[:, 1:] * b
+    da = dl[:, :1] * q
+    db = dl[:, 1:] * q
+    return float((loss * w).mean()), dq.astype(q.dtype), da.astype(q.dtype), db.astype(q.dtype)

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE in the build
+container (CPU, fp32).  Run once from the repo root:
+
+    python tests/golden/make_golden.py
+
+It imports /root/reference/COCO/modeling.py and /root/reference/ANCE/model/models.py
+(read-only) on top of the installed transformers BertModel (eager attention, fp32, eval),
+loads seeded weights from oracle.make_params, and stores ONLY inputs + expected outputs
+(data, no reference source).  /root/reference does not exist on the GPU box; the tests read
+the .npz files committed next to this script.
+
+Harness-side shims (never written into /root/reference):
+  1. ``data_args.train_method`` is set because COCO/modeling.py:179 reads a field that
+     COCO/arguments.py does not define.
+  2. ``model._world_size`` is overridden per instance to emulate world sizes > 1 for the
+     loss scaling at COCO/modeling.py:247 (the real call needs W processes).
+Neither touches the encoder -> [CLS] -> contrastive path arithmetic.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import OracleConfig, make_params  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+STD = 0.08  # larger than HF's 0.02 so that [CLS] rows differ visibly between inputs
+
+
+def hf_config(cfg: OracleConfig):
+    from transformers import BertConfig
+    return BertConfig(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+        num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+        max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager")
+
+
+def load_into(bert, P):
+    sd = bert.state_dict()
+    for k, v in P.items():
+        assert k in sd, k
+        sd[k].copy_(torch.from_numpy(v))
+
+
+def synth_batch(rng, B, L, V, lo=4):
+    ids = np.zeros((B, L), np.int64)
+    mask = np.zeros((B, L), np.int64)
+    for b in range(B):
+        n = L if b == 0 else int(rng.integers(lo, L + 1))
+        ids[b, :n] = rng.integers(5, V, n)
+        ids[b, 0] = 1  # [CLS]-like
+        ids[b, n - 1] = 2  # [SEP]-like
+        mask[b, :n] = 1
+    return ids, mask
+
+
+def selected_grads(named_params, prefix):
+    keep = ("embeddings.position_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias",
+            "encoder.layer.0.attention.self.query.weight", "encoder.layer.0.attention.self.key.bias", "encoder.layer.0.attention.self.query.bias",
+            "encoder.layer.0.attention.self.value.weight", "encoder.layer.0.attention.output.dense.weight",
+            "encoder.layer.0.attention.output.LayerNorm.weight", "encoder.layer.1.intermediate.dense.weight",
+            "encoder.layer.1.intermediate.dense.bias", "encoder.layer.1.output.dense.weight",
+            "encoder.layer.1.output.LayerNorm.bias", "embeddings.token_type_embeddings.weight")
+    out = {}
+    sums = {}
+    for name, p in named_params:
+        if not name.startswith(prefix):
+            continue
+        short = name[len(prefix):]
+        if p.grad is None:
+            continue
+        g = p.grad.detach().numpy()
+        sums[short] = np.array([g.sum(dtype=np.float64), np.abs(g).sum(dtype=np.float64)])
+        if short in keep:
+            out["grad:" + short] = g.copy()
+        if short == "embeddings.word_embeddings.weight":
+            out["grad_rows:" + short] = g[:64].copy()  # ids < 64 are hit often in the synthetic batch
+    names = sorted(sums)
+    out["gradsum_names"] = np.array(names)
+    out["gradsums"] = np.stack([sums[n] for n in names])
+    return out
+
+
+def golden_coco():
+    """COCO path: BertForMaskedLM encoder -> hidden_states -> [CLS] -> compute_contrastive_loss -> backward.
+    Follows COCO/modeling.py:199-208,229,244-248 using the reference's own module objects."""
+    sys.path.insert(0, os.path.join(REF, "COCO"))
+    import modeling as coco_modeling  # reference
+    from arguments import ModelArguments, DataTrainingArguments  # reference
+    from transformers import BertForMaskedLM
+
+    cfg = OracleConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                       intermediate_size=512, max_position_embeddings=64)
+    seed = 1234
+    P = make_params(cfg, seed, std=STD)
+    torch.manual_seed(0)
+    lm = BertForMaskedLM(hf_config(cfg))
+    load_into(lm.bert, P)
+    B, L = 6, 32
+    rng = np.random.Generator(np.random.PCG64(99))
+    ids, mask = synth_batch(rng, B, L, cfg.vocab_size)
+
+    model_args = ModelArguments(n_head_layers=0, skip_from=1, late_mlm=False)
+    data_args = DataTrainingArguments()
+    data_args.train_method = "coco"  # shim 1
+    train_args = types.SimpleNamespace(per_device_train_batch_size=B // 2, local_rank=-1)
+    model = coco_modeling.CoCondenserForPretraining(lm, model_args, data_args, train_args)
+    model.lm.eval()  # COCO/modeling.py:198
+    out = {}
+    res = {}
+    for W in (1, 2):
+        model.zero_grad()
+        lm_out = model.lm(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                          output_hidden_states=True, return_dict=True)
+        cls_hiddens = lm_out.hidden_states[-1][:, :1]
+        co_cls = cls_hiddens.squeeze()
+        model._world_size = (lambda w=W: w)  # shim 2
+        rows = model.compute_contrastive_loss(co_cls)
+        loss = rows.mean()
+        loss.backward()
+        res[W] = (rows.detach().numpy().copy(), float(loss))
+        if W == 1:
+            out["hidden_states"] = np.stack([h.detach().numpy() for h in lm_out.hidden_states])
+            out["co_target"] = model.co_target.numpy().copy()
+            out.update(selected_grads(model.lm.named_parameters(), "bert."))
+    out.update(dict(input_ids=ids, attention_mask=mask, seed=np.int64(seed), std=np.float64(STD),
+                    cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                                  cfg.intermediate_size, cfg.max_position_embeddings, cfg.type_vocab_size]),
+                    loss_rows_w1=res[1][0], loss_w1=np.float64(res[1][1]),
+                    loss_rows_w2=res[2][0], loss_w2=np.float64(res[2][1])))
+    np.savez_compressed(os.path.join(OUT, "coco_contrastive_tiny.npz"), **out)
+    print("coco golden: loss", res[1][1], "hs", out["hidden_states"].shape)
+
+    # stand-alone loss goldens at several M / world sizes on random E (no encoder)
+    stand = {}
+    for M, W, H in ((8, 1, 32), (16, 2, 48), (64, 8, 96)):
+        E = (np.random.Generator(np.random.PCG64(M)).standard_normal((M, H)) * 0.7).astype(np.float32)
+        ta = types.SimpleNamespace(per_device_train_batch_size=M // 2, local_rank=-1)
+        m2 = coco_modeling.CoCondenserForPretraining(lm, model_args, data_args, ta)
+        m2._world_size = (lambda w=W: w)
+        Et = torch.from_numpy(E).requires_grad_(True)
+        rows = m2.compute_contrastive_loss(Et)
+        rows.mean().backward()
+        stand[f"E_{M}"] = E
+        stand[f"W_{M}"] = np.int64(W)
+        stand[f"rows_{M}"] = rows.detach().numpy()
+        stand[f"dE_{M}"] = Et.grad.numpy().copy()
+        stand[f"target_{M}"] = m2.co_target.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "contrastive_loss.npz"), **stand)
+    sys.path.pop(0)
+
+
+def golden_ance():
+    """ANCE path: BertDot_NLL_LN triplet forward/backward - ANCE/model/models.py:97-106,225-232,234-262."""
+    sys.path.insert(0, os.path.join(REF, "ANCE"))
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    from model.models import BertDot_NLL_LN  # reference
+
+    cfg = OracleConfig(vocab_size=800, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                       intermediate_size=256, max_position_embeddings=64)
+    seed = 4321
+    P = make_params(cfg, seed, std=STD)
+    torch.manual_seed(0)
+    model = BertDot_NLL_LN(hf_config(cfg))
+    load_into(model.bert, P)
+    model.eval()  # dropout p=0 anyway (config) - parity tests run without dropout (SURVEY 7 iv)
+    rng = np.random.Generator(np.random.PCG64(7))
+    B = 4
+    q_ids, q_mask = synth_batch(rng, B, 16, cfg.vocab_size)
+    a_ids, a_mask = synth_batch(rng, B, 32, cfg.vocab_size)
+    b_ids, b_mask = synth_batch(rng, B, 32, cfg.vocab_size)
+    weights = np.array([1.0, 0.5, 2.0, 1.0], np.float32)
+    t = torch.from_numpy
+    model.zero_grad()
+    loss, acc, logits = model(t(q_ids), t(q_mask), t(a_ids), t(a_mask), t(b_ids), t(b_mask),
+                              weights=t(weights))
+    loss.backward()
+    with torch.no_grad():
+        qe = model.query_emb(t(q_ids), t(q_mask)).numpy()
+        ae = model.body_emb(t(a_ids), t(a_mask)).numpy()
+        be = model.body_emb(t(b_ids), t(b_mask)).numpy()
+    out = dict(q_ids=q_ids, q_mask=q_mask, a_ids=a_ids, a_mask=a_mask, b_ids=b_ids, b_mask=b_mask,
+               weights=weights, seed=np.int64(seed), std=np.float64(STD), loss=np.float64(float(loss)), logits=logits.detach().numpy(),
+               acc=acc.numpy(), q_emb=qe, a_emb=ae, b_emb=be,
+               cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                             cfg.intermediate_size, cfg.max_position_embeddings, cfg.type_vocab_size]))
+    out.update(selected_grads(model.named_parameters(), "bert."))
+    np.savez_compressed(os.path.join(OUT, "ance_triplet_tiny.npz"), **out)
+    print("ance golden: loss", float(loss), "logits", logits.detach().numpy())
+    sys.path.pop(0)
+
+
+def golden_mrr():
+    """evaluate/evaluation/msmarco_eval.py:109-139 compute_metrics on a seeded synthetic run."""
+    sys.path.insert(0, os.path.join(REF, "evaluate", "evaluation"))
+    import msmarco_eval  # reference, pure stdlib
+    rng = np.random.Generator(np.random.PCG64(5))
+    nq = 50
+    ranked = {q: [int(x) for x in 1 + rng.permutation(40)[:20]] + [0] * 980 for q in range(nq)}
+    relevant = {q: [int(x) for x in rng.integers(1, 41, int(rng.integers(1, 4)))] for q in range(nq)}
+    m = msmarco_eval.compute_metrics(relevant, ranked)
+    np.savez_compressed(os.path.join(OUT, "msmarco_mrr.npz"),
+                        ranked=np.array([ranked[q][:20] for q in range(nq)]),
+                        relevant=np.array([relevant[q] + [-1] * (3 - len(relevant[q])) for q in range(nq)]),
+                        mrr10=np.float64(m["MRR @10"]))
+    print("mrr golden:", m)
+    sys.path.pop(0)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    golden_coco()
+    golden_ance()
+    golden_mrr()

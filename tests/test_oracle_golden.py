@@ -1,0 +1,151 @@
+"""Pin the numpy oracle against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+
+from conftest import cfg_from_golden, load_golden
+import oracle as O
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _check_grad(name, got, ref):
+    if name.endswith("key.bias"):
+        # d/d(key bias) is identically zero (softmax is shift invariant along keys): both sides are round-off
+        assert np.abs(got).max() < 1e-6 and np.abs(ref).max() < 1e-6
+    else:
+        assert _rel(got, ref) < 2e-3, (name, _rel(got, ref))
+
+
+def test_encoder_hidden_states_match_reference(golden_coco):
+    g = golden_coco
+    cfg = cfg_from_golden(g)
+    P = O.make_params(cfg, int(g["seed"]), std=float(g["std"]))
+    hs, _ = O.encoder_fwd(P, cfg, g["input_ids"], g["attention_mask"])
+    ref = g["hidden_states"]
+    assert len(hs) == cfg.num_hidden_layers + 1 == ref.shape[0]
+    for i, h in enumerate(hs):
+        assert _rel(h, ref[i]) < 1e-5, (i, _rel(h, ref[i]))
+
+
+def test_co_target_matches_reference(golden_coco, golden_loss):
+    assert np.array_equal(O.co_target(len(golden_coco["co_target"])), golden_coco["co_target"])
+    for M in (8, 16, 64):
+        assert np.array_equal(O.co_target(M), golden_loss[f"target_{M}"])
+
+
+def test_contrastive_loss_standalone(golden_loss):
+    g = golden_loss
+    for M in (8, 16, 64):
+        E, W = g[f"E_{M}"], int(g[f"W_{M}"])
+        rows = O.contrastive_loss(E.copy(), W)
+        np.testing.assert_allclose(rows, g[f"rows_{M}"], rtol=2e-5, atol=2e-5)
+        loss, dE = O.contrastive_loss_grad(E.copy(), W)
+        np.testing.assert_allclose(dE, g[f"dE_{M}"], rtol=1e-4, atol=1e-5)
+        assert abs(loss - g[f"rows_{M}"].mean()) < 1e-5
+
+
+def test_coco_loss_and_grads_through_encoder(golden_coco):
+    g = golden_coco
+    cfg = cfg_from_golden(g)
+    P = O.make_params(cfg, int(g["seed"]), std=float(g["std"]))
+    hs, cache = O.encoder_fwd(P, cfg, g["input_ids"], g["attention_mask"], keep_cache=True)
+    E = O.cls_embedding(hs[-1])
+    for W in (1, 2):
+        rows = O.contrastive_loss(E.copy(), W)
+        np.testing.assert_allclose(rows, g[f"loss_rows_w{W}"], rtol=1e-4, atol=2e-4)
+    loss, dE = O.contrastive_loss_grad(E.copy(), 1)
+    assert abs(loss - float(g["loss_w1"])) < 2e-4
+    d_last = np.zeros_like(hs[-1])
+    d_last[:, 0] = dE
+    G = O.encoder_bwd(P, cfg, cache, d_last)
+    for key in g.files:
+        if key.startswith("grad:"):
+            name = key[5:]
+            _check_grad(name, G[name], g[key])
+    rows = g["grad_rows:embeddings.word_embeddings.weight"]
+    assert _rel(G["embeddings.word_embeddings.weight"][:64], rows) < 2e-3
+    names = [str(n) for n in g["gradsum_names"]]
+    for n, (s, a) in zip(names, g["gradsums"]):
+        if n not in G or n.endswith("key.bias"):
+            continue  # cls.* / pooler params are outside the encoder; key.bias grads are pure round-off
+        assert abs(np.abs(G[n]).sum(dtype=np.float64) - a) <= 2e-3 * a + 1e-7, n
+
+
+def test_ance_triplet_matches_reference(golden_ance):
+    g = golden_ance
+    cfg = cfg_from_golden(g)
+    P = O.make_params(cfg, int(g["seed"]), std=float(g["std"]))
+    embs, caches = [], []
+    for ids, mask in ((g["q_ids"], g["q_mask"]), (g["a_ids"], g["a_mask"]), (g["b_ids"], g["b_mask"])):
+        hs, cache = O.encoder_fwd(P, cfg, ids, mask, keep_cache=True)
+        embs.append(O.cls_embedding(hs[-1]))
+        caches.append((cache, hs[-1].shape))
+    for e, k in zip(embs, ("q_emb", "a_emb", "b_emb")):
+        assert _rel(e, g[k]) < 1e-5
+    rows, logits = O.triplet_nll(*embs)
+    np.testing.assert_allclose(logits, g["logits"], rtol=1e-5)
+    assert np.array_equal(np.argmax(logits, 1), g["acc"])
+    loss, dq, da, db = O.triplet_nll_grad(*embs, weights=g["weights"])
+    assert abs(loss - float(g["loss"])) < 1e-4
+    G = {}
+    for (cache, shape), de in zip(caches, (dq, da, db)):
+        d_last = np.zeros(shape, np.float32)
+        d_last[:, 0] = de
+        for k, v in O.encoder_bwd(P, cfg, cache, d_last).items():
+            G[k] = G.get(k, 0) + v
+    for key in g.files:
+        if key.startswith("grad:"):
+            name = key[5:]
+            _check_grad(name, G[name], g[key])
+
+
+def test_mrr_matches_reference_script():
+    g = load_golden("msmarco_mrr.npz")
+    ranked = {q: [int(x) for x in row] for q, row in enumerate(g["ranked"])}
+    relevant = {q: [int(x) for x in row if x >= 0] for q, row in enumerate(g["relevant"])}
+    assert abs(O.mrr_at_10(relevant, ranked) - float(g["mrr10"])) < 1e-12
+
+
+def test_topk_and_metrics_hand_cases():
+    Q = np.array([[1.0, 0.0], [0.0, 1.0]], np.float32)
+    P = np.array([[0.5, 0.1], [0.9, 0.2], [0.5, 0.3], [0.1, 0.8]], np.float32)
+    D, I = O.score_topk(Q, P, 3)
+    assert I.tolist() == [[1, 0, 2], [3, 2, 1]]  # tie 0.5/0.5 -> lower position first
+    np.testing.assert_allclose(D[0], [0.9, 0.5, 0.5])
+    # k > Np pads with -1
+    D, I = O.score_topk(Q, P, 6)
+    assert I[0, 4:].tolist() == [-1, -1]
+    # shard merge == global search
+    rng = np.random.Generator(np.random.PCG64(3))
+    Q = rng.standard_normal((5, 16)).astype(np.float32)
+    P = rng.standard_normal((101, 16)).astype(np.float32)
+    Dg, Ig = O.score_topk(Q, P, 10)
+    Ds, Is = [], []
+    for r in range(4):
+        idx = O.shard_indices(101, r, 4)
+        d, i = O.score_topk(Q, P[idx], 10)
+        Ds.append(d)
+        Is.append(idx[i])
+    Dm, Im = O.merge_topk(Ds, Is, 10)
+    assert np.array_equal(Im, Ig)
+    # nDCG hand case: relevant doc at rank 3 of one relevant -> 1/log2(4)
+    assert abs(O.ndcg_cut([7, 8, 9], {9: 1}, 10) - 0.5) < 1e-12
+    assert abs(O.ndcg_cut([9, 7, 8], {9: 2, 7: 1}, 10) - 1.0) < 1e-12
+    assert O.recip_rank([7, 8, 9], {9: 1}) == 1 / 3
+    assert O.merged_order(7, 3).tolist() == [0, 3, 6, 1, 4, 2, 5]
+
+
+def test_eval_dev_query_and_negatives():
+    q2id = [10, 11]
+    p2id = [100, 101, 102, 100, 103]  # position 3 duplicates pid 100
+    I = np.array([[0, 3, 1, 2], [4, 2, 1, 0]])
+    qrels = {10: {101: 1}, 11: {103: 1}}
+    ndcg, mrr, n, pred = O.eval_dev_query(q2id, p2id, qrels, I, 4)
+    assert pred[10] == {100: -1, 101: -2, 102: -3}
+    assert n == 2 and abs(mrr - (0.5 + 1.0) / 2) < 1e-12
+    assert abs(ndcg - (1 / np.log2(3) + 1.0) / 2) < 1e-12
+    negs, rr = O.generate_negatives(q2id, p2id, {10: 101, 11: 103}, I, 2)
+    assert negs == {10: [100], 11: [102, 101]}  # top (negative_sample+1) window, positive and dups dropped
+    assert rr.tolist() == [1 / 3, 1.0]
