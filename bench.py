@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py - contrastive-step throughput of the native MI355X hot path (BASELINE.json metric 1).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full COCO contrastive training step on one batch of synthetic MS MARCO-shaped spans
+(BASELINE.json configs[1]: cocodr-base / BERT-base-uncased shape, seq_len 128, 64 sequences per GPU, bf16
+activations with fp32 accumulation, in-batch negatives): encoder forward -> last-layer [CLS] ->
+(all-gather over ranks) -> span-pair InfoNCE -> encoder backward -> gradient all-reduce -> AdamW + linear
+warm-up schedule.  Inputs are resident in HBM before the timed region.  Weak scaling: 64 sequences per GPU.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events bracketing every launch of the
+dominant kernel class (the bf16 MFMA GEMM, coco-dr_amd/csrc/gemm.hip) inside the timed region;
+`cpu_baseline` times the numpy oracle (the CPU port of the same step, fwd+loss+bwd) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+SEQ_PER_GPU = 64
+SEQ_LEN = 128
+
+
+def synth_batch(rank: int, n_seq: int, L: int, vocab: int, device):
+    """ids ~ U{1000..V-1}, seed 1234+rank, lengths ~ clip(round(N(76,30)), 8, L), [CLS]=101 first,
+    [SEP]=102 last, [PAD]=0 after."""
+    rng = np.random.Generator(np.random.PCG64(1234 + rank))
+    ids = rng.integers(1000, vocab, (n_seq, L))
+    lens = np.clip(np.rint(rng.normal(76, 30, n_seq)), 8, L).astype(np.int64)
+    mask = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
+    ids = ids * mask
+    ids[:, 0] = 101
+    ids[np.arange(n_seq), lens - 1] = 102
+    return torch.from_numpy(ids).to(device), torch.from_numpy(mask).to(device)
+
+
+def train_flops_per_seq(cfg, L: int) -> float:
+    """forward N*(24 H^2 + 4 L H) FLOP per token, training = 3x forward."""
+    H, N = cfg.hidden_size, cfg.num_hidden_layers
+    return 3.0 * L * N * (24.0 * H * H + 4.0 * L * H)
+
+
+def cpu_baseline(n_seq: int = 8, L: int = SEQ_LEN, steps: int = 2):
+    """The oracle (numpy port of the same contrastive step: encoder fwd + InfoNCE + encoder bwd, fp32) timed on the
+    host cores of this box.  Checker/baseline only - never on the product path."""
+    import oracle as O
+    ocfg = O.OracleConfig()
+    P = O.make_params(ocfg, 0)
+    rng = np.random.Generator(np.random.PCG64(0))
+    ids = rng.integers(1000, ocfg.vocab_size, (n_seq, L))
+    mask = np.ones((n_seq, L), np.int64)
+
+    def step():
+        hs, cache = O.encoder_fwd(P, ocfg, ids, mask, keep_cache=True)
+        _, dE = O.contrastive_loss_grad(O.cls_embedding(hs[-1]).copy(), 1)
+        d_last = np.zeros_like(hs[-1])
+        d_last[:, 0] = dE
+        O.encoder_bwd(P, ocfg, cache, d_last)
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": n_seq / dt, "unit": "sequences/sec", "cores": int(cores), "kind": "port",
+            "sample": f"{steps} steps of {n_seq} sequences x L{L}, BERT-base, numpy fp32 oracle fwd+loss+bwd (no optimizer)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="base", choices=["base", "large"])
+    ap.add_argument("--seq-per-gpu", type=int, default=SEQ_PER_GPU)
+    ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd import ops
+    from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertConfig, CocoBertModel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = CocoBertConfig.base() if args.model == "base" else CocoBertConfig.large()
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    bert = CocoBertModel(cfg).to(dev)
+    model = CoCondenserForPretraining(bert)
+    opt = torch.optim.AdamW(bert.param_groups(weight_decay=0.01), lr=1e-4, fused=True)
+    total = args.steps + args.warmup
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / max(1, int(0.1 * total))))
+    ids, mask = synth_batch(rank, args.seq_per_gpu, args.seq_len, cfg.vocab_size, dev)
+    batch = {"input_ids": ids, "attention_mask": mask}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model(batch, None)
+        loss.backward()
+        if world > 1:  # two large fp32 buckets, averaged (what DDP does, without its bucketing overhead)
+            for p in (bert.flat_decay, bert.flat_nodecay):
+                dist.all_reduce(p.grad, op=dist.ReduceOp.AVG)
+        opt.step()
+        sched.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    if not args.no_roofline and rank == 0:
+        ops.prof_begin(1)  # HIP events around every GEMM launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    roof = None
+    if not args.no_roofline and rank == 0:
+        n_launch, gemm_ms, gemm_flops = ops.prof_end()
+        if n_launch and gemm_ms > 0:
+            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "gemm_kernel (bf16 MFMA 32x32x16, all NT/NN/TN launches)",
+                    "launches_per_step": n_launch // max(1, args.steps),
+                    "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
+                    "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3)}
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    final_loss = float(loss)
+
+    if rank == 0:
+        n_seq = args.seq_per_gpu * world * args.steps
+        value = n_seq / dt
+        step_tflops = value * train_flops_per_seq(cfg, args.seq_len) / 1e12
+        out = {
+            "metric": "contrastive-step sequences/sec", "value": round(value, 2), "unit": "sequences/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"cocodr-{args.model} contrastive step (COCO in-batch negatives), seq_len={args.seq_len}, "
+                                   f"{args.seq_per_gpu} sequences/GPU, bf16 + fp32 accumulate, AdamW; BASELINE configs[1]",
+                       "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len,
+                       "parallelism": f"dp{world}" + (" + RCCL all_gather negatives" if world > 1 else "")},
+            "loss": round(final_loss, 4),
+            "algorithmic_tflops_whole_step": round(step_tflops, 1),
+            "whole_step_frac_of_mfma_peak": round(step_tflops / (MFMA_BF16_PEAK_TFLOPS * world), 4),
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+"""ctypes binding of libcocodr_hip.so (include/cocodr.h).  This is the only place the product touches
+native code; there is NO fallback: if the library is missing or fails to load, every op raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcocodr_hip.so")
+
+c_void_p, c_int, c_float, c_size_t, c_longlong, c_double = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong, C.c_double
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p), ("R", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_int), ("ldb", c_int), ("ldc", c_int), ("ldr", c_int),
+        ("trans_a", c_int), ("trans_b", c_int), ("epi", c_int), ("out_f32", c_int),
+        ("batch", c_int),
+        ("strideA", c_longlong), ("strideB", c_longlong), ("strideC", c_longlong), ("strideR", c_longlong),
+        ("strideBias", c_longlong),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [("hidden", c_int), ("heads", c_int), ("layers", c_int), ("inter", c_int), ("vocab", c_int),
+                ("max_pos", c_int), ("ln_eps", c_float)]
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class EmbedParams(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("word", "pos", "type0", "ln_g", "ln_b")]
+
+
+class EmbedGrads(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("word", "pos", "type0", "ln_g", "ln_b")]
+
+
+class EncoderLayout(C.Structure):
+    _fields_ = [(n, c_size_t) for n in (
+        "total_bytes", "hidden", "cls_f32", "qkv", "ctx", "y1", "x1", "u", "h", "y2", "lse", "mean1", "rstd1", "mean2",
+        "rstd2", "emb_mean", "emb_rstd", "bwd_scratch", "bwd_bytes")]
+
+
+EPI_NONE, EPI_GELU, EPI_ADD, EPI_DGELU = 0, 1, 2, 3
+
+# name -> (restype, argtypes); every symbol include/cocodr.h declares
+SIGNATURES = {
+    "cocodr_last_error": (C.c_char_p, []),
+    "cocodr_build_info": (C.c_char_p, []),
+    "cocodr_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
+    "cocodr_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cocodr_attn_bwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
+    "cocodr_embed_ln_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "cocodr_embed_bwd_partial_floats": (c_size_t, [c_int, c_int]),
+    "cocodr_embed_ln_bwd": (c_int, [c_void_p] * 14 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "cocodr_ln_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "cocodr_ln_bwd_partial_floats": (c_size_t, [c_int, c_int]),
+    "cocodr_ln_bwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_void_p]),
+    "cocodr_colsum_partial_floats": (c_size_t, [c_int, c_int, c_int]),
+    "cocodr_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
+    "cocodr_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cocodr_scatter_cls_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cocodr_simce_workspace_floats": (c_size_t, [c_int]),
+    "cocodr_simce_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cocodr_triplet_nll_fwd_bwd": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
+    "cocodr_score_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cocodr_score_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
+    "cocodr_encoder_layout": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),
+    "cocodr_encoder_fwd": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), c_void_p, c_void_p,
+                                   c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "cocodr_encoder_bwd": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), C.POINTER(EmbedGrads),
+                                   C.POINTER(LayerGrads), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                                   c_void_p]),
+    "cocodr_prof_begin": (c_int, [c_int]),
+    "cocodr_prof_end": (c_int, [C.POINTER(c_int), C.POINTER(c_double), C.POINTER(c_double)]),
+    "cocodr_probe_mfma32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cocodr_probe_tr16": (c_int, [c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the native library.  Raises NativeLibraryError - never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for this path.")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. no ROCm runtime on this machine
+            raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+        return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().cocodr_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what}: {msg} (code {rc})")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,336 @@
+// Fused self-attention forward / backward for gfx950, head_dim = 64, key-padding mask only
+// (hf: BertSelfAttention + eager_attention_forward, modeling_bert.py:111-203).
+//
+// Data layout: the fused QKV projection output [B*L, 3H] (Q | K | V column blocks) is read in
+// place; one workgroup stages the K/V (and for the backward Q/dO) rows of ONE (batch, head) into
+// swizzled LDS tiles and its 4 waves each own 32 query rows (or 32 keys in the dK/dV phase).
+//
+// MFMA use (v_mfma_f32_32x32x16_bf16, 64-lane waves):
+//  * scores are computed TRANSPOSED, S^T = K Q^T, so a lane holds one query column: the softmax
+//    max / sum are lane-local plus one exchange with lane^32;
+//  * the fp32 S^T accumulator registers are converted to bf16 and fed straight back as the B
+//    operand of O^T = V^T P^T: which 8 keys a lane contributes per MFMA is fixed by the
+//    accumulator layout, and the matching rows of V are fetched with the transposing LDS read
+//    (ds_read_b64_tr_b16), so P never goes through LDS or cross-lane shuffles.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kScale = 0.125f;  // 1/sqrt(64)
+constexpr float kMaskNeg = -1e30f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// B/A operand fragment of a row-major [rows][64] tile: row r0 + (l & 31), chunk 2s + (l >> 5)
+__device__ __forceinline__ bf16x8 frag_rows(const char* t, int r0, int s, int lane) {
+  return lds_read_b128(t, tile64_off(r0 + (lane & 31), 2 * s + (lane >> 5)));
+}
+// A operand = transpose of a [rows][64] tile: output row i = column dt*32 + (l & 31), contraction
+// slots = tile rows rbase + 4*(l>>5) + {0..3} and + 8 + {0..3}  (the accumulator-register order of
+// a 32x32 MFMA result, see file header).
+__device__ __forceinline__ bf16x8 frag_cols_tr(const char* t, int rbase, int dt, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  const int col = dt * 32 + ((g & 1) << 4) + ((c & 3) << 2);
+  const int row = rbase + ((g >> 1) << 2) + (c >> 2);
+  const int within = (col & 7) << 1;
+  const s16x4 a = lds_read_tr16(t, tile64_off(row, col >> 3) + within);
+  const s16x4 b = lds_read_tr16(t, tile64_off(row + 8, col >> 3) + within);
+  return join_tr(a, b);
+}
+// accumulator registers j*8 .. j*8+7 -> bf16x8 B operand
+__device__ __forceinline__ bf16x8 pack_acc(const float* p, int j) {
+  float t[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = p[j * 8 + e];
+  return as_bf16x8(pack8(t));
+}
+
+__device__ __forceinline__ void stage_tile(char* dst, const uint16_t* src, int ld, int L, int tid, int nthreads) {
+  for (int q = tid; q < L * 8; q += nthreads) {
+    const int row = q >> 3, ch = q & 7;
+    *reinterpret_cast<uint4*>(dst + tile64_off(row, ch)) = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
+  }
+}
+
+// O^T / dQ^T / dK^T / dV^T accumulator (lane: row index l & 31, 4 consecutive d per register group)
+__device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = o[dt][rg * 4 + e] * mul;
+      const int d = dt * 32 + 8 * rg + 4 * (lane >> 5);
+      *reinterpret_cast<uint2*>(dst + (size_t)(lane & 31) * ld + d) = pack4(t);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                       uint16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kt = smem;
+  char* Vt = smem + L * 128;
+  float* madd = reinterpret_cast<float*>(smem + 2 * L * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
+  const int ld = 3 * H;
+  const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
+  stage_tile(Kt, base + H, ld, L, tid, 256);
+  stage_tile(Vt, base + 2 * H, ld, L, tid, 256);
+  for (int i = tid; i < L; i += 256) madd[i] = mask[b * L + i] != 0 ? 0.f : kMaskNeg;
+  __syncthreads();
+
+  const int q0 = blockIdx.z * 128 + wid * 32;
+  if (q0 >= L) return;
+  const int half = lane >> 5;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    qf[s] = as_bf16x8(*reinterpret_cast<const uint4*>(base + (size_t)(q0 + (lane & 31)) * ld + (2 * s + half) * 8));
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m = kMaskNeg, lsum = 0.f;
+  const float sl2 = kScale * kLog2e;
+
+  for (int kb = 0; kb < L / 32; ++kb) {
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, kb * 32, s, lane), qf[s], sacc, 0, 0, 0);
+    float p[16];
+    float bmax = kMaskNeg;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 ma = *reinterpret_cast<const float4*>(madd + kb * 32 + 8 * rg + 4 * half);
+      p[rg * 4 + 0] = sacc[rg * 4 + 0] * sl2 + ma.x;
+      p[rg * 4 + 1] = sacc[rg * 4 + 1] * sl2 + ma.y;
+      p[rg * 4 + 2] = sacc[rg * 4 + 2] * sl2 + ma.z;
+      p[rg * 4 + 3] = sacc[rg * 4 + 3] * sl2 + ma.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, p[r]);
+    bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+    const float mnew = fmaxf(m, bmax);
+    const float alpha = fast_exp2(m - mnew);
+    m = mnew;
+    lsum *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = fast_exp2(p[r] - mnew);
+      lsum += p[r];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16x8 pf = pack_acc(p, j);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Vt, kb * 32 + j * 16, dt, lane), pf, o[dt], 0, 0, 0);
+    }
+  }
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  if (lane < 32) lse[((size_t)b * heads + h) * L + q0 + lane] = (m + __log2f(ltot)) * kLn2;
+  store_acc_T(ctx + (size_t)(b * L + q0) * H + h * 64, H, o, 1.0f / ltot, lane);
+}
+
+// Backward.  All four [L][64] tiles of one (batch, head) live in LDS (L <= 256 -> 128 KiB).
+//  phase A: wave <-> 32 queries,  S^T/dP^T layout (lane = query):  dQ^T += K^T dS^T
+//  phase B: wave <-> 32 keys,     S / dP layout   (lane = key):    dV^T += dO^T P,  dK^T += Q^T dS
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                          const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
+                                                          const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L,
+                                                          int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qt = smem;
+  char* Kt = smem + L * 128;
+  char* Vt = smem + 2 * L * 128;
+  char* Dt = smem + 3 * L * 128;
+  float* madd = reinterpret_cast<float*>(smem + 4 * L * 128);
+  float* lse2 = madd + L;
+  float* delta = lse2 + L;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
+  const int ld = 3 * H;
+  const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
+  const uint16_t* obase = ctx + (size_t)b * L * H + h * 64;
+  const uint16_t* dobase = dctx + (size_t)b * L * H + h * 64;
+  stage_tile(Qt, base, ld, L, tid, 256);
+  stage_tile(Kt, base + H, ld, L, tid, 256);
+  stage_tile(Vt, base + 2 * H, ld, L, tid, 256);
+  for (int q = tid; q < L * 8; q += 256) {  // L*8 is a multiple of 256 (L % 32 == 0): whole waves stay converged
+    const int row = q >> 3, ch = q & 7;
+    const uint4 dv = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
+    const uint4 ov = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
+    *reinterpret_cast<uint4*>(Dt + tile64_off(row, ch)) = dv;
+    float df[8], of[8];
+    unpack8(dv, df);
+    unpack8(ov, of);
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part += df[e] * of[e];
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if (ch == 0) delta[row] = part;
+  }
+  for (int i = tid; i < L; i += 256) {
+    madd[i] = mask[b * L + i] != 0 ? 0.f : kMaskNeg;
+    lse2[i] = lse[((size_t)b * heads + h) * L + i] * kLog2e;
+  }
+  __syncthreads();
+
+  const int half = lane >> 5;
+  const float sl2 = kScale * kLog2e;
+  const int nblk = L / 32;
+
+  // ---------------- phase A: dQ
+  for (int qb = wid; qb < nblk; qb += 4) {
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = frag_rows(Qt, qb * 32, s, lane);
+      dof[s] = frag_rows(Dt, qb * 32, s, lane);
+    }
+    const float my_lse = lse2[qb * 32 + (lane & 31)];
+    const float my_delta = delta[qb * 32 + (lane & 31)];
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    for (int kb = 0; kb < nblk; ++kb) {
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, kb * 32, s, lane), qf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vt, kb * 32, s, lane), dof[s], dpacc, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float4 ma = *reinterpret_cast<const float4*>(madd + kb * 32 + 8 * rg + 4 * half);
+        const float mm[4] = {ma.x, ma.y, ma.z, ma.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = rg * 4 + e;
+          const float p = fast_exp2(sacc[r] * sl2 + mm[e] - my_lse);
+          ds[r] = p * (dpacc[r] - my_delta);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 dsf = pack_acc(ds, j);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Kt, kb * 32 + j * 16, dt, lane), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    store_acc_T(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
+  }
+
+  // ---------------- phase B: dK, dV
+  for (int kb = wid; kb < nblk; kb += 4) {
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = frag_rows(Kt, kb * 32, s, lane);
+      vf[s] = frag_rows(Vt, kb * 32, s, lane);
+    }
+    const float my_madd = madd[kb * 32 + (lane & 31)];
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    for (int qb = 0; qb < nblk; ++qb) {
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qt, qb * 32, s, lane), kf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Dt, qb * 32, s, lane), vf[s], dpacc, 0, 0, 0);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float4 l4 = *reinterpret_cast<const float4*>(lse2 + qb * 32 + 8 * rg + 4 * half);
+        const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = rg * 4 + e;
+          p[r] = fast_exp2(sacc[r] * sl2 + my_madd - ll[e]);
+          ds[r] = p[r] * (dpacc[r] - dd[e]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 pf = pack_acc(p, j), dsf = pack_acc(ds, j);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Dt, qb * 32 + j * 16, dt, lane), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Qt, qb * 32 + j * 16, dt, lane), dsf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
+    store_acc_T(row0 + H, ld, dk, kScale, lane);
+    store_acc_T(row0 + 2 * H, ld, dv, 1.0f, lane);
+  }
+}
+
+}  // namespace
+
+extern "C" int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
+                               cocodr_stream_t stream) {
+  CK_ARG(qkv && mask && ctx && lse, "attn_fwd: null pointer");
+  CK_ARG(B > 0 && heads > 0, "attn_fwd: bad shape");
+  CK_ARG(L % 32 == 0 && L >= 32 && L <= 512, "attn_fwd: L=%d must be a multiple of 32 in [32,512]", L);
+  const int H = heads * 64;
+  const size_t lds = (size_t)2 * L * 128 + (size_t)L * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(PROF_ATTN, st, 4.0 * B * heads * (double)L * L * 64);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads, B, (L + 127) / 128), dim3(256), lds, st, qkv, mask, ctx, lse, L, H);
+  CK_LAUNCH("attn_fwd");
+  return COCODR_OK;
+}
+
+extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
+                               const float* lse, uint16_t* dqkv, int B, int L, int heads, cocodr_stream_t stream) {
+  CK_ARG(qkv && mask && ctx && dctx && lse && dqkv, "attn_bwd: null pointer");
+  CK_ARG(B > 0 && heads > 0, "attn_bwd: bad shape");
+  CK_ARG(L % 32 == 0 && L >= 32 && L <= 256, "attn_bwd: L=%d must be a multiple of 32 in [32,256]", L);
+  const int H = heads * 64;
+  const size_t lds = (size_t)4 * L * 128 + (size_t)3 * L * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(PROF_ATTN, st, 10.0 * B * heads * (double)L * L * 64);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(256), lds, st, qkv, mask, ctx, dctx, lse, dqkv, L, H);
+  CK_LAUNCH("attn_bwd");
+  return COCODR_OK;
+}

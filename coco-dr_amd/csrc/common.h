@@ -1,0 +1,119 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the COCO-DR hot path.
+// wave = 64 lanes everywhere; no CUDA-compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/cocodr.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+
+// ------------------------------------------------------------------ error plumbing (host)
+void cocodr_set_error(const char* fmt, ...);
+#define CK_ARG(cond, ...)                 \
+  do {                                    \
+    if (!(cond)) {                        \
+      cocodr_set_error(__VA_ARGS__);      \
+      return COCODR_ERR_INVALID;          \
+    }                                     \
+  } while (0)
+#define CK_LAUNCH(name)                                                        \
+  do {                                                                         \
+    hipError_t e_ = hipGetLastError();                                         \
+    if (e_ != hipSuccess) {                                                    \
+      cocodr_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+      return COCODR_ERR_LAUNCH;                                                \
+    }                                                                          \
+  } while (0)
+
+// ------------------------------------------------------------------ bf16 <-> f32
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {  // round to nearest even
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+__device__ __forceinline__ void unpack4(const uint2& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ uint2 pack4(const float* f) { return make_uint2(pack2bf(f[0], f[1]), pack2bf(f[2], f[3])); }
+
+// ------------------------------------------------------------------ wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------ math
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ------------------------------------------------------------------ LDS tile addressing
+// [rows][64] bf16 tiles (128-B rows, 8 chunks of 16 B).  The chunk index is XOR-swizzled with a
+// 3-bit function of the row chosen so that BOTH access patterns used on such tiles are
+// bank-conflict free on gfx950:
+//   * ds_read_b128 of MFMA 32x32x16 operand fragments (lane -> row, fixed chunk): the 16-lane
+//     service groups see 16 distinct (row&1, f(row)) pairs;
+//   * ds_read_b64_tr_b16 of 4 consecutive rows x 64 B: rows r and r+2 differ in bit 2 of f.
+__host__ __device__ __forceinline__ int swz64(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+// byte offset of 16-B chunk `ch` (0..7) of row `row`
+__host__ __device__ __forceinline__ int tile64_off(int row, int ch) { return row * 128 + ((ch ^ swz64(row)) << 4); }
+// [rows][128] bf16 tiles (256-B rows, 16 chunks): only read through ds_read_b64_tr_b16
+// (4 rows x 64 B per 32 lanes) -> rows r..r+3 are spread over the four 64-B windows.
+__host__ __device__ __forceinline__ int tile128_off(int row, int ch) { return row * 256 + ((ch ^ ((row & 3) << 2)) << 4); }
+
+__device__ __forceinline__ bf16x8 lds_read_b128(const char* lds, int off) {
+  return *reinterpret_cast<const bf16x8*>(lds + off);
+}
+// Transposed 4x16 read: the 16 lanes of a group hand in the addresses of the sixteen 8-byte
+// pieces of a [4 rows][16 cols] bf16 block (lane c -> row c/4, cols 4*(c%4)..+3); lane c gets
+// back column c of the block, rows 0..3.
+__device__ __forceinline__ s16x4 lds_read_tr16(const char* lds, int off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off));
+}
+__device__ __forceinline__ bf16x8 join_tr(s16x4 a, s16x4 b) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// XCD-aware, bijective block remap (8 XCDs, block b is dispatched to XCD b % 8): every XCD gets a
+// contiguous range of logical tiles so neighbouring tiles (sharing operand panels) share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

@@ -1,0 +1,263 @@
+// Whole-encoder orchestration: the BertModel layer loop (hf: BertEncoder / BertLayer,
+// modeling_bert.py) and its backward, enqueued from native code on the caller's stream so one host
+// call covers ~85 (forward) / ~100 (backward) kernel launches with no Python in between.
+//
+// Memory plan (sized for 288 GB HBM, nothing is recomputed and nothing is freed mid-step): every
+// per-layer activation the backward needs is kept in one caller-provided arena as [layers][M, *]
+// arrays with a uniform layer stride.  That uniform stride is what lets the weight gradients of ALL
+// layers be computed after the dgrad chain by ONE batched launch per weight matrix
+// (batch index = layer): thousands of 128x128 tiles per launch instead of 36..144, no split-K, no
+// atomics, deterministic, fp32 results written straight into the caller's gradient buffers.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes);
+    return o;
+  }
+};
+
+struct BwdLayout {
+  size_t dy2, du, dy1, dqkv;  // bf16 [layers][M,*]
+  size_t dxa, dxb, dctx;      // bf16 [M,H]
+  size_t ln_partial, colsum_partial, emb_partial;  // fp32
+  size_t total;
+};
+
+BwdLayout bwd_layout(const cocodr_config* c, int B, int L) {
+  const size_t M = (size_t)B * L, H = c->hidden, I = c->inter, N = c->layers;
+  Carver cv;
+  BwdLayout b;
+  b.dy2 = cv.take(N * M * H * 2);
+  b.du = cv.take(N * M * I * 2);
+  b.dy1 = cv.take(N * M * H * 2);
+  b.dqkv = cv.take(N * M * 3 * H * 2);
+  b.dxa = cv.take(M * H * 2);
+  b.dxb = cv.take(M * H * 2);
+  b.dctx = cv.take(M * H * 2);
+  b.ln_partial = cv.take(cocodr_ln_bwd_partial_floats((int)M, (int)H) * 4);
+  b.colsum_partial = cv.take(cocodr_colsum_partial_floats((int)M, (int)std::max(I, 3 * H), (int)N) * 4);
+  b.emb_partial = cv.take(cocodr_embed_bwd_partial_floats(L, (int)H) * 4);
+  b.total = cv.off;
+  return b;
+}
+
+int check_cfg(const cocodr_config* c, int B, int L) {
+  CK_ARG(c != nullptr, "encoder: null config");
+  CK_ARG(c->heads > 0 && c->hidden == c->heads * 64, "encoder: hidden=%d must be heads*64 (heads=%d)", c->hidden, c->heads);
+  CK_ARG(c->hidden % 128 == 0 && c->hidden <= 1024, "encoder: hidden=%d must be a multiple of 128, <= 1024", c->hidden);
+  CK_ARG(c->inter % 128 == 0 && c->inter > 0, "encoder: intermediate=%d must be a multiple of 128", c->inter);
+  CK_ARG(c->layers > 0 && c->vocab > 0, "encoder: bad layers/vocab");
+  CK_ARG(B > 0 && L >= 32 && L % 32 == 0 && L <= 512 && L <= c->max_pos, "encoder: L=%d must be a multiple of 32 in [32, min(512,%d)]", L, c->max_pos);
+  return COCODR_OK;
+}
+
+#define TRY(expr)                \
+  do {                           \
+    const int rc_ = (expr);      \
+    if (rc_ != COCODR_OK) return rc_; \
+  } while (0)
+
+cocodr_gemm_args gemm_base(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb) {
+  cocodr_gemm_args g = {};
+  g.A = (const uint16_t*)A; g.B = (const uint16_t*)B; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.trans_a = ta; g.trans_b = tb; g.epi = COCODR_EPI_NONE; g.batch = 1;
+  return g;
+}
+
+}  // namespace
+
+extern "C" int cocodr_encoder_layout(const cocodr_config* c, int B, int L, int training, cocodr_encoder_layout_t* out) {
+  TRY(check_cfg(c, B, L));
+  CK_ARG(out != nullptr, "encoder_layout: null out");
+  const size_t M = (size_t)B * L, H = c->hidden, I = c->inter;
+  const size_t NL = training ? c->layers : 1;
+  Carver cv;
+  out->hidden = cv.take((size_t)(c->layers + 1) * M * H * 2);
+  out->cls_f32 = cv.take((size_t)B * H * 4);
+  out->qkv = cv.take(NL * M * 3 * H * 2);
+  out->ctx = cv.take(NL * M * H * 2);
+  out->y1 = cv.take(NL * M * H * 2);
+  out->x1 = cv.take(NL * M * H * 2);
+  out->u = cv.take(NL * M * I * 2);
+  out->h = cv.take(NL * M * I * 2);
+  out->y2 = cv.take(NL * M * H * 2);
+  out->lse = cv.take(NL * M * c->heads * 4);
+  out->mean1 = cv.take(NL * M * 4);
+  out->rstd1 = cv.take(NL * M * 4);
+  out->mean2 = cv.take(NL * M * 4);
+  out->rstd2 = cv.take(NL * M * 4);
+  out->emb_mean = cv.take(M * 4);
+  out->emb_rstd = cv.take(M * 4);
+  out->bwd_scratch = cv.off;
+  out->bwd_bytes = training ? bwd_layout(c, B, L).total : 0;
+  out->total_bytes = cv.off + out->bwd_bytes;
+  return COCODR_OK;
+}
+
+extern "C" int cocodr_encoder_fwd(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
+                                  const int32_t* ids, const int32_t* mask, int B, int L, int training, void* arena,
+                                  size_t arena_bytes, cocodr_stream_t stream) {
+  cocodr_encoder_layout_t lay;
+  TRY(cocodr_encoder_layout(c, B, L, training, &lay));
+  CK_ARG(emb && lp && ids && mask && arena, "encoder_fwd: null pointer");
+  if (arena_bytes < lay.total_bytes) {
+    cocodr_set_error("encoder_fwd: arena %zu B < required %zu B", arena_bytes, lay.total_bytes);
+    return COCODR_ERR_WORKSPACE;
+  }
+  CK_ARG(((uintptr_t)arena & 255) == 0, "encoder_fwd: arena must be 256-byte aligned");
+  char* base = (char*)arena;
+  const int M = B * L, H = c->hidden, I = c->inter, NL = c->layers;
+  const size_t ls = training ? 1 : 0;  // per-layer stride multiplier
+  uint16_t* hidden = (uint16_t*)(base + lay.hidden);
+  float* cls = (float*)(base + lay.cls_f32);
+
+  TRY(cocodr_embed_ln_fwd(ids, emb->word, emb->pos, emb->type0, emb->ln_g, emb->ln_b, hidden, (float*)(base + lay.emb_mean),
+                          (float*)(base + lay.emb_rstd), B, L, H, c->vocab, c->ln_eps, stream));
+  for (int l = 0; l < NL; ++l) {
+    const cocodr_layer_params& w = lp[l];
+    const size_t lo = ls * l;
+    uint16_t* x_in = hidden + (size_t)l * M * H;
+    uint16_t* x_out = hidden + (size_t)(l + 1) * M * H;
+    uint16_t* qkv = (uint16_t*)(base + lay.qkv) + lo * M * 3 * H;
+    uint16_t* ctx = (uint16_t*)(base + lay.ctx) + lo * M * H;
+    uint16_t* y1 = (uint16_t*)(base + lay.y1) + lo * M * H;
+    uint16_t* x1 = (uint16_t*)(base + lay.x1) + lo * M * H;
+    uint16_t* u = (uint16_t*)(base + lay.u) + lo * M * I;
+    uint16_t* h = (uint16_t*)(base + lay.h) + lo * M * I;
+    uint16_t* y2 = (uint16_t*)(base + lay.y2) + lo * M * H;
+    float* lse = (float*)(base + lay.lse) + lo * M * c->heads;
+    float* mean1 = (float*)(base + lay.mean1) + lo * M;
+    float* rstd1 = (float*)(base + lay.rstd1) + lo * M;
+    float* mean2 = (float*)(base + lay.mean2) + lo * M;
+    float* rstd2 = (float*)(base + lay.rstd2) + lo * M;
+
+    cocodr_gemm_args g = gemm_base(x_in, w.wqkv, qkv, M, 3 * H, H, H, H, 3 * H, 0, 0);
+    g.bias = w.bqkv;
+    TRY(cocodr_gemm(&g, stream));
+    TRY(cocodr_attn_fwd(qkv, mask, ctx, lse, B, L, c->heads, stream));
+    g = gemm_base(ctx, w.wo, y1, M, H, H, H, H, H, 0, 0);
+    g.bias = w.bo; g.epi = COCODR_EPI_ADD; g.R = x_in; g.ldr = H;
+    TRY(cocodr_gemm(&g, stream));
+    TRY(cocodr_ln_fwd(y1, w.ln1_g, w.ln1_b, x1, mean1, rstd1, nullptr, 0, M, H, c->ln_eps, stream));
+    g = gemm_base(x1, w.w1, h, M, I, H, H, H, I, 0, 0);
+    g.bias = w.b1; g.epi = COCODR_EPI_GELU; g.C2 = u;
+    TRY(cocodr_gemm(&g, stream));
+    g = gemm_base(h, w.w2, y2, M, H, I, I, I, H, 0, 0);
+    g.bias = w.b2; g.epi = COCODR_EPI_ADD; g.R = x1; g.ldr = H;
+    TRY(cocodr_gemm(&g, stream));
+    TRY(cocodr_ln_fwd(y2, w.ln2_g, w.ln2_b, x_out, mean2, rstd2, (l == NL - 1) ? cls : nullptr, L, M, H, c->ln_eps, stream));
+  }
+  return COCODR_OK;
+}
+
+extern "C" int cocodr_encoder_bwd(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
+                                  const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const int32_t* ids,
+                                  const int32_t* mask, const uint16_t* d_last, int B, int L, void* arena, size_t arena_bytes,
+                                  cocodr_stream_t stream) {
+  cocodr_encoder_layout_t lay;
+  TRY(cocodr_encoder_layout(c, B, L, 1, &lay));
+  CK_ARG(emb && lp && eg && lg && ids && mask && d_last && arena, "encoder_bwd: null pointer");
+  CK_ARG(L <= 256, "encoder_bwd: L=%d > 256 is not supported by the attention backward yet", L);
+  if (arena_bytes < lay.total_bytes) {
+    cocodr_set_error("encoder_bwd: arena %zu B < required %zu B (was the forward run with training=1?)", arena_bytes, lay.total_bytes);
+    return COCODR_ERR_WORKSPACE;
+  }
+  const int M = B * L, H = c->hidden, I = c->inter, NL = c->layers;
+  // uniform layer stride of the gradient blocks (see header)
+  long long s_wqkv = 0, s_wo = 0, s_w1 = 0, s_w2 = 0, s_bqkv = 0, s_bo = 0, s_b1 = 0, s_b2 = 0;
+  if (NL > 1) {
+    s_wqkv = lg[1].wqkv - lg[0].wqkv; s_wo = lg[1].wo - lg[0].wo; s_w1 = lg[1].w1 - lg[0].w1; s_w2 = lg[1].w2 - lg[0].w2;
+    s_bqkv = lg[1].bqkv - lg[0].bqkv; s_bo = lg[1].bo - lg[0].bo; s_b1 = lg[1].b1 - lg[0].b1; s_b2 = lg[1].b2 - lg[0].b2;
+    for (int l = 1; l < NL; ++l) {
+      CK_ARG(lg[l].wqkv - lg[l - 1].wqkv == s_wqkv && lg[l].wo - lg[l - 1].wo == s_wo && lg[l].w1 - lg[l - 1].w1 == s_w1 &&
+                 lg[l].w2 - lg[l - 1].w2 == s_w2 && lg[l].bqkv - lg[l - 1].bqkv == s_bqkv && lg[l].bo - lg[l - 1].bo == s_bo &&
+                 lg[l].b1 - lg[l - 1].b1 == s_b1 && lg[l].b2 - lg[l - 1].b2 == s_b2,
+             "encoder_bwd: gradient blocks of layer %d are not at a uniform stride", l);
+    }
+  }
+  char* base = (char*)arena;
+  const BwdLayout bl = bwd_layout(c, B, L);
+  char* bb = base + lay.bwd_scratch;
+  uint16_t* hidden = (uint16_t*)(base + lay.hidden);
+  uint16_t* dy2_all = (uint16_t*)(bb + bl.dy2);
+  uint16_t* du_all = (uint16_t*)(bb + bl.du);
+  uint16_t* dy1_all = (uint16_t*)(bb + bl.dy1);
+  uint16_t* dqkv_all = (uint16_t*)(bb + bl.dqkv);
+  uint16_t* dxa = (uint16_t*)(bb + bl.dxa);
+  uint16_t* dxb = (uint16_t*)(bb + bl.dxb);
+  uint16_t* dctx = (uint16_t*)(bb + bl.dctx);
+  float* ln_partial = (float*)(bb + bl.ln_partial);
+  float* cs_partial = (float*)(bb + bl.colsum_partial);
+  float* emb_partial = (float*)(bb + bl.emb_partial);
+
+  const uint16_t* dx = d_last;
+  for (int l = NL - 1; l >= 0; --l) {
+    const cocodr_layer_params& w = lp[l];
+    const cocodr_layer_grads& gr = lg[l];
+    const size_t lo = (size_t)l;
+    const uint16_t* qkv = (const uint16_t*)(base + lay.qkv) + lo * M * 3 * H;
+    const uint16_t* ctx = (const uint16_t*)(base + lay.ctx) + lo * M * H;
+    const uint16_t* y1 = (const uint16_t*)(base + lay.y1) + lo * M * H;
+    const uint16_t* u = (const uint16_t*)(base + lay.u) + lo * M * I;
+    const uint16_t* y2 = (const uint16_t*)(base + lay.y2) + lo * M * H;
+    const float* lse = (const float*)(base + lay.lse) + lo * M * c->heads;
+    const float* mean1 = (const float*)(base + lay.mean1) + lo * M;
+    const float* rstd1 = (const float*)(base + lay.rstd1) + lo * M;
+    const float* mean2 = (const float*)(base + lay.mean2) + lo * M;
+    const float* rstd2 = (const float*)(base + lay.rstd2) + lo * M;
+    uint16_t* dy2 = dy2_all + lo * M * H;
+    uint16_t* du = du_all + lo * M * I;
+    uint16_t* dy1 = dy1_all + lo * M * H;
+    uint16_t* dqkv = dqkv_all + lo * M * 3 * H;
+
+    TRY(cocodr_ln_bwd(dx, y2, w.ln2_g, mean2, rstd2, dy2, gr.ln2_g, gr.ln2_b, ln_partial, M, H, stream));
+    cocodr_gemm_args g = gemm_base(dy2, w.w2, du, M, I, H, H, I, I, 0, 1);  // dh = dy2 W2, fused with GELU'(u)
+    g.epi = COCODR_EPI_DGELU; g.R = u; g.ldr = I;
+    TRY(cocodr_gemm(&g, stream));
+    g = gemm_base(du, w.w1, dxa, M, H, I, I, H, H, 0, 1);  // dx1 = du W1 + dy2 (residual branch)
+    g.epi = COCODR_EPI_ADD; g.R = dy2; g.ldr = H;
+    TRY(cocodr_gemm(&g, stream));
+    TRY(cocodr_ln_bwd(dxa, y1, w.ln1_g, mean1, rstd1, dy1, gr.ln1_g, gr.ln1_b, ln_partial, M, H, stream));
+    g = gemm_base(dy1, w.wo, dctx, M, H, H, H, H, H, 0, 1);  // dctx = dy1 Wo
+    TRY(cocodr_gemm(&g, stream));
+    TRY(cocodr_attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, L, c->heads, stream));
+    g = gemm_base(dqkv, w.wqkv, dxb, M, H, 3 * H, 3 * H, H, H, 0, 1);  // dx = dqkv Wqkv + dy1 (residual branch)
+    g.epi = COCODR_EPI_ADD; g.R = dy1; g.ldr = H;
+    TRY(cocodr_gemm(&g, stream));
+    dx = dxb;
+  }
+  TRY(cocodr_embed_ln_bwd(dx, ids, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
+                          (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial, B, L,
+                          H, c->vocab, stream));
+
+  // ---- grouped weight gradients: one batched TN launch per matrix, batch = layer
+  const long long sMH = (long long)M * H, sMI = (long long)M * I, sM3H = (long long)M * 3 * H;
+  cocodr_gemm_args g = gemm_base(dqkv_all, hidden, lg[0].wqkv, 3 * H, H, M, 3 * H, H, H, 1, 1);
+  g.out_f32 = 1; g.batch = NL; g.strideA = sM3H; g.strideB = sMH; g.strideC = s_wqkv;
+  TRY(cocodr_gemm(&g, stream));
+  g = gemm_base(dy1_all, base + lay.ctx, lg[0].wo, H, H, M, H, H, H, 1, 1);
+  g.out_f32 = 1; g.batch = NL; g.strideA = sMH; g.strideB = sMH; g.strideC = s_wo;
+  TRY(cocodr_gemm(&g, stream));
+  g = gemm_base(du_all, base + lay.x1, lg[0].w1, I, H, M, I, H, H, 1, 1);
+  g.out_f32 = 1; g.batch = NL; g.strideA = sMI; g.strideB = sMH; g.strideC = s_w1;
+  TRY(cocodr_gemm(&g, stream));
+  g = gemm_base(dy2_all, base + lay.h, lg[0].w2, H, I, M, H, I, I, 1, 1);
+  g.out_f32 = 1; g.batch = NL; g.strideA = sMH; g.strideB = sMI; g.strideC = s_w2;
+  TRY(cocodr_gemm(&g, stream));
+  // ---- bias gradients: batched column sums of the saved dY
+  TRY(cocodr_colsum(dqkv_all, lg[0].bqkv, cs_partial, M, 3 * H, 3 * H, NL, sM3H, s_bqkv, stream));
+  TRY(cocodr_colsum(dy1_all, lg[0].bo, cs_partial, M, H, H, NL, sMH, s_bo, stream));
+  TRY(cocodr_colsum(du_all, lg[0].b1, cs_partial, M, I, I, NL, sMI, s_b1, stream));
+  TRY(cocodr_colsum(dy2_all, lg[0].b2, cs_partial, M, H, H, NL, sMH, s_b2, stream));
+  return COCODR_OK;
+}

@@ -1,0 +1,227 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues - the dense contractions of the BERT encoder
+// (hf: nn.Linear in BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput) and of
+// their backward passes.  One kernel template covers
+//     forward  Y  = X  W^T   (A [M,K], B [N,K]   : trans_a=0, trans_b=0)
+//     dgrad    dX = dY W     (A [M,K], B [K,N]   : trans_a=0, trans_b=1)
+//     wgrad    dW = dY^T X   (A [K,M], B [K,N]   : trans_a=1, trans_b=1), batched over layers.
+//
+// Tile: 128x128x64 per 256-thread workgroup (4 waves, 2x2, each wave 64x64 = 2x2 MFMA 32x32x16).
+// Operand tiles are staged HBM -> registers -> LDS (double buffered; the loads of tile t+1 are in
+// flight while tile t is multiplied, the LDS write lands after the MFMAs).  Operands whose
+// contraction index is the slow memory axis are kept row-major in LDS and read with the gfx950
+// transposing LDS read (ds_read_b64_tr_b16), so no transposed copy of weights or activations is
+// ever materialised in HBM.  The accumulators go through an fp32 LDS tile so that the epilogue
+// (bias, erf-GELU, residual, GELU') runs row-major with 16-byte coalesced loads/stores.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+constexpr int CT_LD = 132;                // fp32 epilogue tile leading dim (floats)
+
+// ---- global -> registers (4 x 16 B per thread per operand tile), zero filled out of range
+template <int TR>
+__device__ __forceinline__ void load_tile(const uint16_t* __restrict__ G, int ld, int r0, int rlim, int k0, int klim,
+                                          int tid, uint4 (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + 256 * i;
+    int gr, gk;
+    if (TR == 0) {  // [rows][k] : 8 chunks per 64-wide k row
+      gr = r0 + (q >> 3);
+      gk = k0 + ((q & 7) << 3);
+      v[i] = (gr < rlim && gk < klim) ? *reinterpret_cast<const uint4*>(G + (size_t)gr * ld + gk) : make_uint4(0, 0, 0, 0);
+    } else {  // stored [k][rows] : 16 chunks per 128-wide row
+      gk = k0 + (q >> 4);
+      gr = r0 + ((q & 15) << 3);
+      v[i] = (gr < rlim && gk < klim) ? *reinterpret_cast<const uint4*>(G + (size_t)gk * ld + gr) : make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+template <int TR>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const uint4 (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + 256 * i;
+    const int off = (TR == 0) ? tile64_off(q >> 3, q & 7) : tile128_off(q >> 4, q & 15);
+    *reinterpret_cast<uint4*>(lds + off) = v[i];
+  }
+}
+
+// ---- LDS -> MFMA 32x32x16 operand fragment for the 32 rows starting at r0, k-step s (16 wide)
+// lane l supplies row r0 + (l & 31) and the 8 contraction slots 16*s + 8*(l >> 5) + 0..7.
+template <int TR>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int r0, int s, int lane) {
+  if (TR == 0) {
+    return lds_read_b128(lds, tile64_off(r0 + (lane & 31), 2 * s + (lane >> 5)));
+  } else {
+    const int g = lane >> 4, c = lane & 15;
+    const int col = r0 + ((g & 1) << 4) + ((c & 3) << 2);
+    const int row = 16 * s + ((g >> 1) << 3) + (c >> 2);
+    const int off = tile128_off(row, col >> 3) + ((col & 7) << 1);
+    return join_tr(lds_read_tr16(lds, off), lds_read_tr16(lds, off + 4 * 256));
+  }
+}
+
+template <int TA, int TB, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const cocodr_gemm_args p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int ntn = p.N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int z = blockIdx.y;
+  const uint16_t* __restrict__ A = p.A + (size_t)z * p.strideA;
+  const uint16_t* __restrict__ B = p.B + (size_t)z * p.strideB;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nt = (p.K + BK - 1) / BK;
+  uint4 ra[4], rb[4];
+  load_tile<TA>(A, p.lda, m0, p.M, 0, p.K, tid, ra);
+  load_tile<TB>(B, p.ldb, n0, p.N, 0, p.K, tid, rb);
+  store_tile<TA>(smem, tid, ra);
+  store_tile<TB>(smem + TILE_BYTES, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* bufA = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* bufB = bufA + TILE_BYTES;
+    const bool more = (t + 1 < nt);
+    if (more) {
+      load_tile<TA>(A, p.lda, m0, p.M, (t + 1) * BK, p.K, tid, ra);
+      load_tile<TB>(B, p.ldb, n0, p.N, (t + 1) * BK, p.K, tid, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = read_frag<TA>(bufA, wm * 64 + a * 32, s, lane);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = read_frag<TB>(bufB, wn * 64 + b * 32, s, lane);
+      // operands swapped: D[i = n][j = m], so a lane ends up with 4 consecutive n of one m
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    }
+    if (more) {
+      char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+      store_tile<TA>(nb, tid, ra);
+      store_tile<TB>(nb + TILE_BYTES, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue through an fp32 LDS tile, two 64-row halves
+  float* ct = reinterpret_cast<float*>(smem);
+  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
+  const uint16_t* __restrict__ R = p.R ? p.R + (size_t)z * p.strideR : nullptr;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wm == h) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int row = a * 32 + (lane & 31);
+            const int col = wn * 64 + b * 32 + 8 * rg + 4 * (lane >> 5);
+            *reinterpret_cast<float4*>(ct + row * CT_LD + col) =
+                make_float4(acc[a][b][rg * 4 + 0], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int row = (tid >> 4) + 16 * pp;
+      const int gm = m0 + h * 64 + row;
+      const int gn = n0 + ((tid & 15) << 3);
+      if (gm < p.M) {
+        float v[8];
+        const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CT_LD + ((tid & 15) << 3));
+        const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CT_LD + ((tid & 15) << 3) + 4);
+        v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+        if (bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(bias + gn);
+          const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (p.epi == COCODR_EPI_GELU) {
+          *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        } else if (p.epi == COCODR_EPI_ADD) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(R + (size_t)gm * p.ldr + gn), r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += r[j];
+        } else if (p.epi == COCODR_EPI_DGELU) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(R + (size_t)gm * p.ldr + gn), r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(r[j]);
+        }
+        if (OUT_F32) {
+          float* C = reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
+          *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
+          *reinterpret_cast<uint4*>(C) = pack8(v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int TA, int TB>
+void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
+  if (a.out_f32)
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, true>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, false>), grid, dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream) {
+  CK_ARG(args != nullptr, "gemm: null args");
+  cocodr_gemm_args a = *args;
+  if (a.batch <= 0) a.batch = 1;
+  CK_ARG(a.A && a.B && a.C, "gemm: null operand");
+  CK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  CK_ARG(a.N % BN == 0, "gemm: N=%d must be a multiple of 128", a.N);
+  CK_ARG(a.K % 8 == 0, "gemm: K=%d must be a multiple of 8", a.K);
+  CK_ARG(!a.trans_a || a.M % 8 == 0, "gemm: M=%d must be a multiple of 8 when trans_a", a.M);
+  CK_ARG(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0, "gemm: leading dims must be multiples of 8");
+  CK_ARG(a.lda >= (a.trans_a ? a.M : a.K) && a.ldb >= (a.trans_b ? a.N : a.K) && a.ldc >= a.N, "gemm: leading dim too small");
+  CK_ARG(!(a.trans_a && !a.trans_b), "gemm: (trans_a=1, trans_b=0) is not used on this path");
+  CK_ARG(a.epi >= COCODR_EPI_NONE && a.epi <= COCODR_EPI_DGELU, "gemm: bad epilogue %d", a.epi);
+  CK_ARG(a.epi != COCODR_EPI_GELU || (a.C2 && !a.out_f32), "gemm: EPI_GELU needs C2 and bf16 output");
+  CK_ARG((a.epi != COCODR_EPI_ADD && a.epi != COCODR_EPI_DGELU) || (a.R && a.ldr % 8 == 0 && a.ldr >= a.N), "gemm: epilogue needs R");
+  CK_ARG((((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.C2 | (uintptr_t)a.R | (uintptr_t)a.bias) & 15) == 0,
+         "gemm: pointers must be 16-byte aligned");
+  if (a.epi != COCODR_EPI_ADD && a.epi != COCODR_EPI_DGELU) a.R = nullptr;
+  const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
+  dim3 grid(ntm * ntn, a.batch);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(PROF_GEMM, st, 2.0 * a.M * a.N * (double)a.K * a.batch);
+  if (!a.trans_a && !a.trans_b) launch<0, 0>(a, grid, st);
+  else if (!a.trans_a && a.trans_b) launch<0, 1>(a, grid, st);
+  else launch<1, 1>(a, grid, st);
+  CK_LAUNCH("gemm");
+  return COCODR_OK;
+}

@@ -1,0 +1,198 @@
+// Training losses of the COCO-DR hot path, fp32 end to end (the logits are raw un-normalised
+// dot products of LayerNorm outputs - O(100) in magnitude - so the similarity matrix is formed with
+// the exact-fp32 MFMA, v_mfma_f32_32x32x2_f32, not in bf16).
+//
+//  * simce  : COCO/modeling.py:244-248 compute_contrastive_loss (+ co_target :172-177, mean :229)
+//             and the gradient that reaches the LOCAL rows of the gathered [CLS] matrix
+//             (COCO/modeling.py:182-186).  With S = E E^T symmetric and t(i) = i ^ 1 an involution,
+//                 dL/dE_i = (W/M) * sum_j Gs[i][j] E_j,
+//                 Gs[i][j] = exp(S_ij - lse_i) + exp(S_ij - lse_j) - 2 [j == t(i)],  Gs[i][i] = 0
+//             so a rank only needs its own row block of S - never G^T - and no backward collective.
+//  * triplet: ANCE/model/models.py:97-106 (logits, -log_softmax[:,0]) and :260-261 ((loss*w).mean()).
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 64;   // output tile
+constexpr int TK = 32;   // contraction chunk
+constexpr int TLD = 33;  // padded LDS leading dim (floats)
+
+// C tile [64 x 64] += A[64 x 32] * B^T, A and B staged as [row][k] fp32 tiles (ld 33);
+// wave (wm, wn) owns the 32x32 sub-tile.  MFMA 32x32x2 f32: lane l feeds A[i = l&31][k = l>>5].
+__device__ __forceinline__ void mma_chunk_nt(const float* As, const float* Bs, int wm, int wn, int lane, f32x16& acc) {
+#pragma unroll
+  for (int kk = 0; kk < TK; kk += 2) {
+    const float a = As[(wm * 32 + (lane & 31)) * TLD + kk + (lane >> 5)];
+    const float b = Bs[(wn * 32 + (lane & 31)) * TLD + kk + (lane >> 5)];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+}
+
+// S = E E^T with -inf diagonal.  grid (ceil(M/64), ceil(M/64)).
+__global__ __launch_bounds__(256) void simce_scores_kernel(const float* __restrict__ E, float* __restrict__ S, int M, int H) {
+  __shared__ float As[TS * TLD], Bs[TS * TLD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const int i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < H; k0 += TK) {
+    for (int q = tid; q < TS * TK; q += 256) {
+      const int r = q >> 5, k = q & 31;
+      As[r * TLD + k] = (i0 + r < M && k0 + k < H) ? E[(size_t)(i0 + r) * H + k0 + k] : 0.f;
+      Bs[r * TLD + k] = (j0 + r < M && k0 + k < H) ? E[(size_t)(j0 + r) * H + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    mma_chunk_nt(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int j = j0 + wn * 32 + (lane & 31);
+    if (i < M && j < M) S[(size_t)i * M + j] = (i == j) ? -INFINITY : acc[r];
+  }
+}
+
+// one wave per row: lse_i and loss_i = (lse_i - S[i][i^1]) * W
+__global__ __launch_bounds__(256) void simce_rowstats_kernel(const float* __restrict__ S, float* __restrict__ lse,
+                                                             float* __restrict__ loss_rows, int M, float world) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= M) return;
+  const float* row = S + (size_t)i * M;
+  float mx = -INFINITY;
+  for (int j = lane; j < M; j += 64) mx = fmaxf(mx, row[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < M; j += 64) s += __expf(row[j] - mx);
+  s = wave_sum(s);
+  const float l = mx + __logf(s);
+  if (lane == 0) {
+    lse[i] = l;
+    loss_rows[i] = (l - row[i ^ 1]) * world;
+  }
+}
+
+// out[0] = scale * sum_i x[i] * (w ? w[i] : 1)   (single workgroup, fixed order -> deterministic)
+__global__ __launch_bounds__(256) void weighted_mean_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ out, int n, float scale) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i] * (w ? w[i] : 1.f);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+}
+
+// dE_local[r][h] = coef * sum_j Gs[row0 + r][j] * E[j][h].  grid (ceil(H/64), ceil(m_local/64)).
+__global__ __launch_bounds__(256) void simce_grad_kernel(const float* __restrict__ E, const float* __restrict__ S,
+                                                         const float* __restrict__ lse, float* __restrict__ dE, int M, int H,
+                                                         int row0, int m_local, float coef) {
+  __shared__ float Gs[TS * TLD];  // [r][j-chunk]
+  __shared__ float Bs[TS * TLD];  // [h][j-chunk]  (E chunk stored transposed so both operands are [row][k])
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const int r0 = blockIdx.y * TS, h0 = blockIdx.x * TS;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int j0 = 0; j0 < M; j0 += TK) {
+    for (int q = tid; q < TS * TK; q += 256) {
+      const int r = q >> 5, k = q & 31;
+      const int i = row0 + r0 + r, j = j0 + k;
+      float g = 0.f;
+      if (r0 + r < m_local && j < M && j != i) {
+        const float s = S[(size_t)i * M + j];
+        g = __expf(s - lse[i]) + __expf(s - lse[j]) - ((j == (i ^ 1)) ? 2.f : 0.f);
+      }
+      Gs[r * TLD + k] = g;
+    }
+    for (int q = tid; q < TS * TK; q += 256) {
+      const int k = q >> 6, hh = q & 63;  // coalesced along h
+      Bs[hh * TLD + k] = (j0 + k < M && h0 + hh < H) ? E[(size_t)(j0 + k) * H + h0 + hh] : 0.f;
+    }
+    __syncthreads();
+    mma_chunk_nt(Gs, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rr = r0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int hh = h0 + wn * 32 + (lane & 31);
+    if (rr < m_local && hh < H) dE[(size_t)rr * H + hh] = acc[r] * coef;
+  }
+}
+
+// one wave per triplet row
+__global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ q, const float* __restrict__ a,
+                                                      const float* __restrict__ b, const float* __restrict__ w,
+                                                      float* __restrict__ loss_rows, float* __restrict__ logits,
+                                                      float* __restrict__ dq, float* __restrict__ da, float* __restrict__ db, int B,
+                                                      int H) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B) return;
+  const float *qi = q + (size_t)i * H, *ai = a + (size_t)i * H, *bi = b + (size_t)i * H;
+  float s0 = 0.f, s1 = 0.f;
+  for (int h = lane; h < H; h += 64) {
+    s0 += qi[h] * ai[h];
+    s1 += qi[h] * bi[h];
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  const float mx = fmaxf(s0, s1);
+  const float lse = mx + __logf(__expf(s0 - mx) + __expf(s1 - mx));
+  const float p0 = __expf(s0 - lse), p1 = __expf(s1 - lse);
+  const float wi = (w ? w[i] : 1.f) / (float)B;
+  const float c0 = (p0 - 1.f) * wi, c1 = p1 * wi;
+  if (lane == 0) {
+    loss_rows[i] = lse - s0;
+    logits[2 * i] = s0;
+    logits[2 * i + 1] = s1;
+  }
+  for (int h = lane; h < H; h += 64) {
+    const float qv = qi[h];
+    dq[(size_t)i * H + h] = c0 * ai[h] + c1 * bi[h];
+    da[(size_t)i * H + h] = c0 * qv;
+    db[(size_t)i * H + h] = c1 * qv;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t cocodr_simce_workspace_floats(int M) { return (size_t)M * M + (size_t)M; }
+
+extern "C" int cocodr_simce_fwd_bwd(const float* E, int M, int H, int world, int row0, int m_local, float* loss_rows, float* loss,
+                                    float* dE_local, float* workspace, cocodr_stream_t stream) {
+  CK_ARG(E && loss_rows && loss && dE_local && workspace, "simce: null pointer");
+  CK_ARG(M >= 2 && M % 2 == 0 && H > 0 && world >= 1, "simce: bad shape M=%d H=%d world=%d (M must be even: span pairs)", M, H, world);
+  CK_ARG(row0 >= 0 && m_local > 0 && row0 + m_local <= M, "simce: local rows [%d,%d) outside [0,%d)", row0, row0 + m_local, M);
+  hipStream_t st = (hipStream_t)stream;
+  float* S = workspace;
+  float* lse = workspace + (size_t)M * M;
+  const int nt = (M + TS - 1) / TS;
+  hipLaunchKernelGGL(simce_scores_kernel, dim3(nt, nt), dim3(256), 0, st, E, S, M, H);
+  CK_LAUNCH("simce_scores");
+  hipLaunchKernelGGL(simce_rowstats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, S, lse, loss_rows, M, (float)world);
+  CK_LAUNCH("simce_rowstats");
+  hipLaunchKernelGGL(weighted_mean_kernel, dim3(1), dim3(256), 0, st, loss_rows, (const float*)nullptr, loss, M, 1.0f / (float)M);
+  CK_LAUNCH("simce_mean");
+  hipLaunchKernelGGL(simce_grad_kernel, dim3((H + TS - 1) / TS, (m_local + TS - 1) / TS), dim3(256), 0, st, E, S, lse, dE_local, M, H,
+                     row0, m_local, (float)world / (float)M);
+  CK_LAUNCH("simce_grad");
+  return COCODR_OK;
+}
+
+extern "C" int cocodr_triplet_nll_fwd_bwd(const float* q, const float* a, const float* b, const float* weights, int B, int H,
+                                          float* loss_rows, float* logits, float* loss, float* dq, float* da, float* db,
+                                          cocodr_stream_t stream) {
+  CK_ARG(q && a && b && loss_rows && logits && loss && dq && da && db, "triplet: null pointer");
+  CK_ARG(B > 0 && H > 0, "triplet: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(triplet_kernel, dim3((B + 3) / 4), dim3(256), 0, st, q, a, b, weights, loss_rows, logits, dq, da, db, B, H);
+  CK_LAUNCH("triplet");
+  hipLaunchKernelGGL(weighted_mean_kernel, dim3(1), dim3(256), 0, st, loss_rows, weights, loss, B, 1.0f / (float)B);
+  CK_LAUNCH("triplet_mean");
+  return COCODR_OK;
+}

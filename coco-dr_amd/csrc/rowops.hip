@@ -1,0 +1,436 @@
+// HBM-bound row kernels of the encoder: embedding gather + LayerNorm, LayerNorm forward/backward,
+// bias-gradient column sums, fp32->bf16 weight shadow cast.
+// One 64-lane wave owns one token row; a lane owns the 4-element (8 B bf16 / 16 B fp32) chunks
+// lane, lane+64, ... so every wave-level access is a contiguous 512 B / 1 KiB burst; row statistics
+// are wave shuffle reductions (no LDS, no atomics on the activation path).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // chunks per lane -> H <= 1024
+
+struct RowVec {
+  float v[MAXC][4];
+};
+
+__device__ __forceinline__ void load_bf16_row(const uint16_t* row, int nch, int lane, RowVec& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) unpack4(*reinterpret_cast<const uint2*>(row + c * 4), r.v[i]);
+    else r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
+  }
+}
+__device__ __forceinline__ void load_f32_row(const float* row, int nch, int lane, RowVec& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 t = *reinterpret_cast<const float4*>(row + c * 4);
+      r.v[i][0] = t.x; r.v[i][1] = t.y; r.v[i][2] = t.z; r.v[i][3] = t.w;
+    } else r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
+  }
+}
+__device__ __forceinline__ void store_bf16_row(uint16_t* row, int nch, int lane, const RowVec& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) *reinterpret_cast<uint2*>(row + c * 4) = pack4(r.v[i]);
+  }
+}
+__device__ __forceinline__ float row_sum(const RowVec& r) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
+  return wave_sum(s);
+}
+
+// mean / rstd of a row held in registers (two-pass, biased variance; padded chunks hold zeros)
+__device__ __forceinline__ void row_stats(const RowVec& r, int nch, int lane, int H, float eps, float& mean, float& rstd) {
+  mean = row_sum(r) / (float)H;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = r.v[i][e] - mean; s += d * d; }
+    }
+  rstd = rsqrtf(wave_sum(s) / (float)H + eps);
+}
+
+__device__ __forceinline__ void ln_apply(RowVec& r, const float* gamma, const float* beta, int nch, int lane, float mean, float rstd) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c * 4);
+      r.v[i][0] = (r.v[i][0] - mean) * rstd * g.x + b.x;
+      r.v[i][1] = (r.v[i][1] - mean) * rstd * g.y + b.y;
+      r.v[i][2] = (r.v[i][2] - mean) * rstd * g.z + b.z;
+      r.v[i][3] = (r.v[i][3] - mean) * rstd * g.w + b.w;
+    }
+  }
+}
+
+// gather word[id] + pos[l] + type0 into registers
+__device__ __forceinline__ void embed_gather(const float* word, const float* pos, const float* type0, int id, int l, int H,
+                                             int nch, int lane, RowVec& r) {
+  const float* w = word + (size_t)id * H;
+  const float* p = pos + (size_t)l * H;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 a = *reinterpret_cast<const float4*>(w + c * 4);
+      const float4 b = *reinterpret_cast<const float4*>(p + c * 4);
+      const float4 t = *reinterpret_cast<const float4*>(type0 + c * 4);
+      r.v[i][0] = a.x + b.x + t.x; r.v[i][1] = a.y + b.y + t.y; r.v[i][2] = a.z + b.z + t.z; r.v[i][3] = a.w + b.w + t.w;
+    } else r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
+                                                           const float* __restrict__ pos, const float* __restrict__ type0,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           uint16_t* __restrict__ out, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, int M, int L, int H, int vocab, float eps) {
+  const int lane = threadIdx.x & 63, nch = H >> 2;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    RowVec r;
+    embed_gather(word, pos, type0, id, row % L, H, nch, lane, r);
+    float mean, rstd;
+    row_stats(r, nch, lane, H, eps, mean, rstd);
+    ln_apply(r, gamma, beta, nch, lane, mean, rstd);
+    store_bf16_row(out + (size_t)row * H, nch, lane, r);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const uint16_t* __restrict__ y, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, uint16_t* __restrict__ out,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     float* __restrict__ cls_out, int cls_stride, int M, int H, float eps) {
+  const int lane = threadIdx.x & 63, nch = H >> 2;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    RowVec r;
+    load_bf16_row(y + (size_t)row * H, nch, lane, r);
+    float mean, rstd;
+    row_stats(r, nch, lane, H, eps, mean, rstd);
+    ln_apply(r, gamma, beta, nch, lane, mean, rstd);
+    store_bf16_row(out + (size_t)row * H, nch, lane, r);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    if (cls_out && row % cls_stride == 0) {
+      float* dst = cls_out + (size_t)(row / cls_stride) * H;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) *reinterpret_cast<float4*>(dst + c * 4) = make_float4(r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]);
+      }
+    }
+  }
+}
+
+// LayerNorm backward core for one row held in registers:
+//   in : d = upstream gradient, x = LN input (pre-normalisation)
+//   out: d <- gradient w.r.t. the LN input; dg/db accumulate the gamma/beta gradients.
+__device__ __forceinline__ void ln_bwd_row(RowVec& d, const RowVec& x, const float* gamma, int nch, int lane, int H, float mean,
+                                           float rstd, RowVec& dg, RowVec& db) {
+  RowVec xh;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * 4);
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh.v[i][e] = (x.v[i][e] - mean) * rstd;
+        dg.v[i][e] += d.v[i][e] * xh.v[i][e];
+        db.v[i][e] += d.v[i][e];
+        d.v[i][e] *= g[e];  // dxhat
+        s1 += d.v[i][e];
+        s2 += d.v[i][e] * xh.v[i][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xh.v[i][e] = 0.f;
+    }
+  }
+  s1 = wave_sum(s1) / (float)H;
+  s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d.v[i][e] = rstd * (d.v[i][e] - s1 - xh.v[i][e] * s2);
+}
+
+// reduce the 4 waves' per-lane accumulators through LDS and write one partial row [H]
+__device__ __forceinline__ void block_reduce_store(const RowVec& acc, float* lds /* [4][MAXC*256] */, float* dst, int nch, int tid) {
+  const int lane = tid & 63, wid = tid >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    *reinterpret_cast<float4*>(lds + wid * (MAXC * 256) + (lane + 64 * i) * 4) = make_float4(acc.v[i][0], acc.v[i][1], acc.v[i][2], acc.v[i][3]);
+  __syncthreads();
+  for (int c = tid; c < nch; c += 256) {
+    float4 s = *reinterpret_cast<const float4*>(lds + c * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(lds + w * (MAXC * 256) + c * 4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *reinterpret_cast<float4*>(dst + c * 4) = s;
+  }
+}
+
+__device__ __forceinline__ void zero_row(RowVec& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i, uint16_t* __restrict__ dy,
+                                                     float* __restrict__ partial, int M, int H) {
+  __shared__ __attribute__((aligned(16))) float red[4 * MAXC * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
+  const int rows_per = (M + gridDim.x - 1) / gridDim.x;
+  const int r_begin = blockIdx.x * rows_per, r_end = min(M, r_begin + rows_per);
+  RowVec dg, db;
+  zero_row(dg);
+  zero_row(db);
+  for (int row = r_begin + wid; row < r_end; row += 4) {
+    RowVec d, x;
+    load_bf16_row(dout + (size_t)row * H, nch, lane, d);
+    load_bf16_row(y + (size_t)row * H, nch, lane, x);
+    ln_bwd_row(d, x, gamma, nch, lane, H, mean_i[row], rstd_i[row], dg, db);
+    store_bf16_row(dy + (size_t)row * H, nch, lane, d);
+  }
+  block_reduce_store(dg, red, partial + (size_t)blockIdx.x * 2 * H, nch, tid);
+  block_reduce_store(db, red, partial + (size_t)blockIdx.x * 2 * H + H, nch, tid);
+}
+
+// grid.x = L (one workgroup per position): the position-embedding gradient row is a plain sum over
+// the batch (no atomics); only the sparse word-embedding rows use fp32 atomics.
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const uint16_t* __restrict__ dout, const int32_t* __restrict__ ids,
+                                                           const float* __restrict__ word, const float* __restrict__ pos,
+                                                           const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                           float* __restrict__ dword, float* __restrict__ dpos,
+                                                           float* __restrict__ partial, int B, int L, int H, int vocab) {
+  __shared__ __attribute__((aligned(16))) float red[4 * MAXC * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
+  const int l = blockIdx.x;
+  RowVec dg, db, dp;
+  zero_row(dg);
+  zero_row(db);
+  zero_row(dp);
+  for (int b = wid; b < B; b += 4) {
+    const int row = b * L + l;
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    RowVec d, x;
+    load_bf16_row(dout + (size_t)row * H, nch, lane, d);
+    embed_gather(word, pos, type0, id, l, H, nch, lane, x);
+    ln_bwd_row(d, x, gamma, nch, lane, H, mean_i[row], rstd_i[row], dg, db);
+    float* wrow = dword + (size_t)id * H;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dp.v[i][e] += d.v[i][e];
+          atomicAdd(wrow + c * 4 + e, d.v[i][e]);
+        }
+      }
+    }
+  }
+  float* prow = partial + (size_t)l * 3 * H;
+  block_reduce_store(dg, red, prow, nch, tid);
+  block_reduce_store(db, red, prow + H, nch, tid);
+  block_reduce_store(dp, red, prow + 2 * H, nch, tid);
+  __syncthreads();
+  for (int c = tid; c < nch; c += 256)
+    *reinterpret_cast<float4*>(dpos + (size_t)l * H + c * 4) = *reinterpret_cast<const float4*>(prow + 2 * H + c * 4);
+}
+
+// out_s[z*stride_out + n] = sum_p partial[((z*P + p)*nseg + s)*n_len + n], s < nseg
+struct ReduceArgs {
+  const float* partial;
+  float* out[3];
+  int P, nseg, n_len, batch;
+  long long stride_out;
+};
+__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y, z = blockIdx.z;
+  if (n >= a.n_len) return;
+  const float* p = a.partial + ((size_t)z * a.P * a.nseg + s) * a.n_len + n;
+  float acc = 0.f;
+  for (int i = 0; i < a.P; ++i) acc += p[(size_t)i * a.nseg * a.n_len];
+  a.out[s][(size_t)z * a.stride_out + n] = acc;
+}
+
+// column sums: workgroup = 256-column strip x row range; a lane owns 4 adjacent columns
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ X, float* __restrict__ partial, int M, int N,
+                                                     int ldx, long long strideX, int S) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int z = blockIdx.z, s = blockIdx.y;
+  const int col = blockIdx.x * 256 + lane * 4;
+  const int rows_per = (M + S - 1) / S;
+  const int r_begin = s * rows_per, r_end = min(M, r_begin + rows_per);
+  const uint16_t* Xz = X + (size_t)z * strideX;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < N) {
+    for (int row = r_begin + wid; row < r_end; row += 4) {
+      float t[4];
+      unpack4(*reinterpret_cast<const uint2*>(Xz + (size_t)row * ldx + col), t);
+      acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3];
+    }
+  }
+  *reinterpret_cast<float4*>(red + wid * 256 + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (wid == 0 && col < N) {
+    float4 t0 = *reinterpret_cast<const float4*>(red + lane * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(red + w * 256 + lane * 4);
+      t0.x += t.x; t0.y += t.y; t0.z += t.z; t0.w += t.w;
+    }
+    *reinterpret_cast<float4*>(partial + ((size_t)z * S + s) * N + col) = t0;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n8, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const float4 a = *reinterpret_cast<const float4*>(src + i * 8);
+    const float4 b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    *reinterpret_cast<uint4*>(dst + i * 8) = pack8(f);
+  }
+  if (blockIdx.x == 0) {
+    for (size_t i = n8 * 8 + threadIdx.x; i < n; i += 256) dst[i] = f2bf(src[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ dE, uint16_t* __restrict__ d_last, int M, int L, int H) {
+  const int lane = threadIdx.x & 63, nch = H >> 2;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    RowVec r;
+    if (row % L == 0) load_f32_row(dE + (size_t)(row / L) * H, nch, lane, r);
+    else zero_row(r);
+    store_bf16_row(d_last + (size_t)row * H, nch, lane, r);
+  }
+}
+
+int colsum_splits(int M) { return M >= 4096 ? 32 : (M >= 512 ? 8 : 1); }
+int ln_bwd_blocks(int M) { return M >= 1024 ? 256 : (M + 3) / 4; }
+
+int launch_reduce(const float* partial, float* o0, float* o1, float* o2, int P, int nseg, int n_len, int batch, long long stride_out,
+                  hipStream_t st) {
+  ReduceArgs a;
+  a.partial = partial;
+  a.out[0] = o0; a.out[1] = o1; a.out[2] = o2;
+  a.P = P; a.nseg = nseg; a.n_len = n_len; a.batch = batch; a.stride_out = stride_out;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_len + 255) / 256, nseg, batch), dim3(256), 0, st, a);
+  CK_LAUNCH("reduce_partials");
+  return COCODR_OK;
+}
+
+bool row_shape_ok(int H) { return H % 4 == 0 && H >= 4 && H <= MAXC * 256; }
+int row_grid(int M) { return std::min((M + 3) / 4, 2048); }
+
+}  // namespace
+
+extern "C" int cocodr_embed_ln_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                                   const float* beta, uint16_t* out, float* mean, float* rstd, int B, int L, int H, int vocab,
+                                   float eps, cocodr_stream_t stream) {
+  CK_ARG(ids && word && pos && type0 && gamma && beta && out && mean && rstd, "embed_ln_fwd: null pointer");
+  CK_ARG(B > 0 && L > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_fwd: bad shape B=%d L=%d H=%d", B, L, H);
+  const int M = B * L;
+  hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta,
+                     out, mean, rstd, M, L, H, vocab, eps);
+  CK_LAUNCH("embed_ln_fwd");
+  return COCODR_OK;
+}
+
+extern "C" size_t cocodr_embed_bwd_partial_floats(int L, int H) { return (size_t)L * 3 * H; }
+
+extern "C" int cocodr_embed_ln_bwd(const uint16_t* dout, const int32_t* ids, const float* word, const float* pos, const float* type0,
+                                   const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
+                                   float* dtype0, float* dgamma, float* dbeta, float* partial, int B, int L, int H, int vocab,
+                                   cocodr_stream_t stream) {
+  CK_ARG(dout && ids && word && pos && type0 && gamma && mean && rstd && dword && dpos && dtype0 && dgamma && dbeta && partial,
+         "embed_ln_bwd: null pointer");
+  CK_ARG(B > 0 && L > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_bwd: bad shape B=%d L=%d H=%d", B, L, H);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(L), dim3(256), 0, st, dout, ids, word, pos, type0, gamma, mean, rstd, dword, dpos,
+                     partial, B, L, H, vocab);
+  CK_LAUNCH("embed_ln_bwd");
+  return launch_reduce(partial, dgamma, dbeta, dtype0, L, 3, H, 1, 0, st);
+}
+
+extern "C" int cocodr_ln_fwd(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean, float* rstd,
+                             float* cls_out, int cls_stride, int M, int H, float eps, cocodr_stream_t stream) {
+  CK_ARG(y && gamma && beta && out && mean && rstd, "ln_fwd: null pointer");
+  CK_ARG(M > 0 && row_shape_ok(H), "ln_fwd: bad shape M=%d H=%d", M, H);
+  CK_ARG(!cls_out || cls_stride > 0, "ln_fwd: cls_stride must be positive");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, (hipStream_t)stream, y, gamma, beta, out, mean, rstd, cls_out,
+                     cls_stride > 0 ? cls_stride : 1, M, H, eps);
+  CK_LAUNCH("ln_fwd");
+  return COCODR_OK;
+}
+
+extern "C" size_t cocodr_ln_bwd_partial_floats(int M, int H) { return (size_t)ln_bwd_blocks(M) * 2 * H; }
+
+extern "C" int cocodr_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
+                             uint16_t* dy, float* dgamma, float* dbeta, float* partial, int M, int H, cocodr_stream_t stream) {
+  CK_ARG(dout && y && gamma && mean && rstd && dy && dgamma && dbeta && partial, "ln_bwd: null pointer");
+  CK_ARG(M > 0 && row_shape_ok(H), "ln_bwd: bad shape M=%d H=%d", M, H);
+  hipStream_t st = (hipStream_t)stream;
+  const int P = ln_bwd_blocks(M);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(P), dim3(256), 0, st, dout, y, gamma, mean, rstd, dy, partial, M, H);
+  CK_LAUNCH("ln_bwd");
+  return launch_reduce(partial, dgamma, dbeta, nullptr, P, 2, H, 1, 0, st);
+}
+
+extern "C" size_t cocodr_colsum_partial_floats(int M, int N, int batch) { return (size_t)colsum_splits(M) * N * (batch > 0 ? batch : 1); }
+
+extern "C" int cocodr_colsum(const uint16_t* X, float* out, float* partial, int M, int N, int ldx, int batch, long long strideX,
+                             long long strideOut, cocodr_stream_t stream) {
+  CK_ARG(X && out && partial, "colsum: null pointer");
+  CK_ARG(M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N && batch > 0, "colsum: bad shape M=%d N=%d ldx=%d", M, N, ldx);
+  hipStream_t st = (hipStream_t)stream;
+  const int S = colsum_splits(M);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, S, batch), dim3(256), 0, st, X, partial, M, N, ldx, strideX, S);
+  CK_LAUNCH("colsum");
+  return launch_reduce(partial, out, nullptr, nullptr, S, 1, N, batch, strideOut, st);
+}
+
+extern "C" int cocodr_cast_f32_bf16(const float* src, uint16_t* dst, size_t n, cocodr_stream_t stream) {
+  CK_ARG(src && dst, "cast: null pointer");
+  CK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "cast: pointers must be 16-byte aligned");
+  if (n == 0) return COCODR_OK;
+  const size_t n8 = n / 8;
+  const int grid = (int)std::min((size_t)2048, (n8 + 255) / 256 + 1);
+  hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, n8, n);
+  CK_LAUNCH("cast_f32_bf16");
+  return COCODR_OK;
+}
+
+extern "C" int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int H, cocodr_stream_t stream) {
+  CK_ARG(dE && d_last, "scatter_cls_grad: null pointer");
+  CK_ARG(B > 0 && L > 0 && row_shape_ok(H), "scatter_cls_grad: bad shape");
+  const int M = B * L;
+  hipLaunchKernelGGL(scatter_cls_kernel, dim3(row_grid(M)), dim3(256), 0, (hipStream_t)stream, dE, d_last, M, L, H);
+  CK_LAUNCH("scatter_cls_grad");
+  return COCODR_OK;
+}

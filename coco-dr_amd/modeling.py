@@ -1,0 +1,612 @@
+"""HuggingFace-style boundary classes backed by the native gfx950 encoder.
+
+What the reference calls today and what replaces it here:
+
+  AutoModel / BertModel.from_pretrained(path)(input_ids=, attention_mask=)      -> CocoBertModel
+      ANCE/model/models.py:225-229 ``self.bert(...)[0][:, 0]``; README.md:101-116
+  BertForSequenceClassification subclass BertDot_NLL_LN (triplet NLL)           -> BertDotNLL
+      ANCE/model/models.py:194-262
+  CoCondenserForPretraining (encoder -> [CLS] -> all_gather -> contrastive)     -> CoCondenserForPretraining
+      COCO/modeling.py:162-248  (Condenser head + MLM losses are SURVEY 8(f1) "next")
+
+Design (MI355X first, not a port of the torch module tree):
+  * all parameters live in TWO flat fp32 nn.Parameters (`flat_decay`: embeddings + weight matrices,
+    `flat_nodecay`: biases + LayerNorm), laid out so consecutive layers sit at a uniform stride.
+    The optimizer therefore updates two tensors (one fused AdamW kernel each), DDP all-reduces two
+    large buckets over xGMI, and the native backward writes all layers' weight gradients with one
+    grouped launch per matrix.  ``state_dict()`` / ``load_state_dict()`` still speak the HF BERT key
+    names, so reference checkpoints load and ``save_pretrained`` round-trips.
+  * one autograd.Function wraps the whole encoder: forward = one C call, backward = one C call.
+  * a bf16 shadow of the weight matrices is refreshed by one cast kernel whenever the fp32 master
+    changes (tracked through the tensor version counter).
+Dropout is not implemented (treated as p = 0): COCO runs the backbone in eval mode
+(COCO/modeling.py:198); ANCE's training-time dropout cannot be matched bit-wise anyway (SURVEY 7 iv).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import warnings
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _native as N
+from . import ops
+from ._native import check, lib, ptr, stream_ptr
+
+__all__ = ["CocoBertConfig", "CocoBertModel", "BertDotNLL", "CoCondenserForPretraining", "EncoderOutput"]
+
+
+# =============================================================================== config
+class CocoBertConfig:
+    """The BertConfig fields the hot path reads (config.json compatible)."""
+    model_type = "bert"
+
+    def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                 max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12,
+                 pad_token_id=0, **extra):
+        self.vocab_size = int(vocab_size)
+        self.hidden_size = int(hidden_size)
+        self.num_hidden_layers = int(num_hidden_layers)
+        self.num_attention_heads = int(num_attention_heads)
+        self.intermediate_size = int(intermediate_size)
+        self.hidden_act = hidden_act
+        self.hidden_dropout_prob = float(hidden_dropout_prob)
+        self.attention_probs_dropout_prob = float(attention_probs_dropout_prob)
+        self.max_position_embeddings = int(max_position_embeddings)
+        self.type_vocab_size = int(type_vocab_size)
+        self.initializer_range = float(initializer_range)
+        self.layer_norm_eps = float(layer_norm_eps)
+        self.pad_token_id = pad_token_id
+        self.extra = dict(extra)
+        if self.hidden_act != "gelu":
+            raise ValueError(f"hidden_act={self.hidden_act!r}: only the exact-erf 'gelu' of BERT is implemented")
+        if self.hidden_size != 64 * self.num_attention_heads:
+            raise ValueError("head_dim must be 64 (hidden_size == 64 * num_attention_heads)")
+        if self.hidden_size % 128 or self.intermediate_size % 128 or self.hidden_size > 1024:
+            raise ValueError("hidden_size / intermediate_size must be multiples of 128 and hidden_size <= 1024")
+
+    @classmethod
+    def base(cls, **kw):
+        return cls(**kw)
+
+    @classmethod
+    def large(cls, **kw):
+        return cls(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, **kw)
+
+    def to_dict(self) -> dict:
+        d = dict(self.extra)
+        d.update(model_type="bert", vocab_size=self.vocab_size, hidden_size=self.hidden_size,
+                 num_hidden_layers=self.num_hidden_layers, num_attention_heads=self.num_attention_heads,
+                 intermediate_size=self.intermediate_size, hidden_act=self.hidden_act,
+                 hidden_dropout_prob=self.hidden_dropout_prob,
+                 attention_probs_dropout_prob=self.attention_probs_dropout_prob,
+                 max_position_embeddings=self.max_position_embeddings, type_vocab_size=self.type_vocab_size,
+                 initializer_range=self.initializer_range, layer_norm_eps=self.layer_norm_eps,
+                 pad_token_id=self.pad_token_id)
+        return d
+
+    @classmethod
+    def from_pretrained(cls, path: str, **kw):
+        with open(os.path.join(path, "config.json")) as f:
+            d = json.load(f)
+        d.update(kw)
+        d.pop("model_type", None)
+        return cls(**d)
+
+    def save_pretrained(self, path: str) -> None:
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2, sort_keys=True)
+
+
+# =============================================================================== flat parameter layout
+class _Layout:
+    """Offsets (in elements) of every HF-named tensor inside the two flat parameters."""
+
+    def __init__(self, cfg: CocoBertConfig):
+        H, I, NL = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        V, P, T = cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size
+        self.cfg = cfg
+        d = OrderedDict()  # name -> (flat index 0/1, offset, shape)
+        o = 0
+        for name, rows in (("embeddings.word_embeddings.weight", V), ("embeddings.position_embeddings.weight", P),
+                           ("embeddings.token_type_embeddings.weight", T)):
+            d[name] = (0, o, (rows, H))
+            o += rows * H
+        self.emb_decay_end = o
+        o = (o + 63) // 64 * 64
+        self.mat_begin = o
+        self.mat_stride = 3 * H * H + H * H + I * H + H * I
+        self.off_wqkv, self.off_wo, self.off_w1, self.off_w2 = 0, 3 * H * H, 4 * H * H, 4 * H * H + I * H
+        for l in range(NL):
+            b = self.mat_begin + l * self.mat_stride
+            p = f"encoder.layer.{l}."
+            d[p + "attention.self.query.weight"] = (0, b, (H, H))
+            d[p + "attention.self.key.weight"] = (0, b + H * H, (H, H))
+            d[p + "attention.self.value.weight"] = (0, b + 2 * H * H, (H, H))
+            d[p + "attention.output.dense.weight"] = (0, b + self.off_wo, (H, H))
+            d[p + "intermediate.dense.weight"] = (0, b + self.off_w1, (I, H))
+            d[p + "output.dense.weight"] = (0, b + self.off_w2, (H, I))
+        self.decay_numel = self.mat_begin + NL * self.mat_stride
+        # --- no-decay flat: LayerNorm + biases
+        d["embeddings.LayerNorm.weight"] = (1, 0, (H,))
+        d["embeddings.LayerNorm.bias"] = (1, H, (H,))
+        self.vec_begin = 2 * H
+        self.vec_stride = 3 * H + H + I + H + 4 * H
+        self.off_bqkv, self.off_bo, self.off_b1, self.off_b2 = 0, 3 * H, 4 * H, 4 * H + I
+        self.off_ln1g, self.off_ln1b, self.off_ln2g, self.off_ln2b = (5 * H + I, 6 * H + I, 7 * H + I, 8 * H + I)
+        for l in range(NL):
+            b = self.vec_begin + l * self.vec_stride
+            p = f"encoder.layer.{l}."
+            d[p + "attention.self.query.bias"] = (1, b, (H,))
+            d[p + "attention.self.key.bias"] = (1, b + H, (H,))
+            d[p + "attention.self.value.bias"] = (1, b + 2 * H, (H,))
+            d[p + "attention.output.dense.bias"] = (1, b + self.off_bo, (H,))
+            d[p + "intermediate.dense.bias"] = (1, b + self.off_b1, (I,))
+            d[p + "output.dense.bias"] = (1, b + self.off_b2, (H,))
+            d[p + "attention.output.LayerNorm.weight"] = (1, b + self.off_ln1g, (H,))
+            d[p + "attention.output.LayerNorm.bias"] = (1, b + self.off_ln1b, (H,))
+            d[p + "output.LayerNorm.weight"] = (1, b + self.off_ln2g, (H,))
+            d[p + "output.LayerNorm.bias"] = (1, b + self.off_ln2b, (H,))
+        self.nodecay_numel = self.vec_begin + NL * self.vec_stride
+        self.names = d
+
+    def view(self, flats, name: str) -> torch.Tensor:
+        which, off, shape = self.names[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return flats[which][off:off + n].view(shape)
+
+
+class EncoderOutput:
+    """Minimal stand-in for transformers' BaseModelOutputWithPooling: attribute access, ``out[0]`` and
+    tuple-unpacking (ANCE/model/models.py:228 indexes ``outputs1[0]``)."""
+
+    def __init__(self, last_hidden_state, hidden_states=None, cls_fp32=None):
+        self.last_hidden_state = last_hidden_state
+        self.pooler_output = None
+        self.hidden_states = hidden_states
+        self.cls_fp32 = cls_fp32
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state, self.pooler_output, self.hidden_states)[i]
+
+    def __iter__(self):
+        return iter((self.last_hidden_state, self.pooler_output))
+
+
+# =============================================================================== the encoder Function
+class _EncoderFn(torch.autograd.Function):
+    """(flat_decay, flat_nodecay, ids, mask) -> (last_hidden bf16 [B,L,H], cls fp32 [B,H]).
+    forward = cocodr_encoder_fwd, backward = cocodr_encoder_bwd."""
+
+    @staticmethod
+    def forward(ctx, flat_decay, flat_nodecay, ids, mask, model):
+        training = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])  # False under torch.no_grad()
+        arena, lay = model._run_forward(ids, mask, training)
+        B, L = ids.shape
+        H, NL = model.config.hidden_size, model.config.num_hidden_layers
+        M = B * L
+        hidden = arena[lay.hidden: lay.hidden + (NL + 1) * M * H * 2].view(torch.bfloat16).view(NL + 1, B, L, H)
+        cls = arena[lay.cls_f32: lay.cls_f32 + B * H * 4].view(torch.float32).view(B, H)
+        ctx.model = model
+        ctx.training = training
+        ctx.arena = arena if training else None
+        ctx.ids, ctx.mask = ids, mask
+        model._last_hidden_states = hidden
+        last = hidden[NL]
+        ctx.set_materialize_grads(False)
+        return last, cls.clone()
+
+    @staticmethod
+    def backward(ctx, d_last, d_cls):
+        model = ctx.model
+        if not ctx.training or ctx.arena is None:
+            raise RuntimeError("encoder backward called but the forward ran without saved activations")
+        B, L = ctx.ids.shape
+        H = model.config.hidden_size
+        if d_last is None and d_cls is None:
+            return None, None, None, None, None
+        if d_last is None:  # gradient enters at the [CLS] rows only (every reference wrapper)
+            d16 = ops.scatter_cls_grad(d_cls.float().contiguous(), L)
+        else:
+            d16 = d_last.reshape(B * L, H).to(torch.bfloat16).contiguous()
+            if d_cls is not None:
+                if d16.data_ptr() == d_last.data_ptr():
+                    d16 = d16.clone()
+                d16.view(B, L, H)[:, 0] += d_cls.to(torch.bfloat16)
+        gd, gn = model._run_backward(ctx.ids, ctx.mask, d16, ctx.arena)
+        ctx.arena = None
+        return gd, gn, None, None, None
+
+
+# =============================================================================== model
+class CocoBertModel(nn.Module):
+    """BertModel (no pooler) on the native gfx950 kernels.  HF-compatible: ``from_pretrained``,
+    ``save_pretrained``, ``state_dict`` key names, ``forward(input_ids=, attention_mask=)`` ->
+    object with ``[0]`` / ``.last_hidden_state`` / ``.hidden_states``."""
+
+    def __init__(self, config: CocoBertConfig, device: Optional[torch.device] = None):
+        super().__init__()
+        self.config = config
+        self.layout = _Layout(config)
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.flat_decay = nn.Parameter(torch.zeros(self.layout.decay_numel, dtype=torch.float32, device=dev))
+        self.flat_nodecay = nn.Parameter(torch.zeros(self.layout.nodecay_numel, dtype=torch.float32, device=dev))
+        self._shadow = None          # bf16 copy of the weight-matrix region
+        self._shadow_version = -1
+        self._extra_state: Dict[str, torch.Tensor] = {}  # checkpoint tensors outside the encoder (pooler, heads ...)
+        self._last_hidden_states = None
+        self._warned_dropout = False
+        self.reset_parameters()
+
+    # ---------------------------------------------------------------- init / HF naming
+    def reset_parameters(self):
+        """HF ``_init_weights``: normal(0, initializer_range) for Linear / Embedding weights, zeros for
+        biases, ones / zeros for LayerNorm (ANCE/model/models.py:54-60 restates the same rule)."""
+        with torch.no_grad():
+            self.flat_decay.normal_(0.0, self.config.initializer_range)
+            self.flat_nodecay.zero_()
+            for name in self.layout.names:
+                if name.endswith("LayerNorm.weight"):
+                    self.hf_view(name).fill_(1.0)
+            pad = self.config.pad_token_id
+            if pad is not None and 0 <= pad < self.config.vocab_size:
+                self.hf_view("embeddings.word_embeddings.weight")[pad].zero_()  # nn.Embedding(padding_idx=0)
+
+    def hf_view(self, name: str) -> torch.Tensor:
+        return self.layout.view((self.flat_decay.data, self.flat_nodecay.data), name)
+
+    def hf_named_parameters(self):
+        """(HF name, view into the flat parameter) pairs - what ``named_parameters()`` of BertModel yields."""
+        for name in self.layout.names:
+            yield name, self.hf_view(name)
+
+    def hf_named_grads(self):
+        flats = (self.flat_decay.grad, self.flat_nodecay.grad)
+        for name in self.layout.names:
+            if flats[self.layout.names[name][0]] is not None:
+                yield name, self.layout.view(flats, name)
+
+    def param_groups(self, weight_decay: float = 0.0) -> List[dict]:
+        """AdamW groups as the HF Trainer builds them (COCO/trainer.py:66-70 -> Trainer.create_optimizer):
+        no decay on biases and LayerNorm weights."""
+        return [{"params": [self.flat_decay], "weight_decay": weight_decay},
+                {"params": [self.flat_nodecay], "weight_decay": 0.0}]
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = OrderedDict() if destination is None else destination
+        for name, v in self.hf_named_parameters():
+            sd[prefix + name] = v if keep_vars else v.detach().clone()
+        for name, v in self._extra_state.items():
+            sd[prefix + name] = v
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        missing, unexpected = [], []
+        sd = {}
+        for k, v in state_dict.items():
+            if k.startswith("bert."):
+                k = k[len("bert."):]
+            sd[k] = v
+        with torch.no_grad():
+            for name, dst in self.hf_named_parameters():
+                if name in sd:
+                    src = sd.pop(name)
+                    if tuple(src.shape) != tuple(dst.shape):
+                        raise RuntimeError(f"size mismatch for {name}: checkpoint {tuple(src.shape)} vs model {tuple(dst.shape)}")
+                    dst.copy_(src.to(dst.dtype))
+                else:
+                    missing.append(name)
+        for k, v in sd.items():
+            if k == "embeddings.position_ids":
+                continue
+            unexpected.append(k)
+            self._extra_state[k] = v
+        if strict and missing:
+            raise RuntimeError(f"missing keys in state_dict: {missing[:8]}{' ...' if len(missing) > 8 else ''}")
+        self._shadow_version = -1
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    @classmethod
+    def from_pretrained(cls, path: str, config: Optional[CocoBertConfig] = None, device=None, **unused):
+        config = config or CocoBertConfig.from_pretrained(path)
+        model = cls(config, device=device)
+        st = os.path.join(path, "model.safetensors")
+        pt = os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        elif os.path.exists(pt):
+            sd = torch.load(pt, map_location="cpu", weights_only=True)
+        else:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
+        model.load_state_dict(sd, strict=False)
+        return model
+
+    def save_pretrained(self, path: str) -> None:
+        from safetensors.torch import save_file
+        self.config.save_pretrained(path)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+
+    def resize_token_embeddings(self, n: int):
+        """COCO/run_coco_pre_training.py:158 calls this with len(tokenizer) == vocab_size."""
+        if n != self.config.vocab_size:
+            raise NotImplementedError("changing the vocabulary size of the flat parameter layout is not supported")
+        return self
+
+    def get_extended_attention_mask(self, attention_mask, input_shape=None, device=None):
+        """Additive key-padding mask [B,1,1,L] (0 / finfo.min) - COCO/modeling.py:57-61,193-197."""
+        m = attention_mask[:, None, None, :].to(torch.float32)
+        return (1.0 - m) * torch.finfo(torch.float32).min
+
+    # ---------------------------------------------------------------- native plumbing
+    def _c_config(self) -> N.Config:
+        c = self.config
+        return N.Config(c.hidden_size, c.num_attention_heads, c.num_hidden_layers, c.intermediate_size, c.vocab_size,
+                        c.max_position_embeddings, c.layer_norm_eps)
+
+    def _refresh_shadow(self):
+        lo = self.layout
+        n = lo.decay_numel - lo.mat_begin
+        if self._shadow is None or self._shadow.device != self.flat_decay.device:
+            self._shadow = torch.empty(n, dtype=torch.bfloat16, device=self.flat_decay.device)
+            self._shadow_version = -1
+        if self._shadow_version != self.flat_decay._version:
+            ops.cast_f32_bf16(self.flat_decay.data[lo.mat_begin:], self._shadow)
+            self._shadow_version = self.flat_decay._version
+
+    def _param_structs(self, grads: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        lo, cfg = self.layout, self.config
+        H = cfg.hidden_size
+        fd, fn = self.flat_decay.data, self.flat_nodecay.data
+        pd, pn, ps = fd.data_ptr(), fn.data_ptr(), self._shadow.data_ptr()
+        emb = N.EmbedParams(pd, pd + 4 * cfg.vocab_size * H, pd + 4 * (cfg.vocab_size + cfg.max_position_embeddings) * H,
+                            pn, pn + 4 * H)
+        arr = (N.LayerParams * cfg.num_hidden_layers)()
+        for l in range(cfg.num_hidden_layers):
+            mb = ps + 2 * (l * lo.mat_stride)
+            vb = pn + 4 * (lo.vec_begin + l * lo.vec_stride)
+            arr[l] = N.LayerParams(mb + 2 * lo.off_wqkv, mb + 2 * lo.off_wo, mb + 2 * lo.off_w1, mb + 2 * lo.off_w2,
+                                   vb + 4 * lo.off_bqkv, vb + 4 * lo.off_bo, vb + 4 * lo.off_b1, vb + 4 * lo.off_b2,
+                                   vb + 4 * lo.off_ln1g, vb + 4 * lo.off_ln1b, vb + 4 * lo.off_ln2g, vb + 4 * lo.off_ln2b)
+        if grads is None:
+            return emb, arr, None, None
+        gd, gn = grads[0].data_ptr(), grads[1].data_ptr()
+        eg = N.EmbedGrads(gd, gd + 4 * cfg.vocab_size * H, gd + 4 * (cfg.vocab_size + cfg.max_position_embeddings) * H,
+                          gn, gn + 4 * H)
+        garr = (N.LayerGrads * cfg.num_hidden_layers)()
+        for l in range(cfg.num_hidden_layers):
+            mb = gd + 4 * (lo.mat_begin + l * lo.mat_stride)
+            vb = gn + 4 * (lo.vec_begin + l * lo.vec_stride)
+            garr[l] = N.LayerGrads(mb + 4 * lo.off_wqkv, mb + 4 * lo.off_wo, mb + 4 * lo.off_w1, mb + 4 * lo.off_w2,
+                                   vb + 4 * lo.off_bqkv, vb + 4 * lo.off_bo, vb + 4 * lo.off_b1, vb + 4 * lo.off_b2,
+                                   vb + 4 * lo.off_ln1g, vb + 4 * lo.off_ln1b, vb + 4 * lo.off_ln2g, vb + 4 * lo.off_ln2b)
+        return emb, arr, eg, garr
+
+    def _layout_for(self, B: int, L: int, training: bool) -> N.EncoderLayout:
+        lay = N.EncoderLayout()
+        cfg = self._c_config()
+        check(lib().cocodr_encoder_layout(C.byref(cfg), B, L, int(training), C.byref(lay)), "encoder_layout")
+        return lay
+
+    def _run_forward(self, ids: torch.Tensor, mask: torch.Tensor, training: bool):
+        if not self.flat_decay.is_cuda:
+            raise RuntimeError("CocoBertModel runs on an MI355X only: move it with .to('cuda') (there is no CPU fallback)")
+        B, L = ids.shape
+        self._refresh_shadow()
+        lay = self._layout_for(B, L, training)
+        arena = torch.empty(lay.total_bytes, dtype=torch.uint8, device=ids.device)
+        emb, arr, _, _ = self._param_structs()
+        cfg = self._c_config()
+        check(lib().cocodr_encoder_fwd(C.byref(cfg), C.byref(emb), arr, ptr(ids), ptr(mask), B, L, int(training), ptr(arena),
+                                       arena.numel(), stream_ptr()), "encoder_fwd")
+        return arena, lay
+
+    def _run_backward(self, ids, mask, d_last16, arena):
+        B, L = ids.shape
+        lo = self.layout
+        gd = torch.empty_like(self.flat_decay.data)
+        gn = torch.empty_like(self.flat_nodecay.data)
+        gd[:lo.mat_begin].zero_()  # embedding tables: sparse word rows are accumulated, unused position rows stay zero
+        emb, arr, eg, garr = self._param_structs((gd, gn))
+        cfg = self._c_config()
+        check(lib().cocodr_encoder_bwd(C.byref(cfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d_last16), B, L,
+                                       ptr(arena), arena.numel(), stream_ptr()), "encoder_bwd")
+        return gd, gn
+
+    # ---------------------------------------------------------------- public forward
+    @staticmethod
+    def _prep(input_ids, attention_mask):
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [B, L], got {tuple(input_ids.shape)}")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if attention_mask.shape != input_ids.shape:
+            raise ValueError("attention_mask shape must match input_ids")
+        B, L = input_ids.shape
+        Lp = (L + 31) // 32 * 32
+        ids = input_ids.to(torch.int32)
+        mask = attention_mask.to(torch.int32)
+        if Lp != L:  # pad to the kernels' 32-token granularity with masked [PAD]
+            ids = torch.nn.functional.pad(ids, (0, Lp - L))
+            mask = torch.nn.functional.pad(mask, (0, Lp - L))
+        return ids.contiguous(), mask.contiguous(), L
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None,
+                output_hidden_states: bool = False, return_dict: bool = True, **unused):
+        if token_type_ids is not None and bool(token_type_ids.any()):
+            raise NotImplementedError("token_type_ids != 0: the reference never passes segment ids (COCO/data.py:140)")
+        if position_ids is not None:
+            raise NotImplementedError("custom position_ids are not on the reference path")
+        if self.training and self.config.hidden_dropout_prob > 0 and not self._warned_dropout:
+            warnings.warn("cocodr_amd: dropout is not implemented on the native path (treated as p=0)")
+            self._warned_dropout = True
+        ids, mask, L = self._prep(input_ids, attention_mask)
+        if L > self.config.max_position_embeddings:
+            raise ValueError(f"sequence length {L} exceeds max_position_embeddings={self.config.max_position_embeddings}")
+        last, cls = _EncoderFn.apply(self.flat_decay, self.flat_nodecay, ids, mask, self)
+        hs = None
+        if output_hidden_states:
+            hs = tuple(h[:, :L] for h in self._last_hidden_states[:-1].unbind(0)) + (last[:, :L],)
+        out = EncoderOutput(last[:, :L], hs, cls)
+        self._last_hidden_states = None
+        return out if return_dict else (out.last_hidden_state, None)
+
+    def encode_cls(self, input_ids, attention_mask=None) -> torch.Tensor:
+        """fp32 last-layer [CLS] rows [B,H] with autograd (what every reference wrapper consumes)."""
+        return self.forward(input_ids, attention_mask).cls_fp32
+
+
+# =============================================================================== ANCE wrapper
+class _TripletFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, a, b, weights):
+        loss, rows, logits, dq, da, db = ops.triplet_nll_fwd_bwd(q.contiguous(), a.contiguous(), b.contiguous(), weights)
+        ctx.save_for_backward(dq, da, db)
+        ctx.mark_non_differentiable(rows, logits)
+        return loss[0], rows, logits
+
+    @staticmethod
+    def backward(ctx, g, _r, _l):
+        dq, da, db = ctx.saved_tensors
+        return dq * g, da * g, db * g, None
+
+
+class BertDotNLL(nn.Module):
+    """``BertDot_NLL_LN`` (ANCE/model/models.py:194-262): shared-weight bi-encoder, embedding = raw
+    last-layer [CLS] (:225-229), triplet NLL over [q.pos, q.neg] (:97-106), ``(loss*weights).mean()``
+    (:260-261).  The dead ``embeddingHead`` / ``norm`` / ``classifier`` parameters of the reference class
+    are carried through checkpoints untouched."""
+
+    def __init__(self, config: CocoBertConfig, model_argobj=None, device=None):
+        super().__init__()
+        self.config = config
+        self.bert = CocoBertModel(config, device=device)
+        self.total = 0
+
+    @classmethod
+    def from_pretrained(cls, path, config=None, device=None, **unused):
+        config = config or CocoBertConfig.from_pretrained(path)
+        m = cls(config, device=device)
+        m.bert = CocoBertModel.from_pretrained(path, config=config, device=device)
+        return m
+
+    def save_pretrained(self, path):
+        self.bert.save_pretrained(path)
+
+    def query_emb(self, input_ids, attention_mask):
+        return self.bert(input_ids=input_ids, attention_mask=attention_mask).cls_fp32
+
+    def body_emb(self, input_ids, attention_mask):
+        return self.query_emb(input_ids, attention_mask)
+
+    def forward(self, query_ids, attention_mask_q, input_ids_a=None, attention_mask_a=None, input_ids_b=None,
+                attention_mask_b=None, is_query=True, group_ids=None, weights=None):
+        if input_ids_b is None:
+            return self.query_emb(query_ids, attention_mask_q) if is_query else self.body_emb(query_ids, attention_mask_q)
+        if group_ids is not None:
+            raise NotImplementedError("group-DRO re-weighting (ANCE/model/dro_loss.py) is SURVEY 8(f2) 'next'")
+        q = self.query_emb(query_ids, attention_mask_q)
+        B = q.shape[0]
+        if input_ids_a.shape == input_ids_b.shape:  # one encoder pass for positives and negatives
+            ab = self.body_emb(torch.cat([input_ids_a, input_ids_b]), torch.cat([attention_mask_a, attention_mask_b]))
+            a, b = ab[:B], ab[B:]
+        else:
+            a = self.body_emb(input_ids_a, attention_mask_a)
+            b = self.body_emb(input_ids_b, attention_mask_b)
+        w = None if weights is None else weights.to(torch.float32).contiguous()
+        loss, rows, logits = _TripletFn.apply(q, a, b, w)
+        self.total += B * (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
+        return loss, torch.argmax(logits, dim=1), logits
+
+
+# =============================================================================== COCO wrapper
+class _SimCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, E_all, world, row0, m_local):
+        loss, rows, dE = ops.simce_fwd_bwd(E_all.contiguous(), world, row0, m_local)
+        ctx.save_for_backward(dE)
+        ctx.row0, ctx.m_local, ctx.M = row0, m_local, E_all.shape[0]
+        ctx.mark_non_differentiable(rows)
+        return loss[0], rows
+
+    @staticmethod
+    def backward(ctx, g, _rows):
+        (dE,) = ctx.saved_tensors
+        full = dE.new_zeros((ctx.M, dE.shape[1]))
+        full[ctx.row0:ctx.row0 + ctx.m_local] = dE * g
+        return full, None, None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    """COCO/modeling.py:182-190 ``gather_tensors``: all_gather the [2b,H] [CLS] block of every rank into
+    one [W*2b,H] matrix; only the local slot carries gradient (:185), so the backward is a slice - no
+    collective.  One contiguous RCCL all-gather instead of W buffers + cat + slot overwrite."""
+
+    @staticmethod
+    def forward(ctx, t):
+        import torch.distributed as dist
+        W, r = dist.get_world_size(), dist.get_rank()
+        out = torch.empty((W * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous())
+        ctx.r, ctx.m = r, t.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.r * ctx.m:(ctx.r + 1) * ctx.m]
+
+
+class CoCondenserForPretraining(nn.Module):
+    """Contrastive half of ``CoCondenserForPretraining`` (COCO/modeling.py:162-248): encoder -> last-layer
+    [CLS] (:206) -> cross-rank gather (:207-208) -> span-pair InfoNCE (:244-248) -> ``.mean()`` (:229).
+    ``forward(model_input, labels)`` keeps the reference signature; ``labels`` is accepted and ignored
+    because the Condenser head + MLM losses are the SURVEY 8(f1) "next" row."""
+
+    def __init__(self, bert: CocoBertModel, model_args=None, data_args=None, train_args=None):
+        super().__init__()
+        self.lm = bert
+        self.model_args, self.data_args, self.train_args = model_args, data_args, train_args
+        if model_args is not None and getattr(model_args, "n_head_layers", 0) not in (0, None):
+            warnings.warn("cocodr_amd: Condenser head layers / MLM loss are not part of this path yet; "
+                          "forward() returns the contrastive loss only")
+
+    @staticmethod
+    def _world_size():
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    @classmethod
+    def from_pretrained(cls, model_args, data_args, train_args, path, **kw):
+        return cls(CocoBertModel.from_pretrained(path, **kw), model_args, data_args, train_args)
+
+    def save_pretrained(self, output_dir: str):
+        self.lm.save_pretrained(output_dir)
+
+    def compute_contrastive_loss(self, co_cls_hiddens: torch.Tensor) -> torch.Tensor:
+        """Per-row loss [M] (already multiplied by world size), COCO/modeling.py:244-248."""
+        W = self._world_size()
+        _, rows = _SimCEFn.apply(co_cls_hiddens.float(), W, 0, co_cls_hiddens.shape[0])
+        return rows
+
+    def forward(self, model_input, labels=None, **unused):
+        ids, mask = model_input["input_ids"], model_input.get("attention_mask")
+        cls = self.lm.encode_cls(ids, mask)  # [2b, H] fp32
+        W = self._world_size()
+        if W > 1:
+            import torch.distributed as dist
+            E = _GatherRows.apply(cls)
+            row0 = dist.get_rank() * cls.shape[0]
+        else:
+            E, row0 = cls, 0
+        loss, _rows = _SimCEFn.apply(E, W, row0, cls.shape[0])
+        return loss

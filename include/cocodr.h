@@ -1,0 +1,222 @@
+/*
+ * cocodr.h - C ABI of libcocodr_hip.so: the MI355X (gfx950) native implementation of the
+ * COCO-DR contrastive dense-retrieval hot path.
+ *
+ * Everything the reference runs below its model-wrapper boundary is a stock
+ * ATen/cuBLAS op reached through third-party `transformers`; the reference itself has no native
+ * code and no FFI.  This header is therefore the boundary a maintainer binds INSTEAD of those
+ * ops: plain pointers + sizes, a hipStream_t (the caller's current stream), no torch types.
+ * Each entry point cites the reference call site(s) it replaces (paths under /root/reference,
+ * `hf:` = transformers/models/bert/modeling_bert.py).
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers unless the parameter name ends in _host;
+ *  - bf16 tensors are passed as `const uint16_t*` (raw bfloat16 bits), row-major;
+ *  - every function returns 0 on success, <0 on error (no exceptions cross the ABI);
+ *    cocodr_last_error() returns a thread-local message for the last failure;
+ *  - kernels are enqueued asynchronously on `stream`; the library owns no threads, allocates no
+ *    device memory (workspaces are caller-provided) and is re-entrant per stream.
+ */
+#ifndef COCODR_H_
+#define COCODR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cocodr_stream_t; /* hipStream_t */
+
+enum {
+  COCODR_OK = 0,
+  COCODR_ERR_INVALID = -1, /* bad shape / alignment / null pointer */
+  COCODR_ERR_LAUNCH = -2,  /* HIP launch or runtime failure */
+  COCODR_ERR_WORKSPACE = -3 /* caller workspace too small */
+};
+
+const char* cocodr_last_error(void);
+/* "gfx950" + build id; lets the host verify it loaded the native library, not a fallback */
+const char* cocodr_build_info(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  (hf: nn.Linear in BertSelfAttention :111-203, BertSelfOutput :282-293,
+ *        BertIntermediate/BertOutput :325-351, and their autograd backward)
+ *
+ *   C[z] = epilogue( opA(A[z]) * opB(B[z]) ),  z = 0..batch-1, fp32 accumulation on MFMA.
+ *   trans_a = 0: A is [M,K] row-major (lda)        trans_a = 1: A is stored [K,M] (lda)
+ *   trans_b = 0: B is [N,K] row-major (ldb) i.e. a torch Linear weight; trans_b = 1: B is [K,N]
+ *   forward   Y = X W^T      -> (0,0)      dgrad dX = dY W -> (0,1)     wgrad dW = dY^T X -> (1,1)
+ * Epilogues (COCODR_EPI_*): bias add, bias+exact-erf GELU (also emits the pre-activation),
+ * residual add, and multiply by GELU'(U) for the FFN backward.
+ * Requirements: N % 128 == 0; K % 8 == 0; M % 8 == 0 when trans_a; all leading dims % 8 == 0.
+ * ------------------------------------------------------------------------------------------ */
+enum {
+  COCODR_EPI_NONE = 0,      /* C = acc (+bias)                                  */
+  COCODR_EPI_GELU = 1,      /* C2 = acc+bias (pre-activation), C = gelu(C2)     */
+  COCODR_EPI_ADD = 2,       /* C = acc (+bias) + R                              */
+  COCODR_EPI_DGELU = 3      /* C = acc * gelu'(R)   (R = saved pre-activation)  */
+};
+typedef struct {
+  const uint16_t* A;
+  const uint16_t* B;
+  void* C;            /* bf16 [M,N] (out_f32 = 0) or fp32 [M,N] (out_f32 = 1) */
+  uint16_t* C2;       /* bf16 [M,N], EPI_GELU only */
+  const float* bias;  /* fp32 [N] or NULL */
+  const uint16_t* R;  /* bf16 [M,N], EPI_ADD / EPI_DGELU */
+  int M, N, K;
+  int lda, ldb, ldc, ldr;
+  int trans_a, trans_b, epi, out_f32;
+  int batch;
+  long long strideA, strideB, strideC, strideR, strideBias; /* elements, per batch index */
+} cocodr_gemm_args;
+int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused self-attention  (hf: eager_attention_forward :111-203 - softmax(QK^T/sqrt(d) + mask) V,
+ * key-padding mask only, head_dim = 64).  qkv is the fused projection output [B*L, 3H]
+ * (Q | K | V along columns), mask is int32 [B,L] (non-zero = attend).  L % 32 == 0, L <= 512.
+ * lse [B, heads, L] fp32 receives the row log-sum-exp needed by the backward.
+ * ------------------------------------------------------------------------------------------ */
+int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse,
+                    int B, int L, int heads, cocodr_stream_t stream);
+/* backward: dqkv [B*L, 3H] (dQ | dK | dV) from dctx; L <= 256 */
+int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
+                    const float* lse, uint16_t* dqkv, int B, int L, int heads, cocodr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row kernels (HBM bound)
+ * embed_ln: hf BertEmbeddings.forward :68-108 - LN(word[ids] + pos[0..L-1] + type[0]), eps 1e-12;
+ *           the reference never passes token_type_ids / position_ids (COCO/data.py:140,
+ *           ANCE/model/models.py:226-227).
+ * ln:       the LayerNorm of BertSelfOutput / BertOutput; input already holds dense+bias+residual.
+ * ------------------------------------------------------------------------------------------ */
+int cocodr_embed_ln_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0,
+                        const float* gamma, const float* beta, uint16_t* out, float* mean, float* rstd,
+                        int B, int L, int H, int vocab, float eps, cocodr_stream_t stream);
+/* dword must be zeroed by the caller (sparse scatter-add); dpos rows [0,L) are overwritten;
+ * partial: fp32 workspace of cocodr_embed_bwd_partial_floats(L,H) floats */
+size_t cocodr_embed_bwd_partial_floats(int L, int H);
+int cocodr_embed_ln_bwd(const uint16_t* dout, const int32_t* ids, const float* word, const float* pos,
+                        const float* type0, const float* gamma, const float* mean, const float* rstd,
+                        float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                        float* partial, int B, int L, int H, int vocab, cocodr_stream_t stream);
+int cocodr_ln_fwd(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean,
+                  float* rstd, float* cls_out /* fp32 [M/cls_stride, H] or NULL */, int cls_stride,
+                  int M, int H, float eps, cocodr_stream_t stream);
+size_t cocodr_ln_bwd_partial_floats(int M, int H);
+int cocodr_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean,
+                  const float* rstd, uint16_t* dy, float* dgamma, float* dbeta, float* partial, int M, int H,
+                  cocodr_stream_t stream);
+/* column sums of a bf16 [M,N] matrix (bias gradients), batched: out[z][n] = sum_m X[z][m][n] */
+size_t cocodr_colsum_partial_floats(int M, int N, int batch);
+int cocodr_colsum(const uint16_t* X, float* out, float* partial, int M, int N, int ldx, int batch,
+                  long long strideX, long long strideOut, cocodr_stream_t stream);
+int cocodr_cast_f32_bf16(const float* src, uint16_t* dst, size_t n, cocodr_stream_t stream);
+/* d_last[b*L + 0, :] = bf16(dE[b, :]), all other rows zero (gradient enters at [CLS] only) */
+int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int H, cocodr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses
+ * simce: COCO/modeling.py:244-248 compute_contrastive_loss + :172-177 co_target + the `.mean()`
+ *        at :229, and its gradient w.r.t. the LOCAL rows [row0, row0+m_local) of the gathered
+ *        E [M,H] (COCO/modeling.py:182-186 keeps autograd history only in the local slot).
+ *        loss_rows [M] fp32, loss [1] fp32, dE_local [m_local,H] fp32.
+ *        workspace: cocodr_simce_workspace_floats(M) floats.
+ * triplet: ANCE/model/models.py:97-106 + :260-261 - logits=[q.a, q.b], -log_softmax[:,0],
+ *        (loss*weights).mean(); gradients w.r.t. q, a, b.
+ * ------------------------------------------------------------------------------------------ */
+size_t cocodr_simce_workspace_floats(int M);
+int cocodr_simce_fwd_bwd(const float* E, int M, int H, int world, int row0, int m_local, float* loss_rows,
+                         float* loss, float* dE_local, float* workspace, cocodr_stream_t stream);
+int cocodr_triplet_nll_fwd_bwd(const float* q, const float* a, const float* b, const float* weights /* or NULL */,
+                               int B, int H, float* loss_rows, float* logits /* [B,2] */, float* loss,
+                               float* dq, float* da, float* db, cocodr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Brute-force inner-product search: faiss.IndexFlatIP(dim).add(P); .search(Q,k)
+ * (evaluate/evaluation/evaluate_beir.py:220-224, ANCE/drivers/run_ann_data_gen.py:310-317,390,
+ *  ANCE/utils/eval_mrr.py:81-90).  Q [Nq,H] fp32, P [Np,H] fp32; D [Nq,k] fp32 descending,
+ * I [Nq,k] int64 positions into P (+ id_offset), ties -> lower position first, (-inf,-1) padding.
+ * ------------------------------------------------------------------------------------------ */
+size_t cocodr_score_topk_workspace_bytes(int Nq, int Np, int k);
+int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset,
+                      float* D, long long* I, void* workspace, size_t workspace_bytes, cocodr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-encoder entry points: the layer loop lives in native code so one host call enqueues every
+ * kernel of BertModel.forward (COCO/modeling.py:199-204, ANCE/model/models.py:225-229) or of its
+ * backward.  Parameters are borrowed (torch owns them); activations live in a caller arena.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int hidden, heads, layers, inter, vocab, max_pos;
+  float ln_eps;
+} cocodr_config;
+
+typedef struct { /* one BertLayer; w* are bf16 shadows [out,in], vectors are the fp32 masters */
+  const uint16_t* wqkv; /* [3H,H]  query|key|value rows */
+  const uint16_t* wo;   /* [H,H]   attention.output.dense */
+  const uint16_t* w1;   /* [I,H]   intermediate.dense */
+  const uint16_t* w2;   /* [H,I]   output.dense */
+  const float *bqkv, *bo, *b1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+} cocodr_layer_params;
+
+typedef struct { /* fp32 gradient destinations, same shapes as the masters */
+  float *wqkv, *wo, *w1, *w2, *bqkv, *bo, *b1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+} cocodr_layer_grads;
+
+typedef struct {
+  const float *word, *pos, *type0, *ln_g, *ln_b; /* fp32 masters */
+} cocodr_embed_params;
+typedef struct {
+  float *word, *pos, *type0, *ln_g, *ln_b;
+} cocodr_embed_grads;
+
+typedef struct { /* byte offsets into the arena, filled by cocodr_encoder_layout */
+  size_t total_bytes;
+  size_t hidden;      /* bf16 [layers+1][M,H] - hidden_states tuple (output_hidden_states=True) */
+  size_t cls_f32;     /* fp32 [B,H]  last-layer [CLS] rows */
+  size_t qkv, ctx, y1, x1, u, h, y2;        /* bf16 per-layer activations, [layers][M,*] */
+  size_t lse, mean1, rstd1, mean2, rstd2;    /* fp32 per-layer statistics */
+  size_t emb_mean, emb_rstd;
+  size_t bwd_scratch;  /* backward-only region (dgrad chain, saved dY for the grouped wgrad) */
+  size_t bwd_bytes;
+} cocodr_encoder_layout_t;
+
+/* training = 0 keeps only what inference needs (hidden states + one layer of scratch) */
+int cocodr_encoder_layout(const cocodr_config* cfg, int B, int L, int training, cocodr_encoder_layout_t* out);
+
+int cocodr_encoder_fwd(const cocodr_config* cfg, const cocodr_embed_params* emb,
+                       const cocodr_layer_params* layers_host, const int32_t* ids, const int32_t* mask,
+                       int B, int L, int training, void* arena, size_t arena_bytes, cocodr_stream_t stream);
+
+/* d_last: bf16 [M,H] gradient of the loss w.r.t. hidden_states[-1].  Layer gradient blocks must be
+ * laid out with a uniform stride between consecutive layers (grads_host[l+1].x - grads_host[l].x
+ * constant) so the weight gradients of all layers are computed by one grouped launch per matrix.
+ * All gradient destinations are OVERWRITTEN except emb_grads->word which is accumulated into
+ * (caller zeroes it). */
+int cocodr_encoder_bwd(const cocodr_config* cfg, const cocodr_embed_params* emb,
+                       const cocodr_layer_params* layers_host, const cocodr_embed_grads* emb_grads,
+                       const cocodr_layer_grads* grads_host, const int32_t* ids, const int32_t* mask,
+                       const uint16_t* d_last, int B, int L, void* arena, size_t arena_bytes,
+                       cocodr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py roofline): bracket every launch of one kernel class with HIP events
+ * on the launch stream.  kind: 0 = off, 1 = GEMM launches, 2 = attention, 3 = score_topk GEMM.
+ * ------------------------------------------------------------------------------------------ */
+int cocodr_prof_begin(int kind);
+/* synchronises, returns launches / summed ms / summed algorithmic FLOPs, and disables profiling */
+int cocodr_prof_end(int* launches, double* total_ms, double* total_flops);
+
+/* Hardware probes used by the GPU tests to pin the MFMA / transposed-LDS-read lane layouts the
+ * kernels rely on (out: fp32 / int32 device buffers, see tests/test_gpu_probe.py). */
+int cocodr_probe_mfma32(const uint16_t* a /*[32,16]*/, const uint16_t* b /*[32,16]*/, float* out /*[32,32]*/,
+                        cocodr_stream_t stream);
+int cocodr_probe_tr16(const uint16_t* tile /*[16,64]*/, uint16_t* out /*[64 lanes][4]*/, cocodr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COCODR_H_ */

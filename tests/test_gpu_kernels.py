@@ -1,0 +1,199 @@
+"""Kernel-level parity tests, all through the C ABI (ctypes).  Floating-point kernels are compared with
+a plain fp32 torch reference of the same op on identical (bf16-rounded) inputs; tolerances are stated
+per test.  Run on the GPU box:  python -m pytest tests -m gpu"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cocodr_amd  # noqa: E402
+from cocodr_amd import ops  # noqa: E402
+from cocodr_amd import _native as N  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ------------------------------------------------------------------ hardware layout probes
+def test_native_library_is_loaded():
+    assert "gfx950" in ops.build_info()
+
+
+def test_probe_mfma_32x32x16_layout():
+    a, b = rnd(32, 16, seed=1), rnd(32, 16, seed=2)
+    out = ops.probe_mfma32(a, b)
+    ref = a.float() @ b.float().T  # asymmetric operands: a transposed C-write would show
+    assert torch.allclose(out, ref, atol=1e-4, rtol=1e-5), (out - ref).abs().max()
+
+
+def test_probe_ds_read_tr16_layout():
+    tile = torch.arange(16 * 64, dtype=torch.int16, device=DEV).reshape(16, 64)
+    out = ops.probe_tr16(tile.view(torch.bfloat16)).cpu().numpy()
+    t = tile.cpu().numpy()
+    for l in range(64):
+        g, c = l >> 4, l & 15
+        r0, c0 = 4 * g, 16 * ((g + 1) & 3)
+        assert out[l].tolist() == [int(t[r0 + j, c0 + c]) for j in range(4)], (l, out[l])
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,Nn,K", [(256, 128, 64), (192, 384, 128), (8192, 768, 768), (1000, 256, 200)])
+def test_gemm_nt_bias(M, Nn, K):
+    a, w, bias = rnd(M, K, seed=3), rnd(Nn, K, scale=0.05, seed=4), rnd(Nn, seed=5, dtype=torch.float32)
+    out = ops.gemm(a, w, bias=bias)
+    ref = a.float() @ w.float().T + bias
+    assert rel_l2(out, ref) < 5e-3  # bf16 output rounding only (fp32 accumulate)
+
+
+def test_gemm_nt_gelu_and_residual():
+    M, Nn, K = 384, 512, 128
+    a, w, bias, r = rnd(M, K, seed=3), rnd(Nn, K, scale=0.1, seed=4), rnd(Nn, seed=5, dtype=torch.float32), rnd(M, Nn, seed=6)
+    h, u = ops.gemm(a, w, bias=bias, epi=N.EPI_GELU)
+    pre = a.float() @ w.float().T + bias
+    assert rel_l2(u, pre) < 5e-3
+    assert rel_l2(h, torch.nn.functional.gelu(pre)) < 5e-3
+    out = ops.gemm(a, w, bias=bias, epi=N.EPI_ADD, r=r)
+    assert rel_l2(out, pre + r.float()) < 5e-3
+
+
+@pytest.mark.parametrize("M,Nn,K", [(256, 128, 128), (200, 256, 384), (8192, 768, 3072)])
+def test_gemm_nn_dgrad(M, Nn, K):
+    dy, w = rnd(M, K, seed=7), rnd(K, Nn, scale=0.05, seed=8)  # w stored [K,N] = Linear weight [out=K, in=N]
+    out = ops.gemm(dy, w, trans_b=True)
+    assert rel_l2(out, dy.float() @ w.float()) < 5e-3
+    u = rnd(M, Nn, seed=9)
+    out = ops.gemm(dy, w, trans_b=True, epi=N.EPI_DGELU, r=u)
+    x = u.float()
+    gp = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    assert rel_l2(out, (dy.float() @ w.float()) * gp) < 5e-3
+
+
+@pytest.mark.parametrize("nb,Mtok,No,Ni", [(1, 256, 128, 128), (3, 200, 384, 256), (2, 8192, 768, 768)])
+def test_gemm_tn_wgrad_batched_fp32(nb, Mtok, No, Ni):
+    dy, x = rnd(nb, Mtok, No, seed=10), rnd(nb, Mtok, Ni, seed=11)
+    out = ops.gemm(dy, x, trans_a=True, trans_b=True, out_f32=True)
+    ref = torch.einsum("bmo,bmi->boi", dy.float(), x.float())
+    assert out.dtype == torch.float32 and rel_l2(out, ref) < 1e-4  # fp32 out: accumulate-order noise only
+
+
+def test_gemm_rejects_bad_shapes():
+    with pytest.raises(ValueError):
+        ops.gemm(rnd(64, 64), rnd(100, 64))  # N not a multiple of 128
+    with pytest.raises(ValueError):
+        ops.gemm(rnd(64, 64).cpu(), rnd(128, 64))
+
+
+# ------------------------------------------------------------------ attention
+def ref_attention(qkv, mask, B, L, heads):
+    H = heads * 64
+    q, k, v = [t.reshape(B, L, heads, 64).permute(0, 2, 1, 3) for t in qkv.float().split(H, dim=1)]
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    s = s.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+    lse = torch.logsumexp(s, -1)
+    p = torch.softmax(s, -1)
+    ctx = (p @ v).permute(0, 2, 1, 3).reshape(B * L, H)
+    return ctx, lse
+
+
+def make_mask(B, L, seed=0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    m = np.zeros((B, L), np.int32)
+    for b in range(B):
+        m[b, : (L if b == 0 else int(g.integers(3, L + 1)))] = 1
+    return torch.from_numpy(m).to(DEV)
+
+
+@pytest.mark.parametrize("B,L,heads", [(2, 32, 2), (3, 64, 2), (2, 128, 12), (2, 256, 4), (1, 512, 2)])
+def test_attention_fwd(B, L, heads):
+    qkv = rnd(B * L, 3 * heads * 64, seed=12)
+    mask = make_mask(B, L, seed=L)
+    ctx, lse = ops.attn_fwd(qkv, mask, B, L, heads)
+    rctx, rlse = ref_attention(qkv, mask, B, L, heads)
+    assert rel_l2(ctx, rctx) < 1e-2  # P and ctx are rounded to bf16
+    assert torch.allclose(lse, rlse, atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,L,heads", [(2, 32, 2), (3, 64, 2), (2, 128, 12), (2, 256, 4)])
+def test_attention_bwd(B, L, heads):
+    H = heads * 64
+    qkv = rnd(B * L, 3 * H, seed=13)
+    mask = make_mask(B, L, seed=L + 1)
+    dctx = rnd(B * L, H, seed=14)
+    ctx, lse = ops.attn_fwd(qkv, mask, B, L, heads)
+    dqkv = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, heads)
+    q = qkv.float().clone().requires_grad_(True)
+    rctx, _ = ref_attention(q, mask, B, L, heads)
+    rctx.backward(dctx.float())
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert rel_l2(dqkv[:, sl], q.grad[:, sl]) < 2e-2, name
+
+
+# ------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("M,H", [(64, 128), (1000, 768), (515, 1024)])
+def test_layernorm_fwd_bwd(M, H):
+    y, g, b = rnd(M, H, seed=15), 1 + 0.1 * rnd(H, seed=16, dtype=torch.float32), rnd(H, seed=17, dtype=torch.float32)
+    out, mean, rstd = ops.ln_fwd(y, g, b)
+    yf = y.float().requires_grad_(True)
+    gf, bf = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(yf, (H,), gf, bf, 1e-12)
+    assert rel_l2(out, ref) < 5e-3
+    assert torch.allclose(mean, yf.mean(-1), atol=1e-5)
+    dout = rnd(M, H, seed=18)
+    ref.backward(dout.float())
+    dy, dg, db = ops.ln_bwd(dout, y, g, mean, rstd)
+    assert rel_l2(dy, yf.grad) < 5e-3
+    assert rel_l2(dg, gf.grad) < 1e-4 and rel_l2(db, bf.grad) < 1e-4
+
+
+def test_layernorm_cls_rows_fp32():
+    L, B, H = 32, 5, 768
+    y, g, b = rnd(B * L, H, seed=19), 1 + 0.1 * rnd(H, seed=20, dtype=torch.float32), rnd(H, seed=21, dtype=torch.float32)
+    out, mean, rstd, cls = ops.ln_fwd(y, g, b, cls_stride=L)
+    ref = torch.nn.functional.layer_norm(y.float(), (H,), g, b, 1e-12)[::L]
+    assert cls.shape == (B, H) and torch.allclose(cls, ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,L,H,V", [(3, 32, 128, 1000), (16, 128, 768, 30522)])
+def test_embedding_ln_fwd_bwd(B, L, H, V):
+    g = torch.Generator().manual_seed(22)
+    ids = torch.randint(0, V, (B, L), generator=g, dtype=torch.int32)
+    ids[:, 0] = 1  # repeated ids -> scatter-add collisions
+    ids = ids.to(DEV)
+    word, pos, typ = rnd(V, H, scale=0.05, seed=23, dtype=torch.float32), rnd(512, H, scale=0.05, seed=24, dtype=torch.float32), \
+        rnd(2, H, scale=0.05, seed=25, dtype=torch.float32)
+    gam, bet = 1 + 0.1 * rnd(H, seed=26, dtype=torch.float32), rnd(H, seed=27, dtype=torch.float32)
+    out, mean, rstd = ops.embed_ln_fwd(ids, word, pos, typ[0].contiguous(), gam, bet)
+    wf, pf, tf = word.clone().requires_grad_(True), pos.clone().requires_grad_(True), typ.clone().requires_grad_(True)
+    gf, bf = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(wf[ids.long()] + pf[None, :L] + tf[0], (H,), gf, bf, 1e-12).reshape(B * L, H)
+    assert rel_l2(out, ref) < 5e-3
+    dout = rnd(B * L, H, seed=28)
+    ref.backward(dout.float())
+    dword, dpos, dtype0, dgam, dbet = ops.embed_ln_bwd(dout, ids, word, pos, typ[0].contiguous(), gam, mean, rstd)
+    assert rel_l2(dword, wf.grad) < 1e-4  # fp32 atomics: order noise only
+    assert rel_l2(dpos, pf.grad) < 1e-4 and rel_l2(dtype0, tf.grad[0]) < 1e-4
+    assert rel_l2(dgam, gf.grad) < 1e-4 and rel_l2(dbet, bf.grad) < 1e-4
+
+
+def test_colsum_and_cast():
+    x = rnd(3, 1000, 384, seed=29)
+    assert rel_l2(ops.colsum(x), x.float().sum(1)) < 1e-5
+    x2 = rnd(8192, 3072, seed=30)
+    assert rel_l2(ops.colsum(x2), x2.float().sum(0)) < 1e-5
+    src = rnd(12345, seed=31, dtype=torch.float32)
+    assert torch.equal(ops.cast_f32_bf16(src), src.to(torch.bfloat16))  # bit-exact round-to-nearest-even
+    dE = rnd(4, 768, seed=32, dtype=torch.float32)
+    d_last = ops.scatter_cls_grad(dE, 32)
+    assert torch.equal(d_last[::32], dE.to(torch.bfloat16)) and float(d_last.float().abs().sum()) == float(d_last[::32].float().abs().sum())

@@ -1,0 +1,91 @@
+"""Parity of the loss and search kernels against the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cocodr_amd  # noqa: E402
+from cocodr_amd import ops  # noqa: E402
+import oracle as O  # noqa: E402  (checker only)
+
+DEV = "cuda"
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def test_simce_matches_reference_goldens(golden_loss):
+    g = golden_loss
+    for M in (8, 16, 64):
+        E, W = g[f"E_{M}"], int(g[f"W_{M}"])
+        loss, rows, dE = ops.simce_fwd_bwd(t(E), world=W)
+        # fp32 end to end: tolerance = fp32 round-off of a length-H dot product and exp/log
+        np.testing.assert_allclose(rows.cpu().numpy(), g[f"rows_{M}"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dE.cpu().numpy(), g[f"dE_{M}"], rtol=1e-4, atol=2e-6)
+        assert abs(float(loss) - float(g[f"rows_{M}"].mean())) < 2e-5
+
+
+@pytest.mark.parametrize("M,H,W", [(6, 128, 1), (64, 768, 1), (256, 768, 4), (2048, 768, 8)])
+def test_simce_local_rows_vs_oracle(M, H, W):
+    rng = np.random.Generator(np.random.PCG64(M))
+    E = (rng.standard_normal((M, H)) * (6.0 / np.sqrt(H))).astype(np.float32)
+    m = M // W
+    rank = W - 1
+    loss, rows, dE = ops.simce_fwd_bwd(t(E), world=W, row0=rank * m, m_local=m)
+    E64 = E.astype(np.float64)
+    ref_rows = O.contrastive_loss(E64.copy(), W)
+    ref_loss, _ = O.contrastive_loss_grad(E64.copy(), W)
+    ref_dE = O.contrastive_local_grad(E64.copy(), W, rank)
+    np.testing.assert_allclose(rows.cpu().numpy(), ref_rows, rtol=1e-4, atol=1e-4)
+    assert abs(float(loss) - ref_loss) < 1e-4
+    np.testing.assert_allclose(dE.cpu().numpy(), ref_dE, rtol=2e-3, atol=2e-6)
+
+
+def test_triplet_matches_reference_golden(golden_ance):
+    g = golden_ance
+    q, a, b, w = g["q_emb"], g["a_emb"], g["b_emb"], g["weights"]
+    loss, rows, logits, dq, da, db = ops.triplet_nll_fwd_bwd(t(q), t(a), t(b), t(w))
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=1e-5)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    rl, rq, ra, rb = O.triplet_nll_grad(q.astype(np.float64), a.astype(np.float64), b.astype(np.float64), w)
+    # logits are ~130 with gaps ~2: fp32 round-off of the logits (1e-5 abs) moves softmax by ~1e-5 relative,
+    # and dq = c1*(b - a) cancels element-wise, so compare in relative L2 (tolerance 1e-4)
+    for got, ref in ((dq, rq), (da, ra), (db, rb)):
+        got = got.cpu().numpy().astype(np.float64)
+        assert np.linalg.norm(got - ref) <= 1e-4 * np.linalg.norm(ref)
+    loss2, *_ = ops.triplet_nll_fwd_bwd(t(q), t(a), t(b), None)
+    assert abs(float(loss2) - O.triplet_nll_grad(q, a, b)[0]) < 1e-4
+
+
+@pytest.mark.parametrize("Nq,Np,H,k", [(5, 101, 16, 10), (130, 5000, 768, 100), (64, 40000, 1024, 1000), (3, 50, 64, 80)])
+def test_score_topk_vs_oracle(Nq, Np, H, k):
+    rng = np.random.Generator(np.random.PCG64(Np))
+    Q = (rng.standard_normal((Nq, H)) / np.sqrt(H)).astype(np.float32)
+    P = (rng.standard_normal((Np, H)) / np.sqrt(H)).astype(np.float32)
+    D, I = ops.score_topk(t(Q), t(P), k, id_offset=7)
+    Dr, Ir = O.score_topk(Q, P, k)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    kk = min(k, Np)
+    np.testing.assert_allclose(D[:, :kk], Dr[:, :kk], rtol=1e-5, atol=1e-6)
+    # ids must match wherever neighbouring scores are separated by more than fp32 round-off
+    gap_ok = np.ones((Nq, kk), bool)
+    d = np.abs(np.diff(Dr[:, :kk], axis=1)) > 1e-6
+    gap_ok[:, 1:] &= d
+    gap_ok[:, :-1] &= d
+    assert np.array_equal(I[:, :kk][gap_ok], (Ir[:, :kk] + 7)[gap_ok])
+    assert (np.sort(I[:, :kk], 1) == np.sort(I[:, :kk], 1)).all() and all(len(set(r)) == kk for r in I[:, :kk])
+    if k > Np:
+        assert (I[:, Np:] == -1).all() and np.isneginf(D[:, Np:]).all()
+
+
+def test_score_topk_exact_ties_prefer_lower_position():
+    # small-integer vectors: every score is exact in fp32, so ties are exact and the order is fully determined
+    rng = np.random.Generator(np.random.PCG64(1))
+    Q = rng.integers(-2, 3, (7, 32)).astype(np.float32)
+    P = rng.integers(-2, 3, (3000, 32)).astype(np.float32)
+    P[100:200] = P[0]  # 101 exact duplicates
+    D, I = ops.score_topk(t(Q), t(P), 50)
+    Dr, Ir = O.score_topk(Q, P, 50)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
