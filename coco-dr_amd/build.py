@@ -61,6 +61,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+        # a kernel handle left undefined only shows up at dlopen time: catch it here
+        nm = subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True).stdout
+        bad = [l.split()[-1] for l in nm.splitlines() if "cocodr" in l or "_kernel" in l]
+        if bad:
+            os.remove(LIB)
+            raise RuntimeError("unresolved symbols in %s: %s" % (LIB, bad[:4]))
     return LIB
 
 

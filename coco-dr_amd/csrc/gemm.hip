@@ -12,6 +12,8 @@
 // transposing LDS read (ds_read_b64_tr_b16), so no transposed copy of weights or activations is
 // ever materialised in HBM.  The accumulators go through an fp32 LDS tile so that the epilogue
 // (bias, erf-GELU, residual, GELU') runs row-major with 16-byte coalesced loads/stores.
+#include <stdlib.h>
+
 #include "common.h"
 #include "prof.h"
 
@@ -187,6 +189,239 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const cocodr_gemm_args p) 
   }
 }
 
+
+}  // namespace
+
+// =====================================================================================================
+// v2: direct-to-LDS pipeline.  Operand tiles go HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (no VGPR
+// round trip) into a 3-deep ring, two tiles in flight behind a counted s_waitcnt vmcnt(N) and ONE raw
+// s_barrier per K-step.  The LDS image is lane-linear per wave instruction, so the XOR swizzle the
+// fragment reads need is applied to the per-lane SOURCE address (the permutation is an involution).
+// Out-of-range rows come back as zeros through the buffer descriptor's bounds check (one descriptor
+// per batch item), which is what makes ragged token counts legal in the contraction dimension.
+// Tile BM x 128 x 64, BM/64 x 2 waves; BM = 256 runs 8 waves (2 per SIMD) in 144 KiB of LDS.
+// =====================================================================================================
+// (named namespace: hipFuncSetAttribute takes the kernels' addresses, which needs external linkage)
+namespace cocodr_gemm_v2 {
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BMv, int TA, int TB>
+struct GldsGeom {
+  static constexpr int NWAVES = (BMv / 64) * 2;
+  static constexpr int A_BYTES = BMv * 64 * 2;
+  static constexpr int B_BYTES = 128 * 64 * 2;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int GA = (A_BYTES / 1024) / NWAVES;  // wave-level 1 KiB loads per stage
+  static constexpr int GB = (B_BYTES / 1024) / NWAVES;
+  static constexpr int NSTAGE = 3;
+};
+
+// byte offset (relative to the matrix base) of the 16-B chunk that must land at linear LDS chunk p of a tile
+template <int TR, int COLS /* tile width when stored [k][COLS] */>
+__device__ __forceinline__ uint32_t glds_src_off(int p, int r0, int ld) {
+  if (TR == 0) {
+    const int row = p >> 3, ch = (p & 7) ^ swz64(row);
+    return (uint32_t)(((r0 + row) * ld + ch * 8) * 2);
+  } else {
+    constexpr int CPR = COLS / 8;  // chunks per row
+    const int row = p / CPR, ch = (p % CPR) ^ ((row & 3) << 2);
+    return (uint32_t)((row * ld + r0 + ch * 8) * 2);
+  }
+}
+
+template <int TR, int COLS>
+__device__ __forceinline__ bf16x8 read_frag2(const char* lds, int r0, int s, int lane) {
+  if (TR == 0) {
+    return lds_read_b128(lds, tile64_off(r0 + (lane & 31), 2 * s + (lane >> 5)));
+  } else {
+    const int g = lane >> 4, c = lane & 15;
+    const int col = r0 + ((g & 1) << 4) + ((c & 3) << 2);
+    const int row = 16 * s + ((g >> 1) << 3) + (c >> 2);
+    const int off = row * (COLS * 2) + (((col >> 3) ^ ((row & 3) << 2)) << 4) + ((col & 7) << 1);
+    return join_tr(lds_read_tr16(lds, off), lds_read_tr16(lds, off + 4 * COLS * 2));
+  }
+}
+
+template <int BMv, int TA, int TB, bool OUT_F32>
+__global__ __launch_bounds__((BMv / 64) * 128, 1) void gemm_glds_kernel(const cocodr_gemm_args p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type only exists in the device pass; the host pass just needs the stub
+  using G = GldsGeom<BMv, TA, TB>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int ntn = p.N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BMv, n0 = (tile % ntn) * BN;
+  const int z = blockIdx.y;
+  const uint16_t* A = p.A + (size_t)z * p.strideA;
+  const uint16_t* B = p.B + (size_t)z * p.strideB;
+  const uint32_t a_bytes = (uint32_t)((size_t)(TA ? p.K : p.M) * p.lda * 2);
+  const uint32_t b_bytes = (uint32_t)((size_t)(TB ? p.K : p.N) * p.ldb * 2);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+
+  // per-lane source offsets of this wave's loads (tile 0); advancing one K-step adds a constant
+  uint32_t offa[G::GA], offb[G::GB];
+#pragma unroll
+  for (int j = 0; j < G::GA; ++j) offa[j] = glds_src_off<TA, BMv>((wid * G::GA + j) * 64 + lane, m0, p.lda);
+#pragma unroll
+  for (int j = 0; j < G::GB; ++j) offb[j] = glds_src_off<TB, 128>((wid * G::GB + j) * 64 + lane, n0, p.ldb);
+  const uint32_t stepa = TA ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
+  const uint32_t stepb = TB ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
+
+  auto issue = [&](int t) {
+    char* st = smem + (t % G::NSTAGE) * G::STAGE;
+#pragma unroll
+    for (int j = 0; j < G::GA; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))(st + (wid * G::GA + j) * 1024), 16, offa[j] + t * stepa, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < G::GB; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(st + G::A_BYTES + (wid * G::GB + j) * 1024), 16, offb[j] + t * stepb, 0, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nt = (p.K + BK - 1) / BK;
+  issue(0);
+  if (nt > 1) issue(1);
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) wait_vmcnt<G::GA + G::GB>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) issue(t + 2);
+    const char* bufA = smem + (t % G::NSTAGE) * G::STAGE;
+    const char* bufB = bufA + G::A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = read_frag2<TA, BMv>(bufA, wm * 64 + a * 32, s, lane);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = read_frag2<TB, 128>(bufB, wn * 64 + b * 32, s, lane);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue through an fp32 LDS tile, 64 rows at a time (same as v1)
+  float* ct = reinterpret_cast<float*>(smem);
+  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
+  const uint16_t* __restrict__ R = p.R ? p.R + (size_t)z * p.strideR : nullptr;
+  constexpr int NT_ = G::NWAVES * 64;
+#pragma unroll 1
+  for (int h = 0; h < BMv / 64; ++h) {
+    if (wm == h) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int row = a * 32 + (lane & 31);
+            const int col = wn * 64 + b * 32 + 8 * rg + 4 * (lane >> 5);
+            *reinterpret_cast<float4*>(ct + row * CT_LD + col) =
+                make_float4(acc[a][b][rg * 4 + 0], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < 64 * 16 / NT_; ++pp) {
+      const int row = (tid >> 4) + (NT_ / 16) * pp;
+      const int gm = m0 + h * 64 + row;
+      const int gn = n0 + ((tid & 15) << 3);
+      if (gm < p.M) {
+        float v[8];
+        const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CT_LD + ((tid & 15) << 3));
+        const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CT_LD + ((tid & 15) << 3) + 4);
+        v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+        if (bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(bias + gn);
+          const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (p.epi == COCODR_EPI_GELU) {
+          *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        } else if (p.epi == COCODR_EPI_ADD) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(R + (size_t)gm * p.ldr + gn), r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += r[j];
+        } else if (p.epi == COCODR_EPI_DGELU) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(R + (size_t)gm * p.ldr + gn), r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(r[j]);
+        }
+        if (OUT_F32) {
+          float* C = reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
+          *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
+          *reinterpret_cast<uint4*>(C) = pack8(v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#endif
+}
+
+template <int BMv, int TA, int TB>
+void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
+  using G = GldsGeom<BMv, TA, TB>;
+  const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / BN;
+  dim3 grid(ntm * ntn, a.batch);
+  const size_t lds = (size_t)G::NSTAGE * G::STAGE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (a.out_f32)
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, TA, TB, true>), grid, dim3(G::NWAVES * 64), lds, st, a);
+  else
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, TA, TB, false>), grid, dim3(G::NWAVES * 64), lds, st, a);
+}
+
+template <int BMv>
+void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
+  if (!a.trans_a && !a.trans_b) launch_glds<BMv, 0, 0>(a, st);
+  else if (!a.trans_a && a.trans_b) launch_glds<BMv, 0, 1>(a, st);
+  else launch_glds<BMv, 1, 1>(a, st);
+}
+
+}  // namespace cocodr_gemm_v2
+using cocodr_gemm_v2::launch_glds_any;
+
+namespace {
+
+int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, 2 = glds 128x128, 3 = glds 256x128
+int gemm_impl_override() {
+  if (g_gemm_impl < 0) {
+    const char* e = getenv("COCODR_GEMM_IMPL");
+    g_gemm_impl = e ? atoi(e) : 0;
+  }
+  return g_gemm_impl;
+}
+
 template <int TA, int TB>
 void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
   if (a.out_f32)
@@ -196,6 +431,12 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int cocodr_gemm_set_impl(int impl) {
+  CK_ARG(impl >= 0 && impl <= 3, "gemm_set_impl: impl must be 0 (auto), 1, 2 or 3");
+  g_gemm_impl = impl;
+  return COCODR_OK;
+}
 
 extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream) {
   CK_ARG(args != nullptr, "gemm: null args");
@@ -219,7 +460,16 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   dim3 grid(ntm * ntn, a.batch);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_GEMM, st, 2.0 * a.M * a.N * (double)a.K * a.batch);
-  if (!a.trans_a && !a.trans_b) launch<0, 0>(a, grid, st);
+  // the direct-to-LDS pipeline needs whole 64-wide K-steps for every operand whose contraction index is the
+  // fast axis (ragged K is only zero-filled along rows), and 32-bit byte offsets per batch item
+  const bool k_ok = (a.K % BK == 0) || (a.trans_a && a.trans_b);
+  const bool small = (size_t)(a.trans_a ? a.K : a.M) * a.lda * 2 < (1ull << 32) && (size_t)(a.trans_b ? a.K : a.N) * a.ldb * 2 < (1ull << 32);
+  int impl = gemm_impl_override();
+  if (impl == 0) impl = (k_ok && small) ? 2 : 1;
+  if (impl != 1 && !(k_ok && small)) impl = 1;
+  if (impl == 3) launch_glds_any<256>(a, st);
+  else if (impl == 2) launch_glds_any<128>(a, st);
+  else if (!a.trans_a && !a.trans_b) launch<0, 0>(a, grid, st);
   else if (!a.trans_a && a.trans_b) launch<0, 1>(a, grid, st);
   else launch<1, 1>(a, grid, st);
   CK_LAUNCH("gemm");

@@ -170,18 +170,20 @@ __device__ __forceinline__ void ln_bwd_row(RowVec& d, const RowVec& x, const flo
     for (int e = 0; e < 4; ++e) d.v[i][e] = rstd * (d.v[i][e] - s1 - xh.v[i][e] * s2);
 }
 
-// reduce the 4 waves' per-lane accumulators through LDS and write one partial row [H]
-__device__ __forceinline__ void block_reduce_store(const RowVec& acc, float* lds /* [4][MAXC*256] */, float* dst, int nch, int tid) {
+// reduce the NW waves' per-lane accumulators through LDS and write one partial row [H]
+constexpr int NW = 16;          // waves per workgroup in the backward row kernels
+constexpr int RB_THREADS = NW * 64;
+__device__ __forceinline__ void block_reduce_store(const RowVec& acc, float* lds /* [NW][MAXC*256] */, float* dst, int nch, int tid) {
   const int lane = tid & 63, wid = tid >> 6;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < MAXC; ++i)
     *reinterpret_cast<float4*>(lds + wid * (MAXC * 256) + (lane + 64 * i) * 4) = make_float4(acc.v[i][0], acc.v[i][1], acc.v[i][2], acc.v[i][3]);
   __syncthreads();
-  for (int c = tid; c < nch; c += 256) {
+  for (int c = tid; c < nch; c += RB_THREADS) {
     float4 s = *reinterpret_cast<const float4*>(lds + c * 4);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NW; ++w) {
       const float4 t = *reinterpret_cast<const float4*>(lds + w * (MAXC * 256) + c * 4);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
@@ -194,18 +196,18 @@ __device__ __forceinline__ void zero_row(RowVec& r) {
   for (int i = 0; i < MAXC; ++i) r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y,
+__global__ __launch_bounds__(RB_THREADS) void ln_bwd_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, uint16_t* __restrict__ dy,
                                                      float* __restrict__ partial, int M, int H) {
-  __shared__ __attribute__((aligned(16))) float red[4 * MAXC * 256];
+  __shared__ __attribute__((aligned(16))) float red[NW * MAXC * 256];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
   const int rows_per = (M + gridDim.x - 1) / gridDim.x;
   const int r_begin = blockIdx.x * rows_per, r_end = min(M, r_begin + rows_per);
   RowVec dg, db;
   zero_row(dg);
   zero_row(db);
-  for (int row = r_begin + wid; row < r_end; row += 4) {
+  for (int row = r_begin + wid; row < r_end; row += NW) {
     RowVec d, x;
     load_bf16_row(dout + (size_t)row * H, nch, lane, d);
     load_bf16_row(y + (size_t)row * H, nch, lane, x);
@@ -218,20 +220,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
 
 // grid.x = L (one workgroup per position): the position-embedding gradient row is a plain sum over
 // the batch (no atomics); only the sparse word-embedding rows use fp32 atomics.
-__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const uint16_t* __restrict__ dout, const int32_t* __restrict__ ids,
+__global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_kernel(const uint16_t* __restrict__ dout, const int32_t* __restrict__ ids,
                                                            const float* __restrict__ word, const float* __restrict__ pos,
                                                            const float* __restrict__ type0, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                            float* __restrict__ dword, float* __restrict__ dpos,
                                                            float* __restrict__ partial, int B, int L, int H, int vocab) {
-  __shared__ __attribute__((aligned(16))) float red[4 * MAXC * 256];
+  __shared__ __attribute__((aligned(16))) float red[NW * MAXC * 256];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
   const int l = blockIdx.x;
   RowVec dg, db, dp;
   zero_row(dg);
   zero_row(db);
   zero_row(dp);
-  for (int b = wid; b < B; b += 4) {
+  for (int b = wid; b < B; b += NW) {
     const int row = b * L + l;
     int id = ids[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const uint16_t* __res
   block_reduce_store(db, red, prow + H, nch, tid);
   block_reduce_store(dp, red, prow + 2 * H, nch, tid);
   __syncthreads();
-  for (int c = tid; c < nch; c += 256)
+  for (int c = tid; c < nch; c += RB_THREADS)
     *reinterpret_cast<float4*>(dpos + (size_t)l * H + c * 4) = *reinterpret_cast<const float4*>(prow + 2 * H + c * 4);
 }
 
@@ -269,13 +271,28 @@ struct ReduceArgs {
   long long stride_out;
 };
 __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+  // block = 64 columns x 4 partial-row groups; 8 independent loads in flight per thread
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
   const int s = blockIdx.y, z = blockIdx.z;
-  if (n >= a.n_len) return;
-  const float* p = a.partial + ((size_t)z * a.P * a.nseg + s) * a.n_len + n;
   float acc = 0.f;
-  for (int i = 0; i < a.P; ++i) acc += p[(size_t)i * a.nseg * a.n_len];
-  a.out[s][(size_t)z * a.stride_out + n] = acc;
+  if (n < a.n_len) {
+    const size_t step = (size_t)a.nseg * a.n_len;
+    const float* p = a.partial + ((size_t)z * a.P * a.nseg + s) * a.n_len + n;
+    int i = rg;
+    for (; i + 28 < a.P; i += 32) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(i + 4 * u) * step];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; i < a.P; i += 4) acc += p[(size_t)i * step];
+  }
+  red[rg][c] = acc;
+  __syncthreads();
+  if (rg == 0 && n < a.n_len) a.out[s][(size_t)z * a.stride_out + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // column sums: workgroup = 256-column strip x row range; a lane owns 4 adjacent columns
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restric
 }
 
 int colsum_splits(int M) { return M >= 4096 ? 32 : (M >= 512 ? 8 : 1); }
-int ln_bwd_blocks(int M) { return M >= 1024 ? 256 : (M + 3) / 4; }
+int ln_bwd_blocks(int M) { return M >= 256 * NW ? 256 : (M + NW - 1) / NW; }
 
 int launch_reduce(const float* partial, float* o0, float* o1, float* o2, int P, int nseg, int n_len, int batch, long long stride_out,
                   hipStream_t st) {
@@ -340,7 +357,7 @@ int launch_reduce(const float* partial, float* o0, float* o1, float* o2, int P, 
   a.partial = partial;
   a.out[0] = o0; a.out[1] = o1; a.out[2] = o2;
   a.P = P; a.nseg = nseg; a.n_len = n_len; a.batch = batch; a.stride_out = stride_out;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_len + 255) / 256, nseg, batch), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_len + 63) / 64, nseg, batch), dim3(256), 0, st, a);
   CK_LAUNCH("reduce_partials");
   return COCODR_OK;
 }
@@ -372,7 +389,7 @@ extern "C" int cocodr_embed_ln_bwd(const uint16_t* dout, const int32_t* ids, con
          "embed_ln_bwd: null pointer");
   CK_ARG(B > 0 && L > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_bwd: bad shape B=%d L=%d H=%d", B, L, H);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(L), dim3(256), 0, st, dout, ids, word, pos, type0, gamma, mean, rstd, dword, dpos,
+  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(L), dim3(RB_THREADS), 0, st, dout, ids, word, pos, type0, gamma, mean, rstd, dword, dpos,
                      partial, B, L, H, vocab);
   CK_LAUNCH("embed_ln_bwd");
   return launch_reduce(partial, dgamma, dbeta, dtype0, L, 3, H, 1, 0, st);
@@ -397,7 +414,7 @@ extern "C" int cocodr_ln_bwd(const uint16_t* dout, const uint16_t* y, const floa
   CK_ARG(M > 0 && row_shape_ok(H), "ln_bwd: bad shape M=%d H=%d", M, H);
   hipStream_t st = (hipStream_t)stream;
   const int P = ln_bwd_blocks(M);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(P), dim3(256), 0, st, dout, y, gamma, mean, rstd, dy, partial, M, H);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(P), dim3(RB_THREADS), 0, st, dout, y, gamma, mean, rstd, dy, partial, M, H);
   CK_LAUNCH("ln_bwd");
   return launch_reduce(partial, dgamma, dbeta, nullptr, P, 2, H, 1, 0, st);
 }

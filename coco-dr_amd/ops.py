@@ -81,6 +81,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
     return (out, c2) if epi == N.EPI_GELU else out
 
 
+def gemm_set_impl(impl: int) -> None:
+    check(lib().cocodr_gemm_set_impl(int(impl)), "gemm_set_impl")
+
+
 # ----------------------------------------------------------------------------------------------- attention
 def attn_fwd(qkv: torch.Tensor, mask: torch.Tensor, B: int, L: int, heads: int) -> Tuple[torch.Tensor, torch.Tensor]:
     _req(qkv, BF16, "qkv", 2)

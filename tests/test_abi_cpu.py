@@ -1,0 +1,122 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every
+symbol include/cocodr.h declares (no compute calls here - there is no GPU in this container); host-side
+validation raises the documented errors; the product never imports the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    import cocodr_amd
+    from cocodr_amd import _native
+    return _native.lib()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cocodr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cocodr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from cocodr_amd import _native
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/cocodr.h but not exported"
+        assert n in _native.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(_native.SIGNATURES) <= set(names)
+    assert b"gfx950" in lib.cocodr_build_info()
+
+
+def test_library_has_no_unresolved_kernel_symbols():
+    out = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "coco-dr_amd", "libcocodr_hip.so")],
+                         capture_output=True, text=True).stdout
+    assert not [l for l in out.splitlines() if "_kernel" in l or "cocodr" in l]
+
+
+def test_argument_validation_without_gpu(lib):
+    from cocodr_amd import _native as N
+    g = N.GemmArgs()
+    assert lib.cocodr_gemm(ctypes.byref(g), None) == -1 and b"null operand" in lib.cocodr_last_error()
+    cfg = N.Config(100, 2, 2, 256, 1000, 64, 1e-12)  # hidden != heads*64
+    lay = N.EncoderLayout()
+    assert lib.cocodr_encoder_layout(ctypes.byref(cfg), 4, 32, 1, ctypes.byref(lay)) == -1
+    cfg = N.Config(128, 2, 2, 256, 1000, 64, 1e-12)
+    assert lib.cocodr_encoder_layout(ctypes.byref(cfg), 4, 33, 1, ctypes.byref(lay)) == -1  # L % 32
+    assert lib.cocodr_encoder_layout(ctypes.byref(cfg), 4, 32, 1, ctypes.byref(lay)) == 0
+    assert lay.total_bytes > lay.bwd_scratch > lay.hidden >= 0 and lay.bwd_bytes > 0
+    lay0 = N.EncoderLayout()
+    assert lib.cocodr_encoder_layout(ctypes.byref(cfg), 4, 32, 0, ctypes.byref(lay0)) == 0
+    assert lay0.total_bytes < lay.total_bytes and lay0.bwd_bytes == 0
+    assert lib.cocodr_score_topk_workspace_bytes(100, 1000, 10) >= 100 * 1000 * 4
+
+
+def test_ops_reject_cpu_tensors_and_model_refuses_cpu():
+    from cocodr_amd import ops
+    from cocodr_amd.modeling import CocoBertConfig, CocoBertModel
+    with pytest.raises(ValueError, match="GPU"):
+        ops.gemm(torch.zeros(128, 64, dtype=torch.bfloat16), torch.zeros(128, 64, dtype=torch.bfloat16))
+    m = CocoBertModel(CocoBertConfig(vocab_size=100, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                     intermediate_size=128, max_position_embeddings=32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 32, dtype=torch.long))
+    with pytest.raises(ValueError):
+        CocoBertConfig(hidden_size=100, num_attention_heads=2)
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from cocodr_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeLibraryError, match="no CPU / PyTorch fallback"):
+        _native.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "coco-dr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+    code = "import sys; sys.path.insert(0, %r); import cocodr_amd, cocodr_amd.ops, cocodr_amd.modeling; " \
+           "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)" % ROOT
+    subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_state_dict_uses_hf_bert_names_and_flat_layout_is_uniform():
+    from cocodr_amd.modeling import CocoBertConfig, CocoBertModel
+    cfg = CocoBertConfig(vocab_size=200, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=64)
+    m = CocoBertModel(cfg)
+    from transformers import BertConfig, BertModel
+    hf = BertModel(BertConfig(vocab_size=200, hidden_size=128, num_hidden_layers=3, num_attention_heads=2,
+                              intermediate_size=256, max_position_embeddings=64), add_pooling_layer=False)
+    assert set(m.state_dict().keys()) == {k for k in hf.state_dict().keys() if "position_ids" not in k}
+    for k, v in hf.state_dict().items():
+        if "position_ids" not in k:
+            assert tuple(m.state_dict()[k].shape) == tuple(v.shape), k
+    # load an HF checkpoint (with the 'bert.' prefix MLM checkpoints carry) and read it back
+    m.load_state_dict({"bert." + k: v for k, v in hf.state_dict().items()}, strict=False)
+    for k, v in hf.state_dict().items():
+        if "position_ids" not in k:
+            assert torch.equal(m.state_dict()[k], v), k
+    lo = m.layout
+    q0 = lo.names["encoder.layer.0.attention.self.query.weight"][1]
+    q1 = lo.names["encoder.layer.1.attention.self.query.weight"][1]
+    q2 = lo.names["encoder.layer.2.attention.self.query.weight"][1]
+    assert q1 - q0 == q2 - q1 == lo.mat_stride
+    groups = m.param_groups(0.01)
+    assert groups[0]["weight_decay"] == 0.01 and groups[1]["weight_decay"] == 0.0
+    assert len(list(m.parameters())) == 2

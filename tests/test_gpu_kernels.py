@@ -49,15 +49,22 @@ def test_probe_ds_read_tr16_layout():
 
 
 # ------------------------------------------------------------------ GEMM
+@pytest.fixture(params=[1, 2, 3], ids=["regstage", "glds128", "glds256"], autouse=False)
+def gemm_impl(request):
+    ops.gemm_set_impl(request.param)
+    yield request.param
+    ops.gemm_set_impl(0)
+
+
 @pytest.mark.parametrize("M,Nn,K", [(256, 128, 64), (192, 384, 128), (8192, 768, 768), (1000, 256, 200)])
-def test_gemm_nt_bias(M, Nn, K):
+def test_gemm_nt_bias(M, Nn, K, gemm_impl):
     a, w, bias = rnd(M, K, seed=3), rnd(Nn, K, scale=0.05, seed=4), rnd(Nn, seed=5, dtype=torch.float32)
     out = ops.gemm(a, w, bias=bias)
     ref = a.float() @ w.float().T + bias
     assert rel_l2(out, ref) < 5e-3  # bf16 output rounding only (fp32 accumulate)
 
 
-def test_gemm_nt_gelu_and_residual():
+def test_gemm_nt_gelu_and_residual(gemm_impl):
     M, Nn, K = 384, 512, 128
     a, w, bias, r = rnd(M, K, seed=3), rnd(Nn, K, scale=0.1, seed=4), rnd(Nn, seed=5, dtype=torch.float32), rnd(M, Nn, seed=6)
     h, u = ops.gemm(a, w, bias=bias, epi=N.EPI_GELU)
@@ -69,7 +76,7 @@ def test_gemm_nt_gelu_and_residual():
 
 
 @pytest.mark.parametrize("M,Nn,K", [(256, 128, 128), (200, 256, 384), (8192, 768, 3072)])
-def test_gemm_nn_dgrad(M, Nn, K):
+def test_gemm_nn_dgrad(M, Nn, K, gemm_impl):
     dy, w = rnd(M, K, seed=7), rnd(K, Nn, scale=0.05, seed=8)  # w stored [K,N] = Linear weight [out=K, in=N]
     out = ops.gemm(dy, w, trans_b=True)
     assert rel_l2(out, dy.float() @ w.float()) < 5e-3
@@ -81,7 +88,7 @@ def test_gemm_nn_dgrad(M, Nn, K):
 
 
 @pytest.mark.parametrize("nb,Mtok,No,Ni", [(1, 256, 128, 128), (3, 200, 384, 256), (2, 8192, 768, 768)])
-def test_gemm_tn_wgrad_batched_fp32(nb, Mtok, No, Ni):
+def test_gemm_tn_wgrad_batched_fp32(nb, Mtok, No, Ni, gemm_impl):
     dy, x = rnd(nb, Mtok, No, seed=10), rnd(nb, Mtok, Ni, seed=11)
     out = ops.gemm(dy, x, trans_a=True, trans_b=True, out_f32=True)
     ref = torch.einsum("bmo,bmi->boi", dy.float(), x.float())

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""A/B micro-benchmark of the GEMM implementations on the encoder's shapes (interleaved rounds, one process).
+Usage (GPU box): python tools/gemm_bench.py [--rounds 5]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cocodr_amd  # noqa: E402
+from cocodr_amd import ops  # noqa: E402
+
+SHAPES = [  # (name, M, N, K, ta, tb, batch, out_f32)
+    ("fwd qkv   8192x2304x768", 8192, 2304, 768, 0, 0, 1, 0),
+    ("fwd out   8192x768x768", 8192, 768, 768, 0, 0, 1, 0),
+    ("fwd ffn1  8192x3072x768", 8192, 3072, 768, 0, 0, 1, 0),
+    ("fwd ffn2  8192x768x3072", 8192, 768, 3072, 0, 0, 1, 0),
+    ("dgrad ffn2 8192x3072x768", 8192, 3072, 768, 0, 1, 1, 0),
+    ("dgrad ffn1 8192x768x3072", 8192, 768, 3072, 0, 1, 1, 0),
+    ("dgrad qkv 8192x768x2304", 8192, 768, 2304, 0, 1, 1, 0),
+    ("wgrad qkv 12x 2304x768x8192", 2304, 768, 8192, 1, 1, 12, 1),
+    ("wgrad out 12x 768x768x8192", 768, 768, 8192, 1, 1, 12, 1),
+    ("wgrad ffn1 12x 3072x768x8192", 3072, 768, 8192, 1, 1, 12, 1),
+    ("wgrad ffn2 12x 768x3072x8192", 768, 3072, 8192, 1, 1, 12, 1),
+    ("large fwd ffn1 8192x4096x1024", 8192, 4096, 1024, 0, 0, 1, 0),
+    ("large fwd qkv 2048x3072x1024", 2048, 3072, 1024, 0, 0, 1, 0),
+    # K sweep at a fixed 8192x3072 output (3 full rounds of 128x128 tiles at 2 WG/CU): time = fixed + per-K-step
+    ("ksweep 8192x3072x64", 8192, 3072, 64, 0, 0, 1, 0),
+    ("ksweep 8192x3072x128", 8192, 3072, 128, 0, 0, 1, 0),
+    ("ksweep 8192x3072x256", 8192, 3072, 256, 0, 0, 1, 0),
+    ("ksweep 8192x3072x1536", 8192, 3072, 1536, 0, 0, 1, 0),
+    ("ksweep 8192x3072x3072", 8192, 3072, 3072, 0, 0, 1, 0),
+    ("ksweep 8192x3072x6144", 8192, 3072, 6144, 0, 0, 1, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--impls", default="1,2,3")
+    ap.add_argument("--shapes", default="", help="comma separated indices into SHAPES (default all)")
+    args = ap.parse_args()
+    impls = [int(x) for x in args.impls.split(",")]
+    dev = "cuda"
+    print(f"{'shape':34s} " + " ".join(f"impl{i:d} TF/s(us)".rjust(18) for i in impls))
+    sel = [int(x) for x in args.shapes.split(',')] if args.shapes else range(len(SHAPES))
+    for name, M, N, K, ta, tb, nb, f32 in [SHAPES[i] for i in sel]:
+        g = torch.Generator().manual_seed(0)
+        ashape = (K, M) if ta else (M, K)
+        bshape = (K, N) if tb else (N, K)
+        if nb > 1:
+            ashape, bshape = (nb,) + ashape, (nb,) + bshape
+        a = torch.randn(ashape, generator=g).to(torch.bfloat16).to(dev)
+        b = (torch.randn(bshape, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+        out = torch.empty((nb, M, N) if nb > 1 else (M, N), dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
+        best = {i: 1e9 for i in impls}
+        for r in range(args.rounds + 1):
+            for i in impls:
+                ops.gemm_set_impl(i)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    ops.gemm(a, b, trans_a=bool(ta), trans_b=bool(tb), out_f32=bool(f32), out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                if r > 0:
+                    best[i] = min(best[i], e0.elapsed_time(e1) / 5 * 1e3)
+        flops = 2.0 * M * N * K * nb
+        print(f"{name:34s} " + " ".join(f"{flops / best[i] / 1e6:8.0f} ({best[i]:7.1f})".rjust(18) for i in impls), flush=True)
+    ops.gemm_set_impl(0)
+
+
+if __name__ == "__main__":
+    main()
