@@ -199,57 +199,142 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const cocodr_gemm_args p) 
 // fragment reads need is applied to the per-lane SOURCE address (the permutation is an involution).
 // Out-of-range rows come back as zeros through the buffer descriptor's bounds check (one descriptor
 // per batch item), which is what makes ragged token counts legal in the contraction dimension.
-// Tile BM x 128 x 64, BM/64 x 2 waves; BM = 256 runs 8 waves (2 per SIMD) in 144 KiB of LDS.
+//
+// Geometry <BM, BK>: tile BM x 128 x BK, (BM/64) x 2 waves, each wave 64x64 = 2x2 MFMA 32x32x16.
+//   <256,64>: 8 waves, 144 KiB LDS, 1 workgroup / CU      <256,32>: 8 waves, 72 KiB, 2 workgroups / CU
+//   <128,64>: 4 waves,  96 KiB LDS, 1 workgroup / CU      <128,32>: 4 waves, 48 KiB, 3 workgroups / CU
+// With >= 2 workgroups per CU one workgroup's prologue / epilogue overlaps the other's MFMA loop.
+//
+// LDS fragment reads are issued from inline asm: hipcc drains every in-flight LDS-DMA
+// (s_waitcnt vmcnt(0)) in front of a ds_read_b64_tr_b16 it can see, which serialises the ring for the
+// dgrad / wgrad forms.  Completion is counted by hand (LDS reads return in order): the reads of K-sub-step
+// s+1 are issued before the MFMAs of s and `s_waitcnt lgkmcnt(R)` (R = reads per sub-step) retires s.
+// Register moves that assemble a fragment sit after the wait.
 // =====================================================================================================
 // (named namespace: hipFuncSetAttribute takes the kernels' addresses, which needs external linkage)
 namespace cocodr_gemm_v2 {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int OFF>
+__device__ __forceinline__ void asm_ds_read_b128(v4i& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void asm_ds_read_tr16(v2i& dst, uint32_t addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
 
-template <int BMv, int TA, int TB>
-struct GldsGeom {
+template <int BMv, int BKv>
+struct Geom {
   static constexpr int NWAVES = (BMv / 64) * 2;
-  static constexpr int A_BYTES = BMv * 64 * 2;
-  static constexpr int B_BYTES = 128 * 64 * 2;
+  static constexpr int A_BYTES = BMv * BKv * 2;
+  static constexpr int B_BYTES = 128 * BKv * 2;
   static constexpr int STAGE = A_BYTES + B_BYTES;
   static constexpr int GA = (A_BYTES / 1024) / NWAVES;  // wave-level 1 KiB loads per stage
   static constexpr int GB = (B_BYTES / 1024) / NWAVES;
   static constexpr int NSTAGE = 3;
+  static constexpr int KS = BKv / 16;  // MFMA K-sub-steps per stage
+  static constexpr int WG_PER_CU = (160 * 1024) / (NSTAGE * STAGE);
 };
 
+// chunk swizzle of a row-major [rows][BK] tile (16-B chunks): conflict-free ds_read_b128 fragment reads
+template <int BKv>
+__device__ __forceinline__ int swz_rows(int row) {
+  return BKv == 64 ? swz64(row) : ((row >> 2) & 3);
+}
+template <int BKv>
+__device__ __forceinline__ int tile_rows_off(int row, int ch) {
+  return row * (BKv * 2) + ((ch ^ swz_rows<BKv>(row)) << 4);
+}
+
 // byte offset (relative to the matrix base) of the 16-B chunk that must land at linear LDS chunk p of a tile
-template <int TR, int COLS /* tile width when stored [k][COLS] */>
+template <int TR, int COLS /* tile width when stored [k][COLS] */, int BKv>
 __device__ __forceinline__ uint32_t glds_src_off(int p, int r0, int ld) {
   if (TR == 0) {
-    const int row = p >> 3, ch = (p & 7) ^ swz64(row);
+    constexpr int CPR = BKv / 8;
+    const int row = p / CPR, ch = (p % CPR) ^ swz_rows<BKv>(row);
     return (uint32_t)(((r0 + row) * ld + ch * 8) * 2);
   } else {
-    constexpr int CPR = COLS / 8;  // chunks per row
+    constexpr int CPR = COLS / 8;
     const int row = p / CPR, ch = (p % CPR) ^ ((row & 3) << 2);
     return (uint32_t)((row * ld + r0 + ch * 8) * 2);
   }
 }
 
-template <int TR, int COLS>
-__device__ __forceinline__ bf16x8 read_frag2(const char* lds, int r0, int s, int lane) {
+template <int TR>
+struct FragSet {  // the two 32-row fragments (a = 0, 1) of one operand for one K-sub-step
+  v4i q[2];
+  v2i lo[2], hi[2];
+};
+
+// per-lane LDS byte offsets inside an operand tile: TR=0 -> one per K-sub-step (fragment a adds 32 rows),
+// TR=1 -> one per fragment a (sub-step s and the +4-row half are immediates)
+template <int TR, int COLS, int BKv>
+__device__ __forceinline__ void frag_addrs(int r0, int lane, uint32_t (&ad)[4]) {
+  ad[0] = ad[1] = ad[2] = ad[3] = 0;
   if (TR == 0) {
-    return lds_read_b128(lds, tile64_off(r0 + (lane & 31), 2 * s + (lane >> 5)));
+#pragma unroll
+    for (int s = 0; s < BKv / 16; ++s) ad[s] = (uint32_t)tile_rows_off<BKv>(r0 + (lane & 31), 2 * s + (lane >> 5));
   } else {
     const int g = lane >> 4, c = lane & 15;
-    const int col = r0 + ((g & 1) << 4) + ((c & 3) << 2);
-    const int row = 16 * s + ((g >> 1) << 3) + (c >> 2);
-    const int off = row * (COLS * 2) + (((col >> 3) ^ ((row & 3) << 2)) << 4) + ((col & 7) << 1);
-    return join_tr(lds_read_tr16(lds, off), lds_read_tr16(lds, off + 4 * COLS * 2));
+    const int row = ((g >> 1) << 3) + (c >> 2);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int col = r0 + a * 32 + ((g & 1) << 4) + ((c & 3) << 2);
+      ad[a] = (uint32_t)(row * (COLS * 2) + (((col >> 3) ^ ((row & 3) << 2)) << 4) + ((col & 7) << 1));
+    }
   }
 }
 
-template <int BMv, int TA, int TB, bool OUT_F32>
-__global__ __launch_bounds__((BMv / 64) * 128, 1) void gemm_glds_kernel(const cocodr_gemm_args p) {
+template <int TR, int COLS, int BKv, int S>
+__device__ __forceinline__ void frags_issue(const uint32_t (&cur)[4], FragSet<TR>& f) {
+  if constexpr (TR == 0) {
+    asm_ds_read_b128<0>(f.q[0], cur[S]);
+    asm_ds_read_b128<32 * BKv * 2>(f.q[1], cur[S]);
+  } else {
+    constexpr int o = S * 16 * COLS * 2;
+    asm_ds_read_tr16<o>(f.lo[0], cur[0]);
+    asm_ds_read_tr16<o + 4 * COLS * 2>(f.hi[0], cur[0]);
+    asm_ds_read_tr16<o>(f.lo[1], cur[1]);
+    asm_ds_read_tr16<o + 4 * COLS * 2>(f.hi[1], cur[1]);
+  }
+}
+template <int TR>
+__device__ __forceinline__ bf16x8 frag_get(const FragSet<TR>& f, int a) {
+  if constexpr (TR == 0) {
+    return __builtin_bit_cast(bf16x8, f.q[a]);
+  } else {
+    const v4i v = {f.lo[a][0], f.lo[a][1], f.hi[a][0], f.hi[a][1]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+template <int TA, int TB>
+__device__ __forceinline__ void mfma_step(const FragSet<TA>& fa, const FragSet<TB>& fb, f32x16 (&acc)[2][2]) {
+  bf16x8 a[2] = {frag_get<TA>(fa, 0), frag_get<TA>(fa, 1)};
+  bf16x8 b[2] = {frag_get<TB>(fb, 0), frag_get<TB>(fb, 1)};
+  // operands swapped: D[i = n][j = m], so a lane ends up with 4 consecutive n of one m
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+}
+
+template <int BMv, int BKv, int TA, int TB, bool OUT_F32>
+__global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv / 64) * 128) / 256) void gemm_glds_kernel(
+    const cocodr_gemm_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type only exists in the device pass; the host pass just needs the stub
-  using G = GldsGeom<BMv, TA, TB>;
+  using G = Geom<BMv, BKv>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -268,11 +353,11 @@ __global__ __launch_bounds__((BMv / 64) * 128, 1) void gemm_glds_kernel(const co
   // per-lane source offsets of this wave's loads (tile 0); advancing one K-step adds a constant
   uint32_t offa[G::GA], offb[G::GB];
 #pragma unroll
-  for (int j = 0; j < G::GA; ++j) offa[j] = glds_src_off<TA, BMv>((wid * G::GA + j) * 64 + lane, m0, p.lda);
+  for (int j = 0; j < G::GA; ++j) offa[j] = glds_src_off<TA, BMv, BKv>((wid * G::GA + j) * 64 + lane, m0, p.lda);
 #pragma unroll
-  for (int j = 0; j < G::GB; ++j) offb[j] = glds_src_off<TB, 128>((wid * G::GB + j) * 64 + lane, n0, p.ldb);
-  const uint32_t stepa = TA ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
-  const uint32_t stepb = TB ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
+  for (int j = 0; j < G::GB; ++j) offb[j] = glds_src_off<TB, 128, BKv>((wid * G::GB + j) * 64 + lane, n0, p.ldb);
+  const uint32_t stepa = TA ? (uint32_t)(BKv * p.lda * 2) : (uint32_t)(BKv * 2);
+  const uint32_t stepb = TB ? (uint32_t)(BKv * p.ldb * 2) : (uint32_t)(BKv * 2);
 
   auto issue = [&](int t) {
     char* st = smem + (t % G::NSTAGE) * G::STAGE;
@@ -292,7 +377,13 @@ __global__ __launch_bounds__((BMv / 64) * 128, 1) void gemm_glds_kernel(const co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nt = (p.K + BK - 1) / BK;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+  uint32_t adA[4], adB[4];
+  frag_addrs<TA, BMv, BKv>(wm * 64, lane, adA);
+  frag_addrs<TB, 128, BKv>(wn * 64, lane, adB);
+  constexpr int R = (TA ? 4 : 2) + (TB ? 4 : 2);  // LDS reads per K-sub-step
+
+  const int nt = (p.K + BKv - 1) / BKv;
   issue(0);
   if (nt > 1) issue(1);
   for (int t = 0; t < nt; ++t) {
@@ -300,27 +391,33 @@ __global__ __launch_bounds__((BMv / 64) * 128, 1) void gemm_glds_kernel(const co
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (t + 2 < nt) issue(t + 2);
-    const char* bufA = smem + (t % G::NSTAGE) * G::STAGE;
-    const char* bufB = bufA + G::A_BYTES;
+    const uint32_t sbA = lds_base + (uint32_t)((t % G::NSTAGE) * G::STAGE), sbB = sbA + G::A_BYTES;
+    uint32_t curA[4], curB[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8 fa[2], fb[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = read_frag2<TA, BMv>(bufA, wm * 64 + a * 32, s, lane);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) fb[b] = read_frag2<TB, 128>(bufB, wn * 64 + b * 32, s, lane);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + sbA; curB[i] = adB[i] + sbB; }
+    FragSet<TA> fa0, fa1;
+    FragSet<TB> fb0, fb1;
+    frags_issue<TA, BMv, BKv, 0>(curA, fa0); frags_issue<TB, 128, BKv, 0>(curB, fb0);
+    frags_issue<TA, BMv, BKv, 1>(curA, fa1); frags_issue<TB, 128, BKv, 1>(curB, fb1);
+    wait_lgkmcnt<R>();
+    mfma_step<TA, TB>(fa0, fb0, acc);
+    if constexpr (G::KS == 4) {
+      frags_issue<TA, BMv, BKv, 2>(curA, fa0); frags_issue<TB, 128, BKv, 2>(curB, fb0);
+      wait_lgkmcnt<R>();
+      mfma_step<TA, TB>(fa1, fb1, acc);
+      frags_issue<TA, BMv, BKv, 3>(curA, fa1); frags_issue<TB, 128, BKv, 3>(curB, fb1);
+      wait_lgkmcnt<R>();
+      mfma_step<TA, TB>(fa0, fb0, acc);
     }
+    wait_lgkmcnt<0>();
+    mfma_step<TA, TB>(fa1, fb1, acc);
   }
   __syncthreads();
 
   // ---- epilogue through an fp32 LDS tile, 64 rows at a time (same as v1)
   float* ct = reinterpret_cast<float*>(smem);
   const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
-  const uint16_t* __restrict__ R = p.R ? p.R + (size_t)z * p.strideR : nullptr;
+  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
   constexpr int NT_ = G::NWAVES * 64;
 #pragma unroll 1
   for (int h = 0; h < BMv / 64; ++h) {
@@ -359,12 +456,12 @@ __global__ __launch_bounds__((BMv / 64) * 128, 1) void gemm_glds_kernel(const co
           for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
         } else if (p.epi == COCODR_EPI_ADD) {
           float r[8];
-          unpack8(*reinterpret_cast<const uint4*>(R + (size_t)gm * p.ldr + gn), r);
+          unpack8(*reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += r[j];
         } else if (p.epi == COCODR_EPI_DGELU) {
           float r[8];
-          unpack8(*reinterpret_cast<const uint4*>(R + (size_t)gm * p.ldr + gn), r);
+          unpack8(*reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(r[j]);
         }
@@ -383,29 +480,29 @@ __global__ __launch_bounds__((BMv / 64) * 128, 1) void gemm_glds_kernel(const co
 #endif
 }
 
-template <int BMv, int TA, int TB>
+template <int BMv, int BKv, int TA, int TB>
 void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
-  using G = GldsGeom<BMv, TA, TB>;
+  using G = Geom<BMv, BKv>;
   const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / BN;
   dim3 grid(ntm * ntn, a.batch);
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, TA, TB, true>), grid, dim3(G::NWAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, TA, TB, true>), grid, dim3(G::NWAVES * 64), lds, st, a);
   else
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, TA, TB, false>), grid, dim3(G::NWAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, TA, TB, false>), grid, dim3(G::NWAVES * 64), lds, st, a);
 }
 
-template <int BMv>
+template <int BMv, int BKv>
 void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
-  if (!a.trans_a && !a.trans_b) launch_glds<BMv, 0, 0>(a, st);
-  else if (!a.trans_a && a.trans_b) launch_glds<BMv, 0, 1>(a, st);
-  else launch_glds<BMv, 1, 1>(a, st);
+  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, 0, 0>(a, st);
+  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, 0, 1>(a, st);
+  else launch_glds<BMv, BKv, 1, 1>(a, st);
 }
 
 }  // namespace cocodr_gemm_v2
@@ -413,7 +510,7 @@ using cocodr_gemm_v2::launch_glds_any;
 
 namespace {
 
-int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, 2 = glds 128x128, 3 = glds 256x128
+int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, direct-to-LDS <BM,BK>: 2 = <128,64>, 3 = <256,64>, 4 = <128,32>, 5 = <256,32>
 int gemm_impl_override() {
   if (g_gemm_impl < 0) {
     const char* e = getenv("COCODR_GEMM_IMPL");
@@ -433,7 +530,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG(impl >= 0 && impl <= 3, "gemm_set_impl: impl must be 0 (auto), 1, 2 or 3");
+  CK_ARG(impl >= 0 && impl <= 5, "gemm_set_impl: impl must be in [0,5]");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -465,10 +562,22 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   const bool k_ok = (a.K % BK == 0) || (a.trans_a && a.trans_b);
   const bool small = (size_t)(a.trans_a ? a.K : a.M) * a.lda * 2 < (1ull << 32) && (size_t)(a.trans_b ? a.K : a.N) * a.ldb * 2 < (1ull << 32);
   int impl = gemm_impl_override();
-  if (impl == 0) impl = (k_ok && small) ? 2 : 1;
+  if (impl == 0) {
+    // auto (measured on MI355X, tools/gemm_bench.py): with >= 1.5 tiles per CU the BK=32 geometry wins because a
+    // second resident workgroup hides prologue/epilogue; with fewer tiles the deeper BK=64 ring wins; below half a
+    // wave of 256-row tiles fall back to 128-row tiles to occupy more CUs.
+    const long long tiles256 = (long long)((a.M + 255) / 256) * (a.N / BN) * a.batch;
+    const long long tiles128 = (long long)((a.M + 127) / 128) * (a.N / BN) * a.batch;
+    if (!(k_ok && small)) impl = 1;
+    else if (tiles256 >= 384) impl = 5;
+    else if (tiles256 >= 128) impl = 3;
+    else impl = tiles128 >= 512 ? 4 : 2;
+  }
   if (impl != 1 && !(k_ok && small)) impl = 1;
-  if (impl == 3) launch_glds_any<256>(a, st);
-  else if (impl == 2) launch_glds_any<128>(a, st);
+  if (impl == 5) launch_glds_any<256, 32>(a, st);
+  else if (impl == 4) launch_glds_any<128, 32>(a, st);
+  else if (impl == 3) launch_glds_any<256, 64>(a, st);
+  else if (impl == 2) launch_glds_any<128, 64>(a, st);
   else if (!a.trans_a && !a.trans_b) launch<0, 0>(a, grid, st);
   else if (!a.trans_a && a.trans_b) launch<0, 1>(a, grid, st);
   else launch<1, 1>(a, grid, st);

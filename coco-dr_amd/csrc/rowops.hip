@@ -233,13 +233,23 @@ __global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_kernel(const uint16_t
   zero_row(dg);
   zero_row(db);
   zero_row(dp);
-  for (int b = wid; b < B; b += NW) {
+  const int b_per = (B + gridDim.y - 1) / gridDim.y;
+  const int b_end = min(B, (int)(blockIdx.y + 1) * b_per);
+  for (int b = blockIdx.y * b_per + wid; b < b_end; b += NW) {
     const int row = b * L + l;
     int id = ids[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     RowVec d, x;
     load_bf16_row(dout + (size_t)row * H, nch, lane, d);
     embed_gather(word, pos, type0, id, l, H, nch, lane, x);
+    // padded positions carry an exactly-zero upstream gradient (nothing attends to them): skipping them removes
+    // the thousands-way same-address contention on the [PAD] row, which serialises at the memory-side atomic unit
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(d.v[i][e]));
+    if (wave_max(amax) == 0.f) continue;
     ln_bwd_row(d, x, gamma, nch, lane, H, mean_i[row], rstd_i[row], dg, db);
     float* wrow = dword + (size_t)id * H;
 #pragma unroll
@@ -254,13 +264,21 @@ __global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_kernel(const uint16_t
       }
     }
   }
-  float* prow = partial + (size_t)l * 3 * H;
+  // partial rows: [split][l][3][H]; dpos / dtype0 / dgamma / dbeta are finished by reduce kernels
+  float* prow = partial + ((size_t)blockIdx.y * gridDim.x + l) * 3 * H;
   block_reduce_store(dg, red, prow, nch, tid);
   block_reduce_store(db, red, prow + H, nch, tid);
   block_reduce_store(dp, red, prow + 2 * H, nch, tid);
-  __syncthreads();
-  for (int c = tid; c < nch; c += RB_THREADS)
-    *reinterpret_cast<float4*>(dpos + (size_t)l * H + c * 4) = *reinterpret_cast<const float4*>(prow + 2 * H + c * 4);
+}
+
+// dpos[l][:] = sum over batch splits of the position partial rows
+__global__ __launch_bounds__(256) void embed_dpos_kernel(const float* __restrict__ partial, float* __restrict__ dpos, int L, int H, int S) {
+  const int l = blockIdx.x;
+  for (int h = threadIdx.x; h < H; h += 256) {
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += partial[((size_t)s * L + l) * 3 * H + 2 * H + h];
+    dpos[(size_t)l * H + h] = acc;
+  }
 }
 
 // out_s[z*stride_out + n] = sum_p partial[((z*P + p)*nseg + s)*n_len + n], s < nseg
@@ -379,7 +397,8 @@ extern "C" int cocodr_embed_ln_fwd(const int32_t* ids, const float* word, const 
   return COCODR_OK;
 }
 
-extern "C" size_t cocodr_embed_bwd_partial_floats(int L, int H) { return (size_t)L * 3 * H; }
+int embed_bwd_splits(int B) { return B >= 64 ? 8 : (B >= 16 ? 2 : 1); }
+extern "C" size_t cocodr_embed_bwd_partial_floats(int L, int H) { return (size_t)8 * L * 3 * H; }
 
 extern "C" int cocodr_embed_ln_bwd(const uint16_t* dout, const int32_t* ids, const float* word, const float* pos, const float* type0,
                                    const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
@@ -389,10 +408,13 @@ extern "C" int cocodr_embed_ln_bwd(const uint16_t* dout, const int32_t* ids, con
          "embed_ln_bwd: null pointer");
   CK_ARG(B > 0 && L > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_bwd: bad shape B=%d L=%d H=%d", B, L, H);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(L), dim3(RB_THREADS), 0, st, dout, ids, word, pos, type0, gamma, mean, rstd, dword, dpos,
+  const int S = embed_bwd_splits(B);
+  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(L, S), dim3(RB_THREADS), 0, st, dout, ids, word, pos, type0, gamma, mean, rstd, dword, dpos,
                      partial, B, L, H, vocab);
   CK_LAUNCH("embed_ln_bwd");
-  return launch_reduce(partial, dgamma, dbeta, dtype0, L, 3, H, 1, 0, st);
+  hipLaunchKernelGGL(embed_dpos_kernel, dim3(L), dim3(256), 0, st, partial, dpos, L, H, S);
+  CK_LAUNCH("embed_dpos");
+  return launch_reduce(partial, dgamma, dbeta, dtype0, L * S, 3, H, 1, 0, st);
 }
 
 extern "C" int cocodr_ln_fwd(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean, float* rstd,

@@ -72,8 +72,9 @@ typedef struct {
   long long strideA, strideB, strideC, strideR, strideBias; /* elements, per batch index */
 } cocodr_gemm_args;
 int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream);
-/* tuning / test hook: 0 = auto, 1 = register-staged pipeline, 2 = direct-to-LDS 128x128 tile,
- * 3 = direct-to-LDS 256x128 tile (also settable through the COCODR_GEMM_IMPL environment variable) */
+/* tuning / test hook: 0 = auto, 1 = register-staged pipeline,
+ * direct-to-LDS <BM,BK>: 2 = <128,64>, 3 = <256,64>, 4 = <128,32>, 5 = <256,32>
+ * (also settable through the COCODR_GEMM_IMPL environment variable) */
 int cocodr_gemm_set_impl(int impl);
 
 /* ------------------------------------------------------------------------------------------
