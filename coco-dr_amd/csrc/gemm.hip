@@ -330,7 +330,41 @@ __device__ __forceinline__ void mfma_step(const FragSet<TA>& fa, const FragSet<T
     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
 }
 
-template <int BMv, int BKv, int TA, int TB, bool OUT_F32>
+// one 8-column slice of an output row: bias / GELU / residual / GELU' and the store (shared by both epilogues)
+template <bool OUT_F32>
+__device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z, const float* __restrict__ bias,
+                                                const uint16_t* __restrict__ R_, int gm, int gn, float (&v)[8]) {
+  if (bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + gn);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (p.epi == COCODR_EPI_GELU) {
+    *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+  } else if (p.epi == COCODR_EPI_ADD) {
+    float r[8];
+    unpack8(*reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += r[j];
+  } else if (p.epi == COCODR_EPI_DGELU) {
+    float r[8];
+    unpack8(*reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(r[j]);
+  }
+  if (OUT_F32) {
+    float* C = reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
+    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
+    *reinterpret_cast<uint4*>(C) = pack8(v);
+  }
+}
+
+template <int BMv, int BKv, int TA, int TB, bool OUT_F32, bool DIRECT>
 __global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv / 64) * 128) / 256) void gemm_glds_kernel(
     const cocodr_gemm_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type only exists in the device pass; the host pass just needs the stub
@@ -413,11 +447,50 @@ __global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv
     mfma_step<TA, TB>(fa1, fb1, acc);
   }
   __syncthreads();
+  if (p.epi == 100) {  // measurement hook (COCODR_GEMM_SKIP_EPI): keep the accumulators live, store one value per lane
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[a][b][r];
+    if (sum == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = sum;
+    return;
+  }
+
+  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
+  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
+  if constexpr (DIRECT) {
+    // ---- register epilogue: no LDS round trip, no barriers, every wave drains on its own.
+    // A lane holds row m = lane & 31 and, per register group rg, the 4 columns 8*rg + 4*(lane>>5) + 0..3.
+    // v_permlane32_swap between groups rg and rg+1 gives the low half-wave columns 16*q + 0..7 and the high
+    // half-wave 16*q + 8..15 of that row: 8 consecutive columns per lane -> one 16-B (bf16) store per lane.
+    const int half = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int gm = m0 + wm * 64 + a * 32 + (lane & 31);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[a][b][(2 * q) * 4 + e]),
+                                                             __float_as_uint(acc[a][b][(2 * q + 1) * 4 + e]), false, false);
+            v[e] = __uint_as_float(sw[0]);
+            v[4 + e] = __uint_as_float(sw[1]);
+          }
+          const int gn = n0 + wn * 64 + b * 32 + 16 * q + 8 * half;
+          if (gm < p.M) epilogue_store8<OUT_F32>(p, z, bias, R_, gm, gn, v);
+        }
+    }
+    return;
+  }
 
   // ---- epilogue through an fp32 LDS tile, 64 rows at a time (same as v1)
   float* ct = reinterpret_cast<float*>(smem);
-  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
-  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
   constexpr int NT_ = G::NWAVES * 64;
 #pragma unroll 1
   for (int h = 0; h < BMv / 64; ++h) {
@@ -445,34 +518,7 @@ __global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv
         const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CT_LD + ((tid & 15) << 3));
         const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CT_LD + ((tid & 15) << 3) + 4);
         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-        if (bias) {
-          const float4 b0 = *reinterpret_cast<const float4*>(bias + gn);
-          const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (p.epi == COCODR_EPI_GELU) {
-          *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
-        } else if (p.epi == COCODR_EPI_ADD) {
-          float r[8];
-          unpack8(*reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += r[j];
-        } else if (p.epi == COCODR_EPI_DGELU) {
-          float r[8];
-          unpack8(*reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(r[j]);
-        }
-        if (OUT_F32) {
-          float* C = reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
-          *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
-          *reinterpret_cast<uint4*>(C) = pack8(v);
-        }
+        epilogue_store8<OUT_F32>(p, z, bias, R_, gm, gn, v);
       }
     }
     __syncthreads();
@@ -480,7 +526,7 @@ __global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv
 #endif
 }
 
-template <int BMv, int BKv, int TA, int TB>
+template <int BMv, int BKv, int TA, int TB, bool DIRECT>
 void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
   using G = Geom<BMv, BKv>;
   const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / BN;
@@ -488,21 +534,27 @@ void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, TA, TB, true, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, TA, TB, false, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, TA, TB, true>), grid, dim3(G::NWAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, TA, TB, true, DIRECT>), grid, dim3(G::NWAVES * 64), lds, st, a);
   else
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, TA, TB, false>), grid, dim3(G::NWAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, TA, TB, false, DIRECT>), grid, dim3(G::NWAVES * 64), lds, st, a);
 }
 
 template <int BMv, int BKv>
-void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
-  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, 0, 0>(a, st);
-  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, 0, 1>(a, st);
-  else launch_glds<BMv, BKv, 1, 1>(a, st);
+void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st, bool direct) {
+  if (direct) {
+    if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, 0, 0, true>(a, st);
+    else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, 0, 1, true>(a, st);
+    else launch_glds<BMv, BKv, 1, 1, true>(a, st);
+  } else {
+    if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, 0, 0, false>(a, st);
+    else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, 0, 1, false>(a, st);
+    else launch_glds<BMv, BKv, 1, 1, false>(a, st);
+  }
 }
 
 }  // namespace cocodr_gemm_v2
@@ -574,10 +626,18 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
     else impl = tiles128 >= 512 ? 4 : 2;
   }
   if (impl != 1 && !(k_ok && small)) impl = 1;
-  if (impl == 5) launch_glds_any<256, 32>(a, st);
-  else if (impl == 4) launch_glds_any<128, 32>(a, st);
-  else if (impl == 3) launch_glds_any<256, 64>(a, st);
-  else if (impl == 2) launch_glds_any<128, 64>(a, st);
+  {
+    static int skip = -1;
+    if (skip < 0) skip = getenv("COCODR_GEMM_SKIP_EPI") ? 1 : 0;
+    if (skip && impl != 1) a.epi = 100;
+  }
+  static int lds_epi = -1;  // COCODR_GEMM_EPI=lds selects the LDS-staged epilogue (A/B measurements)
+  if (lds_epi < 0) { const char* e = getenv("COCODR_GEMM_EPI"); lds_epi = (e && e[0] == 'l') ? 1 : 0; }
+  const bool direct = !lds_epi;
+  if (impl == 5) launch_glds_any<256, 32>(a, st, direct);
+  else if (impl == 4) launch_glds_any<128, 32>(a, st, direct);
+  else if (impl == 3) launch_glds_any<256, 64>(a, st, direct);
+  else if (impl == 2) launch_glds_any<128, 64>(a, st, direct);
   else if (!a.trans_a && !a.trans_b) launch<0, 0>(a, grid, st);
   else if (!a.trans_a && a.trans_b) launch<0, 1>(a, grid, st);
   else launch<1, 1>(a, grid, st);
