@@ -1,0 +1,189 @@
+"""Retrieval half of the hot path: corpus encoding, the reference's shard rule / merge order, sharded
+brute-force search, ranking metrics and hard-negative selection.
+
+Reference call sites mirrored here (paths under /root/reference):
+  * ``StreamingDataset.__iter__``            ANCE/utils/util.py:384-399      -> shard_indices
+  * ``barrier_array_merge``                  ANCE/utils/util.py:87-155       -> merged_order (rank-major)
+  * ``InferenceEmbeddingFromStreamDataLoader`` ANCE/drivers/run_ann_data_gen.py:157-212 -> encode_corpus
+  * ``faiss.IndexFlatIP(dim).add(P); .search(Q,k)`` evaluate/evaluation/evaluate_beir.py:220-224 -> search /
+    sharded_search (embeddings stay resident on the GPUs; only queries and per-shard top-k lists travel)
+  * ``EvalDevQuery``                         evaluate/evaluation/evaluate_beir.py:105-194 -> eval_dev_query
+  * ``GenerateNegativePassaageID``           ANCE/drivers/run_ann_data_gen.py:497-570 -> generate_negatives
+The per-query Python walks stay Python, as in the reference; the FLOPs (encode, score, top-k) are native.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+__all__ = ["shard_indices", "merged_order", "encode_corpus", "search", "sharded_search", "merge_topk", "eval_dev_query",
+           "generate_negatives", "ndcg_at_10", "mrr_at_10"]
+
+
+# ----------------------------------------------------------------------------------------------- sharding
+def shard_indices(n: int, rank: int, world: int) -> torch.Tensor:
+    """Record i belongs to rank i % world (ANCE/utils/util.py:390-392)."""
+    return torch.arange(rank, n, world, dtype=torch.int64)
+
+
+def merged_order(n: int, world: int) -> torch.Tensor:
+    """Original record index at every position of the rank-major merged array (ANCE/utils/util.py:117-154)."""
+    return torch.cat([shard_indices(n, r, world) for r in range(world)])
+
+
+# ----------------------------------------------------------------------------------------------- encode
+@torch.no_grad()
+def encode_corpus(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, batch_size: int = 512,
+                  record_ids: Optional[torch.Tensor] = None, is_query: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval-mode ``query_emb`` / ``body_emb`` over a token cache, fp32 [n,H] kept ON DEVICE plus the record ids -
+    the reference copies every batch to the host (``.cpu().numpy()``, run_ann_data_gen.py:191-199); here the shard
+    stays in HBM for the search that follows."""
+    n = input_ids.shape[0]
+    fn = model.query_emb if is_query else model.body_emb
+    outs = []
+    for s in range(0, n, batch_size):
+        outs.append(fn(input_ids[s:s + batch_size], attention_mask[s:s + batch_size]).float())
+    emb = torch.cat(outs) if outs else torch.empty((0, model.config.hidden_size), device=input_ids.device)
+    ids = torch.arange(n, dtype=torch.int64) if record_ids is None else record_ids
+    return emb, ids
+
+
+# ----------------------------------------------------------------------------------------------- search
+def search(Q: torch.Tensor, P: torch.Tensor, k: int, id_offset: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(D, I) = IndexFlatIP(P).search(Q, k) on one GPU."""
+    return ops.score_topk(Q.contiguous(), P.contiguous(), k, id_offset)
+
+
+def merge_topk(D: torch.Tensor, I: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge candidate lists [Nq, C] into the top k by (score descending, position ascending); -1 ids last."""
+    big = torch.iinfo(torch.int64).max
+    key_i = torch.where(I < 0, torch.full_like(I, big), I)
+    o1 = torch.argsort(key_i, dim=1, stable=True)
+    D1, I1 = torch.gather(D, 1, o1), torch.gather(I, 1, o1)
+    o2 = torch.argsort(D1, dim=1, descending=True, stable=True)[:, :k]
+    return torch.gather(D1, 1, o2), torch.gather(I1, 1, o2)
+
+
+def sharded_search(Q_local: torch.Tensor, P_local: torch.Tensor, k: int,
+                   local_search: Optional[Callable] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Search ALL queries against the corpus sharded over the ranks: all-gather the queries, search the
+    resident shard, all-gather the per-shard (score, position) lists, merge.  Positions are indices into the
+    rank-major merged corpus (what ``barrier_array_merge`` + ``IndexFlatIP`` would produce); map them through
+    ``merged_order`` / ``passage_embedding2id`` for record ids.  Every rank returns the full [Nq_total, k] result."""
+    import torch.distributed as dist
+    fn = local_search or search
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return fn(Q_local, P_local, k, 0)
+    W, r = dist.get_world_size(), dist.get_rank()
+    dev = Q_local.device
+    counts = torch.tensor([Q_local.shape[0], P_local.shape[0]], dtype=torch.int64, device=dev)
+    allc = [torch.empty_like(counts) for _ in range(W)]
+    dist.all_gather(allc, counts)
+    nq = [int(c[0]) for c in allc]
+    npass = [int(c[1]) for c in allc]
+    H = Q_local.shape[1]
+    qmax = max(nq)
+    qpad = torch.zeros((qmax, H), dtype=Q_local.dtype, device=dev)
+    qpad[:Q_local.shape[0]] = Q_local
+    qall = torch.empty((W * qmax, H), dtype=Q_local.dtype, device=dev)
+    dist.all_gather_into_tensor(qall, qpad)
+    Q = torch.cat([qall[i * qmax:i * qmax + nq[i]] for i in range(W)])
+    offset = sum(npass[:r])
+    D, I = fn(Q, P_local, k, offset)
+    Dall = torch.empty((W,) + tuple(D.shape), dtype=D.dtype, device=dev)
+    Iall = torch.empty((W,) + tuple(I.shape), dtype=I.dtype, device=dev)
+    dist.all_gather_into_tensor(Dall.view(-1, D.shape[1]), D.contiguous())
+    dist.all_gather_into_tensor(Iall.view(-1, I.shape[1]), I.contiguous())
+    Dc = Dall.permute(1, 0, 2).reshape(D.shape[0], -1)
+    Ic = Iall.permute(1, 0, 2).reshape(I.shape[0], -1)
+    return merge_topk(Dc, Ic, k)
+
+
+# ----------------------------------------------------------------------------------------------- metrics
+def ndcg_at_10(ranked: Sequence[int], qrel: Dict[int, int]) -> float:
+    """trec_eval ``ndcg_cut_10`` (gain = rel, discount 1/log2(rank+1), ideal = judged docs by rel)."""
+    gains = np.array([max(qrel.get(int(p), 0), 0) for p in ranked[:10]], dtype=np.float64)
+    disc = 1.0 / np.log2(np.arange(2, gains.size + 2))
+    ideal = np.sort(np.array([v for v in qrel.values() if v > 0], dtype=np.float64))[::-1][:10]
+    idcg = float((ideal / np.log2(np.arange(2, ideal.size + 2))).sum())
+    return float((gains * disc).sum() / idcg) if idcg > 0 else 0.0
+
+
+def mrr_at_10(qids_to_relevant: Dict[int, List[int]], qids_to_ranked: Dict[int, List[int]]) -> float:
+    """MS MARCO MRR@10 (evaluate/evaluation/msmarco_eval.py:109-139)."""
+    if not qids_to_ranked:
+        return 0.0
+    acc = 0.0
+    for qid, cand in qids_to_ranked.items():
+        rel = qids_to_relevant.get(qid)
+        if rel is None:
+            continue
+        hits = [i for i, pid in enumerate(cand[:10]) if pid in rel]
+        if hits:
+            acc += 1.0 / (hits[0] + 1)
+    return acc / len(qids_to_ranked)
+
+
+def eval_dev_query(query_embedding2id, passage_embedding2id, dev_query_positive_id: Dict[int, Dict[int, int]],
+                   I_nearest_neighbor, topN: int, offset2qchar: Optional[dict] = None, offset2pchar: Optional[dict] = None):
+    """``EvalDevQuery`` (evaluate/evaluation/evaluate_beir.py:105-194): positions -> pids, de-duplicate, score = -rank,
+    skip the ArguAna self match after the rank advanced; nDCG@10 and reciprocal rank averaged over the queries that
+    have qrels.  Returns (ndcg@10, mrr, n_queries, prediction)."""
+    I = np.asarray(I_nearest_neighbor.cpu() if isinstance(I_nearest_neighbor, torch.Tensor) else I_nearest_neighbor)
+    q2id = np.asarray(query_embedding2id)
+    p2id = np.asarray(passage_embedding2id)
+    prediction: Dict[int, Dict[int, int]] = {}
+    nd = rr = 0.0
+    n = 0
+    for qi in range(I.shape[0]):
+        qid = int(q2id[qi])
+        pos = I[qi, :topN]
+        pids = p2id[pos[pos >= 0]]
+        _, first = np.unique(pids, return_index=True)
+        uniq = pids[np.sort(first)]  # first occurrence order
+        docs: Dict[int, int] = {}
+        for rank, pid in enumerate(uniq.tolist(), start=1):
+            if offset2qchar and offset2pchar and qid in offset2qchar and pid in offset2pchar and \
+                    offset2pchar[pid] == offset2qchar[qid]:
+                continue
+            docs[pid] = -rank
+        prediction[qid] = docs
+        qrel = dev_query_positive_id.get(qid)
+        if qrel is None:
+            continue
+        ranked = list(docs.keys())  # insertion order == descending score
+        nd += ndcg_at_10(ranked, qrel)
+        hit = [i for i, pid in enumerate(ranked) if qrel.get(pid, 0) > 0]
+        rr += 1.0 / (hit[0] + 1) if hit else 0.0
+        n += 1
+    return (nd / n if n else 0.0), (rr / n if n else 0.0), n, prediction
+
+
+def generate_negatives(query_embedding2id, passage_embedding2id, training_query_positive_id: Dict[int, int],
+                       I_nearest_neighbor, negative_sample: int, effective_q_id: Optional[Iterable[int]] = None):
+    """``GenerateNegativePassaageID`` with ``--ann_measure_topk_mrr`` (run_ann_data_gen.py:497-570): the first
+    ``negative_sample + 1`` retrieved passages minus the positive minus duplicates, at most ``negative_sample``;
+    plus the reciprocal rank of the positive over the whole retrieved list."""
+    I = np.asarray(I_nearest_neighbor.cpu() if isinstance(I_nearest_neighbor, torch.Tensor) else I_nearest_neighbor)
+    q2id = np.asarray(query_embedding2id)
+    p2id = np.asarray(passage_embedding2id)
+    eff = None if effective_q_id is None else {int(x) for x in effective_q_id}
+    negatives: Dict[int, List[int]] = {}
+    rr: List[float] = []
+    for qi in range(I.shape[0]):
+        qid = int(q2id[qi])
+        if eff is not None and qid not in eff:
+            continue
+        pos = training_query_positive_id[qid]
+        pids = p2id[I[qi]]
+        where = np.nonzero(pids == pos)[0]
+        rr.append(1.0 / (int(where[0]) + 1) if where.size else 0.0)
+        window = pids[:negative_sample + 1]
+        window = window[window != pos]
+        _, first = np.unique(window, return_index=True)
+        negatives[qid] = window[np.sort(first)][:negative_sample].tolist()
+    return negatives, np.array(rr)
