@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dp-chunks", type=int, default=2, help="layer ranges whose gradient all-reduce overlaps the backward")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -109,7 +110,8 @@ def main():
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("COCODR_FORCE_DIST"))  # FORCE: exercise the N>1 path on one GPU
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -117,6 +119,8 @@ def main():
     torch.manual_seed(0)  # identical random-init weights on every rank
     bert = CocoBertModel(cfg).to(dev)
     model = CoCondenserForPretraining(bert)
+    if use_dist:
+        bert.enable_grad_allreduce(chunks=args.dp_chunks)  # averaged inside the backward, overlapped with it
     opt = torch.optim.AdamW(bert.param_groups(weight_decay=0.01), lr=1e-4, fused=True)
     total = args.steps + args.warmup
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / max(1, int(0.1 * total))))
@@ -126,17 +130,14 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         loss = model(batch, None)
-        loss.backward()
-        if world > 1:  # two large fp32 buckets, averaged (what DDP does, without its bucketing overhead)
-            for p in (bert.flat_decay, bert.flat_nodecay):
-                dist.all_reduce(p.grad, op=dist.ReduceOp.AVG)
+        loss.backward()  # with N > 1 the gradient all-reduce is issued chunk by chunk inside this call
         opt.step()
         sched.step()
         return loss
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -161,7 +162,7 @@ def main():
                     "launches_per_step": n_launch // max(1, args.steps),
                     "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                     "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3)}
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
@@ -188,7 +189,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

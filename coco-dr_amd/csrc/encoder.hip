@@ -160,13 +160,15 @@ extern "C" int cocodr_encoder_fwd(const cocodr_config* c, const cocodr_embed_par
   return COCODR_OK;
 }
 
-extern "C" int cocodr_encoder_bwd(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
-                                  const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const int32_t* ids,
-                                  const int32_t* mask, const uint16_t* d_last, int B, int L, void* arena, size_t arena_bytes,
-                                  cocodr_stream_t stream) {
+extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
+                                        const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const int32_t* ids,
+                                        const int32_t* mask, const uint16_t* d_in, int B, int L, void* arena,
+                                        size_t arena_bytes, int layer_hi, int layer_lo, int do_embed, cocodr_stream_t stream) {
   cocodr_encoder_layout_t lay;
   TRY(cocodr_encoder_layout(c, B, L, 1, &lay));
-  CK_ARG(emb && lp && eg && lg && ids && mask && d_last && arena, "encoder_bwd: null pointer");
+  CK_ARG(emb && lp && eg && lg && ids && mask && arena, "encoder_bwd: null pointer");
+  CK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= c->layers, "encoder_bwd: bad layer range [%d,%d)", layer_lo, layer_hi);
+  CK_ARG(d_in != nullptr || layer_hi < c->layers, "encoder_bwd: the first (top) range needs the upstream gradient d_in");
   CK_ARG(L <= 256, "encoder_bwd: L=%d > 256 is not supported by the attention backward yet", L);
   if (arena_bytes < lay.total_bytes) {
     cocodr_set_error("encoder_bwd: arena %zu B < required %zu B (was the forward run with training=1?)", arena_bytes, lay.total_bytes);
@@ -200,8 +202,10 @@ extern "C" int cocodr_encoder_bwd(const cocodr_config* c, const cocodr_embed_par
   float* cs_partial = (float*)(bb + bl.colsum_partial);
   float* emb_partial = (float*)(bb + bl.emb_partial);
 
-  const uint16_t* dx = d_last;
-  for (int l = NL - 1; l >= 0; --l) {
+  // a continuation range (d_in == NULL) picks up the gradient the previous range left in the arena
+  const uint16_t* dx = d_in ? d_in : dxb;
+  const int NG = layer_hi - layer_lo;  // layers in this range
+  for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const cocodr_layer_params& w = lp[l];
     const cocodr_layer_grads& gr = lg[l];
     const size_t lo = (size_t)l;
@@ -236,28 +240,42 @@ extern "C" int cocodr_encoder_bwd(const cocodr_config* c, const cocodr_embed_par
     TRY(cocodr_gemm(&g, stream));
     dx = dxb;
   }
-  TRY(cocodr_embed_ln_bwd(dx, ids, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
-                          (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial, B, L,
-                          H, c->vocab, stream));
+  if (do_embed) {
+    CK_ARG(layer_lo == 0, "encoder_bwd: the embedding backward belongs to the range that ends at layer 0");
+    TRY(cocodr_embed_ln_bwd(dx, ids, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
+                            (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial, B,
+                            L, H, c->vocab, stream));
+  }
+  if (NG == 0) return COCODR_OK;
 
-  // ---- grouped weight gradients: one batched TN launch per matrix, batch = layer
+  // ---- grouped weight gradients of this range: one batched TN launch per matrix, batch = layer
   const long long sMH = (long long)M * H, sMI = (long long)M * I, sM3H = (long long)M * 3 * H;
-  cocodr_gemm_args g = gemm_base(dqkv_all, hidden, lg[0].wqkv, 3 * H, H, M, 3 * H, H, H, 1, 1);
-  g.out_f32 = 1; g.batch = NL; g.strideA = sM3H; g.strideB = sMH; g.strideC = s_wqkv;
+  const size_t l0 = (size_t)layer_lo;
+  const cocodr_layer_grads& g0 = lg[layer_lo];
+  cocodr_gemm_args g = gemm_base(dqkv_all + l0 * sM3H, hidden + l0 * sMH, g0.wqkv, 3 * H, H, M, 3 * H, H, H, 1, 1);
+  g.out_f32 = 1; g.batch = NG; g.strideA = sM3H; g.strideB = sMH; g.strideC = s_wqkv;
   TRY(cocodr_gemm(&g, stream));
-  g = gemm_base(dy1_all, base + lay.ctx, lg[0].wo, H, H, M, H, H, H, 1, 1);
-  g.out_f32 = 1; g.batch = NL; g.strideA = sMH; g.strideB = sMH; g.strideC = s_wo;
+  g = gemm_base(dy1_all + l0 * sMH, (const uint16_t*)(base + lay.ctx) + l0 * sMH, g0.wo, H, H, M, H, H, H, 1, 1);
+  g.out_f32 = 1; g.batch = NG; g.strideA = sMH; g.strideB = sMH; g.strideC = s_wo;
   TRY(cocodr_gemm(&g, stream));
-  g = gemm_base(du_all, base + lay.x1, lg[0].w1, I, H, M, I, H, H, 1, 1);
-  g.out_f32 = 1; g.batch = NL; g.strideA = sMI; g.strideB = sMH; g.strideC = s_w1;
+  g = gemm_base(du_all + l0 * sMI, (const uint16_t*)(base + lay.x1) + l0 * sMH, g0.w1, I, H, M, I, H, H, 1, 1);
+  g.out_f32 = 1; g.batch = NG; g.strideA = sMI; g.strideB = sMH; g.strideC = s_w1;
   TRY(cocodr_gemm(&g, stream));
-  g = gemm_base(dy2_all, base + lay.h, lg[0].w2, H, I, M, H, I, I, 1, 1);
-  g.out_f32 = 1; g.batch = NL; g.strideA = sMH; g.strideB = sMI; g.strideC = s_w2;
+  g = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
+  g.out_f32 = 1; g.batch = NG; g.strideA = sMH; g.strideB = sMI; g.strideC = s_w2;
   TRY(cocodr_gemm(&g, stream));
   // ---- bias gradients: batched column sums of the saved dY
-  TRY(cocodr_colsum(dqkv_all, lg[0].bqkv, cs_partial, M, 3 * H, 3 * H, NL, sM3H, s_bqkv, stream));
-  TRY(cocodr_colsum(dy1_all, lg[0].bo, cs_partial, M, H, H, NL, sMH, s_bo, stream));
-  TRY(cocodr_colsum(du_all, lg[0].b1, cs_partial, M, I, I, NL, sMI, s_b1, stream));
-  TRY(cocodr_colsum(dy2_all, lg[0].b2, cs_partial, M, H, H, NL, sMH, s_b2, stream));
+  TRY(cocodr_colsum(dqkv_all + l0 * sM3H, g0.bqkv, cs_partial, M, 3 * H, 3 * H, NG, sM3H, s_bqkv, stream));
+  TRY(cocodr_colsum(dy1_all + l0 * sMH, g0.bo, cs_partial, M, H, H, NG, sMH, s_bo, stream));
+  TRY(cocodr_colsum(du_all + l0 * sMI, g0.b1, cs_partial, M, I, I, NG, sMI, s_b1, stream));
+  TRY(cocodr_colsum(dy2_all + l0 * sMH, g0.b2, cs_partial, M, H, H, NG, sMH, s_b2, stream));
   return COCODR_OK;
+}
+
+extern "C" int cocodr_encoder_bwd(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
+                                  const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const int32_t* ids,
+                                  const int32_t* mask, const uint16_t* d_last, int B, int L, void* arena, size_t arena_bytes,
+                                  cocodr_stream_t stream) {
+  CK_ARG(c && d_last, "encoder_bwd: null pointer");
+  return cocodr_encoder_bwd_range(c, emb, lp, eg, lg, ids, mask, d_last, B, L, arena, arena_bytes, c->layers, 0, 1, stream);
 }

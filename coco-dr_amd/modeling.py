@@ -411,16 +411,48 @@ class CocoBertModel(nn.Module):
                                        arena.numel(), stream_ptr()), "encoder_fwd")
         return arena, lay
 
+    def enable_grad_allreduce(self, group=None, chunks: int = 4) -> None:
+        """Data-parallel gradient averaging folded into the backward: the layer stack is walked in ``chunks`` ranges
+        (top-down); as soon as a range's kernels are enqueued its slice of the two flat gradient tensors is
+        all-reduced asynchronously (RCCL over xGMI, on the process group's stream) while the next range computes.
+        Replaces DDP's bucketing (ANCE/drivers/run_ann.py:177-184, HF Trainer for COCO) for this model."""
+        self._dp_group = group
+        self._dp_chunks = max(1, int(chunks))
+        self._dp_enabled = True
+
     def _run_backward(self, ids, mask, d_last16, arena):
         B, L = ids.shape
         lo = self.layout
+        NL = self.config.num_hidden_layers
         gd = torch.empty_like(self.flat_decay.data)
         gn = torch.empty_like(self.flat_nodecay.data)
         gd[:lo.mat_begin].zero_()  # embedding tables: sparse word rows are accumulated, unused position rows stay zero
         emb, arr, eg, garr = self._param_structs((gd, gn))
         cfg = self._c_config()
-        check(lib().cocodr_encoder_bwd(C.byref(cfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d_last16), B, L,
-                                       ptr(arena), arena.numel(), stream_ptr()), "encoder_bwd")
+        dp = getattr(self, "_dp_enabled", False)
+        if not dp:
+            check(lib().cocodr_encoder_bwd(C.byref(cfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d_last16),
+                                           B, L, ptr(arena), arena.numel(), stream_ptr()), "encoder_bwd")
+            return gd, gn
+        import torch.distributed as dist
+        nchunk = min(self._dp_chunks, NL)
+        bounds = [round(i * NL / nchunk) for i in range(nchunk + 1)]  # layer boundaries, ascending
+        works = []
+        for ci in reversed(range(nchunk)):
+            l_lo, l_hi = bounds[ci], bounds[ci + 1]
+            top = l_hi == NL
+            check(lib().cocodr_encoder_bwd_range(C.byref(cfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask),
+                                                 ptr(d_last16) if top else None, B, L, ptr(arena), arena.numel(), l_hi, l_lo,
+                                                 int(l_lo == 0), stream_ptr()), "encoder_bwd_range")
+            # this range's gradients: [l_lo, l_hi) layer blocks of both flats (+ the embedding blocks with the last range)
+            d0 = lo.mat_begin + l_lo * lo.mat_stride if l_lo > 0 else 0
+            d1 = lo.mat_begin + l_hi * lo.mat_stride
+            n0 = lo.vec_begin + l_lo * lo.vec_stride if l_lo > 0 else 0
+            n1 = lo.vec_begin + l_hi * lo.vec_stride
+            for t in (gd[d0:d1], gn[n0:n1]):
+                works.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self._dp_group, async_op=True))
+        for w in works:
+            w.wait()  # stream-level: the current stream waits for the collectives, the host does not
         return gd, gn
 
     # ---------------------------------------------------------------- public forward
@@ -602,7 +634,9 @@ class CoCondenserForPretraining(nn.Module):
         ids, mask = model_input["input_ids"], model_input.get("attention_mask")
         cls = self.lm.encode_cls(ids, mask)  # [2b, H] fp32
         W = self._world_size()
-        if W > 1:
+        import os
+        force = bool(os.environ.get("COCODR_FORCE_DIST")) and torch.distributed.is_initialized()  # 1-rank test of the N>1 path
+        if W > 1 or force:
             import torch.distributed as dist
             E = _GatherRows.apply(cls)
             row0 = dist.get_rank() * cls.shape[0]

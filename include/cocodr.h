@@ -206,6 +206,17 @@ int cocodr_encoder_bwd(const cocodr_config* cfg, const cocodr_embed_params* emb,
                        const uint16_t* d_last, int B, int L, void* arena, size_t arena_bytes,
                        cocodr_stream_t stream);
 
+/* Same backward, restricted to the layers [layer_lo, layer_hi) (walked top-down) plus - when do_embed != 0 and
+ * layer_lo == 0 - the embedding backward.  The top range (layer_hi == layers) takes d_in = dL/d(hidden_states[-1]);
+ * continuation ranges pass d_in = NULL and pick up the gradient the previous range left in the arena.  The weight /
+ * bias gradients of the range are complete when the call returns (enqueued), so a data-parallel host can start
+ * all-reducing them while the next range runs (gradient layout: layer blocks at a uniform stride, see above). */
+int cocodr_encoder_bwd_range(const cocodr_config* cfg, const cocodr_embed_params* emb,
+                             const cocodr_layer_params* layers_host, const cocodr_embed_grads* emb_grads,
+                             const cocodr_layer_grads* grads_host, const int32_t* ids, const int32_t* mask,
+                             const uint16_t* d_in, int B, int L, void* arena, size_t arena_bytes, int layer_hi,
+                             int layer_lo, int do_embed, cocodr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py roofline): bracket every launch of one kernel class with HIP events
  * on the launch stream.  kind: 0 = off, 1 = GEMM launches, 2 = attention, 3 = score_topk GEMM.

@@ -201,3 +201,38 @@ def test_full_size_config2_step_properties():
     # linearity: doubling the loss doubles every gradient up to bf16 rounding of the upstream gradient
     ratio_d = float((runs[2][1][lo.mat_begin:] - 2 * gd0[lo.mat_begin:]).norm() / (2 * gd0[lo.mat_begin:]).norm())
     assert ratio_d < 2e-2, ratio_d
+
+
+def test_chunked_backward_with_overlapped_allreduce_matches_single_call():
+    """The data-parallel path: backward walked in layer ranges with an async RCCL all-reduce per range (1-rank
+    group here, so AVG is the identity) must give bit-identical gradients to the single-call backward."""
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        cfg = CocoBertConfig(vocab_size=2000, hidden_size=256, num_hidden_layers=6, num_attention_heads=4,
+                             intermediate_size=512, max_position_embeddings=128)
+        torch.manual_seed(3)
+        m = CocoBertModel(cfg).to(DEV)
+        model = CoCondenserForPretraining(m)
+        ids = torch.randint(5, 2000, (8, 64), device=DEV)
+        mask = torch.ones_like(ids)
+        mask[2, 30:] = 0
+        grads = []
+        for chunks in (0, 1, 4, 6):
+            m.zero_grad(set_to_none=True)
+            m._dp_enabled = False
+            if chunks:
+                m.enable_grad_allreduce(chunks=chunks)
+            model({"input_ids": ids, "attention_mask": mask}, None).backward()
+            grads.append((m.flat_decay.grad.clone(), m.flat_nodecay.grad.clone()))
+        lo = m.layout
+        for gd, gn in grads[1:]:
+            assert torch.equal(gd[lo.mat_begin:], grads[0][0][lo.mat_begin:]) and torch.equal(gn, grads[0][1])
+            assert torch.allclose(gd[:lo.mat_begin], grads[0][0][:lo.mat_begin], rtol=1e-5, atol=1e-7)  # atomics order
+    finally:
+        if created:
+            dist.destroy_process_group()
