@@ -121,7 +121,8 @@ def main():
     model = CoCondenserForPretraining(bert)
     if use_dist:
         bert.enable_grad_allreduce(chunks=args.dp_chunks)  # averaged inside the backward, overlapped with it
-    opt = torch.optim.AdamW(bert.param_groups(weight_decay=0.01), lr=1e-4, fused=True)
+    from cocodr_amd.optim import FlatAdamW
+    opt = FlatAdamW.for_model(bert, lr=1e-4, weight_decay=0.01)  # torch.optim.AdamW semantics, one native pass per flat
     total = args.steps + args.warmup
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / max(1, int(0.1 * total))))
     ids, mask = synth_batch(rank, args.seq_per_gpu, args.seq_len, cfg.vocab_size, dev)
@@ -156,9 +157,15 @@ def main():
         n_launch, gemm_ms, gemm_flops = ops.prof_end()
         if n_launch and gemm_ms > 0:
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+            traffic = None  # HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01c_*.md)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")) as f:
+                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
+            except Exception:
+                pass
             roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": "gemm_kernel (bf16 MFMA 32x32x16, all NT/NN/TN launches)",
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "kernel": "gemm_glds_kernel (bf16 MFMA 32x32x16, all NT/NN/TN launches)",
                     "launches_per_step": n_launch // max(1, args.steps),
                     "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                     "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3)}

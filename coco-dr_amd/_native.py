@@ -70,6 +70,8 @@ SIGNATURES = {
     "cocodr_colsum_partial_floats": (c_size_t, [c_int, c_int, c_int]),
     "cocodr_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
     "cocodr_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cocodr_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_float, c_float,
+                                  c_float, c_float, c_int, c_float, c_void_p]),
     "cocodr_scatter_cls_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cocodr_simce_workspace_floats": (c_size_t, [c_int]),
     "cocodr_simce_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -473,3 +473,56 @@ extern "C" int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B,
   CK_LAUNCH("scatter_cls_grad");
   return COCODR_OK;
 }
+
+// ------------------------------------------------------------------ fused AdamW over a flat parameter
+// torch.optim.AdamW semantics (decoupled weight decay, bias correction, eps outside the sqrt of the corrected
+// second moment), one pass over p / g / m / v (16 B-per-lane vectors) that also refreshes the bf16 shadow of
+// the weight matrices, so the separate fp32->bf16 cast pass disappears from the step.
+namespace {
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, uint16_t* __restrict__ shadow, size_t shadow_begin,
+                                                    size_t n4, float lr, float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, float grad_scale) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float pa[4] = {pv.x, pv.y, pv.z, pv.w};
+    const float ga[4] = {gv.x * grad_scale, gv.y * grad_scale, gv.z * grad_scale, gv.w * grad_scale};
+    float ma[4] = {mv.x, mv.y, mv.z, mv.w};
+    float va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pa[e] *= (1.0f - lr * wd);
+      ma[e] = beta1 * ma[e] + (1.0f - beta1) * ga[e];
+      va[e] = beta2 * va[e] + (1.0f - beta2) * ga[e] * ga[e];
+      const float denom = sqrtf(va[e]) / bc2_sqrt + eps;
+      pa[e] -= (lr / bc1) * (ma[e] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
+    if (shadow && i * 4 >= shadow_begin) *reinterpret_cast<uint2*>(shadow + (i * 4 - shadow_begin)) = pack4(pa);
+  }
+}
+}  // namespace
+
+extern "C" int cocodr_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin, size_t n,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                 cocodr_stream_t stream) {
+  CK_ARG(p && g && m && v, "adamw_step: null pointer");
+  CK_ARG(n % 4 == 0 && shadow_begin % 4 == 0, "adamw_step: n and shadow_begin must be multiples of 4");
+  CK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)shadow) & 7) == 0,
+         "adamw_step: pointers must be 16-byte aligned");
+  CK_ARG(step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adamw_step: bad hyper-parameters");
+  if (n == 0) return COCODR_OK;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = sqrtf(1.0f - powf(beta2, (float)step));
+  const size_t n4 = n / 4;
+  const int grid = (int)std::min((size_t)4096, (n4 + 255) / 256);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, shadow_begin, n4, lr, beta1,
+                     beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  CK_LAUNCH("adamw_step");
+  return COCODR_OK;
+}

@@ -354,12 +354,16 @@ class CocoBertModel(nn.Module):
         return N.Config(c.hidden_size, c.num_attention_heads, c.num_hidden_layers, c.intermediate_size, c.vocab_size,
                         c.max_position_embeddings, c.layer_norm_eps)
 
-    def _refresh_shadow(self):
+    def _ensure_shadow(self):
         lo = self.layout
         n = lo.decay_numel - lo.mat_begin
         if self._shadow is None or self._shadow.device != self.flat_decay.device:
             self._shadow = torch.empty(n, dtype=torch.bfloat16, device=self.flat_decay.device)
             self._shadow_version = -1
+
+    def _refresh_shadow(self):
+        lo = self.layout
+        self._ensure_shadow()
         if self._shadow_version != self.flat_decay._version:
             ops.cast_f32_bf16(self.flat_decay.data[lo.mat_begin:], self._shadow)
             self._shadow_version = self.flat_decay._version

@@ -121,6 +121,14 @@ int cocodr_cast_f32_bf16(const float* src, uint16_t* dst, size_t n, cocodr_strea
 /* d_last[b*L + 0, :] = bf16(dE[b, :]), all other rows zero (gradient enters at [CLS] only) */
 int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int H, cocodr_stream_t stream);
 
+/* Fused AdamW over one flat fp32 parameter (torch.optim.AdamW semantics; the reference steps AdamW through the HF
+ * Trainer, COCO/trainer.py:66-70, or its own loop, ANCE/drivers/run_ann.py:345-356).  g is multiplied by grad_scale
+ * first.  When shadow != NULL the updated values of elements [shadow_begin, n) are also written as bf16 to
+ * shadow[0 .. n - shadow_begin) - the weight-matrix shadow the GEMMs read - in the same pass. */
+int cocodr_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin, size_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                      cocodr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Losses
  * simce: COCO/modeling.py:244-248 compute_contrastive_loss + :172-177 co_target + the `.mean()`

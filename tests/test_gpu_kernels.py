@@ -204,3 +204,28 @@ def test_colsum_and_cast():
     dE = rnd(4, 768, seed=32, dtype=torch.float32)
     d_last = ops.scatter_cls_grad(dE, 32)
     assert torch.equal(d_last[::32], dE.to(torch.bfloat16)) and float(d_last.float().abs().sum()) == float(d_last[::32].float().abs().sum())
+
+
+def test_flat_adamw_matches_torch_adamw_and_updates_shadow():
+    from cocodr_amd.modeling import CocoBertConfig, CocoBertModel
+    from cocodr_amd.optim import FlatAdamW
+    cfg = CocoBertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=64)
+    torch.manual_seed(0)
+    m = CocoBertModel(cfg).to(DEV)
+    ref = [p.detach().clone().requires_grad_(True) for p in (m.flat_decay, m.flat_nodecay)]
+    opt = FlatAdamW.for_model(m, lr=3e-3, weight_decay=0.01)
+    ropt = torch.optim.AdamW([{"params": [ref[0]], "weight_decay": 0.01}, {"params": [ref[1]], "weight_decay": 0.0}], lr=3e-3)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for step in range(4):
+        for p, r in zip((m.flat_decay, m.flat_nodecay), ref):
+            grad = (torch.randn(p.shape, generator=g) * 0.1).to(DEV)
+            p.grad = grad.clone()
+            r.grad = grad.clone()
+        opt.step()
+        ropt.step()
+    for p, r in zip((m.flat_decay, m.flat_nodecay), ref):
+        assert torch.allclose(p, r, rtol=1e-5, atol=1e-7), float((p - r).abs().max())  # fp32 op-order differences only
+    lo = m.layout
+    assert torch.equal(m._shadow, m.flat_decay.data[lo.mat_begin:].to(torch.bfloat16))
+    assert m._shadow_version == m.flat_decay._version
