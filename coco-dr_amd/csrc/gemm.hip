@@ -200,10 +200,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const cocodr_gemm_args p) 
 // Out-of-range rows come back as zeros through the buffer descriptor's bounds check (one descriptor
 // per batch item), which is what makes ragged token counts legal in the contraction dimension.
 //
-// Geometry <BM, BK>: tile BM x 128 x BK, (BM/64) x 2 waves, each wave 64x64 = 2x2 MFMA 32x32x16.
-//   <256,64>: 8 waves, 144 KiB LDS, 1 workgroup / CU      <256,32>: 8 waves, 72 KiB, 2 workgroups / CU
-//   <128,64>: 4 waves,  96 KiB LDS, 1 workgroup / CU      <128,32>: 4 waves, 48 KiB, 3 workgroups / CU
-// With >= 2 workgroups per CU one workgroup's prologue / epilogue overlaps the other's MFMA loop.
+// Geometry <BM, BK, WTM>: workgroup tile BM x 128 x BK; a wave owns (32*WTM) x 64 outputs = WTM x 2 MFMA
+// 32x32x16 tiles, so the workgroup has (BM / (32*WTM)) x 2 waves.
+//   <256,64,2>: 8 waves, 144 KiB LDS, 1 workgroup / CU     <256,32,2>: 8 waves, 72 KiB, 2 workgroups / CU
+//   <128,64,2>: 4 waves,  96 KiB LDS, 1 workgroup / CU     <128,32,2>: 4 waves, 48 KiB, 3 workgroups / CU
+//   <256,32,4>: 4 waves of 128x64 (6 LDS fragment reads per 8 MFMAs instead of 4 per 4), 72 KiB, 2 / CU
+// With >= 2 workgroups per CU one workgroup's prologue / epilogue / LDS phase overlaps the other's MFMAs.
 //
 // LDS fragment reads are issued from inline asm: hipcc drains every in-flight LDS-DMA
 // (s_waitcnt vmcnt(0)) in front of a ds_read_b64_tr_b16 it can see, which serialises the ring for the
@@ -238,8 +240,7 @@ __device__ __forceinline__ void asm_ds_read_tr16(v2i& dst, uint32_t addr) {
 // L2-aware tile order (each XCD has a private 4 MiB L2 and receives a contiguous range of tile ids, see
 // xcd_remap): ids walk GM row-panels down, then across the columns, so any ~32 consecutive ids (= the tiles an
 // XCD's CUs hold at once) form a GM x (32/GM) rectangle whose A and B panels fit the L2 together; the next
-// rectangle reuses the same A panels.  Without it every XCD re-streams the whole weight matrix from the
-// memory side once per row panel (measured: 2.6x the compulsory fabric reads on the 8192x3072x768 GEMM).
+// rectangle reuses the same A panels.
 __device__ __forceinline__ void grouped_tile(int id, int ntm, int ntn, int gm, int& tm, int& tn) {
   const int per_group = gm * ntn;
   const int grp = id / per_group;
@@ -250,9 +251,10 @@ __device__ __forceinline__ void grouped_tile(int id, int ntm, int ntn, int gm, i
   tn = r / rows;
 }
 
-template <int BMv, int BKv>
+template <int BMv, int BKv, int WTM>
 struct Geom {
-  static constexpr int NWAVES = (BMv / 64) * 2;
+  static constexpr int NWAVES = (BMv / (32 * WTM)) * 2;
+  static constexpr int NTHREADS = NWAVES * 64;
   static constexpr int A_BYTES = BMv * BKv * 2;
   static constexpr int B_BYTES = 128 * BKv * 2;
   static constexpr int STAGE = A_BYTES + B_BYTES;
@@ -261,6 +263,7 @@ struct Geom {
   static constexpr int NSTAGE = 3;
   static constexpr int KS = BKv / 16;  // MFMA K-sub-steps per stage
   static constexpr int WG_PER_CU = (160 * 1024) / (NSTAGE * STAGE);
+  static constexpr int MIN_WAVES_PER_SIMD = (WG_PER_CU * NWAVES + 3) / 4;
 };
 
 // chunk swizzle of a row-major [rows][BK] tile (16-B chunks): conflict-free ds_read_b128 fragment reads
@@ -287,15 +290,15 @@ __device__ __forceinline__ uint32_t glds_src_off(int p, int r0, int ld) {
   }
 }
 
-template <int TR>
-struct FragSet {  // the two 32-row fragments (a = 0, 1) of one operand for one K-sub-step
-  v4i q[2];
-  v2i lo[2], hi[2];
+template <int TR, int NF>
+struct FragSet {  // the NF 32-row fragments of one operand for one K-sub-step
+  v4i q[NF];
+  v2i lo[NF], hi[NF];
 };
 
 // per-lane LDS byte offsets inside an operand tile: TR=0 -> one per K-sub-step (fragment a adds 32 rows),
 // TR=1 -> one per fragment a (sub-step s and the +4-row half are immediates)
-template <int TR, int COLS, int BKv>
+template <int TR, int COLS, int BKv, int NF>
 __device__ __forceinline__ void frag_addrs(int r0, int lane, uint32_t (&ad)[4]) {
   ad[0] = ad[1] = ad[2] = ad[3] = 0;
   if (TR == 0) {
@@ -305,28 +308,28 @@ __device__ __forceinline__ void frag_addrs(int r0, int lane, uint32_t (&ad)[4]) 
     const int g = lane >> 4, c = lane & 15;
     const int row = ((g >> 1) << 3) + (c >> 2);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < NF; ++a) {
       const int col = r0 + a * 32 + ((g & 1) << 4) + ((c & 3) << 2);
       ad[a] = (uint32_t)(row * (COLS * 2) + (((col >> 3) ^ ((row & 3) << 2)) << 4) + ((col & 7) << 1));
     }
   }
 }
 
-template <int TR, int COLS, int BKv, int S>
-__device__ __forceinline__ void frags_issue(const uint32_t (&cur)[4], FragSet<TR>& f) {
-  if constexpr (TR == 0) {
-    asm_ds_read_b128<0>(f.q[0], cur[S]);
-    asm_ds_read_b128<32 * BKv * 2>(f.q[1], cur[S]);
-  } else {
-    constexpr int o = S * 16 * COLS * 2;
-    asm_ds_read_tr16<o>(f.lo[0], cur[0]);
-    asm_ds_read_tr16<o + 4 * COLS * 2>(f.hi[0], cur[0]);
-    asm_ds_read_tr16<o>(f.lo[1], cur[1]);
-    asm_ds_read_tr16<o + 4 * COLS * 2>(f.hi[1], cur[1]);
+template <int TR, int COLS, int BKv, int NF, int S, int A = 0>
+__device__ __forceinline__ void frags_issue(const uint32_t (&cur)[4], FragSet<TR, NF>& f) {
+  if constexpr (A < NF) {
+    if constexpr (TR == 0) {
+      asm_ds_read_b128<A * 32 * BKv * 2>(f.q[A], cur[S]);
+    } else {
+      constexpr int o = S * 16 * COLS * 2;
+      asm_ds_read_tr16<o>(f.lo[A], cur[A]);
+      asm_ds_read_tr16<o + 4 * COLS * 2>(f.hi[A], cur[A]);
+    }
+    frags_issue<TR, COLS, BKv, NF, S, A + 1>(cur, f);
   }
 }
-template <int TR>
-__device__ __forceinline__ bf16x8 frag_get(const FragSet<TR>& f, int a) {
+template <int TR, int NF>
+__device__ __forceinline__ bf16x8 frag_get(const FragSet<TR, NF>& f, int a) {
   if constexpr (TR == 0) {
     return __builtin_bit_cast(bf16x8, f.q[a]);
   } else {
@@ -334,18 +337,21 @@ __device__ __forceinline__ bf16x8 frag_get(const FragSet<TR>& f, int a) {
     return __builtin_bit_cast(bf16x8, v);
   }
 }
-template <int TA, int TB>
-__device__ __forceinline__ void mfma_step(const FragSet<TA>& fa, const FragSet<TB>& fb, f32x16 (&acc)[2][2]) {
-  bf16x8 a[2] = {frag_get<TA>(fa, 0), frag_get<TA>(fa, 1)};
-  bf16x8 b[2] = {frag_get<TB>(fb, 0), frag_get<TB>(fb, 1)};
+template <int TA, int TB, int WTM>
+__device__ __forceinline__ void mfma_step(const FragSet<TA, WTM>& fa, const FragSet<TB, 2>& fb, f32x16 (&acc)[WTM][2]) {
+  bf16x8 a[WTM], b[2];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) a[i] = frag_get<TA, WTM>(fa, i);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b[j] = frag_get<TB, 2>(fb, j);
   // operands swapped: D[i = n][j = m], so a lane ends up with 4 consecutive n of one m
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
 }
 
-// one 8-column slice of an output row: bias / GELU / residual / GELU' and the store (shared by both epilogues)
+// one 8-column slice of an output row: bias / GELU / residual / GELU' and the store
 template <bool OUT_F32>
 __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z, const float* __restrict__ bias,
                                                 const uint16_t* __restrict__ R_, int gm, int gn, float (&v)[8]) {
@@ -379,11 +385,11 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
   }
 }
 
-template <int BMv, int BKv, int TA, int TB, bool OUT_F32, bool DIRECT>
-__global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv / 64) * 128) / 256) void gemm_glds_kernel(
+template <int BMv, int BKv, int WTM, int TA, int TB, bool OUT_F32>
+__global__ __launch_bounds__((Geom<BMv, BKv, WTM>::NTHREADS), (Geom<BMv, BKv, WTM>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
     const cocodr_gemm_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type only exists in the device pass; the host pass just needs the stub
-  using G = Geom<BMv, BKv>;
+  using G = Geom<BMv, BKv, WTM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -421,9 +427,9 @@ __global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(st + G::A_BYTES + (wid * G::GB + j) * 1024), 16, offb[j] + t * stepb, 0, 0, 0);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[WTM][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < WTM; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -431,9 +437,9 @@ __global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
   uint32_t adA[4], adB[4];
-  frag_addrs<TA, BMv, BKv>(wm * 64, lane, adA);
-  frag_addrs<TB, 128, BKv>(wn * 64, lane, adB);
-  constexpr int R = (TA ? 4 : 2) + (TB ? 4 : 2);  // LDS reads per K-sub-step
+  frag_addrs<TA, BMv, BKv, WTM>(wm * 32 * WTM, lane, adA);
+  frag_addrs<TB, 128, BKv, 2>(wn * 64, lane, adB);
+  constexpr int R = (TA ? 2 : 1) * WTM + (TB ? 4 : 2);  // LDS reads per K-sub-step (<= 12 < the 4-bit lgkmcnt range)
 
   const int nt = (p.K + BKv - 1) / BKv;
   issue(0);
@@ -447,88 +453,53 @@ __global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv
     uint32_t curA[4], curB[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + sbA; curB[i] = adB[i] + sbB; }
-    FragSet<TA> fa0, fa1;
-    FragSet<TB> fb0, fb1;
-    frags_issue<TA, BMv, BKv, 0>(curA, fa0); frags_issue<TB, 128, BKv, 0>(curB, fb0);
-    frags_issue<TA, BMv, BKv, 1>(curA, fa1); frags_issue<TB, 128, BKv, 1>(curB, fb1);
+    FragSet<TA, WTM> fa0, fa1;
+    FragSet<TB, 2> fb0, fb1;
+    frags_issue<TA, BMv, BKv, WTM, 0>(curA, fa0); frags_issue<TB, 128, BKv, 2, 0>(curB, fb0);
+    frags_issue<TA, BMv, BKv, WTM, 1>(curA, fa1); frags_issue<TB, 128, BKv, 2, 1>(curB, fb1);
     wait_lgkmcnt<R>();
-    mfma_step<TA, TB>(fa0, fb0, acc);
+    mfma_step<TA, TB, WTM>(fa0, fb0, acc);
     if constexpr (G::KS == 4) {
-      frags_issue<TA, BMv, BKv, 2>(curA, fa0); frags_issue<TB, 128, BKv, 2>(curB, fb0);
+      frags_issue<TA, BMv, BKv, WTM, 2>(curA, fa0); frags_issue<TB, 128, BKv, 2, 2>(curB, fb0);
       wait_lgkmcnt<R>();
-      mfma_step<TA, TB>(fa1, fb1, acc);
-      frags_issue<TA, BMv, BKv, 3>(curA, fa1); frags_issue<TB, 128, BKv, 3>(curB, fb1);
+      mfma_step<TA, TB, WTM>(fa1, fb1, acc);
+      frags_issue<TA, BMv, BKv, WTM, 3>(curA, fa1); frags_issue<TB, 128, BKv, 2, 3>(curB, fb1);
       wait_lgkmcnt<R>();
-      mfma_step<TA, TB>(fa0, fb0, acc);
+      mfma_step<TA, TB, WTM>(fa0, fb0, acc);
     }
     wait_lgkmcnt<0>();
-    mfma_step<TA, TB>(fa1, fb1, acc);
+    mfma_step<TA, TB, WTM>(fa1, fb1, acc);
   }
   __syncthreads();
-  if (p.epi == 100) {  // measurement hook (COCODR_GEMM_SKIP_EPI): keep the accumulators live, store one value per lane
-    float sum = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += acc[a][b][r];
-    if (sum == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = sum;
-    return;
-  }
 
+  // ---- epilogue through an fp32 LDS tile, 64 output rows per pass, row-major 16-B loads / stores
   const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
   const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
-  if constexpr (DIRECT) {
-    // ---- register epilogue: no LDS round trip, no barriers, every wave drains on its own.
-    // A lane holds row m = lane & 31 and, per register group rg, the 4 columns 8*rg + 4*(lane>>5) + 0..3.
-    // v_permlane32_swap between groups rg and rg+1 gives the low half-wave columns 16*q + 0..7 and the high
-    // half-wave 16*q + 8..15 of that row: 8 consecutive columns per lane -> one 16-B (bf16) store per lane.
-    const int half = lane >> 5;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int gm = m0 + wm * 64 + a * 32 + (lane & 31);
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[a][b][(2 * q) * 4 + e]),
-                                                             __float_as_uint(acc[a][b][(2 * q + 1) * 4 + e]), false, false);
-            v[e] = __uint_as_float(sw[0]);
-            v[4 + e] = __uint_as_float(sw[1]);
-          }
-          const int gn = n0 + wn * 64 + b * 32 + 16 * q + 8 * half;
-          if (gm < p.M) epilogue_store8<OUT_F32>(p, z, bias, R_, gm, gn, v);
-        }
-    }
-    return;
-  }
-
-  // ---- epilogue through an fp32 LDS tile, 64 rows at a time (same as v1)
   float* ct = reinterpret_cast<float*>(smem);
-  constexpr int NT_ = G::NWAVES * 64;
+  constexpr int GPW = WTM / 2;  // 64-row groups per wave
 #pragma unroll 1
   for (int h = 0; h < BMv / 64; ++h) {
-    if (wm == h) {
+    if (h / GPW == wm) {
+      const int a0 = (h % GPW) * 2;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int ai = 0; ai < 2; ++ai)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int row = a * 32 + (lane & 31);
+            const int row = ai * 32 + (lane & 31);
             const int col = wn * 64 + b * 32 + 8 * rg + 4 * (lane >> 5);
-            *reinterpret_cast<float4*>(ct + row * CT_LD + col) =
-                make_float4(acc[a][b][rg * 4 + 0], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
+            float4 v4;
+            if (GPW == 1 || a0 == 0) v4 = make_float4(acc[ai][b][rg * 4 + 0], acc[ai][b][rg * 4 + 1], acc[ai][b][rg * 4 + 2], acc[ai][b][rg * 4 + 3]);
+            else v4 = make_float4(acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 0], acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 1],
+                                  acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 2], acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 3]);
+            *reinterpret_cast<float4*>(ct + row * CT_LD + col) = v4;
           }
     }
     __syncthreads();
 #pragma unroll
-    for (int pp = 0; pp < 64 * 16 / NT_; ++pp) {
-      const int row = (tid >> 4) + (NT_ / 16) * pp;
+    for (int pp = 0; pp < 64 * 16 / G::NTHREADS; ++pp) {
+      const int row = (tid >> 4) + (G::NTHREADS / 16) * pp;
       const int gm = m0 + h * 64 + row;
       const int gn = n0 + ((tid & 15) << 3);
       if (gm < p.M) {
@@ -544,44 +515,37 @@ __global__ __launch_bounds__((BMv / 64) * 128, (Geom<BMv, BKv>::WG_PER_CU * (BMv
 #endif
 }
 
-template <int BMv, int BKv, int TA, int TB, bool DIRECT>
+template <int BMv, int BKv, int WTM, int TA, int TB>
 void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
-  using G = Geom<BMv, BKv>;
+  using G = Geom<BMv, BKv, WTM>;
   const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / BN;
   dim3 grid(ntm * ntn, a.batch);
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, TA, TB, true, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, TA, TB, false, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, TA, TB, true, DIRECT>), grid, dim3(G::NWAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, TA, TB, true>), grid, dim3(G::NTHREADS), lds, st, a);
   else
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, TA, TB, false, DIRECT>), grid, dim3(G::NWAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, TA, TB, false>), grid, dim3(G::NTHREADS), lds, st, a);
 }
 
-template <int BMv, int BKv>
-void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st, bool direct) {
-  if (direct) {
-    if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, 0, 0, true>(a, st);
-    else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, 0, 1, true>(a, st);
-    else launch_glds<BMv, BKv, 1, 1, true>(a, st);
-  } else {
-    if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, 0, 0, false>(a, st);
-    else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, 0, 1, false>(a, st);
-    else launch_glds<BMv, BKv, 1, 1, false>(a, st);
-  }
+template <int BMv, int BKv, int WTM>
+void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
+  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, WTM, 0, 0>(a, st);
+  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, WTM, 0, 1>(a, st);
+  else launch_glds<BMv, BKv, WTM, 1, 1>(a, st);
 }
-
 
 }  // namespace cocodr_gemm_v2
 using cocodr_gemm_v2::launch_glds_any;
 
 namespace {
 
-int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, direct-to-LDS <BM,BK>: 2 = <128,64>, 3 = <256,64>, 4 = <128,32>, 5 = <256,32>
+int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, direct-to-LDS <BM,BK,WTM>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>
 int gemm_impl_override() {
   if (g_gemm_impl < 0) {
     const char* e = getenv("COCODR_GEMM_IMPL");
@@ -601,7 +565,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG(impl >= 0 && impl <= 5, "gemm_set_impl: impl must be in [0,5]");
+  CK_ARG(impl >= 0 && impl <= 7, "gemm_set_impl: impl must be in [0,7]");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -645,18 +609,12 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
     else impl = tiles128 >= 512 ? 4 : 2;
   }
   if (impl != 1 && !(k_ok && small)) impl = 1;
-  {
-    static int skip = -1;
-    if (skip < 0) skip = getenv("COCODR_GEMM_SKIP_EPI") ? 1 : 0;
-    if (skip && impl != 1) a.epi = 100;
-  }
-  static int direct_epi = -1;  // COCODR_GEMM_EPI=direct selects the register epilogue (measured ~equal; A/B hook)
-  if (direct_epi < 0) { const char* e = getenv("COCODR_GEMM_EPI"); direct_epi = (e && e[0] == 'd') ? 1 : 0; }
-  const bool direct = direct_epi != 0;
-  if (impl == 5) launch_glds_any<256, 32>(a, st, direct);
-  else if (impl == 4) launch_glds_any<128, 32>(a, st, direct);
-  else if (impl == 3) launch_glds_any<256, 64>(a, st, direct);
-  else if (impl == 2) launch_glds_any<128, 64>(a, st, direct);
+  if (impl == 7) launch_glds_any<256, 64, 4>(a, st);
+  else if (impl == 6) launch_glds_any<256, 32, 4>(a, st);
+  else if (impl == 5) launch_glds_any<256, 32, 2>(a, st);
+  else if (impl == 4) launch_glds_any<128, 32, 2>(a, st);
+  else if (impl == 3) launch_glds_any<256, 64, 2>(a, st);
+  else if (impl == 2) launch_glds_any<128, 64, 2>(a, st);
   else if (!a.trans_a && !a.trans_b) launch<0, 0>(a, grid, st);
   else if (!a.trans_a && a.trans_b) launch<0, 1>(a, grid, st);
   else launch<1, 1>(a, grid, st);
