@@ -48,7 +48,7 @@ class EmbedGrads(C.Structure):
 class EncoderLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in (
         "total_bytes", "hidden", "cls_f32", "qkv", "ctx", "y1", "x1", "u", "h", "y2", "lse", "mean1", "rstd1", "mean2",
-        "rstd2", "emb_mean", "emb_rstd", "bwd_scratch", "bwd_bytes")]
+        "rstd2", "emb_mean", "emb_rstd", "bwd_scratch", "bwd_bytes", "bwd_dx")]
 
 
 EPI_NONE, EPI_GELU, EPI_ADD, EPI_DGELU = 0, 1, 2, 3
@@ -82,6 +82,9 @@ SIGNATURES = {
     "cocodr_encoder_layout": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),
     "cocodr_encoder_fwd": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "cocodr_stack_fwd": (c_int, [C.POINTER(Config), C.POINTER(LayerParams), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
+                                 c_void_p]),
+    "cocodr_ce_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cocodr_encoder_bwd": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), C.POINTER(EmbedGrads),
                                    C.POINTER(LayerGrads), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                    c_void_p]),

@@ -100,16 +100,36 @@ extern "C" int cocodr_encoder_layout(const cocodr_config* c, int B, int L, int t
   out->emb_rstd = cv.take(M * 4);
   out->bwd_scratch = cv.off;
   out->bwd_bytes = training ? bwd_layout(c, B, L).total : 0;
+  out->bwd_dx = training ? cv.off + bwd_layout(c, B, L).dxb : 0;
   out->total_bytes = cv.off + out->bwd_bytes;
   return COCODR_OK;
+}
+
+namespace {
+int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp, const int32_t* ids,
+                     const int32_t* mask, int B, int L, int training, void* arena, size_t arena_bytes, bool from_hidden,
+                     cocodr_stream_t stream);
 }
 
 extern "C" int cocodr_encoder_fwd(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
                                   const int32_t* ids, const int32_t* mask, int B, int L, int training, void* arena,
                                   size_t arena_bytes, cocodr_stream_t stream) {
+  CK_ARG(emb && ids, "encoder_fwd: null pointer");
+  return encoder_fwd_impl(c, emb, lp, ids, mask, B, L, training, arena, arena_bytes, false, stream);
+}
+
+extern "C" int cocodr_stack_fwd(const cocodr_config* c, const cocodr_layer_params* lp, const int32_t* mask, int B, int L,
+                                int training, void* arena, size_t arena_bytes, cocodr_stream_t stream) {
+  return encoder_fwd_impl(c, nullptr, lp, nullptr, mask, B, L, training, arena, arena_bytes, true, stream);
+}
+
+namespace {
+int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp, const int32_t* ids,
+                     const int32_t* mask, int B, int L, int training, void* arena, size_t arena_bytes, bool from_hidden,
+                     cocodr_stream_t stream) {
   cocodr_encoder_layout_t lay;
   TRY(cocodr_encoder_layout(c, B, L, training, &lay));
-  CK_ARG(emb && lp && ids && mask && arena, "encoder_fwd: null pointer");
+  CK_ARG(lp && mask && arena, "encoder_fwd: null pointer");
   if (arena_bytes < lay.total_bytes) {
     cocodr_set_error("encoder_fwd: arena %zu B < required %zu B", arena_bytes, lay.total_bytes);
     return COCODR_ERR_WORKSPACE;
@@ -121,8 +141,9 @@ extern "C" int cocodr_encoder_fwd(const cocodr_config* c, const cocodr_embed_par
   uint16_t* hidden = (uint16_t*)(base + lay.hidden);
   float* cls = (float*)(base + lay.cls_f32);
 
-  TRY(cocodr_embed_ln_fwd(ids, emb->word, emb->pos, emb->type0, emb->ln_g, emb->ln_b, hidden, (float*)(base + lay.emb_mean),
-                          (float*)(base + lay.emb_rstd), B, L, H, c->vocab, c->ln_eps, stream));
+  if (!from_hidden)  // a bare layer stack (Condenser head) starts from hidden slot 0, filled by the caller
+    TRY(cocodr_embed_ln_fwd(ids, emb->word, emb->pos, emb->type0, emb->ln_g, emb->ln_b, hidden, (float*)(base + lay.emb_mean),
+                            (float*)(base + lay.emb_rstd), B, L, H, c->vocab, c->ln_eps, stream));
   for (int l = 0; l < NL; ++l) {
     const cocodr_layer_params& w = lp[l];
     const size_t lo = ls * l;
@@ -159,6 +180,7 @@ extern "C" int cocodr_encoder_fwd(const cocodr_config* c, const cocodr_embed_par
   }
   return COCODR_OK;
 }
+}  // namespace
 
 extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
                                         const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const int32_t* ids,
@@ -166,7 +188,7 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
                                         size_t arena_bytes, int layer_hi, int layer_lo, int do_embed, cocodr_stream_t stream) {
   cocodr_encoder_layout_t lay;
   TRY(cocodr_encoder_layout(c, B, L, 1, &lay));
-  CK_ARG(emb && lp && eg && lg && ids && mask && arena, "encoder_bwd: null pointer");
+  CK_ARG(lp && lg && mask && arena && (!do_embed || (emb && eg && ids)), "encoder_bwd: null pointer");
   CK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= c->layers, "encoder_bwd: bad layer range [%d,%d)", layer_lo, layer_hi);
   CK_ARG(d_in != nullptr || layer_hi < c->layers, "encoder_bwd: the first (top) range needs the upstream gradient d_in");
   CK_ARG(L <= 256, "encoder_bwd: L=%d > 256 is not supported by the attention backward yet", L);

@@ -159,7 +159,66 @@ __global__ __launch_bounds__(256) void triplet_kernel(const float* __restrict__ 
   }
 }
 
+// one 256-thread workgroup per row: V ~ 30 k logits, three passes (max, sum-exp, gradient) from L2
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                 const float* __restrict__ row_scale, float* __restrict__ loss_rows,
+                                                 uint16_t* __restrict__ dlogits, int V, int ld) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const float* row = logits + (size_t)i * ld;
+  float mx = -INFINITY;
+  for (int j = tid * 4; j < V; j += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + j);
+    mx = fmaxf(mx, v.x);
+    if (j + 1 < V) mx = fmaxf(mx, v.y);
+    if (j + 2 < V) mx = fmaxf(mx, v.z);
+    if (j + 3 < V) mx = fmaxf(mx, v.w);
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int j = tid * 4; j < V; j += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + j);
+    s += __expf(v.x - mx);
+    if (j + 1 < V) s += __expf(v.y - mx);
+    if (j + 2 < V) s += __expf(v.z - mx);
+    if (j + 3 < V) s += __expf(v.w - mx);
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  const float lse = mx + __logf(s);
+  const int lab = labels[i];
+  const float sc = row_scale[i];
+  if (tid == 0) loss_rows[i] = lse - row[lab];
+  uint16_t* drow = dlogits + (size_t)i * ld;
+  for (int j = tid * 4; j < ld; j += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + j);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    float g[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = j + e;
+      g[e] = col < V ? sc * (__expf(x[e] - lse) - (col == lab ? 1.f : 0.f)) : 0.f;
+    }
+    *reinterpret_cast<uint2*>(drow + j) = pack4(g);
+  }
+}
+
 }  // namespace
+
+extern "C" int cocodr_ce_fwd_bwd(const float* logits, const int32_t* labels, const float* row_scale, int n, int V, int ld,
+                                 float* loss_rows, uint16_t* dlogits, cocodr_stream_t stream) {
+  CK_ARG(logits && labels && row_scale && loss_rows && dlogits, "ce: null pointer");
+  CK_ARG(n > 0 && V > 0 && ld >= V && ld % 4 == 0, "ce: bad shape n=%d V=%d ld=%d (ld %% 4 == 0)", n, V, ld);
+  hipLaunchKernelGGL(ce_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logits, labels, row_scale, loss_rows, dlogits, V, ld);
+  CK_LAUNCH("ce");
+  return COCODR_OK;
+}
 
 extern "C" size_t cocodr_simce_workspace_floats(int M) { return (size_t)M * M + (size_t)M; }
 

@@ -146,6 +146,13 @@ int cocodr_triplet_nll_fwd_bwd(const float* q, const float* a, const float* b, c
                                int B, int H, float* loss_rows, float* logits /* [B,2] */, float* loss,
                                float* dq, float* da, float* db, cocodr_stream_t stream);
 
+/* Masked-LM cross entropy over the vocabulary (hf BertForMaskedLM loss / COCO/modeling.py:87-93 mlm_loss):
+ * logits fp32 [n, ld] (columns >= V are padding), labels int32 [n] in [0,V); row_scale fp32 [n] carries the
+ * 1/(number of labelled rows of the row's group) factor of the mean.  loss_rows[i] = lse_i - logit_i[label_i];
+ * dlogits bf16 [n, ld] = row_scale_i * (softmax_i - onehot_i), zero in the padding columns. */
+int cocodr_ce_fwd_bwd(const float* logits, const int32_t* labels, const float* row_scale, int n, int V, int ld,
+                      float* loss_rows, uint16_t* dlogits, cocodr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Brute-force inner-product search: faiss.IndexFlatIP(dim).add(P); .search(Q,k)
  * (evaluate/evaluation/evaluate_beir.py:220-224, ANCE/drivers/run_ann_data_gen.py:310-317,390,
@@ -194,6 +201,7 @@ typedef struct { /* byte offsets into the arena, filled by cocodr_encoder_layout
   size_t emb_mean, emb_rstd;
   size_t bwd_scratch;  /* backward-only region (dgrad chain, saved dY for the grouped wgrad) */
   size_t bwd_bytes;
+  size_t bwd_dx;       /* bf16 [M,H]: where a backward range leaves dL/d(hidden_states[layer_lo]) */
 } cocodr_encoder_layout_t;
 
 /* training = 0 keeps only what inference needs (hidden states + one layer of scratch) */
@@ -202,6 +210,14 @@ int cocodr_encoder_layout(const cocodr_config* cfg, int B, int L, int training, 
 int cocodr_encoder_fwd(const cocodr_config* cfg, const cocodr_embed_params* emb,
                        const cocodr_layer_params* layers_host, const int32_t* ids, const int32_t* mask,
                        int B, int L, int training, void* arena, size_t arena_bytes, cocodr_stream_t stream);
+
+/* A bare stack of BertLayers (no embeddings): the Condenser head of COCO/modeling.py:43-46,73-79,212-220
+ * (`c_head`, n_head_layers BertLayers applied to cat(cls, hidden_states[skip_from][:,1:])).  Same arena layout as
+ * the encoder with cfg->layers = number of stacked layers; the caller fills hidden slot 0 ([M,H] bf16 at
+ * layout.hidden) before the call.  Its backward is cocodr_encoder_bwd_range(..., layer_lo = 0, do_embed = 0)
+ * (emb / emb_grads / ids may then be NULL); the input gradient is left at layout.bwd_dx. */
+int cocodr_stack_fwd(const cocodr_config* cfg, const cocodr_layer_params* layers_host, const int32_t* mask, int B, int L,
+                     int training, void* arena, size_t arena_bytes, cocodr_stream_t stream);
 
 /* d_last: bf16 [M,H] gradient of the loss w.r.t. hidden_states[-1].  Layer gradient blocks must be
  * laid out with a uniform stride between consecutive layers (grads_host[l+1].x - grads_host[l].x

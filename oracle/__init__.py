@@ -19,3 +19,4 @@ reference's evaluate/evaluation/msmarco_eval.py).
 """
 from .bert_oracle import *  # noqa: F401,F403
 from .retrieval_oracle import *  # noqa: F401,F403
+from .condenser_oracle import *  # noqa: F401,F403

@@ -21,7 +21,7 @@ __all__ = [
     "OracleConfig", "make_params", "layer_names", "embeddings_fwd", "encoder_fwd",
     "encoder_bwd", "cls_embedding", "co_target", "contrastive_loss",
     "contrastive_loss_grad", "contrastive_local_grad", "triplet_nll",
-    "triplet_nll_grad", "gelu", "layer_norm_fwd",
+    "triplet_nll_grad", "gelu", "gelu_grad", "layer_norm_fwd", "layer_norm_bwd", "layers_bwd", "_layer_fwd",
 ]
 
 LN_EPS = 1e-12  # BertConfig.layer_norm_eps default (hf: BertEmbeddings / BertSelfOutput)
@@ -42,8 +42,8 @@ class OracleConfig:
         return self.hidden_size // self.num_attention_heads
 
 
-def layer_names(i: int) -> Dict[str, str]:
-    p = f"encoder.layer.{i}."
+def layer_names(i: int, stack: str = "encoder.layer.") -> Dict[str, str]:
+    p = f"{stack}{i}."
     return dict(
         wq=p + "attention.self.query.weight", bq=p + "attention.self.query.bias",
         wk=p + "attention.self.key.weight", bk=p + "attention.self.key.bias",
@@ -151,9 +151,9 @@ def embeddings_fwd(P, input_ids: np.ndarray, cache: Optional[dict] = None) -> np
     return out
 
 
-def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optional[dict]):
+def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optional[dict], stack: str = "encoder.layer."):
     """One BertLayer: hf BertSelfAttention (eager) + BertSelfOutput + BertIntermediate + BertOutput."""
-    n = layer_names(i)
+    n = layer_names(i, stack)
     B, L, H = x.shape
     d = H // nh
     q = x @ P[n["wq"]].T + P[n["bq"]]
@@ -205,13 +205,13 @@ def cls_embedding(last_hidden: np.ndarray) -> np.ndarray:
     return last_hidden[:, 0]
 
 
-def encoder_bwd(P, cfg: OracleConfig, cache: dict, d_last: np.ndarray) -> Dict[str, np.ndarray]:
-    """Reverse-mode gradient of ``encoder_fwd`` w.r.t. every parameter given dL/d(hidden_states[-1])."""
-    G: Dict[str, np.ndarray] = {}
-    nh = cfg.num_attention_heads
-    dx = d_last
-    for i in reversed(range(cfg.num_hidden_layers)):
-        n = layer_names(i)
+def layers_bwd(P, nh: int, cache: dict, layer_ids, dx: np.ndarray, G: Dict[str, np.ndarray], stack: str = "encoder.layer.",
+               extra: Optional[Dict[int, np.ndarray]] = None) -> np.ndarray:
+    """Backward through the BertLayers ``layer_ids`` (walked in reverse); returns dL/d(input of the first one).
+    ``extra[i]`` is added to the gradient of hidden state i (the INPUT of layer i) - how the Condenser head's
+    gradient re-enters the backbone at ``skip_from`` (COCO/modeling.py:212-213)."""
+    for i in reversed(list(layer_ids)):
+        n = layer_names(i, stack)
         c = cache[i]
         B, L, H = c["x"].shape
         d = H // nh
@@ -247,6 +247,17 @@ def encoder_bwd(P, cfg: OracleConfig, cache: dict, d_last: np.ndarray) -> Dict[s
         G[n["bk"]] = dk.reshape(-1, H).sum(0)
         G[n["bv"]] = dv.reshape(-1, H).sum(0)
         dx = dq @ P[n["wq"]] + dk @ P[n["wk"]] + dv @ P[n["wv"]] + dy1
+        if extra is not None and i in extra:
+            dx = dx + extra[i]
+    return dx
+
+
+def encoder_bwd(P, cfg: OracleConfig, cache: dict, d_last: np.ndarray,
+                extra: Optional[Dict[int, np.ndarray]] = None) -> Dict[str, np.ndarray]:
+    """Reverse-mode gradient of ``encoder_fwd`` w.r.t. every parameter given dL/d(hidden_states[-1]) (plus optional
+    gradients ``extra[i]`` w.r.t. intermediate hidden_states[i])."""
+    G: Dict[str, np.ndarray] = {}
+    dx = layers_bwd(P, cfg.num_attention_heads, cache, range(cfg.num_hidden_layers), d_last, G, extra=extra)
     e = cache["emb"]
     dy, G["embeddings.LayerNorm.weight"], G["embeddings.LayerNorm.bias"] = layer_norm_bwd(
         dx, e["xhat"], e["rstd"], P["embeddings.LayerNorm.weight"])

@@ -216,8 +216,99 @@ def golden_mrr():
     sys.path.pop(0)
 
 
+def golden_condenser():
+    """Full coCondenser step: Condenser head + both MLM losses + contrastive loss, forward/backward
+    through the reference's CoCondenserForPretraining.forward (COCO/modeling.py:192-235).  Harness-side shims
+    (none touches /root/reference): (1) data_args.train_method; (2) get_extended_attention_mask is
+    wrapped to drop the 3rd positional `device` argument that transformers 5.x reads as `dtype`; (3) every c_head
+    layer is wrapped to return a 1-tuple, restoring the <=4.x BertLayer return convention `layer_out[0]` relies on."""
+    sys.path.insert(0, os.path.join(REF, "COCO"))
+    import modeling as coco_modeling  # reference
+    from arguments import ModelArguments, DataTrainingArguments  # reference
+    from transformers import BertForMaskedLM
+    from oracle import make_head_params, layer_names
+
+    cfg = OracleConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                       intermediate_size=512, max_position_embeddings=64)
+    seed, seed_h, n_head, skip_from = 2468, 1357, 2, 1
+    P = make_params(cfg, seed, std=STD)
+    Ph = make_head_params(cfg, n_head, seed_h, std=STD)
+    torch.manual_seed(0)
+    lm = BertForMaskedLM(hf_config(cfg))
+    load_into(lm.bert, P)
+    with torch.no_grad():
+        tr = lm.cls.predictions.transform
+        tr.dense.weight.copy_(torch.from_numpy(Ph["cls.predictions.transform.dense.weight"]))
+        tr.dense.bias.copy_(torch.from_numpy(Ph["cls.predictions.transform.dense.bias"]))
+        tr.LayerNorm.weight.copy_(torch.from_numpy(Ph["cls.predictions.transform.LayerNorm.weight"]))
+        tr.LayerNorm.bias.copy_(torch.from_numpy(Ph["cls.predictions.transform.LayerNorm.bias"]))
+        lm.cls.predictions.bias.copy_(torch.from_numpy(Ph["cls.predictions.bias"]))
+        lm.cls.predictions.decoder.bias = lm.cls.predictions.bias
+    assert lm.cls.predictions.decoder.weight is lm.bert.embeddings.word_embeddings.weight  # tied
+    B, L = 6, 32
+    rng = np.random.Generator(np.random.PCG64(77))
+    ids, mask = synth_batch(rng, B, L, cfg.vocab_size)
+    labels = np.full((B, L), -100, np.int64)
+    for b in range(B):
+        n = int(mask[b].sum())
+        pick = 1 + rng.permutation(n - 2)[: max(1, int(0.15 * n))]
+        labels[b, pick] = ids[b, pick]
+        ids[b, pick] = 3  # [MASK]-like
+    model_args = ModelArguments(n_head_layers=n_head, skip_from=skip_from, late_mlm=True)
+    data_args = DataTrainingArguments()
+    data_args.train_method = "coco"  # shim 1
+    train_args = types.SimpleNamespace(per_device_train_batch_size=B // 2, local_rank=-1)
+    model = coco_modeling.CoCondenserForPretraining(lm, model_args, data_args, train_args)
+    with torch.no_grad():
+        for i in range(n_head):
+            sd = model.c_head[i].state_dict()
+            names = layer_names(i, "c_head.")
+            for k in sd:
+                sd[k].copy_(torch.from_numpy(Ph[f"c_head.{i}." + k]))
+    orig_mask_fn = model.lm.get_extended_attention_mask
+    model.lm.get_extended_attention_mask = lambda m, shape, device=None: orig_mask_fn(m, shape)  # shim 2
+
+    class TupleOut(torch.nn.Module):  # shim 3
+        def __init__(self, layer):
+            super().__init__()
+            self.layer = layer
+
+        def forward(self, hidden, attention_mask):
+            out = self.layer(hidden, attention_mask)
+            return out if isinstance(out, tuple) else (out,)
+
+    model.c_head = torch.nn.ModuleList([TupleOut(l) for l in model.c_head])
+    model.zero_grad()
+    loss = model({"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}, torch.from_numpy(labels))
+    loss.backward()
+    out = dict(input_ids=ids, attention_mask=mask, labels=labels, seed=np.int64(seed), seed_head=np.int64(seed_h),
+               std=np.float64(STD), n_head_layers=np.int64(n_head), skip_from=np.int64(skip_from), loss=np.float64(float(loss)),
+               cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                             cfg.intermediate_size, cfg.max_position_embeddings, cfg.type_vocab_size]))
+    out.update(selected_grads(model.lm.named_parameters(), "bert."))
+    head = {}
+    for name, p_ in model.named_parameters():
+        if name.startswith("c_head.") and p_.grad is not None:
+            short = name.replace(".layer.", ".", 1)  # undo the TupleOut nesting: c_head.0.layer.attention... -> c_head.0.attention...
+            if any(t in short for t in ("0.attention.self.query.weight", "1.intermediate.dense.weight", "1.output.LayerNorm.weight",
+                                        "0.attention.output.dense.bias", "1.attention.self.value.weight")):
+                head["hgrad:" + short] = p_.grad.numpy().copy()
+        if name.startswith("lm.cls.") and p_.grad is not None and "decoder" not in name:
+            head["hgrad:" + name[len("lm."):]] = p_.grad.numpy().copy()
+    out.update(head)
+    np.savez_compressed(os.path.join(OUT, "coco_condenser_tiny.npz"), **out)
+    print("condenser golden: loss", float(loss), "head grads", sorted(head)[:3], len(head))
+    sys.path.pop(0)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    golden_coco()
-    golden_ance()
-    golden_mrr()
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser"]
+    if "coco" in which:
+        golden_coco()
+    if "condenser" in which:
+        golden_condenser()
+    if "ance" in which:
+        golden_ance()
+    if "mrr" in which:
+        golden_mrr()

@@ -149,3 +149,25 @@ def test_eval_dev_query_and_negatives():
     negs, rr = O.generate_negatives(q2id, p2id, {10: 101, 11: 103}, I, 2)
     assert negs == {10: [100], 11: [102, 101]}  # top (negative_sample+1) window, positive and dups dropped
     assert rr.tolist() == [1 / 3, 1.0]
+
+
+def test_full_condenser_step_matches_reference():
+    """Condenser head + both MLM losses + contrastive loss through the reference's
+    CoCondenserForPretraining.forward (3 disclosed harness shims, tests/golden/make_golden.py)."""
+    g = load_golden("coco_condenser_tiny.npz")
+    cfg = cfg_from_golden(g)
+    P = O.make_params(cfg, int(g["seed"]), std=float(g["std"]))
+    Ph = O.make_head_params(cfg, int(g["n_head_layers"]), int(g["seed_head"]), std=float(g["std"]))
+    total, parts, G, Gh = O.condenser_step(P, Ph, cfg, g["input_ids"], g["attention_mask"], g["labels"],
+                                           int(g["n_head_layers"]), int(g["skip_from"]), late_mlm=True)
+    assert abs(total - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert parts["mlm_head"] > 0 and parts["mlm_late"] > 0 and parts["co"] > 0
+    for key in g.files:
+        if key.startswith("grad:"):
+            _check_grad(key[5:], G[key[5:]], g[key])
+        elif key.startswith("hgrad:"):
+            name = key[6:]
+            if name.endswith("key.bias"):
+                continue
+            assert _rel(Gh[name], g[key]) < 2e-3, (name, _rel(Gh[name], g[key]))
+    assert _rel(G["embeddings.word_embeddings.weight"][:64], g["grad_rows:embeddings.word_embeddings.weight"]) < 2e-3
