@@ -1,0 +1,268 @@
+"""The rest of the coCondenser pre-training step: the Condenser head and the two masked-LM losses on
+top of the encoder / contrastive path.
+
+Reference: COCO/modeling.py:192-235 -
+    lm_out   = lm(**input, labels, output_hidden_states=True)               # backbone + "late" MLM loss
+    hiddens  = cat(hidden_states[-1][:, :1], hidden_states[skip_from][:, 1:])
+    hiddens  = c_head layers (n_head_layers BertLayers, :43-46)(hiddens)
+    loss     = CE(lm.cls(hiddens), labels) [+ lm_out.loss if late_mlm] + contrastive.mean()
+`lm.cls` is hf BertOnlyMLMHead: dense + erf-GELU + LayerNorm, then a decoder tied to the word embeddings (+ bias).
+
+Native mapping: the head layers reuse the encoder's layer kernels through `cocodr_stack_fwd` /
+`cocodr_encoder_bwd_range`; the MLM head runs ONLY on the labelled rows (~15 % of the tokens; the reference forms the
+full [B*L, V] logits and lets CE ignore -100 - same loss, 6x less work), both applications of `lm.cls` batched into
+one set of GEMMs; the vocabulary CE is `cocodr_ce_fwd_bwd`.  The head's gradient re-enters the backbone at
+`skip_from` between two ranges of the ranged encoder backward.  Row gather / scatter and the [CLS] splice are torch
+indexing ops (plumbing on a few MB).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _native as N
+from . import ops
+from ._native import check, lib, ptr, stream_ptr
+from .modeling import CocoBertConfig, CocoBertModel, _Layout
+
+__all__ = ["CondenserHead", "condenser_step"]
+
+_NEG = -1e30
+
+
+class CondenserHead(nn.Module):
+    """Parameters of `c_head` (COCO/modeling.py:43-46) and of `lm.cls` (hf BertOnlyMLMHead) in two flat tensors.
+    State-dict names follow the reference: ``c_head.{i}.attention.self.query.weight`` ...,
+    ``cls.predictions.transform.dense.weight`` ..., ``cls.predictions.bias`` (the decoder weight is the backbone's
+    word-embedding table)."""
+
+    def __init__(self, config: CocoBertConfig, n_head_layers: int = 2, device=None):
+        super().__init__()
+        H, V = config.hidden_size, config.vocab_size
+        self.config = config
+        self.n_head_layers = int(n_head_layers)
+        self.layout = _Layout(
+            config, self.n_head_layers, "c_head.",
+            decay_pre=[("cls.predictions.transform.dense.weight", (H, H))],
+            nodecay_pre=[("cls.predictions.transform.dense.bias", (H,)), ("cls.predictions.transform.LayerNorm.weight", (H,)),
+                         ("cls.predictions.transform.LayerNorm.bias", (H,)), ("cls.predictions.bias", (V,))])
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.flat_decay = nn.Parameter(torch.zeros(self.layout.decay_numel, dtype=torch.float32, device=dev))
+        self.flat_nodecay = nn.Parameter(torch.zeros(self.layout.nodecay_numel, dtype=torch.float32, device=dev))
+        self._shadow = None
+        self._shadow_version = -1
+        self.vpad = (V + 127) // 128 * 128
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            self.flat_decay.normal_(0.0, self.config.initializer_range)
+            self.flat_nodecay.zero_()
+            for name in self.layout.names:
+                if name.endswith("LayerNorm.weight"):
+                    self.hf_view(name).fill_(1.0)
+
+    def hf_view(self, name):
+        return self.layout.view((self.flat_decay.data, self.flat_nodecay.data), name)
+
+    def hf_named_grads(self):
+        flats = (self.flat_decay.grad, self.flat_nodecay.grad)
+        for name in self.layout.names:
+            if flats[self.layout.names[name][0]] is not None:
+                yield name, self.layout.view(flats, name)
+
+    def param_groups(self, weight_decay: float = 0.0):
+        return [{"params": [self.flat_decay], "weight_decay": weight_decay},
+                {"params": [self.flat_nodecay], "weight_decay": 0.0}]
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = OrderedDict() if destination is None else destination
+        for name in self.layout.names:
+            v = self.hf_view(name)
+            sd[prefix + name] = v if keep_vars else v.detach().clone()
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        missing = []
+        with torch.no_grad():
+            for name in self.layout.names:
+                if name in state_dict:
+                    self.hf_view(name).copy_(state_dict[name].to(torch.float32))
+                else:
+                    missing.append(name)
+        if strict and missing:
+            raise RuntimeError(f"missing keys in state_dict: {missing[:8]}")
+        self._shadow_version = -1
+        return torch.nn.modules.module._IncompatibleKeys(missing, [])
+
+    def _refresh_shadow(self):
+        if self._shadow is None or self._shadow.device != self.flat_decay.device:
+            self._shadow = torch.empty(self.layout.decay_numel, dtype=torch.bfloat16, device=self.flat_decay.device)
+            self._shadow_version = -1
+        if self._shadow_version != self.flat_decay._version:
+            ops.cast_f32_bf16(self.flat_decay.data, self._shadow)
+            self._shadow_version = self.flat_decay._version
+
+
+def _gelu_grad(x: torch.Tensor) -> torch.Tensor:
+    return 0.5 * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0)))) + x * torch.exp(-0.5 * x * x) * (1.0 / math.sqrt(2.0 * math.pi))
+
+
+class _CondenserStepFn(torch.autograd.Function):
+    """(backbone flats, head flats, ids, mask, labels) -> (mlm loss scalar, fp32 [CLS] rows).  The contrastive loss
+    is applied on the returned [CLS] rows by the caller (it needs the cross-rank gather)."""
+
+    @staticmethod
+    def forward(ctx, fd, fn, hd, hn, ids, mask, labels, bert: CocoBertModel, head: CondenserHead, skip_from: int, late_mlm: bool):
+        cfg = bert.config
+        B, L = ids.shape
+        M, H, V, NL = B * L, cfg.hidden_size, cfg.vocab_size, cfg.num_hidden_layers
+        nh = head.n_head_layers
+        dev = ids.device
+        rows = torch.nonzero(labels.reshape(-1) != -100).squeeze(1)  # host sync: the GEMM row count must be known
+        n_lab = int(rows.numel())
+        if n_lab == 0:
+            raise ValueError("condenser step: no labelled positions in the batch (cross_entropy would be NaN)")
+        lab = labels.reshape(-1)[rows].to(torch.int32)
+        # ---- backbone
+        arena, lay = bert._run_forward(ids, mask, True)
+        hidden = arena[lay.hidden: lay.hidden + (NL + 1) * M * H * 2].view(torch.bfloat16).view(NL + 1, B, L, H)
+        cls = arena[lay.cls_f32: lay.cls_f32 + B * H * 4].view(torch.float32).view(B, H).clone()
+        last = hidden[NL]
+        # ---- Condenser head on cat(cls of the last layer, skip_from states without their first token)
+        head._refresh_shadow()
+        hcfg = N.Config(H, cfg.num_attention_heads, nh, cfg.intermediate_size, V, cfg.max_position_embeddings, cfg.layer_norm_eps)
+        hlay = N.EncoderLayout()
+        check(lib().cocodr_encoder_layout(C.byref(hcfg), B, L, 1, C.byref(hlay)), "encoder_layout(head)")
+        harena = torch.empty(hlay.total_bytes, dtype=torch.uint8, device=dev)
+        hhidden = harena[hlay.hidden: hlay.hidden + (nh + 1) * M * H * 2].view(torch.bfloat16).view(nh + 1, B, L, H)
+        hhidden[0].copy_(hidden[skip_from])
+        hhidden[0][:, 0].copy_(last[:, 0])
+        hlo = head.layout
+        harr, _ = hlo.layer_structs(head._shadow.data_ptr(), 0, head.flat_nodecay.data_ptr())
+        check(lib().cocodr_stack_fwd(C.byref(hcfg), harr, ptr(mask), B, L, 1, ptr(harena), harena.numel(), stream_ptr()), "stack_fwd")
+        head_out = hhidden[nh]
+        # ---- lm.cls on the labelled rows of the head output (and of the last backbone layer: "late" MLM)
+        # each group of rows is padded to a multiple of 64 with copies of row 0 that carry scale 0 (their dlogits,
+        # and therefore every gradient they touch, are exactly zero): the wgrad GEMMs contract over this axis
+        n_pad = (n_lab + 63) // 64 * 64
+        rows_p = torch.cat([rows, rows.new_zeros(n_pad - n_lab)])
+        lab_p = torch.cat([lab, lab.new_zeros(n_pad - n_lab)])
+        scale_p = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        scale_p[:n_lab] = 1.0 / n_lab
+        xg = head_out.reshape(M, H).index_select(0, rows_p)
+        if late_mlm:
+            xg = torch.cat([xg, last.reshape(M, H).index_select(0, rows_p)])
+        n2 = xg.shape[0]
+        wt = head._shadow[: H * H].view(H, H)
+        b_t = head.hf_view("cls.predictions.transform.dense.bias")
+        g_act, a_pre = ops.gemm(xg.contiguous(), wt, bias=b_t, epi=N.EPI_GELU)
+        t, t_mean, t_rstd = ops.ln_fwd(g_act, head.hf_view("cls.predictions.transform.LayerNorm.weight"),
+                                       head.hf_view("cls.predictions.transform.LayerNorm.bias"), cfg.layer_norm_eps)
+        word16 = torch.zeros((head.vpad, H), dtype=torch.bfloat16, device=dev)  # tied decoder weight, rows padded to 128
+        ops.cast_f32_bf16(bert.hf_view("embeddings.word_embeddings.weight"), word16[:V])
+        dec_bias = torch.full((head.vpad,), _NEG, dtype=torch.float32, device=dev)
+        dec_bias[:V].copy_(head.hf_view("cls.predictions.bias"))
+        logits = ops.gemm(t, word16, bias=dec_bias, out_f32=True)  # [n2, vpad] fp32
+        scale = torch.cat([scale_p, scale_p]) if late_mlm else scale_p
+        lab2 = torch.cat([lab_p, lab_p]) if late_mlm else lab_p
+        loss_rows = torch.empty(n2, dtype=torch.float32, device=dev)
+        dlogits = torch.empty((n2, head.vpad), dtype=torch.bfloat16, device=dev)
+        check(lib().cocodr_ce_fwd_bwd(ptr(logits), ptr(lab2), ptr(scale), n2, V, head.vpad, ptr(loss_rows), ptr(dlogits),
+                                      stream_ptr()), "ce_fwd_bwd")
+        mlm_loss = (loss_rows * scale).sum()  # mean over the head rows + mean over the late rows
+        del logits
+        ctx.bert, ctx.head = bert, head
+        ctx.skip_from, ctx.late_mlm, ctx.n_lab, ctx.n_pad = skip_from, late_mlm, n_lab, n_pad
+        ctx.arena, ctx.lay, ctx.harena, ctx.hlay, ctx.hcfg = arena, lay, harena, hlay, hcfg
+        ctx.ids, ctx.mask = ids, mask
+        ctx.saved = (rows, xg, a_pre, g_act, t, t_mean, t_rstd, word16, dlogits)
+        ctx.set_materialize_grads(False)
+        return mlm_loss, cls
+
+    @staticmethod
+    def backward(ctx, g_mlm, d_cls):
+        bert, head = ctx.bert, ctx.head
+        cfg = bert.config
+        B, L = ctx.ids.shape
+        M, H, V, NL = B * L, cfg.hidden_size, cfg.vocab_size, cfg.num_hidden_layers
+        nh, n_lab, skip_from = head.n_head_layers, ctx.n_lab, ctx.skip_from
+        rows, xg, a_pre, g_act, t, t_mean, t_rstd, word16, dlogits = ctx.saved
+        dev = ctx.ids.device
+        hlo, lo = head.layout, bert.layout
+        ghd = torch.zeros_like(head.flat_decay.data)
+        ghn = torch.zeros_like(head.flat_nodecay.data)
+        gv = lambda name: hlo.view((ghd, ghn), name)
+        d_head_out = torch.zeros((M, H), dtype=torch.bfloat16, device=dev)
+        d_last = torch.zeros((M, H), dtype=torch.float32, device=dev)
+        dword_mlm = None
+        if g_mlm is not None:
+            dlog = dlogits.mul_(g_mlm.to(dlogits.dtype))  # upstream scale (1.0 in the reference step); no host sync
+            # decoder (tied to the word embeddings) and its bias
+            dt = ops.gemm(dlog, word16, trans_b=True)                                   # [n2,H]   dlogits . Word
+            dword_mlm = ops.gemm(dlog, t, trans_a=True, trans_b=True, out_f32=True)       # [vpad,H] dlogits^T . t
+            gv("cls.predictions.bias").copy_(ops.colsum(dlog)[:V])
+            # transform: LayerNorm, erf-GELU, dense
+            dg, dlnw, dlnb = ops.ln_bwd(dt, g_act, head.hf_view("cls.predictions.transform.LayerNorm.weight"), t_mean, t_rstd)
+            gv("cls.predictions.transform.LayerNorm.weight").copy_(dlnw)
+            gv("cls.predictions.transform.LayerNorm.bias").copy_(dlnb)
+            da = (dg.float() * _gelu_grad(a_pre.float())).to(torch.bfloat16)
+            gv("cls.predictions.transform.dense.weight").copy_(ops.gemm(da, xg, trans_a=True, trans_b=True, out_f32=True))
+            gv("cls.predictions.transform.dense.bias").copy_(ops.colsum(da))
+            wt = head._shadow[: H * H].view(H, H)
+            dxg = ops.gemm(da, wt, trans_b=True)                                        # [n2,H]
+            d_head_out.index_copy_(0, rows, dxg[:n_lab])
+            if ctx.late_mlm:
+                d_last.index_add_(0, rows, dxg[ctx.n_pad:ctx.n_pad + n_lab].float())
+        # ---- Condenser head backward (layers nh-1 .. 0), input gradient left at hlay.bwd_dx
+        harr, hgarr = hlo.layer_structs(head._shadow.data_ptr(), 0, head.flat_nodecay.data_ptr(), (ghd.data_ptr(), ghn.data_ptr()))
+        check(lib().cocodr_encoder_bwd_range(C.byref(ctx.hcfg), None, harr, None, hgarr, None, ptr(ctx.mask), ptr(d_head_out), B, L,
+                                             ptr(ctx.harena), ctx.harena.numel(), nh, 0, 0, stream_ptr()), "encoder_bwd_range(head)")
+        d_hin = ctx.harena[ctx.hlay.bwd_dx: ctx.hlay.bwd_dx + M * H * 2].view(torch.bfloat16).view(B, L, H)
+        d_last.view(B, L, H)[:, 0] += d_hin[:, 0].float()
+        if d_cls is not None:
+            d_last.view(B, L, H)[:, 0] += d_cls.float()
+        d_skip = d_hin.clone()
+        d_skip[:, 0] = 0
+        # ---- backbone backward in two ranges; the head's gradient joins at hidden_states[skip_from]
+        bgd = torch.empty_like(bert.flat_decay.data)
+        bgn = torch.empty_like(bert.flat_nodecay.data)
+        bgd[:lo.mat_begin].zero_()
+        emb, arr, eg, garr = bert._param_structs((bgd, bgn))
+        bcfg = bert._c_config()
+        d_last16 = d_last.to(torch.bfloat16)
+        dx_view = ctx.arena[ctx.lay.bwd_dx: ctx.lay.bwd_dx + M * H * 2].view(torch.bfloat16).view(B, L, H)
+
+        def bwd_range(hi, lo_, d_in, do_embed):
+            check(lib().cocodr_encoder_bwd_range(C.byref(bcfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ctx.ids), ptr(ctx.mask),
+                                                 ptr(d_in) if d_in is not None else None, B, L, ptr(ctx.arena), ctx.arena.numel(),
+                                                 hi, lo_, int(do_embed), stream_ptr()), "encoder_bwd_range")
+
+        if skip_from >= NL:       # head reads the last layer itself: its gradient simply adds to d_last
+            bwd_range(NL, 0, (d_last.view(B, L, H) + d_skip.float()).to(torch.bfloat16).view(M, H), True)
+        else:
+            bwd_range(NL, skip_from, d_last16, False)
+            dx_view += d_skip
+            bwd_range(skip_from, 0, None, True)
+        if dword_mlm is not None:
+            bgd[: V * H].view(V, H).add_(dword_mlm[:V])
+        ctx.arena = ctx.harena = None
+        ctx.saved = None
+        return bgd, bgn, ghd, ghn, None, None, None, None, None, None, None
+
+
+def condenser_step(bert: CocoBertModel, head: CondenserHead, input_ids, attention_mask, labels, skip_from: int, late_mlm: bool):
+    """Returns (mlm_loss, cls_fp32): the MLM part of COCO/modeling.py:222-224 and the last-layer [CLS] rows for the
+    contrastive part (:206-210, :226-230)."""
+    ids, mask, L = bert._prep(input_ids, attention_mask)
+    if L != ids.shape[1]:
+        labels = torch.nn.functional.pad(labels, (0, ids.shape[1] - L), value=-100)
+    if not (0 <= skip_from <= bert.config.num_hidden_layers):
+        raise ValueError(f"skip_from={skip_from} outside [0, {bert.config.num_hidden_layers}]")
+    return _CondenserStepFn.apply(bert.flat_decay, bert.flat_nodecay, head.flat_decay, head.flat_nodecay, ids, mask,
+                                  labels.contiguous(), bert, head, int(skip_from), bool(late_mlm))

@@ -107,18 +107,35 @@ class CocoBertConfig:
 
 # =============================================================================== flat parameter layout
 class _Layout:
-    """Offsets (in elements) of every HF-named tensor inside the two flat parameters."""
+    """Offsets (in elements) of every HF-named tensor inside two flat parameters (decay / no-decay): a preamble of
+    free-form tensors followed by ``n_layers`` BertLayer blocks at a uniform stride."""
 
-    def __init__(self, cfg: CocoBertConfig):
-        H, I, NL = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    def __init__(self, cfg: CocoBertConfig, n_layers: Optional[int] = None, layer_prefix: str = "encoder.layer.",
+                 decay_pre=None, nodecay_pre=None):
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        NL = cfg.num_hidden_layers if n_layers is None else n_layers
         V, P, T = cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size
+        if decay_pre is None:
+            decay_pre = [("embeddings.word_embeddings.weight", (V, H)), ("embeddings.position_embeddings.weight", (P, H)),
+                         ("embeddings.token_type_embeddings.weight", (T, H))]
+        if nodecay_pre is None:
+            nodecay_pre = [("embeddings.LayerNorm.weight", (H,)), ("embeddings.LayerNorm.bias", (H,))]
         self.cfg = cfg
+        self.n_layers = NL
         d = OrderedDict()  # name -> (flat index 0/1, offset, shape)
+
+        def numel(shape):
+            n = 1
+            for x in shape:
+                n *= x
+            return n
+
         o = 0
-        for name, rows in (("embeddings.word_embeddings.weight", V), ("embeddings.position_embeddings.weight", P),
-                           ("embeddings.token_type_embeddings.weight", T)):
-            d[name] = (0, o, (rows, H))
-            o += rows * H
+        for name, shape in decay_pre:
+            d[name] = (0, o, tuple(shape))
+            o += numel(shape)
+            if not name.startswith("embeddings."):
+                o = (o + 63) // 64 * 64  # the embedding tables stay contiguous (native side derives pos/type from word)
         self.emb_decay_end = o
         o = (o + 63) // 64 * 64
         self.mat_begin = o
@@ -126,7 +143,7 @@ class _Layout:
         self.off_wqkv, self.off_wo, self.off_w1, self.off_w2 = 0, 3 * H * H, 4 * H * H, 4 * H * H + I * H
         for l in range(NL):
             b = self.mat_begin + l * self.mat_stride
-            p = f"encoder.layer.{l}."
+            p = f"{layer_prefix}{l}."
             d[p + "attention.self.query.weight"] = (0, b, (H, H))
             d[p + "attention.self.key.weight"] = (0, b + H * H, (H, H))
             d[p + "attention.self.value.weight"] = (0, b + 2 * H * H, (H, H))
@@ -135,15 +152,19 @@ class _Layout:
             d[p + "output.dense.weight"] = (0, b + self.off_w2, (H, I))
         self.decay_numel = self.mat_begin + NL * self.mat_stride
         # --- no-decay flat: LayerNorm + biases
-        d["embeddings.LayerNorm.weight"] = (1, 0, (H,))
-        d["embeddings.LayerNorm.bias"] = (1, H, (H,))
-        self.vec_begin = 2 * H
+        o = 0
+        for name, shape in nodecay_pre:
+            d[name] = (1, o, tuple(shape))
+            o += numel(shape)
+            if not name.startswith("embeddings."):
+                o = (o + 63) // 64 * 64
+        self.vec_begin = (o + 3) // 4 * 4
         self.vec_stride = 3 * H + H + I + H + 4 * H
         self.off_bqkv, self.off_bo, self.off_b1, self.off_b2 = 0, 3 * H, 4 * H, 4 * H + I
         self.off_ln1g, self.off_ln1b, self.off_ln2g, self.off_ln2b = (5 * H + I, 6 * H + I, 7 * H + I, 8 * H + I)
         for l in range(NL):
             b = self.vec_begin + l * self.vec_stride
-            p = f"encoder.layer.{l}."
+            p = f"{layer_prefix}{l}."
             d[p + "attention.self.query.bias"] = (1, b, (H,))
             d[p + "attention.self.key.bias"] = (1, b + H, (H,))
             d[p + "attention.self.value.bias"] = (1, b + 2 * H, (H,))
@@ -163,6 +184,28 @@ class _Layout:
         for s in shape:
             n *= s
         return flats[which][off:off + n].view(shape)
+
+    def layer_structs(self, shadow_ptr: int, shadow_begin: int, nodecay_ptr: int, grads=None):
+        """ctypes arrays of cocodr_layer_params (bf16 shadow matrices + fp32 vectors) and, with ``grads`` = (decay
+        grad ptr, nodecay grad ptr), of cocodr_layer_grads for the layer blocks of this layout."""
+        arr = (N.LayerParams * self.n_layers)()
+        for l in range(self.n_layers):
+            mb = shadow_ptr + 2 * (self.mat_begin - shadow_begin + l * self.mat_stride)
+            vb = nodecay_ptr + 4 * (self.vec_begin + l * self.vec_stride)
+            arr[l] = N.LayerParams(mb + 2 * self.off_wqkv, mb + 2 * self.off_wo, mb + 2 * self.off_w1, mb + 2 * self.off_w2,
+                                   vb + 4 * self.off_bqkv, vb + 4 * self.off_bo, vb + 4 * self.off_b1, vb + 4 * self.off_b2,
+                                   vb + 4 * self.off_ln1g, vb + 4 * self.off_ln1b, vb + 4 * self.off_ln2g, vb + 4 * self.off_ln2b)
+        if grads is None:
+            return arr, None
+        gd, gn = grads
+        garr = (N.LayerGrads * self.n_layers)()
+        for l in range(self.n_layers):
+            mb = gd + 4 * (self.mat_begin + l * self.mat_stride)
+            vb = gn + 4 * (self.vec_begin + l * self.vec_stride)
+            garr[l] = N.LayerGrads(mb + 4 * self.off_wqkv, mb + 4 * self.off_wo, mb + 4 * self.off_w1, mb + 4 * self.off_w2,
+                                   vb + 4 * self.off_bqkv, vb + 4 * self.off_bo, vb + 4 * self.off_b1, vb + 4 * self.off_b2,
+                                   vb + 4 * self.off_ln1g, vb + 4 * self.off_ln1b, vb + 4 * self.off_ln2g, vb + 4 * self.off_ln2b)
+        return arr, garr
 
 
 class EncoderOutput:
@@ -375,25 +418,13 @@ class CocoBertModel(nn.Module):
         pd, pn, ps = fd.data_ptr(), fn.data_ptr(), self._shadow.data_ptr()
         emb = N.EmbedParams(pd, pd + 4 * cfg.vocab_size * H, pd + 4 * (cfg.vocab_size + cfg.max_position_embeddings) * H,
                             pn, pn + 4 * H)
-        arr = (N.LayerParams * cfg.num_hidden_layers)()
-        for l in range(cfg.num_hidden_layers):
-            mb = ps + 2 * (l * lo.mat_stride)
-            vb = pn + 4 * (lo.vec_begin + l * lo.vec_stride)
-            arr[l] = N.LayerParams(mb + 2 * lo.off_wqkv, mb + 2 * lo.off_wo, mb + 2 * lo.off_w1, mb + 2 * lo.off_w2,
-                                   vb + 4 * lo.off_bqkv, vb + 4 * lo.off_bo, vb + 4 * lo.off_b1, vb + 4 * lo.off_b2,
-                                   vb + 4 * lo.off_ln1g, vb + 4 * lo.off_ln1b, vb + 4 * lo.off_ln2g, vb + 4 * lo.off_ln2b)
         if grads is None:
+            arr, _ = lo.layer_structs(ps, lo.mat_begin, pn)
             return emb, arr, None, None
         gd, gn = grads[0].data_ptr(), grads[1].data_ptr()
+        arr, garr = lo.layer_structs(ps, lo.mat_begin, pn, (gd, gn))
         eg = N.EmbedGrads(gd, gd + 4 * cfg.vocab_size * H, gd + 4 * (cfg.vocab_size + cfg.max_position_embeddings) * H,
                           gn, gn + 4 * H)
-        garr = (N.LayerGrads * cfg.num_hidden_layers)()
-        for l in range(cfg.num_hidden_layers):
-            mb = gd + 4 * (lo.mat_begin + l * lo.mat_stride)
-            vb = gn + 4 * (lo.vec_begin + l * lo.vec_stride)
-            garr[l] = N.LayerGrads(mb + 4 * lo.off_wqkv, mb + 4 * lo.off_wo, mb + 4 * lo.off_w1, mb + 4 * lo.off_w2,
-                                   vb + 4 * lo.off_bqkv, vb + 4 * lo.off_bo, vb + 4 * lo.off_b1, vb + 4 * lo.off_b2,
-                                   vb + 4 * lo.off_ln1g, vb + 4 * lo.off_ln1b, vb + 4 * lo.off_ln2g, vb + 4 * lo.off_ln2b)
         return emb, arr, eg, garr
 
     def _layout_for(self, B: int, L: int, training: bool) -> N.EncoderLayout:
@@ -603,18 +634,20 @@ class _GatherRows(torch.autograd.Function):
 
 
 class CoCondenserForPretraining(nn.Module):
-    """Contrastive half of ``CoCondenserForPretraining`` (COCO/modeling.py:162-248): encoder -> last-layer
-    [CLS] (:206) -> cross-rank gather (:207-208) -> span-pair InfoNCE (:244-248) -> ``.mean()`` (:229).
-    ``forward(model_input, labels)`` keeps the reference signature; ``labels`` is accepted and ignored
-    because the Condenser head + MLM losses are the SURVEY 8(f1) "next" row."""
+    """``CoCondenserForPretraining`` (COCO/modeling.py:162-248): encoder -> last-layer [CLS] (:206) -> cross-rank
+    gather (:207-208) -> span-pair InfoNCE (:244-248) -> ``.mean()`` (:229), plus - when ``model_args.n_head_layers``
+    > 0 and ``labels`` are given - the Condenser head and the MLM losses (:212-224, cocodr_amd.condenser).
+    ``forward(model_input, labels)`` keeps the reference signature and returns the summed loss."""
 
     def __init__(self, bert: CocoBertModel, model_args=None, data_args=None, train_args=None):
         super().__init__()
         self.lm = bert
         self.model_args, self.data_args, self.train_args = model_args, data_args, train_args
-        if model_args is not None and getattr(model_args, "n_head_layers", 0) not in (0, None):
-            warnings.warn("cocodr_amd: Condenser head layers / MLM loss are not part of this path yet; "
-                          "forward() returns the contrastive loss only")
+        n_head = int(getattr(model_args, "n_head_layers", 0) or 0) if model_args is not None else 0
+        self.c_head = None
+        if n_head > 0:
+            from .condenser import CondenserHead
+            self.c_head = CondenserHead(bert.config, n_head, device=bert.flat_decay.device)
 
     @staticmethod
     def _world_size():
@@ -623,10 +656,23 @@ class CoCondenserForPretraining(nn.Module):
 
     @classmethod
     def from_pretrained(cls, model_args, data_args, train_args, path, **kw):
-        return cls(CocoBertModel.from_pretrained(path, **kw), model_args, data_args, train_args)
+        model = cls(CocoBertModel.from_pretrained(path, **kw), model_args, data_args, train_args)
+        extra = os.path.join(path, "model.pt")  # head weights saved next to the HF checkpoint (COCO/modeling.py:103-107)
+        if model.c_head is not None and os.path.exists(extra):
+            sd = torch.load(extra, map_location="cpu", weights_only=True)
+            model.c_head.load_state_dict(sd, strict=False)
+        return model
 
     def save_pretrained(self, output_dir: str):
         self.lm.save_pretrained(output_dir)
+        if self.c_head is not None:
+            torch.save({k: v.cpu() for k, v in self.c_head.state_dict().items()}, os.path.join(output_dir, "model.pt"))
+
+    def param_groups(self, weight_decay: float = 0.0):
+        groups = self.lm.param_groups(weight_decay)
+        if self.c_head is not None:
+            groups += self.c_head.param_groups(weight_decay)
+        return groups
 
     def compute_contrastive_loss(self, co_cls_hiddens: torch.Tensor) -> torch.Tensor:
         """Per-row loss [M] (already multiplied by world size), COCO/modeling.py:244-248."""
@@ -636,9 +682,15 @@ class CoCondenserForPretraining(nn.Module):
 
     def forward(self, model_input, labels=None, **unused):
         ids, mask = model_input["input_ids"], model_input.get("attention_mask")
-        cls = self.lm.encode_cls(ids, mask)  # [2b, H] fp32
+        mlm_loss = None
+        if self.c_head is not None and labels is not None:
+            from .condenser import condenser_step
+            skip_from = int(getattr(self.model_args, "skip_from", 2))
+            late_mlm = bool(getattr(self.model_args, "late_mlm", False))
+            mlm_loss, cls = condenser_step(self.lm, self.c_head, ids, mask, labels, skip_from, late_mlm)
+        else:
+            cls = self.lm.encode_cls(ids, mask)  # [2b, H] fp32
         W = self._world_size()
-        import os
         force = bool(os.environ.get("COCODR_FORCE_DIST")) and torch.distributed.is_initialized()  # 1-rank test of the N>1 path
         if W > 1 or force:
             import torch.distributed as dist
@@ -647,4 +699,4 @@ class CoCondenserForPretraining(nn.Module):
         else:
             E, row0 = cls, 0
         loss, _rows = _SimCEFn.apply(E, W, row0, cls.shape[0])
-        return loss
+        return loss if mlm_loss is None else loss + mlm_loss

@@ -236,3 +236,59 @@ def test_chunked_backward_with_overlapped_allreduce_matches_single_call():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_full_condenser_step_matches_reference_golden():
+    """Condenser head + both MLM losses + contrastive loss, native path vs the reference's
+    CoCondenserForPretraining.forward golden (tests/golden/coco_condenser_tiny.npz).  Tolerances as above; the MLM
+    logits go through bf16 hidden states and a bf16 tied decoder, loss within 1e-2 relative."""
+    import types
+    from conftest import load_golden
+    g = load_golden("coco_condenser_tiny.npz")
+    ocfg = cfg_from_golden(g)
+    P = O.make_params(ocfg, int(g["seed"]), std=float(g["std"]))
+    Ph = O.make_head_params(ocfg, int(g["n_head_layers"]), int(g["seed_head"]), std=float(g["std"]))
+    m = model_from_oracle(ocfg, P)
+    margs = types.SimpleNamespace(n_head_layers=int(g["n_head_layers"]), skip_from=int(g["skip_from"]), late_mlm=True)
+    model = CoCondenserForPretraining(m, margs)
+    model.c_head.load_state_dict({k: torch.from_numpy(v) for k, v in Ph.items()})
+    model.to(DEV)
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    loss = model({"input_ids": t("input_ids"), "attention_mask": t("attention_mask")}, t("labels"))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-2 * abs(float(g["loss"]))
+    total, parts, Gref, Ghref = O.condenser_step(P, Ph, ocfg, g["input_ids"], g["attention_mask"], g["labels"],
+                                                 int(g["n_head_layers"]), int(g["skip_from"]), late_mlm=True)
+    G = grads_by_name(m)
+    Gh = {k: v.detach().float().cpu().numpy() for k, v in model.c_head.hf_named_grads()}
+    bad = {n: rel_l2(G[n], Gref[n]) for n in Gref if not n.endswith("key.bias") and rel_l2(G[n], Gref[n]) > 8e-2}
+    badh = {n: rel_l2(Gh[n], Ghref[n]) for n in Ghref if not n.endswith("key.bias") and rel_l2(Gh[n], Ghref[n]) > 8e-2}
+    assert not bad and not badh, (bad, badh)
+    for key in g.files:  # and directly against the reference's own gradients
+        if key.startswith("grad:") and not key.endswith("key.bias"):
+            assert rel_l2(G[key[5:]], g[key]) < 8e-2, key
+        if key.startswith("hgrad:") and not key.endswith("key.bias"):
+            assert rel_l2(Gh[key[6:]], g[key]) < 8e-2, key
+
+
+def test_full_condenser_step_base_size_properties():
+    """BERT-base, 64 x 128 tokens, 2 head layers, skip_from 6, late MLM (COCO/README.md:49 settings): finite loss,
+    all gradients finite and non-zero, MLM loss near log(V) at init."""
+    import types
+    torch.manual_seed(0)
+    m = CocoBertModel(CocoBertConfig.base()).to(DEV)
+    model = CoCondenserForPretraining(m, types.SimpleNamespace(n_head_layers=2, skip_from=6, late_mlm=True)).to(DEV)
+    B, L = 64, 128
+    gen = torch.Generator().manual_seed(1)
+    ids = torch.randint(1000, 30522, (B, L), generator=gen)
+    mask = torch.ones(B, L, dtype=torch.long)
+    labels = torch.full((B, L), -100, dtype=torch.long)
+    pick = torch.rand(B, L, generator=gen) < 0.15
+    pick[:, 0] = False
+    labels[pick] = ids[pick]
+    loss = model({"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV)}, labels.to(DEV))
+    loss.backward()
+    lv = float(loss.detach())
+    assert np.isfinite(lv) and 2 * np.log(30522) * 0.8 < lv < 2 * np.log(30522) * 1.3 + 60
+    for p in list(m.parameters()) + list(model.c_head.parameters()):
+        assert torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
