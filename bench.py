@@ -83,6 +83,47 @@ def cpu_baseline(n_seq: int = 8, L: int = SEQ_LEN, steps: int = 2):
             "sample": f"{steps} steps of {n_seq} sequences x L{L}, BERT-base, numpy fp32 oracle fwd+loss+bwd (no optimizer)"}
 
 
+def full_coco_step(cfg, args, dev, ids, mask, steps: int = 8, warmup: int = 3):
+    """The reference's whole pre-training step (COCO/modeling.py:192-235 with COCO/README.md:49 settings: 2 Condenser
+    head layers, skip_from 6, late MLM): backbone + head + two label-sparse MLM losses + contrastive + AdamW.
+    Reported next to the headline metric, never instead of it."""
+    import types
+    from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
+    from cocodr_amd.optim import FlatAdamW
+    torch.manual_seed(0)
+    bert = CocoBertModel(cfg).to(dev)
+    margs = types.SimpleNamespace(n_head_layers=2, skip_from=min(6, cfg.num_hidden_layers), late_mlm=True)
+    model = CoCondenserForPretraining(bert, margs).to(dev)
+    opt = FlatAdamW.for_model(bert, lr=1e-4, weight_decay=0.01)
+    opt_h = torch.optim.AdamW(model.c_head.param_groups(0.01), lr=1e-4, fused=True)
+    g = torch.Generator().manual_seed(5)
+    pick = (torch.rand(ids.shape, generator=g) < 0.15).to(dev) & (mask > 0)
+    pick[:, 0] = False
+    labels = torch.where(pick, ids, torch.full_like(ids, -100))
+    inp = torch.where(pick, torch.full_like(ids, 103), ids)  # [MASK]
+    batch = {"input_ids": inp, "attention_mask": mask}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        opt_h.zero_grad(set_to_none=True)
+        loss = model(batch, labels)
+        loss.backward()
+        opt.step()
+        opt_h.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"sequences_per_sec": round(ids.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss.detach()), 3),
+            "scope": "backbone + 2 Condenser head layers (skip_from 6) + head & late MLM losses (label-sparse, 15 %) + contrastive + AdamW"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +134,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-full-step", action="store_true", help="skip the extra full-coCondenser-step measurement")
     ap.add_argument("--dp-chunks", type=int, default=2, help="layer ranges whose gradient all-reduce overlaps the backward")
     args = ap.parse_args()
 
@@ -169,11 +211,14 @@ def main():
                     "launches_per_step": n_launch // max(1, args.steps),
                     "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                     "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3)}
+    full = None
+    if not args.no_full_step and not use_dist:
+        full = full_coco_step(cfg, args, dev, ids, mask)  # second scope: what the reference's step really runs
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         n_seq = args.seq_per_gpu * world * args.steps
@@ -193,6 +238,8 @@ def main():
         }
         if roof is not None:
             out["roofline"] = roof
+        if full is not None:
+            out["full_coco_step"] = full
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -301,9 +301,47 @@ def golden_condenser():
     sys.path.pop(0)
 
 
+def golden_token_cache():
+    """A small token cache written with the reference's record formula (ANCE/data/msmarco_data.py:279) using its own
+    ``pad_input_ids`` and read back with its own ``EmbeddingCache`` (ANCE/utils/util.py:316-370).  Harness shim: an
+    empty stand-in module for the absent ``pytrec_eval`` so that ANCE/utils/util.py imports (the cache code never
+    touches it)."""
+    sys.modules.setdefault("pytrec_eval", types.ModuleType("pytrec_eval"))
+    sys.path.insert(0, os.path.join(REF, "ANCE"))
+    from utils.util import EmbeddingCache, pad_input_ids  # reference
+    import json
+    import tempfile
+    rng = np.random.Generator(np.random.PCG64(21))
+    L, n = 16, 9
+    recs = []
+    blob = b""
+    for i in range(n):
+        toks = [int(x) for x in rng.integers(1, 30000, int(rng.integers(1, 25)))]
+        ln = min(len(toks), L)
+        blob += ln.to_bytes(4, "big") + np.array(pad_input_ids(toks, L), np.int32).tobytes()
+    d = tempfile.mkdtemp()
+    path = os.path.join(d, "passages")
+    with open(path, "wb") as f:
+        f.write(blob)
+    with open(path + "_meta", "w") as f:
+        json.dump({"type": "int32", "total_number": n, "embedding_size": L}, f)
+    lens, toks = [], []
+    with EmbeddingCache(path) as cache:
+        for i in range(n):
+            ln, t = cache[i]
+            lens.append(ln)
+            toks.append(np.array(t))
+    np.savez_compressed(os.path.join(OUT, "token_cache.npz"), blob=np.frombuffer(blob, np.uint8), max_len=np.int64(L),
+                        lengths=np.array(lens), tokens=np.stack(toks))
+    print("token cache golden:", lens)
+    sys.path.pop(0)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser"]
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache"]
+    if "cache" in which:
+        golden_token_cache()
     if "coco" in which:
         golden_coco()
     if "condenser" in which:
