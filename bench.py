@@ -124,6 +124,25 @@ def full_coco_step(cfg, args, dev, ids, mask, steps: int = 8, warmup: int = 3):
             "scope": "backbone + 2 Condenser head layers (skip_from 6) + head & late MLM losses (label-sparse, 15 %) + contrastive + AdamW"}
 
 
+def eval_search(dev, nq: int = 2048, npass: int = 125000, dim: int = 1024, k: int = 1000, iters: int = 3):
+    """BASELINE.json's second metric on one shard of config 5 (cocodr-large width, 125 k passages per GPU, k = 1000):
+    query x passage dot-products/sec = Nq*Np / wall time of (exact fp32 score + exact top-k), embeddings resident in HBM."""
+    from cocodr_amd import ops
+    g = torch.Generator().manual_seed(7)
+    Q = (torch.randn(nq, dim, generator=g) / dim ** 0.5).to(dev)
+    P = (torch.randn(npass, dim, generator=g) / dim ** 0.5).to(dev)
+    ws = torch.empty(ops.lib().cocodr_score_topk_workspace_bytes(nq, npass, k), dtype=torch.uint8, device=dev)
+    ops.score_topk(Q, P, k, workspace=ws)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ops.score_topk(Q, P, k, workspace=ws)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"dot_products_per_sec": round(nq * npass / dt), "ms": round(dt * 1e3, 2),
+            "workload": f"{nq} queries x {npass} passages x {dim} fp32, k={k}, exact scores + exact top-k, 1 GPU shard of config 5"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,7 +153,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-full-step", action="store_true", help="skip the extra full-coCondenser-step measurement")
+    ap.add_argument("--no-full-step", action="store_true", help="skip the extra full-coCondenser-step and eval-search measurements")
     ap.add_argument("--dp-chunks", type=int, default=2, help="layer ranges whose gradient all-reduce overlaps the backward")
     args = ap.parse_args()
 
@@ -214,6 +233,7 @@ def main():
     full = None
     if not args.no_full_step and not use_dist:
         full = full_coco_step(cfg, args, dev, ids, mask)  # second scope: what the reference's step really runs
+    search = eval_search(dev) if (not args.no_full_step and not use_dist) else None
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -240,6 +260,8 @@ def main():
             out["roofline"] = roof
         if full is not None:
             out["full_coco_step"] = full
+        if search is not None:
+            out["eval_search"] = search
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

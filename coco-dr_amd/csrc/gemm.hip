@@ -251,12 +251,14 @@ __device__ __forceinline__ void grouped_tile(int id, int ntm, int ntn, int gm, i
   tn = r / rows;
 }
 
-template <int BMv, int BKv, int WTM>
+template <int BMv, int BKv, int WTM, int WTN>
 struct Geom {
+  static constexpr int BNv = 64 * WTN;  // two wave columns of 32*WTN
   static constexpr int NWAVES = (BMv / (32 * WTM)) * 2;
   static constexpr int NTHREADS = NWAVES * 64;
   static constexpr int A_BYTES = BMv * BKv * 2;
-  static constexpr int B_BYTES = 128 * BKv * 2;
+  static constexpr int B_BYTES = BNv * BKv * 2;
+  static constexpr int CT_LDv = BNv + 4;  // fp32 epilogue tile leading dim
   static constexpr int STAGE = A_BYTES + B_BYTES;
   static constexpr int GA = (A_BYTES / 1024) / NWAVES;  // wave-level 1 KiB loads per stage
   static constexpr int GB = (B_BYTES / 1024) / NWAVES;
@@ -276,6 +278,14 @@ __device__ __forceinline__ int tile_rows_off(int row, int ch) {
   return row * (BKv * 2) + ((ch ^ swz_rows<BKv>(row)) << 4);
 }
 
+// chunk swizzle of a [k][COLS] tile read with ds_read_b64_tr_b16 (4 rows x 64 B per 32 lanes): rows r..r+3 must fall
+// into the four 64-B windows of a 256-B bank row.  256-B / 512-B rows: XOR the chunk with (row & 3) << 2; 384-B rows
+// (COLS = 192) already alternate 128-B halves, so only bit 2 is flipped on rows 2,3 (keeps chunk < 24).
+template <int COLS>
+__device__ __forceinline__ int swz_cols(int row) {
+  return COLS == 192 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
+}
+
 // byte offset (relative to the matrix base) of the 16-B chunk that must land at linear LDS chunk p of a tile
 template <int TR, int COLS /* tile width when stored [k][COLS] */, int BKv>
 __device__ __forceinline__ uint32_t glds_src_off(int p, int r0, int ld) {
@@ -285,7 +295,7 @@ __device__ __forceinline__ uint32_t glds_src_off(int p, int r0, int ld) {
     return (uint32_t)(((r0 + row) * ld + ch * 8) * 2);
   } else {
     constexpr int CPR = COLS / 8;
-    const int row = p / CPR, ch = (p % CPR) ^ ((row & 3) << 2);
+    const int row = p / CPR, ch = (p % CPR) ^ swz_cols<COLS>(row);
     return (uint32_t)((row * ld + r0 + ch * 8) * 2);
   }
 }
@@ -310,7 +320,7 @@ __device__ __forceinline__ void frag_addrs(int r0, int lane, uint32_t (&ad)[4]) 
 #pragma unroll
     for (int a = 0; a < NF; ++a) {
       const int col = r0 + a * 32 + ((g & 1) << 4) + ((c & 3) << 2);
-      ad[a] = (uint32_t)(row * (COLS * 2) + (((col >> 3) ^ ((row & 3) << 2)) << 4) + ((col & 7) << 1));
+      ad[a] = (uint32_t)(row * (COLS * 2) + (((col >> 3) ^ swz_cols<COLS>(row)) << 4) + ((col & 7) << 1));
     }
   }
 }
@@ -337,18 +347,18 @@ __device__ __forceinline__ bf16x8 frag_get(const FragSet<TR, NF>& f, int a) {
     return __builtin_bit_cast(bf16x8, v);
   }
 }
-template <int TA, int TB, int WTM>
-__device__ __forceinline__ void mfma_step(const FragSet<TA, WTM>& fa, const FragSet<TB, 2>& fb, f32x16 (&acc)[WTM][2]) {
-  bf16x8 a[WTM], b[2];
+template <int TA, int TB, int WTM, int WTN>
+__device__ __forceinline__ void mfma_step(const FragSet<TA, WTM>& fa, const FragSet<TB, WTN>& fb, f32x16 (&acc)[WTM][WTN]) {
+  bf16x8 a[WTM], b[WTN];
 #pragma unroll
   for (int i = 0; i < WTM; ++i) a[i] = frag_get<TA, WTM>(fa, i);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) b[j] = frag_get<TB, 2>(fb, j);
+  for (int j = 0; j < WTN; ++j) b[j] = frag_get<TB, WTN>(fb, j);
   // operands swapped: D[i = n][j = m], so a lane ends up with 4 consecutive n of one m
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
 }
 
 // one 8-column slice of an output row: bias / GELU / residual / GELU' and the store
@@ -385,21 +395,22 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
   }
 }
 
-template <int BMv, int BKv, int WTM, int TA, int TB, bool OUT_F32>
-__global__ __launch_bounds__((Geom<BMv, BKv, WTM>::NTHREADS), (Geom<BMv, BKv, WTM>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
+template <int BMv, int BKv, int WTM, int WTN, int TA, int TB, bool OUT_F32>
+__global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN>::NTHREADS), (Geom<BMv, BKv, WTM, WTN>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
     const cocodr_gemm_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type only exists in the device pass; the host pass just needs the stub
-  using G = Geom<BMv, BKv, WTM>;
+  using G = Geom<BMv, BKv, WTM, WTN>;
+  constexpr int BNv = G::BNv;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
-  const int ntn = p.N / BN, ntm = (p.M + BMv - 1) / BMv;
+  const int ntn = p.N / BNv, ntm = (p.M + BMv - 1) / BMv;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   int tm_, tn_;
   if (TA == 0) grouped_tile(tile, ntm, ntn, 1024 / BMv, tm_, tn_);  // measured: helps fwd/dgrad, hurts the long-K wgrad
   else { tm_ = tile / ntn; tn_ = tile % ntn; }
-  const int m0 = tm_ * BMv, n0 = tn_ * BN;
+  const int m0 = tm_ * BMv, n0 = tn_ * BNv;
   const int z = blockIdx.y;
   const uint16_t* A = p.A + (size_t)z * p.strideA;
   const uint16_t* B = p.B + (size_t)z * p.strideB;
@@ -413,7 +424,7 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM>::NTHREADS), (Geom<BMv, BKv, WT
 #pragma unroll
   for (int j = 0; j < G::GA; ++j) offa[j] = glds_src_off<TA, BMv, BKv>((wid * G::GA + j) * 64 + lane, m0, p.lda);
 #pragma unroll
-  for (int j = 0; j < G::GB; ++j) offb[j] = glds_src_off<TB, 128, BKv>((wid * G::GB + j) * 64 + lane, n0, p.ldb);
+  for (int j = 0; j < G::GB; ++j) offb[j] = glds_src_off<TB, BNv, BKv>((wid * G::GB + j) * 64 + lane, n0, p.ldb);
   const uint32_t stepa = TA ? (uint32_t)(BKv * p.lda * 2) : (uint32_t)(BKv * 2);
   const uint32_t stepb = TB ? (uint32_t)(BKv * p.ldb * 2) : (uint32_t)(BKv * 2);
 
@@ -427,19 +438,19 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM>::NTHREADS), (Geom<BMv, BKv, WT
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(st + G::A_BYTES + (wid * G::GB + j) * 1024), 16, offb[j] + t * stepb, 0, 0, 0);
   };
 
-  f32x16 acc[WTM][2];
+  f32x16 acc[WTM][WTN];
 #pragma unroll
   for (int a = 0; a < WTM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < WTN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
   uint32_t adA[4], adB[4];
   frag_addrs<TA, BMv, BKv, WTM>(wm * 32 * WTM, lane, adA);
-  frag_addrs<TB, 128, BKv, 2>(wn * 64, lane, adB);
-  constexpr int R = (TA ? 2 : 1) * WTM + (TB ? 4 : 2);  // LDS reads per K-sub-step (<= 12 < the 4-bit lgkmcnt range)
+  frag_addrs<TB, BNv, BKv, WTN>(wn * 32 * WTN, lane, adB);
+  constexpr int R = (TA ? 2 : 1) * WTM + (TB ? 2 : 1) * WTN;  // LDS reads per K-sub-step (<= 12 < the 4-bit lgkmcnt range)
 
   const int nt = (p.K + BKv - 1) / BKv;
   issue(0);
@@ -454,21 +465,21 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM>::NTHREADS), (Geom<BMv, BKv, WT
 #pragma unroll
     for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + sbA; curB[i] = adB[i] + sbB; }
     FragSet<TA, WTM> fa0, fa1;
-    FragSet<TB, 2> fb0, fb1;
-    frags_issue<TA, BMv, BKv, WTM, 0>(curA, fa0); frags_issue<TB, 128, BKv, 2, 0>(curB, fb0);
-    frags_issue<TA, BMv, BKv, WTM, 1>(curA, fa1); frags_issue<TB, 128, BKv, 2, 1>(curB, fb1);
+    FragSet<TB, WTN> fb0, fb1;
+    frags_issue<TA, BMv, BKv, WTM, 0>(curA, fa0); frags_issue<TB, BNv, BKv, WTN, 0>(curB, fb0);
+    frags_issue<TA, BMv, BKv, WTM, 1>(curA, fa1); frags_issue<TB, BNv, BKv, WTN, 1>(curB, fb1);
     wait_lgkmcnt<R>();
-    mfma_step<TA, TB, WTM>(fa0, fb0, acc);
+    mfma_step<TA, TB, WTM, WTN>(fa0, fb0, acc);
     if constexpr (G::KS == 4) {
-      frags_issue<TA, BMv, BKv, WTM, 2>(curA, fa0); frags_issue<TB, 128, BKv, 2, 2>(curB, fb0);
+      frags_issue<TA, BMv, BKv, WTM, 2>(curA, fa0); frags_issue<TB, BNv, BKv, WTN, 2>(curB, fb0);
       wait_lgkmcnt<R>();
-      mfma_step<TA, TB, WTM>(fa1, fb1, acc);
-      frags_issue<TA, BMv, BKv, WTM, 3>(curA, fa1); frags_issue<TB, 128, BKv, 2, 3>(curB, fb1);
+      mfma_step<TA, TB, WTM, WTN>(fa1, fb1, acc);
+      frags_issue<TA, BMv, BKv, WTM, 3>(curA, fa1); frags_issue<TB, BNv, BKv, WTN, 3>(curB, fb1);
       wait_lgkmcnt<R>();
-      mfma_step<TA, TB, WTM>(fa0, fb0, acc);
+      mfma_step<TA, TB, WTM, WTN>(fa0, fb0, acc);
     }
     wait_lgkmcnt<0>();
-    mfma_step<TA, TB, WTM>(fa1, fb1, acc);
+    mfma_step<TA, TB, WTM, WTN>(fa1, fb1, acc);
   }
   __syncthreads();
 
@@ -477,6 +488,8 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM>::NTHREADS), (Geom<BMv, BKv, WT
   const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
   float* ct = reinterpret_cast<float*>(smem);
   constexpr int GPW = WTM / 2;  // 64-row groups per wave
+  constexpr int CLD = G::CT_LDv;
+  constexpr int CPRW = BNv / 8;  // 8-column chunks per output row
 #pragma unroll 1
   for (int h = 0; h < BMv / 64; ++h) {
     if (h / GPW == wm) {
@@ -484,28 +497,27 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM>::NTHREADS), (Geom<BMv, BKv, WT
 #pragma unroll
       for (int ai = 0; ai < 2; ++ai)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WTN; ++b)
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
             const int row = ai * 32 + (lane & 31);
-            const int col = wn * 64 + b * 32 + 8 * rg + 4 * (lane >> 5);
+            const int col = wn * 32 * WTN + b * 32 + 8 * rg + 4 * (lane >> 5);
             float4 v4;
             if (GPW == 1 || a0 == 0) v4 = make_float4(acc[ai][b][rg * 4 + 0], acc[ai][b][rg * 4 + 1], acc[ai][b][rg * 4 + 2], acc[ai][b][rg * 4 + 3]);
             else v4 = make_float4(acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 0], acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 1],
                                   acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 2], acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 3]);
-            *reinterpret_cast<float4*>(ct + row * CT_LD + col) = v4;
+            *reinterpret_cast<float4*>(ct + row * CLD + col) = v4;
           }
     }
     __syncthreads();
-#pragma unroll
-    for (int pp = 0; pp < 64 * 16 / G::NTHREADS; ++pp) {
-      const int row = (tid >> 4) + (G::NTHREADS / 16) * pp;
+    for (int c = tid; c < 64 * CPRW; c += G::NTHREADS) {
+      const int row = c / CPRW, c8 = (c % CPRW) << 3;
       const int gm = m0 + h * 64 + row;
-      const int gn = n0 + ((tid & 15) << 3);
+      const int gn = n0 + c8;
       if (gm < p.M) {
         float v[8];
-        const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CT_LD + ((tid & 15) << 3));
-        const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CT_LD + ((tid & 15) << 3) + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CLD + c8);
+        const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CLD + c8 + 4);
         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
         epilogue_store8<OUT_F32>(p, z, bias, R_, gm, gn, v);
       }
@@ -515,29 +527,29 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM>::NTHREADS), (Geom<BMv, BKv, WT
 #endif
 }
 
-template <int BMv, int BKv, int WTM, int TA, int TB>
+template <int BMv, int BKv, int WTM, int WTN, int TA, int TB>
 void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
-  using G = Geom<BMv, BKv, WTM>;
-  const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / BN;
+  using G = Geom<BMv, BKv, WTM, WTN>;
+  const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / G::BNv;
   dim3 grid(ntm * ntn, a.batch);
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, TA, TB, true>), grid, dim3(G::NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, TA, TB, true>), grid, dim3(G::NTHREADS), lds, st, a);
   else
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, TA, TB, false>), grid, dim3(G::NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, TA, TB, false>), grid, dim3(G::NTHREADS), lds, st, a);
 }
 
-template <int BMv, int BKv, int WTM>
+template <int BMv, int BKv, int WTM, int WTN = 2>
 void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
-  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, WTM, 0, 0>(a, st);
-  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, WTM, 0, 1>(a, st);
-  else launch_glds<BMv, BKv, WTM, 1, 1>(a, st);
+  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, WTM, WTN, 0, 0>(a, st);
+  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, WTM, WTN, 0, 1>(a, st);
+  else launch_glds<BMv, BKv, WTM, WTN, 1, 1>(a, st);
 }
 
 }  // namespace cocodr_gemm_v2
@@ -545,7 +557,7 @@ using cocodr_gemm_v2::launch_glds_any;
 
 namespace {
 
-int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, direct-to-LDS <BM,BK,WTM>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>
+int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, direct-to-LDS <BM,BK,WTM>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile <128,64,2> with 64x96 wave tiles
 int gemm_impl_override() {
   if (g_gemm_impl < 0) {
     const char* e = getenv("COCODR_GEMM_IMPL");
@@ -565,7 +577,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG(impl >= 0 && impl <= 7, "gemm_set_impl: impl must be in [0,7]");
+  CK_ARG(impl >= 0 && impl <= 8, "gemm_set_impl: impl must be in [0,8]");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -609,7 +621,9 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
     else impl = tiles128 >= 512 ? 4 : 2;
   }
   if (impl != 1 && !(k_ok && small)) impl = 1;
-  if (impl == 7) launch_glds_any<256, 64, 4>(a, st);
+  if (impl == 8 && a.N % 192 != 0) impl = 3;  // the 128x192 tile needs N % 192 == 0
+  if (impl == 8) launch_glds_any<128, 64, 2, 3>(a, st);
+  else if (impl == 7) launch_glds_any<256, 64, 4>(a, st);
   else if (impl == 6) launch_glds_any<256, 32, 4>(a, st);
   else if (impl == 5) launch_glds_any<256, 32, 2>(a, st);
   else if (impl == 4) launch_glds_any<128, 32, 2>(a, st);
