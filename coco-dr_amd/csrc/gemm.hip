@@ -13,6 +13,7 @@
 // ever materialised in HBM.  The accumulators go through an fp32 LDS tile so that the epilogue
 // (bias, erf-GELU, residual, GELU') runs row-major with 16-byte coalesced loads/stores.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "prof.h"
@@ -225,6 +226,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 template <int N>
 __device__ __forceinline__ void wait_lgkmcnt() {
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -251,21 +253,36 @@ __device__ __forceinline__ void grouped_tile(int id, int ntm, int ntn, int gm, i
   tn = r / rows;
 }
 
-template <int BMv, int BKv, int WTM, int WTN>
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (LO < HI) {
+    f(std::integral_constant<int, LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
+
+template <int BMv, int BKv, int WTM, int WTN, int LD = 0>
 struct Geom {
   static constexpr int BNv = 64 * WTN;  // two wave columns of 32*WTN
-  static constexpr int NWAVES = (BMv / (32 * WTM)) * 2;
-  static constexpr int NTHREADS = NWAVES * 64;
+  static constexpr int NWAVES = (BMv / (32 * WTM)) * 2;  // MFMA waves
+  static constexpr int NLOAD = LD;                       // dedicated loader waves (0: the MFMA waves issue the DMA themselves)
+  static constexpr int NISSUE = LD ? LD : NWAVES;        // waves that issue DMA pieces
+  static constexpr int NTHREADS = (NWAVES + NLOAD) * 64;
+  static constexpr int CTHREADS = NWAVES * 64;
   static constexpr int A_BYTES = BMv * BKv * 2;
   static constexpr int B_BYTES = BNv * BKv * 2;
   static constexpr int CT_LDv = BNv + 4;  // fp32 epilogue tile leading dim
   static constexpr int STAGE = A_BYTES + B_BYTES;
-  static constexpr int GA = (A_BYTES / 1024) / NWAVES;  // wave-level 1 KiB loads per stage
-  static constexpr int GB = (B_BYTES / 1024) / NWAVES;
+  static constexpr int GA = (A_BYTES / 1024) / NISSUE;  // wave-level 1 KiB loads per stage and issuing wave
+  static constexpr int GB = (B_BYTES / 1024) / NISSUE;
+  static_assert(GA * NISSUE * 1024 == A_BYTES && GB * NISSUE * 1024 == B_BYTES, "operand tiles must split evenly over the issuing waves");
   static constexpr int NSTAGE = 3;
   static constexpr int KS = BKv / 16;  // MFMA K-sub-steps per stage
   static constexpr int WG_PER_CU = (160 * 1024) / (NSTAGE * STAGE);
-  static constexpr int MIN_WAVES_PER_SIMD = (WG_PER_CU * NWAVES + 3) / 4;
+  static constexpr int MIN_WAVES_PER_SIMD = (WG_PER_CU * (NWAVES + NLOAD) + 3) / 4;
+  // epilogue: rows of the fp32 tile that fit the ring's LDS, rounded down to a power-of-two multiple of a wave's rows
+  static constexpr int EPI_FIT = (NSTAGE * STAGE) / (CT_LDv * 4);
+  static constexpr int EPI_ROWS = EPI_FIT >= BMv ? BMv : (EPI_FIT >= BMv / 2 ? BMv / 2 : BMv / 4);
 };
 
 // chunk swizzle of a row-major [rows][BK] tile (16-B chunks): conflict-free ds_read_b128 fragment reads
@@ -327,6 +344,9 @@ __device__ __forceinline__ void frag_addrs(int r0, int lane, uint32_t (&ad)[4]) 
 
 template <int TR, int COLS, int BKv, int NF, int S, int A = 0>
 __device__ __forceinline__ void frags_issue(const uint32_t (&cur)[4], FragSet<TR, NF>& f) {
+#if defined(COCODR_ABL_NO_LDSREAD)
+  return;
+#endif
   if constexpr (A < NF) {
     if constexpr (TR == 0) {
       asm_ds_read_b128<A * 32 * BKv * 2>(f.q[A], cur[S]);
@@ -349,6 +369,9 @@ __device__ __forceinline__ bf16x8 frag_get(const FragSet<TR, NF>& f, int a) {
 }
 template <int TA, int TB, int WTM, int WTN>
 __device__ __forceinline__ void mfma_step(const FragSet<TA, WTM>& fa, const FragSet<TB, WTN>& fb, f32x16 (&acc)[WTM][WTN]) {
+#if defined(COCODR_ABL_NO_MFMA)
+  return;
+#endif
   bf16x8 a[WTM], b[WTN];
 #pragma unroll
   for (int i = 0; i < WTM; ++i) a[i] = frag_get<TA, WTM>(fa, i);
@@ -395,11 +418,11 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
   }
 }
 
-template <int BMv, int BKv, int WTM, int WTN, int TA, int TB, bool OUT_F32>
-__global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN>::NTHREADS), (Geom<BMv, BKv, WTM, WTN>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
-    const cocodr_gemm_args p) {
+template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, bool OUT_F32>
+__global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD>::NTHREADS), (Geom<BMv, BKv, WTM, WTN, LD>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
+    const cocodr_gemm_args p, const int stagger) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type only exists in the device pass; the host pass just needs the stub
-  using G = Geom<BMv, BKv, WTM, WTN>;
+  using G = Geom<BMv, BKv, WTM, WTN, LD>;
   constexpr int BNv = G::BNv;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -419,24 +442,47 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN>::NTHREADS), (Geom<BMv, BK
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
 
+  // LD > 0: the last LD waves of the workgroup only issue the operand DMA (one per SIMD next to two MFMA waves).  A
+  // buffer_load ... lds has to wait for its turn in the CU's address unit, which at this tile shape is busy for most of a
+  // K-step; a wave that also carries MFMAs is stuck behind its own loads meanwhile (in-order issue), a loader wave is not.
+  constexpr bool SELF_ISSUE = (LD == 0);
+  const bool is_loader = LD > 0 && wid >= G::NWAVES;
+  const int iw = LD > 0 ? wid - G::NWAVES : wid;  // index among the issuing waves
   // per-lane source offsets of this wave's loads (tile 0); advancing one K-step adds a constant
   uint32_t offa[G::GA], offb[G::GB];
 #pragma unroll
-  for (int j = 0; j < G::GA; ++j) offa[j] = glds_src_off<TA, BMv, BKv>((wid * G::GA + j) * 64 + lane, m0, p.lda);
+  for (int j = 0; j < G::GA; ++j) offa[j] = glds_src_off<TA, BMv, BKv>((iw * G::GA + j) * 64 + lane, m0, p.lda);
 #pragma unroll
-  for (int j = 0; j < G::GB; ++j) offb[j] = glds_src_off<TB, BNv, BKv>((wid * G::GB + j) * 64 + lane, n0, p.ldb);
+  for (int j = 0; j < G::GB; ++j) offb[j] = glds_src_off<TB, BNv, BKv>((iw * G::GB + j) * 64 + lane, n0, p.ldb);
   const uint32_t stepa = TA ? (uint32_t)(BKv * p.lda * 2) : (uint32_t)(BKv * 2);
   const uint32_t stepb = TB ? (uint32_t)(BKv * p.ldb * 2) : (uint32_t)(BKv * 2);
 
-  auto issue = [&](int t) {
+  // De-phasing of the workgroups that share a CU: all first-round workgroups start together, run the same number of
+  // K-steps and would reach their store-bound epilogues (and the next prologues) at the same moment, every round, with
+  // the MFMA pipes idle meanwhile.  The first-round workgroup that was given the upper part of the CU's LDS sleeps for
+  // `stagger` x 4096 clocks once; its successors inherit the offset, so one workgroup's epilogue / prologue runs under
+  // the other's main loop from then on.
+  uint32_t lds_slot_base = 0;
+  if (G::WG_PER_CU >= 2 && stagger > 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) < 256 * G::WG_PER_CU) {
+    lds_slot_base = __builtin_amdgcn_s_getreg(6 | (11 << 11));  // HW_REG_LDS_ALLOC bits [11:0]: LDS_BASE
+    if (lds_slot_base != 0)
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+#if defined(COCODR_ABL_TIMELINE)  // per-workgroup phase stamps (100 MHz wall clock) into C2: [start, loop entry, loop exit, end, LDS base]
+  unsigned long long* tl = reinterpret_cast<unsigned long long*>(p.C2) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+  if (tid == 0) { tl[0] = wall_clock64(); tl[4] = __builtin_amdgcn_s_getreg(6 | (31 << 11)); }
+#endif
+  // one 1-KiB wave-level piece of K-step t's operand tiles (pieces 0..GA-1 belong to A, the rest to B)
+  auto issue_piece = [&](auto jc, int t) {
+    constexpr int j = decltype(jc)::value;
     char* st = smem + (t % G::NSTAGE) * G::STAGE;
-#pragma unroll
-    for (int j = 0; j < G::GA; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))(st + (wid * G::GA + j) * 1024), 16, offa[j] + t * stepa, 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < G::GB; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(st + G::A_BYTES + (wid * G::GB + j) * 1024), 16, offb[j] + t * stepb, 0, 0, 0);
+    if constexpr (j < G::GA)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))(st + (iw * G::GA + j) * 1024), 16, offa[j] + t * stepa, 0, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(st + G::A_BYTES + (iw * G::GB + (j - G::GA)) * 1024), 16,
+                                               offb[j - G::GA] + t * stepb, 0, 0, 0);
   };
+  constexpr int NP = G::GA + G::GB;
 
   f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -452,69 +498,128 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN>::NTHREADS), (Geom<BMv, BK
   frag_addrs<TB, BNv, BKv, WTN>(wn * 32 * WTN, lane, adB);
   constexpr int R = (TA ? 2 : 1) * WTM + (TB ? 2 : 1) * WTN;  // LDS reads per K-sub-step (<= 12 < the 4-bit lgkmcnt range)
 
+  // Schedule of one K-step (KS sub-steps of 16): the fragment reads of sub-step s+1 and a share of the NEXT-but-one
+  // stage's DMA pieces are issued in front of the MFMAs of sub-step s, so a wave's DMA issue slots and LDS latency sit
+  // under MFMAs already in the pipe.  The stage hand-off (own pieces landed -> barrier) is taken BEFORE the last
+  // sub-step's MFMAs, and the next stage's first fragments are requested right behind it: the barrier wait and that
+  // read latency are covered by the MFMAs still executing, instead of opening a bubble at every K-step boundary.
   const int nt = (p.K + BKv - 1) / BKv;
-  issue(0);
-  if (nt > 1) issue(1);
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) wait_vmcnt<G::GA + G::GB>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (t + 2 < nt) issue(t + 2);
-    const uint32_t sbA = lds_base + (uint32_t)((t % G::NSTAGE) * G::STAGE), sbB = sbA + G::A_BYTES;
-    uint32_t curA[4], curB[4];
+  if (SELF_ISSUE || is_loader) {
+    static_for<0, NP>([&](auto jc) { issue_piece(jc, 0); });
+    if (nt > 1) {
+      static_for<0, NP>([&](auto jc) { issue_piece(jc, 1); });
+      wait_vmcnt<NP>();
+    } else {
+      wait_vmcnt<0>();
+    }
+  }
+  __builtin_amdgcn_s_barrier();  // barrier 0: stage 0 complete
+  if (is_loader) {
+    // loader wave: after barrier t every MFMA wave has finished reading stage t-1 = (t+2) % 3 -> refill it, then hand
+    // over stage t+1 (own pieces landed) at barrier t+1.  Same barrier sequence as the MFMA waves below.
+    for (int t = 0; t < nt; ++t) {
+      if (t + 2 < nt) static_for<0, NP>([&](auto jc) { issue_piece(jc, t + 2); });
+      if (t + 1 < nt) {
+        if (t + 2 < nt) wait_vmcnt<NP>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  } else {
+#if defined(COCODR_ABL_NO_LDSREAD)
+  FragSet<TA, WTM> fa0{}, fa1{};
+  FragSet<TB, WTN> fb0{}, fb1{};
+#else
+  FragSet<TA, WTM> fa0, fa1;
+  FragSet<TB, WTN> fb0, fb1;
+#endif
+  uint32_t curA[4], curB[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + sbA; curB[i] = adB[i] + sbB; }
-    FragSet<TA, WTM> fa0, fa1;
-    FragSet<TB, WTN> fb0, fb1;
-    frags_issue<TA, BMv, BKv, WTM, 0>(curA, fa0); frags_issue<TB, BNv, BKv, WTN, 0>(curB, fb0);
+  for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + lds_base; curB[i] = adB[i] + lds_base + G::A_BYTES; }
+  frags_issue<TA, BMv, BKv, WTM, 0>(curA, fa0); frags_issue<TB, BNv, BKv, WTN, 0>(curB, fb0);
+#if defined(COCODR_ABL_TIMELINE)
+  if (tid == 0) tl[1] = wall_clock64();
+#endif
+  constexpr int SLOTS = G::KS - 1;  // DMA issue slots per K-step (in front of the MFMAs of sub-steps 0 .. KS-2)
+  for (int t = 0; t < nt; ++t) {
+    const bool more = SELF_ISSUE && t + 2 < nt;  // every wave is past barrier t: stage (t+2) % 3 == (t-1) % 3 is free
     frags_issue<TA, BMv, BKv, WTM, 1>(curA, fa1); frags_issue<TB, BNv, BKv, WTN, 1>(curB, fb1);
+#if !defined(COCODR_ABL_NO_DMA)  // ablation builds (tools/gemm_ablate.py) only; never defined in the product library
+    if (more) static_for<0, NP / SLOTS>([&](auto jc) { issue_piece(jc, t + 2); });
+#endif
     wait_lgkmcnt<R>();
     mfma_step<TA, TB, WTM, WTN>(fa0, fb0, acc);
     if constexpr (G::KS == 4) {
       frags_issue<TA, BMv, BKv, WTM, 2>(curA, fa0); frags_issue<TB, BNv, BKv, WTN, 2>(curB, fb0);
+#if !defined(COCODR_ABL_NO_DMA)
+      if (more) static_for<NP / SLOTS, 2 * NP / SLOTS>([&](auto jc) { issue_piece(jc, t + 2); });
+#endif
       wait_lgkmcnt<R>();
       mfma_step<TA, TB, WTM, WTN>(fa1, fb1, acc);
       frags_issue<TA, BMv, BKv, WTM, 3>(curA, fa1); frags_issue<TB, BNv, BKv, WTN, 3>(curB, fb1);
+#if !defined(COCODR_ABL_NO_DMA)
+      if (more) static_for<2 * NP / SLOTS, NP>([&](auto jc) { issue_piece(jc, t + 2); });
+#endif
       wait_lgkmcnt<R>();
       mfma_step<TA, TB, WTM, WTN>(fa0, fb0, acc);
     }
-    wait_lgkmcnt<0>();
+    wait_lgkmcnt<0>();  // this wave is done reading stage t
+    if (t + 1 < nt) {
+      if (SELF_ISSUE) {
+        if (more) wait_vmcnt<NP>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();  // barrier t+1: stage t+1 complete, stage t released
+      const uint32_t sb = lds_base + (uint32_t)(((t + 1) % G::NSTAGE) * G::STAGE);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + sb; curB[i] = adB[i] + sb + G::A_BYTES; }
+      frags_issue<TA, BMv, BKv, WTM, 0>(curA, fa0); frags_issue<TB, BNv, BKv, WTN, 0>(curB, fb0);
+    }
     mfma_step<TA, TB, WTM, WTN>(fa1, fb1, acc);
   }
+  }  // MFMA waves
   __syncthreads();
+#if defined(COCODR_ABL_TIMELINE)
+  if (tid == 0) tl[2] = wall_clock64();
+#endif
 
-  // ---- epilogue through an fp32 LDS tile, 64 output rows per pass, row-major 16-B loads / stores
+  // ---- epilogue through an fp32 LDS tile (as many rows per pass as the ring's LDS holds), row-major 16-B stores.
+  // The barriers between the passes only order LDS traffic (lgkmcnt): waiting on vmcnt there would stall every pass
+  // on the write acknowledgements of the previous one's global stores.
   const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
   const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
   float* ct = reinterpret_cast<float*>(smem);
-  constexpr int GPW = WTM / 2;  // 64-row groups per wave
   constexpr int CLD = G::CT_LDv;
-  constexpr int CPRW = BNv / 8;  // 8-column chunks per output row
+  constexpr int CPRW = BNv / 8;        // 8-column chunks per output row
+  constexpr int WROWS = 32 * WTM;      // rows owned by one wave
+  constexpr int RP = G::EPI_ROWS;      // rows per pass (multiple of WROWS)
+  constexpr int NCH = RP * CPRW / G::CTHREADS;  // the copy-out is done by the MFMA waves
+  static_assert(RP % WROWS == 0 && (RP * CPRW) % G::CTHREADS == 0, "epilogue pass geometry");
 #pragma unroll 1
-  for (int h = 0; h < BMv / 64; ++h) {
-    if (h / GPW == wm) {
-      const int a0 = (h % GPW) * 2;
+  for (int h = 0; h < BMv / RP; ++h) {
+    if (!is_loader && (wm * WROWS) / RP == h) {
+      const int rbase = wm * WROWS - h * RP;
 #pragma unroll
-      for (int ai = 0; ai < 2; ++ai)
+      for (int ai = 0; ai < WTM; ++ai)
 #pragma unroll
         for (int b = 0; b < WTN; ++b)
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int row = ai * 32 + (lane & 31);
+            const int row = rbase + ai * 32 + (lane & 31);
             const int col = wn * 32 * WTN + b * 32 + 8 * rg + 4 * (lane >> 5);
-            float4 v4;
-            if (GPW == 1 || a0 == 0) v4 = make_float4(acc[ai][b][rg * 4 + 0], acc[ai][b][rg * 4 + 1], acc[ai][b][rg * 4 + 2], acc[ai][b][rg * 4 + 3]);
-            else v4 = make_float4(acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 0], acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 1],
-                                  acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 2], acc[(WTM > 2 ? 2 : 0) + ai][b][rg * 4 + 3]);
-            *reinterpret_cast<float4*>(ct + row * CLD + col) = v4;
+            *reinterpret_cast<float4*>(ct + row * CLD + col) =
+                make_float4(acc[ai][b][rg * 4 + 0], acc[ai][b][rg * 4 + 1], acc[ai][b][rg * 4 + 2], acc[ai][b][rg * 4 + 3]);
           }
     }
-    __syncthreads();
-    for (int c = tid; c < 64 * CPRW; c += G::NTHREADS) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * G::CTHREADS;
       const int row = c / CPRW, c8 = (c % CPRW) << 3;
-      const int gm = m0 + h * 64 + row;
+      const int gm = m0 + h * RP + row;
       const int gn = n0 + c8;
-      if (gm < p.M) {
+      if (!is_loader && gm < p.M) {
         float v[8];
         const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CLD + c8);
         const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CLD + c8 + 4);
@@ -522,34 +627,46 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN>::NTHREADS), (Geom<BMv, BK
         epilogue_store8<OUT_F32>(p, z, bias, R_, gm, gn, v);
       }
     }
-    __syncthreads();
+    if (h + 1 < BMv / RP) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
+#if defined(COCODR_ABL_TIMELINE)
+  if (tid == 0) tl[3] = wall_clock64();
+#endif
 #endif
 }
 
-template <int BMv, int BKv, int WTM, int WTN, int TA, int TB>
+template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB>
 void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
-  using G = Geom<BMv, BKv, WTM, WTN>;
+  using G = Geom<BMv, BKv, WTM, WTN, LD>;
   const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / G::BNv;
   dim3 grid(ntm * ntn, a.batch);
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  static int stagger = -1;  // x 4096 clocks; COCODR_GEMM_STAGGER overrides (0 disables)
+  if (stagger < 0) {
+    const char* e = getenv("COCODR_GEMM_STAGGER");
+    stagger = e ? atoi(e) : 0;
+  }
+  const int sg = (int)(grid.x * grid.y) > 256 * G::WG_PER_CU / 2 ? stagger : 0;
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, TA, TB, true>), grid, dim3(G::NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true>), grid, dim3(G::NTHREADS), lds, st, a, sg);
   else
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, TA, TB, false>), grid, dim3(G::NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false>), grid, dim3(G::NTHREADS), lds, st, a, sg);
 }
 
-template <int BMv, int BKv, int WTM, int WTN = 2>
+template <int BMv, int BKv, int WTM, int WTN = 2, int LD = 0>
 void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
-  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, WTM, WTN, 0, 0>(a, st);
-  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, WTM, WTN, 0, 1>(a, st);
-  else launch_glds<BMv, BKv, WTM, WTN, 1, 1>(a, st);
+  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 0>(a, st);
+  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 1>(a, st);
+  else launch_glds<BMv, BKv, WTM, WTN, LD, 1, 1>(a, st);
 }
 
 }  // namespace cocodr_gemm_v2
@@ -557,7 +674,7 @@ using cocodr_gemm_v2::launch_glds_any;
 
 namespace {
 
-int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, direct-to-LDS <BM,BK,WTM>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile <128,64,2> with 64x96 wave tiles
+int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, direct-to-LDS <BM,BK,WTM>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile <128,64,2> with 64x96 wave tiles, 9 = <256,64,2> + 4 loader waves, 10 = <256,64,4> + 4 loader waves
 int gemm_impl_override() {
   if (g_gemm_impl < 0) {
     const char* e = getenv("COCODR_GEMM_IMPL");
@@ -577,7 +694,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG(impl >= 0 && impl <= 8, "gemm_set_impl: impl must be in [0,8]");
+  CK_ARG(impl >= 0 && impl <= 10, "gemm_set_impl: impl must be in [0,10]");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -592,7 +709,9 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   CK_ARG(a.K % 8 == 0, "gemm: K=%d must be a multiple of 8", a.K);
   CK_ARG(!a.trans_a || a.M % 8 == 0, "gemm: M=%d must be a multiple of 8 when trans_a", a.M);
   CK_ARG(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0, "gemm: leading dims must be multiples of 8");
+#if !defined(COCODR_ABL_ALIAS_LD)  // ablation builds may alias operand rows (L2-resident window)
   CK_ARG(a.lda >= (a.trans_a ? a.M : a.K) && a.ldb >= (a.trans_b ? a.N : a.K) && a.ldc >= a.N, "gemm: leading dim too small");
+#endif
   CK_ARG(!(a.trans_a && !a.trans_b), "gemm: (trans_a=1, trans_b=0) is not used on this path");
   CK_ARG(a.epi >= COCODR_EPI_NONE && a.epi <= COCODR_EPI_DGELU, "gemm: bad epilogue %d", a.epi);
   CK_ARG(a.epi != COCODR_EPI_GELU || (a.C2 && !a.out_f32), "gemm: EPI_GELU needs C2 and bf16 output");
@@ -611,18 +730,21 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   int impl = gemm_impl_override();
   if (impl == 0) {
     // auto (measured on MI355X, tools/gemm_bench.py): with >= 1.5 tiles per CU the BK=32 geometry wins because a
-    // second resident workgroup hides prologue/epilogue; with fewer tiles the deeper BK=64 ring wins; below half a
-    // wave of 256-row tiles fall back to 128-row tiles to occupy more CUs.
+    // second resident workgroup hides prologue/epilogue; with fewer tiles (and for the mid-sized grouped wgrad) the
+    // deeper BK=64 ring with four loader waves wins; below half a wave of 256-row tiles fall back to 128-row tiles to
+    // occupy more CUs.
     const long long tiles256 = (long long)((a.M + 255) / 256) * (a.N / BN) * a.batch;
     const long long tiles128 = (long long)((a.M + 127) / 128) * (a.N / BN) * a.batch;
     if (!(k_ok && small)) impl = 1;
-    else if (tiles256 >= 384) impl = 5;
-    else if (tiles256 >= 128) impl = 3;
+    else if (tiles256 >= 384 && !(a.trans_a && tiles256 < 768)) impl = 5;
+    else if (tiles256 >= 128) impl = 9;
     else impl = tiles128 >= 512 ? 4 : 2;
   }
   if (impl != 1 && !(k_ok && small)) impl = 1;
   if (impl == 8 && a.N % 192 != 0) impl = 3;  // the 128x192 tile needs N % 192 == 0
-  if (impl == 8) launch_glds_any<128, 64, 2, 3>(a, st);
+  if (impl == 10) launch_glds_any<256, 64, 4, 2, 4>(a, st);
+  else if (impl == 9) launch_glds_any<256, 64, 2, 2, 4>(a, st);
+  else if (impl == 8) launch_glds_any<128, 64, 2, 3>(a, st);
   else if (impl == 7) launch_glds_any<256, 64, 4>(a, st);
   else if (impl == 6) launch_glds_any<256, 32, 4>(a, st);
   else if (impl == 5) launch_glds_any<256, 32, 2>(a, st);
