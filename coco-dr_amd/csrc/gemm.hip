@@ -385,9 +385,10 @@ __device__ __forceinline__ void mfma_step(const FragSet<TA, WTM>& fa, const Frag
 }
 
 // one 8-column slice of an output row: bias / GELU / residual / GELU' and the store
-template <bool OUT_F32>
+template <bool OUT_F32, bool RPRE = false>
 __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z, const float* __restrict__ bias,
-                                                const uint16_t* __restrict__ R_, int gm, int gn, float (&v)[8]) {
+                                                const uint16_t* __restrict__ R_, int gm, int gn, float (&v)[8],
+                                                uint4 rpre = make_uint4(0, 0, 0, 0)) {
   if (bias) {
     const float4 b0 = *reinterpret_cast<const float4*>(bias + gn);
     const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
@@ -399,12 +400,12 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
     for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
   } else if (p.epi == COCODR_EPI_ADD) {
     float r[8];
-    unpack8(*reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
+    unpack8(RPRE ? rpre : *reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += r[j];
   } else if (p.epi == COCODR_EPI_DGELU) {
     float r[8];
-    unpack8(*reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
+    unpack8(RPRE ? rpre : *reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(r[j]);
   }
@@ -578,6 +579,26 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD>::NTHREADS), (Geom<BMv
     mfma_step<TA, TB, WTM, WTN>(fa1, fb1, acc);
   }
   }  // MFMA waves
+  // residual / pre-activation chunks of the first epilogue pass: requested before the LDS transposition so their L2 / HBM
+  // latency runs under it (each pass requests the next one's once its own stores are issued)
+  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
+  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
+  constexpr int CPRW = BNv / 8;        // 8-column chunks per output row
+  constexpr int RP = G::EPI_ROWS;      // rows per pass
+  constexpr int NCH = RP * CPRW / G::CTHREADS;  // the copy-out is done by the MFMA waves
+  constexpr bool PREFETCH_R = G::WG_PER_CU == 1;  // the 2-3 workgroups / CU geometries have no registers to spare for it
+  const bool need_r = PREFETCH_R && R_ != nullptr && (p.epi == COCODR_EPI_ADD || p.epi == COCODR_EPI_DGELU) && !is_loader;
+  uint4 rcur[PREFETCH_R ? NCH : 1];
+  auto fetch_r = [&](int h, uint4 (&dst)[PREFETCH_R ? NCH : 1]) {
+#pragma unroll
+    for (int i = 0; i < (PREFETCH_R ? NCH : 0); ++i) {
+      const int c = tid + i * G::CTHREADS;
+      const int gm = m0 + h * RP + c / CPRW;
+      dst[i] = make_uint4(0, 0, 0, 0);
+      if (need_r && gm < p.M) dst[i] = *reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + n0 + ((c % CPRW) << 3));
+    }
+  };
+  fetch_r(0, rcur);
   __syncthreads();
 #if defined(COCODR_ABL_TIMELINE)
   if (tid == 0) tl[2] = wall_clock64();
@@ -586,14 +607,9 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD>::NTHREADS), (Geom<BMv
   // ---- epilogue through an fp32 LDS tile (as many rows per pass as the ring's LDS holds), row-major 16-B stores.
   // The barriers between the passes only order LDS traffic (lgkmcnt): waiting on vmcnt there would stall every pass
   // on the write acknowledgements of the previous one's global stores.
-  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
-  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
   float* ct = reinterpret_cast<float*>(smem);
   constexpr int CLD = G::CT_LDv;
-  constexpr int CPRW = BNv / 8;        // 8-column chunks per output row
   constexpr int WROWS = 32 * WTM;      // rows owned by one wave
-  constexpr int RP = G::EPI_ROWS;      // rows per pass (multiple of WROWS)
-  constexpr int NCH = RP * CPRW / G::CTHREADS;  // the copy-out is done by the MFMA waves
   static_assert(RP % WROWS == 0 && (RP * CPRW) % G::CTHREADS == 0, "epilogue pass geometry");
 #pragma unroll 1
   for (int h = 0; h < BMv / RP; ++h) {
@@ -624,10 +640,11 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD>::NTHREADS), (Geom<BMv
         const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CLD + c8);
         const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CLD + c8 + 4);
         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-        epilogue_store8<OUT_F32>(p, z, bias, R_, gm, gn, v);
+        epilogue_store8<OUT_F32, PREFETCH_R>(p, z, bias, R_, gm, gn, v, rcur[PREFETCH_R ? i : 0]);
       }
     }
     if (h + 1 < BMv / RP) {
+      fetch_r(h + 1, rcur);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }

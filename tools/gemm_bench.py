@@ -35,13 +35,54 @@ SHAPES = [  # (name, M, N, K, ta, tb, batch, out_f32)
 ]
 
 
+EPI_SHAPES = [  # the encoder's fused epilogues: (name, M, N, K, tb, epi, bias, residual)
+    ("fwd qkv  +bias        8192x2304x768", 8192, 2304, 768, 0, "none", True, False),
+    ("fwd out  +bias+res    8192x768x768", 8192, 768, 768, 0, "add", True, True),
+    ("fwd ffn1 +bias+gelu   8192x3072x768", 8192, 3072, 768, 0, "gelu", True, False),
+    ("fwd ffn2 +bias+res    8192x768x3072", 8192, 768, 3072, 0, "add", True, True),
+    ("dgrad ffn2 *gelu'     8192x3072x768", 8192, 3072, 768, 1, "dgelu", False, True),
+    ("dgrad ffn1 +res       8192x768x3072", 8192, 768, 3072, 1, "add", False, True),
+    ("dgrad qkv +res        8192x768x2304", 8192, 768, 2304, 1, "add", False, True),
+]
+
+
+def epi_bench(args, impls):
+    from cocodr_amd import _native as N
+    codes = {"none": N.EPI_NONE, "add": N.EPI_ADD, "gelu": N.EPI_GELU, "dgelu": N.EPI_DGELU}
+    print(f"{'shape (fused epilogue)':42s} " + " ".join(f"impl{i:d} TF/s(us)".rjust(18) for i in impls))
+    for name, M, N_, K, tb, epi, has_bias, has_r in EPI_SHAPES:
+        a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        b = (torch.randn((K, N_) if tb else (N_, K), device="cuda") * 0.05).to(torch.bfloat16)
+        bias = torch.randn(N_, device="cuda") if has_bias else None
+        r = torch.randn(M, N_, device="cuda").to(torch.bfloat16) if has_r else None
+        out = torch.empty(M, N_, dtype=torch.bfloat16, device="cuda")
+        best = {i: 1e9 for i in impls}
+        for rnd in range(args.rounds + 1):
+            for i in impls:
+                ops.gemm_set_impl(i)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    ops.gemm(a, b, trans_b=bool(tb), bias=bias, epi=codes[epi], r=r, out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd > 0:
+                    best[i] = min(best[i], e0.elapsed_time(e1) / 5 * 1e3)
+        flops = 2.0 * M * N_ * K
+        print(f"{name:42s} " + " ".join(f"{flops / best[i] / 1e6:8.0f} ({best[i]:7.1f})".rjust(18) for i in impls), flush=True)
+    ops.gemm_set_impl(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--epi", action="store_true", help="time the encoder's fused-epilogue forms instead of plain GEMMs")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--impls", default="1,2,3")
     ap.add_argument("--shapes", default="", help="comma separated indices into SHAPES (default all)")
     args = ap.parse_args()
     impls = [int(x) for x in args.impls.split(",")]
+    if args.epi:
+        return epi_bench(args, impls)
     dev = "cuda"
     print(f"{'shape':34s} " + " ".join(f"impl{i:d} TF/s(us)".rjust(18) for i in impls))
     sel = [int(x) for x in args.shapes.split(',')] if args.shapes else range(len(SHAPES))
