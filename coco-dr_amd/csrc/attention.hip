@@ -12,6 +12,7 @@
 //    operand of O^T = V^T P^T: which 8 keys a lane contributes per MFMA is fixed by the
 //    accumulator layout, and the matching rows of V are fetched with the transposing LDS read
 //    (ds_read_b64_tr_b16), so P never goes through LDS or cross-lane shuffles.
+#include <stdlib.h>
 #include "common.h"
 #include "prof.h"
 
@@ -55,7 +56,44 @@ __device__ __forceinline__ void stage_tile(char* dst, const uint16_t* src, int l
   }
 }
 
-// O^T / dQ^T / dK^T / dV^T accumulator (lane: row index l & 31, 4 consecutive d per register group)
+// Same tile, fetched with the LDS DMA (buffer_load ... lds, 1 KiB = 8 rows per wave instruction, no VGPR round trip).
+// The DMA writes lane-linear, so the chunk swizzle is applied to the per-lane SOURCE address (the XOR is an involution).
+// Wave `wid` of `nw` issues pieces wid, wid + nw, ...; completion = s_waitcnt vmcnt(0) + barrier by the caller.
+__device__ __forceinline__ void stage_tile_dma(char* dst, const uint16_t* src, int ld, int L, int lane, int wid, int nw) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (uint32_t)(((size_t)(L - 1) * ld + 64) * 2), 0x00020000);
+  for (int p = wid; p < L / 8; p += nw) {
+    const int q = p * 64 + lane;
+    const int row = q >> 3, ch = (q & 7) ^ swz64(row);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_PTR(void))(dst + p * 1024), 16, (uint32_t)((row * ld + ch * 8) * 2), 0, 0, 0);
+  }
+#endif
+}
+
+// O^T / dQ^T / dK^T / dV^T accumulator (lane: row index l & 31, 4 consecutive d per register group).  Lanes l and
+// l ^ 32 hold the two 4-wide halves of an 8-column group: they trade halves so that every lane issues 16-B stores.
+__device__ __forceinline__ void store_acc_T16(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane) {
+  const int half = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {  // register-group pair (2 rp, 2 rp + 1): half 0 stores group 2 rp, half 1 stores 2 rp + 1
+      float mine[2][4];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine[g][e] = o[dt][(2 * rp + g) * 4 + e] * mul;
+      const uint2 keep = pack4(mine[half]);        // my 4 columns of the group I store
+      const uint2 give = pack4(mine[half ^ 1]);    // my 4 columns of the group the partner stores
+      uint2 got;
+      got.x = __shfl_xor((int)give.x, 32, 64);
+      got.y = __shfl_xor((int)give.y, 32, 64);
+      const int d = dt * 32 + 8 * (2 * rp + half);  // columns d .. d+7: half-0 lane owns d..d+3, half-1 lane d+4..d+7
+      const uint4 v = half == 0 ? make_uint4(keep.x, keep.y, got.x, got.y) : make_uint4(got.x, got.y, keep.x, keep.y);
+      *reinterpret_cast<uint4*>(dst + (size_t)(lane & 31) * ld + d) = v;
+    }
+}
+
 __device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane) {
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -79,18 +117,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
   const int ld = 3 * H;
   const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
-  stage_tile(Kt, base + H, ld, L, tid, 256);
-  stage_tile(Vt, base + 2 * H, ld, L, tid, 256);
+  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
+  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4);
   for (int i = tid; i < L; i += 256) madd[i] = mask[b * L + i] != 0 ? 0.f : kMaskNeg;
-  __syncthreads();
-
   const int q0 = blockIdx.z * 128 + wid * 32;
-  if (q0 >= L) return;
   const int half = lane >> 5;
   bf16x8 qf[4];
+  if (q0 < L) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
-    qf[s] = as_bf16x8(*reinterpret_cast<const uint4*>(base + (size_t)(q0 + (lane & 31)) * ld + (2 * s + half) * 8));
+    for (int s = 0; s < 4; ++s)
+      qf[s] = as_bf16x8(*reinterpret_cast<const uint4*>(base + (size_t)(q0 + (lane & 31)) * ld + (2 * s + half) * 8));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (q0 >= L) return;
 
   f32x16 o[2];
 #pragma unroll
@@ -145,13 +185,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   store_acc_T(ctx + (size_t)(b * L + q0) * H + h * 64, H, o, 1.0f / ltot, lane);
 }
 
+#if defined(COCODR_ABL_TIMELINE)  // tools/attn_timeline.py builds: per-workgroup phase stamps (100 MHz wall clock)
+__device__ unsigned long long* g_attn_tl = nullptr;
+#define ATTN_STAMP(i) do { if (g_attn_tl && threadIdx.x == 0) g_attn_tl[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+
 // Backward.  All four [L][64] tiles of one (batch, head) live in LDS (L <= 256 -> 128 KiB).
 //  phase A: wave <-> 32 queries,  S^T/dP^T layout (lane = query):  dQ^T += K^T dS^T
 //  phase B: wave <-> 32 keys,     S / dP layout   (lane = key):    dV^T += dO^T P,  dK^T += Q^T dS
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                           const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
                                                           const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L,
-                                                          int H) {
+                                                          int H, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qt = smem;
   char* Kt = smem + L * 128;
@@ -166,30 +213,50 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const uint16_t* __rest
   const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
   const uint16_t* obase = ctx + (size_t)b * L * H + h * 64;
   const uint16_t* dobase = dctx + (size_t)b * L * H + h * 64;
-  stage_tile(Qt, base, ld, L, tid, 256);
-  stage_tile(Kt, base + H, ld, L, tid, 256);
-  stage_tile(Vt, base + 2 * H, ld, L, tid, 256);
-  for (int q = tid; q < L * 8; q += 256) {  // L*8 is a multiple of 256 (L % 32 == 0): whole waves stay converged
-    const int row = q >> 3, ch = q & 7;
-    const uint4 dv = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
-    const uint4 ov = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
-    *reinterpret_cast<uint4*>(Dt + tile64_off(row, ch)) = dv;
-    float df[8], of[8];
-    unpack8(dv, df);
-    unpack8(ov, of);
-    float part = 0.f;
+  // Two workgroups share a CU and all of them take the same time: un-staggered, both stage (an HBM burst of the whole
+  // grid) and then both compute, round after round.  The first-round workgroup in the upper LDS slot starts
+  // `stagger` x 4096 clocks late once, so from then on one workgroup's loads run under the other's MFMAs.
+  if (stagger > 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) < 512 && __builtin_amdgcn_s_getreg(6 | (11 << 11)) != 0)
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  ATTN_STAMP(0);
+  // Q, K, V go HBM -> LDS by DMA; dO and O pass through registers (delta = rowsum(dO * O) needs them there anyway).
+  // Every global load of the prologue is in flight before the first one is consumed.
+  stage_tile_dma(Qt, base, ld, L, lane, wid, 4);
+  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
+  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4);
+  constexpr int kMaxIt = 8;  // L <= 256 -> L * 8 / 256 <= 8 chunks per thread
+  const int nit = L * 8 / 256;  // whole waves stay converged (L % 32 == 0)
+  uint4 dreg[kMaxIt], oreg[kMaxIt];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part += df[e] * of[e];
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    if (ch == 0) delta[row] = part;
-  }
+  for (int i = 0; i < kMaxIt; ++i)
+    if (i < nit) {
+      const int q = tid + i * 256, row = q >> 3, ch = q & 7;
+      dreg[i] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
+      oreg[i] = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
+    }
   for (int i = tid; i < L; i += 256) {
     madd[i] = mask[b * L + i] != 0 ? 0.f : kMaskNeg;
     lse2[i] = lse[((size_t)b * heads + h) * L + i] * kLog2e;
   }
+#pragma unroll
+  for (int i = 0; i < kMaxIt; ++i)
+    if (i < nit) {
+      const int q = tid + i * 256, row = q >> 3, ch = q & 7;
+      *reinterpret_cast<uint4*>(Dt + tile64_off(row, ch)) = dreg[i];
+      float df[8], of[8];
+      unpack8(dreg[i], df);
+      unpack8(oreg[i], of);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += df[e] * of[e];
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64);
+      if (ch == 0) delta[row] = part;
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  ATTN_STAMP(1);
 
   const int half = lane >> 5;
   const float sl2 = kScale * kLog2e;
@@ -239,8 +306,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const uint16_t* __rest
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Kt, kb * 32 + j * 16, dt, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    store_acc_T(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
+    ATTN_STAMP(2);
+    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
   }
+  ATTN_STAMP(3);
 
   // ---------------- phase B: dK, dV
   for (int kb = wid; kb < nblk; kb += 4) {
@@ -289,13 +358,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const uint16_t* __rest
         }
       }
     }
+    ATTN_STAMP(4);
     uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
-    store_acc_T(row0 + H, ld, dk, kScale, lane);
-    store_acc_T(row0 + 2 * H, ld, dv, 1.0f, lane);
+    store_acc_T16(row0 + H, ld, dk, kScale, lane);
+    store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
   }
+  ATTN_STAMP(5);
 }
 
 }  // namespace
+
+#if defined(COCODR_ABL_TIMELINE)
+extern "C" int cocodr_debug_attn_timeline(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_tl), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
                                cocodr_stream_t stream) {
@@ -330,7 +407,13 @@ extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const u
   }
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_ATTN, st, 10.0 * B * heads * (double)L * L * 64);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(256), lds, st, qkv, mask, ctx, dctx, lse, dqkv, L, H);
+  static int stagger = -1;  // x 4096 clocks; COCODR_ATTN_STAGGER overrides (0 disables)
+  if (stagger < 0) {
+    const char* e = getenv("COCODR_ATTN_STAGGER");
+    stagger = e ? atoi(e) : 2;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(256), lds, st, qkv, mask, ctx, dctx, lse, dqkv, L, H,
+                     2 * lds <= 160 * 1024 && heads * B > 512 ? stagger : 0);
   CK_LAUNCH("attn_bwd");
   return COCODR_OK;
 }
