@@ -21,6 +21,7 @@ class GemmArgs(C.Structure):
         ("batch", c_int),
         ("strideA", c_longlong), ("strideB", c_longlong), ("strideC", c_longlong), ("strideR", c_longlong),
         ("strideBias", c_longlong),
+        ("colsum", c_void_p), ("colsum_partial", c_void_p),
     ]
 
 
@@ -66,7 +67,8 @@ SIGNATURES = {
     "cocodr_embed_ln_bwd": (c_int, [c_void_p] * 14 + [c_int, c_int, c_int, c_int, c_void_p]),
     "cocodr_ln_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
     "cocodr_ln_bwd_partial_floats": (c_size_t, [c_int, c_int]),
-    "cocodr_ln_bwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_void_p]),
+    "cocodr_ln_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
+    "cocodr_gemm_colsum_partial_floats": (c_size_t, [c_int, c_int]),
     "cocodr_colsum_partial_floats": (c_size_t, [c_int, c_int, c_int]),
     "cocodr_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
     "cocodr_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -135,3 +135,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
 }
+
+// internal (csrc/rowops.hip): out[n] = sum_p partial[p * n_len + n]
+int cocodr_reduce_partials(const float* partial, float* out, int P, int n_len, hipStream_t st);

@@ -44,7 +44,8 @@ BwdLayout bwd_layout(const cocodr_config* c, int B, int L) {
   b.dxb = cv.take(M * H * 2);
   b.dctx = cv.take(M * H * 2);
   b.ln_partial = cv.take(cocodr_ln_bwd_partial_floats((int)M, (int)H) * 4);
-  b.colsum_partial = cv.take(cocodr_colsum_partial_floats((int)M, (int)std::max(I, 3 * H), (int)N) * 4);
+  b.colsum_partial = cv.take(std::max(cocodr_colsum_partial_floats((int)M, (int)std::max(I, 3 * H), (int)N),
+                                      cocodr_gemm_colsum_partial_floats((int)M, (int)std::max(I, 3 * H))) * 4);
   b.emb_partial = cv.take(cocodr_embed_bwd_partial_floats(L, (int)H) * 4);
   b.total = cv.off;
   return b;
@@ -246,15 +247,19 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
     uint16_t* dy1 = dy1_all + lo * M * H;
     uint16_t* dqkv = dqkv_all + lo * M * 3 * H;
 
-    TRY(cocodr_ln_bwd(dx, y2, w.ln2_g, mean2, rstd2, dy2, gr.ln2_g, gr.ln2_b, ln_partial, M, H, stream));
+    // bias gradients ride on the kernels that produce the matrices they sum: b2 / bo on the LayerNorm backward, b1 on the
+    // GELU' epilogue, and the value bias on the context-gradient GEMM (sum_k dV[k] = sum_q dctx[q]: softmax rows sum to 1)
+    TRY(cocodr_ln_bwd(dx, y2, w.ln2_g, mean2, rstd2, dy2, gr.ln2_g, gr.ln2_b, gr.b2, ln_partial, M, H, stream));
     cocodr_gemm_args g = gemm_base(dy2, w.w2, du, M, I, H, H, I, I, 0, 1);  // dh = dy2 W2, fused with GELU'(u)
     g.epi = COCODR_EPI_DGELU; g.R = u; g.ldr = I;
+    g.colsum = gr.b1; g.colsum_partial = cs_partial;
     TRY(cocodr_gemm(&g, stream));
     g = gemm_base(du, w.w1, dxa, M, H, I, I, H, H, 0, 1);  // dx1 = du W1 + dy2 (residual branch)
     g.epi = COCODR_EPI_ADD; g.R = dy2; g.ldr = H;
     TRY(cocodr_gemm(&g, stream));
-    TRY(cocodr_ln_bwd(dxa, y1, w.ln1_g, mean1, rstd1, dy1, gr.ln1_g, gr.ln1_b, ln_partial, M, H, stream));
+    TRY(cocodr_ln_bwd(dxa, y1, w.ln1_g, mean1, rstd1, dy1, gr.ln1_g, gr.ln1_b, gr.bo, ln_partial, M, H, stream));
     g = gemm_base(dy1, w.wo, dctx, M, H, H, H, H, H, 0, 1);  // dctx = dy1 Wo
+    g.colsum = gr.bqkv + 2 * H; g.colsum_partial = cs_partial;
     TRY(cocodr_gemm(&g, stream));
     TRY(cocodr_attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, L, c->heads, stream));
     g = gemm_base(dqkv, w.wqkv, dxb, M, H, 3 * H, 3 * H, H, H, 0, 1);  // dx = dqkv Wqkv + dy1 (residual branch)
@@ -286,11 +291,8 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
   g = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
   g.out_f32 = 1; g.batch = NG; g.strideA = sMH; g.strideB = sMI; g.strideC = s_w2;
   TRY(cocodr_gemm(&g, stream));
-  // ---- bias gradients: batched column sums of the saved dY
-  TRY(cocodr_colsum(dqkv_all + l0 * sM3H, g0.bqkv, cs_partial, M, 3 * H, 3 * H, NG, sM3H, s_bqkv, stream));
-  TRY(cocodr_colsum(dy1_all + l0 * sMH, g0.bo, cs_partial, M, H, H, NG, sMH, s_bo, stream));
-  TRY(cocodr_colsum(du_all + l0 * sMI, g0.b1, cs_partial, M, I, I, NG, sMI, s_b1, stream));
-  TRY(cocodr_colsum(dy2_all + l0 * sMH, g0.b2, cs_partial, M, H, H, NG, sMH, s_b2, stream));
+  // ---- the remaining bias gradients (query, key): batched column sums of the first 2H columns of the saved dqkv
+  TRY(cocodr_colsum(dqkv_all + l0 * sM3H, g0.bqkv, cs_partial, M, 2 * H, 3 * H, NG, sM3H, s_bqkv, stream));
   return COCODR_OK;
 }
 

@@ -283,6 +283,7 @@ struct Geom {
   // epilogue: rows of the fp32 tile that fit the ring's LDS, rounded down to a power-of-two multiple of a wave's rows
   static constexpr int EPI_FIT = (NSTAGE * STAGE) / (CT_LDv * 4);
   static constexpr int EPI_ROWS = EPI_FIT >= BMv ? BMv : (EPI_FIT >= BMv / 2 ? BMv / 2 : BMv / 4);
+  static_assert(EPI_ROWS * CT_LDv * 4 + NWAVES * BNv * 4 <= NSTAGE * STAGE, "no room for the column-sum row behind the epilogue tile");
 };
 
 // chunk swizzle of a row-major [rows][BK] tile (16-B chunks): conflict-free ds_read_b128 fragment reads
@@ -610,6 +611,10 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD>::NTHREADS), (Geom<BMv
   float* ct = reinterpret_cast<float*>(smem);
   constexpr int CLD = G::CT_LDv;
   constexpr int WROWS = 32 * WTM;      // rows owned by one wave
+  // fused column sums (bias gradient): a thread's chunks all lie in the same 8 columns (CTHREADS % CPRW == 0)
+  constexpr bool CAN_COLSUM = (CPRW == 16) && (G::CTHREADS % CPRW == 0);
+  const bool do_colsum = CAN_COLSUM && p.colsum_partial != nullptr;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   static_assert(RP % WROWS == 0 && (RP * CPRW) % G::CTHREADS == 0, "epilogue pass geometry");
 #pragma unroll 1
   for (int h = 0; h < BMv / RP; ++h) {
@@ -641,12 +646,40 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD>::NTHREADS), (Geom<BMv
         const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CLD + c8 + 4);
         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
         epilogue_store8<OUT_F32, PREFETCH_R>(p, z, bias, R_, gm, gn, v, rcur[PREFETCH_R ? i : 0]);
+        if (do_colsum) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) csum[j] += v[j];
+        }
       }
     }
     if (h + 1 < BMv / RP) {
       fetch_r(h + 1, rcur);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+    }
+  }
+  if constexpr (CAN_COLSUM) {
+    if (do_colsum) {  // workgroup-uniform
+      // lanes l, l^16, l^32, l^48 hold the same 8 columns (4 rows per wave instruction); then one row of 128 partial
+      // sums per MFMA wave goes through the LDS behind the fp32 tile and 128 threads add them in wave order
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        csum[j] += __shfl_xor(csum[j], 16, 64);
+        csum[j] += __shfl_xor(csum[j], 32, 64);
+      }
+      float* cred = ct + RP * CLD;
+      if (!is_loader && lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cred[wid * BNv + lane * 8 + j] = csum[j];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid < BNv) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < G::NWAVES; ++w) t += cred[w * BNv + tid];
+        p.colsum_partial[(size_t)tm_ * p.N + n0 + tid] = t;
+      }
     }
   }
 #if defined(COCODR_ABL_TIMELINE)
@@ -736,6 +769,10 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   CK_ARG((((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.C2 | (uintptr_t)a.R | (uintptr_t)a.bias) & 15) == 0,
          "gemm: pointers must be 16-byte aligned");
   if (a.epi != COCODR_EPI_ADD && a.epi != COCODR_EPI_DGELU) a.R = nullptr;
+  CK_ARG(!a.colsum || (a.colsum_partial && a.batch == 1 && !a.out_f32), "gemm: colsum needs colsum_partial, batch == 1 and a bf16 output");
+  float* const cs_out = a.colsum;
+  float* const cs_part = a.colsum_partial;
+  if (!cs_out) a.colsum_partial = nullptr;
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
   dim3 grid(ntm * ntn, a.batch);
   hipStream_t st = (hipStream_t)stream;
@@ -759,6 +796,8 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   }
   if (impl != 1 && !(k_ok && small)) impl = 1;
   if (impl == 8 && a.N % 192 != 0) impl = 3;  // the 128x192 tile needs N % 192 == 0
+  const bool fused_colsum = cs_out && impl != 1 && impl != 8;  // the kernels with 128-column tiles reduce in their epilogue
+  if (!fused_colsum) a.colsum_partial = nullptr;
   if (impl == 10) launch_glds_any<256, 64, 4, 2, 4>(a, st);
   else if (impl == 9) launch_glds_any<256, 64, 2, 2, 4>(a, st);
   else if (impl == 8) launch_glds_any<128, 64, 2, 3>(a, st);
@@ -772,5 +811,17 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   else if (!a.trans_a && a.trans_b) launch<0, 1>(a, grid, st);
   else launch<1, 1>(a, grid, st);
   CK_LAUNCH("gemm");
+  if (cs_out) {
+    if (fused_colsum) {
+      const int bm = (impl == 2 || impl == 4) ? 128 : 256;
+      return cocodr_reduce_partials(cs_part, cs_out, (a.M + bm - 1) / bm, a.N, st);
+    }
+    return cocodr_colsum((const uint16_t*)a.C, cs_out, cs_part, a.M, a.N, a.ldc, 1, 0, 0, stream);
+  }
   return COCODR_OK;
+}
+
+extern "C" size_t cocodr_gemm_colsum_partial_floats(int M, int N) {
+  const size_t panels = (size_t)(M + 127) / 128;
+  return (panels > 32 ? panels : 32) * (size_t)(N > 0 ? N : 0);  // >= cocodr_colsum_partial_floats(M, N, 1) for the fallback
 }

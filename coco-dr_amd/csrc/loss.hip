@@ -28,29 +28,55 @@ __device__ __forceinline__ void mma_chunk_nt(const float* As, const float* Bs, i
   }
 }
 
-// S = E E^T with -inf diagonal.  grid (ceil(M/64), ceil(M/64)).
-__global__ __launch_bounds__(256) void simce_scores_kernel(const float* __restrict__ E, float* __restrict__ S, int M, int H) {
-  __shared__ float As[TS * TLD], Bs[TS * TLD];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+// S = E E^T with -inf diagonal.  grid (ceil(M/64), ceil(M/64)), 1024 threads = 4 output sub-tiles x 4 K-splits.
+// E is small and L2-resident and the fp32 MFMA chain of one 32x32 tile is latency-bound (64 clocks per dependent
+// 32x32x2 step), so the contraction is split over four waves per sub-tile; operands go global -> registers as float4
+// (lane half h feeds k = 8g + 4h + e: any k assignment shared by both operands is a valid contraction order) and the
+// four partial tiles are added in a fixed order through LDS (deterministic).
+__global__ __launch_bounds__(1024) void simce_scores_kernel(const float* __restrict__ E, float* __restrict__ S, int M, int H) {
+  __shared__ float part[3 * 4 * 64 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int sub = wid & 3, ks = wid >> 2, wm = sub >> 1, wn = sub & 1, half = lane >> 5;
   const int i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
+  const int ri = i0 + wm * 32 + (lane & 31), rj = j0 + wn * 32 + (lane & 31);
+  const float* __restrict__ ea = E + (size_t)min(ri, M - 1) * H;
+  const float* __restrict__ eb = E + (size_t)min(rj, M - 1) * H;
+  const bool va = ri < M, vb = rj < M;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < H; k0 += TK) {
-    for (int q = tid; q < TS * TK; q += 256) {
-      const int r = q >> 5, k = q & 31;
-      As[r * TLD + k] = (i0 + r < M && k0 + k < H) ? E[(size_t)(i0 + r) * H + k0 + k] : 0.f;
-      Bs[r * TLD + k] = (j0 + r < M && k0 + k < H) ? E[(size_t)(j0 + r) * H + k0 + k] : 0.f;
-    }
-    __syncthreads();
-    mma_chunk_nt(As, Bs, wm, wn, lane, acc);
-    __syncthreads();
-  }
+  const int ng = (H + 7) / 8;
+#pragma unroll 4
+  for (int g = ks; g < ng; g += 4) {
+    const int k = 8 * g + 4 * half;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k + 3 < H && (H & 3) == 0) {
+      const float4 a4 = *reinterpret_cast<const float4*>(ea + k), b4 = *reinterpret_cast<const float4*>(eb + k);
+      a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+      b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+    } else {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int j = j0 + wn * 32 + (lane & 31);
-    if (i < M && j < M) S[(size_t)i * M + j] = (i == j) ? -INFINITY : acc[r];
+      for (int e = 0; e < 4; ++e)
+        if (k + e < H) { a[e] = ea[k + e]; b[e] = eb[k + e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va ? a[e] : 0.f, vb ? b[e] : 0.f, acc, 0, 0, 0);
+  }
+  if (ks > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(((ks - 1) * 4 + sub) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (ks == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v += part[((q * 4 + sub) * 16 + r) * 64 + lane];
+      const int i = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int j = j0 + wn * 32 + (lane & 31);
+      if (i < M && j < M) S[(size_t)i * M + j] = (i == j) ? -INFINITY : v;
+    }
   }
 }
 
@@ -231,7 +257,7 @@ extern "C" int cocodr_simce_fwd_bwd(const float* E, int M, int H, int world, int
   float* S = workspace;
   float* lse = workspace + (size_t)M * M;
   const int nt = (M + TS - 1) / TS;
-  hipLaunchKernelGGL(simce_scores_kernel, dim3(nt, nt), dim3(256), 0, st, E, S, M, H);
+  hipLaunchKernelGGL(simce_scores_kernel, dim3(nt, nt), dim3(1024), 0, st, E, S, M, H);
   CK_LAUNCH("simce_scores");
   hipLaunchKernelGGL(simce_rowstats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, S, lse, loss_rows, M, (float)world);
   CK_LAUNCH("simce_rowstats");

@@ -199,23 +199,32 @@ __device__ __forceinline__ void zero_row(RowVec& r) {
 __global__ __launch_bounds__(RB_THREADS) void ln_bwd_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, uint16_t* __restrict__ dy,
-                                                     float* __restrict__ partial, int M, int H) {
+                                                     float* __restrict__ partial, int M, int H, int nseg) {
   __shared__ __attribute__((aligned(16))) float red[NW * MAXC * 256];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
   const int rows_per = (M + gridDim.x - 1) / gridDim.x;
   const int r_begin = blockIdx.x * rows_per, r_end = min(M, r_begin + rows_per);
-  RowVec dg, db;
+  RowVec dg, db, dxs;  // dxs: column sums of the input gradient = bias gradient of the Linear that feeds this LayerNorm
   zero_row(dg);
   zero_row(db);
+  zero_row(dxs);
   for (int row = r_begin + wid; row < r_end; row += NW) {
     RowVec d, x;
     load_bf16_row(dout + (size_t)row * H, nch, lane, d);
     load_bf16_row(y + (size_t)row * H, nch, lane, x);
     ln_bwd_row(d, x, gamma, nch, lane, H, mean_i[row], rstd_i[row], dg, db);
     store_bf16_row(dy + (size_t)row * H, nch, lane, d);
+    if (nseg == 3) {
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dxs.v[i][e] += d.v[i][e];
+    }
   }
-  block_reduce_store(dg, red, partial + (size_t)blockIdx.x * 2 * H, nch, tid);
-  block_reduce_store(db, red, partial + (size_t)blockIdx.x * 2 * H + H, nch, tid);
+  float* prow = partial + (size_t)blockIdx.x * nseg * H;
+  block_reduce_store(dg, red, prow, nch, tid);
+  block_reduce_store(db, red, prow + H, nch, tid);
+  if (nseg == 3) block_reduce_store(dxs, red, prow + 2 * H, nch, tid);
 }
 
 // grid.x = L (one workgroup per position): the position-embedding gradient row is a plain sum over
@@ -381,6 +390,14 @@ int launch_reduce(const float* partial, float* o0, float* o1, float* o2, int P, 
 }
 
 bool row_shape_ok(int H) { return H % 4 == 0 && H >= 4 && H <= MAXC * 256; }
+}  // namespace
+
+// out[n] = sum_p partial[p * n_len + n]  (used by the GEMM's fused column sums, csrc/gemm.hip)
+int cocodr_reduce_partials(const float* partial, float* out, int P, int n_len, hipStream_t st) {
+  return launch_reduce(partial, out, nullptr, nullptr, P, 1, n_len, 1, 0, st);
+}
+
+namespace {
 int row_grid(int M) { return std::min((M + 3) / 4, 2048); }
 
 }  // namespace
@@ -428,17 +445,19 @@ extern "C" int cocodr_ln_fwd(const uint16_t* y, const float* gamma, const float*
   return COCODR_OK;
 }
 
-extern "C" size_t cocodr_ln_bwd_partial_floats(int M, int H) { return (size_t)ln_bwd_blocks(M) * 2 * H; }
+extern "C" size_t cocodr_ln_bwd_partial_floats(int M, int H) { return (size_t)ln_bwd_blocks(M) * 3 * H; }
 
 extern "C" int cocodr_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
-                             uint16_t* dy, float* dgamma, float* dbeta, float* partial, int M, int H, cocodr_stream_t stream) {
+                             uint16_t* dy, float* dgamma, float* dbeta, float* dy_colsum, float* partial, int M, int H,
+                             cocodr_stream_t stream) {
   CK_ARG(dout && y && gamma && mean && rstd && dy && dgamma && dbeta && partial, "ln_bwd: null pointer");
   CK_ARG(M > 0 && row_shape_ok(H), "ln_bwd: bad shape M=%d H=%d", M, H);
   hipStream_t st = (hipStream_t)stream;
   const int P = ln_bwd_blocks(M);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(P), dim3(RB_THREADS), 0, st, dout, y, gamma, mean, rstd, dy, partial, M, H);
+  const int nseg = dy_colsum ? 3 : 2;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(P), dim3(RB_THREADS), 0, st, dout, y, gamma, mean, rstd, dy, partial, M, H, nseg);
   CK_LAUNCH("ln_bwd");
-  return launch_reduce(partial, dgamma, dbeta, nullptr, P, 2, H, 1, 0, st);
+  return launch_reduce(partial, dgamma, dbeta, dy_colsum, P, nseg, H, 1, 0, st);
 }
 
 extern "C" size_t cocodr_colsum_partial_floats(int M, int N, int batch) { return (size_t)colsum_splits(M) * N * (batch > 0 ? batch : 1); }

@@ -35,8 +35,9 @@ def build_info() -> str:
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          bias: Optional[torch.Tensor] = None, epi: int = N.EPI_NONE, r: Optional[torch.Tensor] = None,
-         out_f32: bool = False, out: Optional[torch.Tensor] = None):
-    """C = epi(op(a) @ op(b)); a, b bf16 2-D (or 3-D batched with equal batch).  See cocodr_gemm."""
+         out_f32: bool = False, out: Optional[torch.Tensor] = None, colsum: bool = False):
+    """C = epi(op(a) @ op(b)); a, b bf16 2-D (or 3-D batched with equal batch).  See cocodr_gemm.
+    colsum=True (unbatched) also returns the fp32 column sums of C as the last element of the result tuple."""
     batched = a.dim() == 3
     _req(a, BF16, "a", 3 if batched else 2)
     _req(b, BF16, "b", 3 if batched else 2)
@@ -77,8 +78,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
     g.trans_a, g.trans_b, g.epi, g.out_f32 = int(trans_a), int(trans_b), int(epi), int(out_f32)
     g.batch = nb
     g.strideA, g.strideB, g.strideC = a2.numel(), b2.numel(), M * Nn
+    cs = None
+    if colsum:
+        if batched:
+            raise ValueError("gemm: colsum needs an unbatched call")
+        cs = torch.empty(Nn, dtype=F32, device=a.device)
+        part = torch.empty(lib().cocodr_gemm_colsum_partial_floats(M, Nn), dtype=F32, device=a.device)
+        g.colsum, g.colsum_partial = cs.data_ptr(), part.data_ptr()
     check(lib().cocodr_gemm(C.byref(g), stream_ptr()), "gemm")
-    return (out, c2) if epi == N.EPI_GELU else out
+    res = (out, c2) if epi == N.EPI_GELU else (out,)
+    if colsum:
+        res = res + (cs,)
+    return res if len(res) > 1 else res[0]
 
 
 def gemm_set_impl(impl: int) -> None:
@@ -156,16 +167,18 @@ def ln_fwd(y, gamma, beta, eps: float = 1e-12, cls_stride: int = 0):
     return (out, mean, rstd, cls) if cls_stride > 0 else (out, mean, rstd)
 
 
-def ln_bwd(dout, y, gamma, mean, rstd):
+def ln_bwd(dout, y, gamma, mean, rstd, colsum: bool = False):
+    """(dy, dgamma, dbeta[, column sums of dy])"""
     _req(dout, BF16, "dout", 2); _req(y, BF16, "y", 2)
     M, H = y.shape
     dy = torch.empty_like(y)
     dgamma = torch.empty(H, dtype=F32, device=y.device)
     dbeta = torch.empty(H, dtype=F32, device=y.device)
+    dcs = torch.empty(H, dtype=F32, device=y.device) if colsum else None
     partial = torch.empty(lib().cocodr_ln_bwd_partial_floats(M, H), dtype=F32, device=y.device)
     check(lib().cocodr_ln_bwd(ptr(dout), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(dy), ptr(dgamma), ptr(dbeta),
-                              ptr(partial), M, H, stream_ptr()), "ln_bwd")
-    return dy, dgamma, dbeta
+                              ptr(dcs) if colsum else None, ptr(partial), M, H, stream_ptr()), "ln_bwd")
+    return (dy, dgamma, dbeta, dcs) if colsum else (dy, dgamma, dbeta)
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:

@@ -70,7 +70,12 @@ typedef struct {
   int trans_a, trans_b, epi, out_f32;
   int batch;
   long long strideA, strideB, strideC, strideR, strideBias; /* elements, per batch index */
+  /* optional (batch == 1): colsum[n] = sum_m C[m][n] of the fp32 epilogue result, i.e. the bias gradient of a Linear
+   * whose output gradient this GEMM produces; colsum_partial is a workspace of cocodr_gemm_colsum_partial_floats(M,N) */
+  float* colsum;
+  float* colsum_partial;
 } cocodr_gemm_args;
+size_t cocodr_gemm_colsum_partial_floats(int M, int N);
 int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream);
 /* tuning / test hook: 0 = auto, 1 = register-staged pipeline,
  * direct-to-LDS <BM,BK,wave rows/32>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile,
@@ -110,10 +115,12 @@ int cocodr_embed_ln_bwd(const uint16_t* dout, const int32_t* ids, const float* w
 int cocodr_ln_fwd(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean,
                   float* rstd, float* cls_out /* fp32 [M/cls_stride, H] or NULL */, int cls_stride,
                   int M, int H, float eps, cocodr_stream_t stream);
+/* dy_colsum (fp32 [H] or NULL) receives the column sums of dy: the bias gradient of the Linear whose output
+ * (+ residual) this LayerNorm normalises, so the backward needs no separate pass over dy for it */
 size_t cocodr_ln_bwd_partial_floats(int M, int H);
 int cocodr_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean,
-                  const float* rstd, uint16_t* dy, float* dgamma, float* dbeta, float* partial, int M, int H,
-                  cocodr_stream_t stream);
+                  const float* rstd, uint16_t* dy, float* dgamma, float* dbeta, float* dy_colsum, float* partial,
+                  int M, int H, cocodr_stream_t stream);
 /* column sums of a bf16 [M,N] matrix (bias gradients), batched: out[z][n] = sum_m X[z][m][n] */
 size_t cocodr_colsum_partial_floats(int M, int N, int batch);
 int cocodr_colsum(const uint16_t* X, float* out, float* partial, int M, int N, int ldx, int batch,

@@ -87,6 +87,20 @@ def test_gemm_nn_dgrad(M, Nn, K, gemm_impl):
     assert rel_l2(out, (dy.float() @ w.float()) * gp) < 5e-3
 
 
+@pytest.mark.parametrize("M,Nn,K", [(200, 256, 384), (8192, 768, 768), (1000, 3072, 768)])
+def test_gemm_fused_column_sums(M, Nn, K, gemm_impl):
+    """colsum = column sums of the fp32 epilogue result (bias gradient produced next to dX), all epilogue forms."""
+    dy, w, u = rnd(M, K, seed=31), rnd(K, Nn, scale=0.05, seed=32), rnd(M, Nn, seed=33)
+    out, cs = ops.gemm(dy, w, trans_b=True, colsum=True)
+    ref = dy.float() @ w.float()
+    assert torch.equal(out, ops.gemm(dy, w, trans_b=True))
+    assert (cs - ref.sum(0)).abs().max() < 2e-3 * float(ref.abs().sum(0).max())
+    out, cs = ops.gemm(dy, w, trans_b=True, epi=N.EPI_DGELU, r=u, colsum=True)
+    x = u.float()
+    gp = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    assert (cs - (ref * gp).sum(0)).abs().max() < 2e-3 * float((ref * gp).abs().sum(0).max())
+
+
 @pytest.mark.parametrize("nb,Mtok,No,Ni", [(1, 256, 128, 128), (3, 200, 384, 256), (2, 8192, 768, 768)])
 def test_gemm_tn_wgrad_batched_fp32(nb, Mtok, No, Ni, gemm_impl):
     dy, x = rnd(nb, Mtok, No, seed=10), rnd(nb, Mtok, Ni, seed=11)
@@ -162,6 +176,11 @@ def test_layernorm_fwd_bwd(M, H):
     dy, dg, db = ops.ln_bwd(dout, y, g, mean, rstd)
     assert rel_l2(dy, yf.grad) < 5e-3
     assert rel_l2(dg, gf.grad) < 1e-4 and rel_l2(db, bf.grad) < 1e-4
+    # fused column sums of dy (the bias gradient of the Linear in front of the LayerNorm)
+    dy2, dg2, db2, cs = ops.ln_bwd(dout, y, g, mean, rstd, colsum=True)
+    assert torch.equal(dy2, dy) and torch.equal(dg2, dg) and torch.equal(db2, db)
+    ref_cs = yf.grad.sum(0)
+    assert (cs - ref_cs).abs().max() < 1e-3 * max(1.0, float(ref_cs.abs().max()))
 
 
 def test_layernorm_cls_rows_fp32():
