@@ -69,6 +69,7 @@ SIGNATURES = {
     "cocodr_ln_bwd_partial_floats": (c_size_t, [c_int, c_int]),
     "cocodr_ln_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
     "cocodr_gemm_colsum_partial_floats": (c_size_t, [c_int, c_int]),
+    "cocodr_gemm_colsum_rows": (c_int, [C.POINTER(GemmArgs)]),
     "cocodr_colsum_partial_floats": (c_size_t, [c_int, c_int, c_int]),
     "cocodr_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
     "cocodr_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -136,5 +136,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + idx;
 }
 
-// internal (csrc/rowops.hip): out[n] = sum_p partial[p * n_len + n]
-int cocodr_reduce_partials(const float* partial, float* out, int P, int n_len, hipStream_t st);
+// internal (csrc/rowops.hip), used by the GEMM's fused column sums and the encoder backward's deferred reductions:
+// out_s[z * stride_out + n] = sum_p partial[((z * P + p) * nseg + s) * n_len + n],  s < nseg <= 3
+int cocodr_reduce_partials(const float* partial, float* o0, float* o1, float* o2, int P, int nseg, int n_len, int batch,
+                           long long stride_out, hipStream_t st);
+// LayerNorm backward without the final reduction: partial [ln_bwd_blocks(M)][nseg][H] (dgamma, dbeta[, dy column sums])
+int cocodr_ln_bwd_blocks(int M);
+int cocodr_ln_bwd_partials(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
+                           uint16_t* dy, float* partial, int M, int H, int nseg, hipStream_t st);

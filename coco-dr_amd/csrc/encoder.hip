@@ -29,6 +29,7 @@ struct BwdLayout {
   size_t dy2, du, dy1, dqkv;  // bf16 [layers][M,*]
   size_t dxa, dxb, dctx;      // bf16 [M,H]
   size_t ln_partial, colsum_partial, emb_partial;  // fp32
+  size_t ln2_slots, ln1_slots, b1_slots, bv_slots;  // fp32 per-layer partial rows of the deferred reductions
   size_t total;
 };
 
@@ -47,6 +48,10 @@ BwdLayout bwd_layout(const cocodr_config* c, int B, int L) {
   b.colsum_partial = cv.take(std::max(cocodr_colsum_partial_floats((int)M, (int)std::max(I, 3 * H), (int)N),
                                       cocodr_gemm_colsum_partial_floats((int)M, (int)std::max(I, 3 * H))) * 4);
   b.emb_partial = cv.take(cocodr_embed_bwd_partial_floats(L, (int)H) * 4);
+  b.ln2_slots = cv.take(N * cocodr_ln_bwd_partial_floats((int)M, (int)H) * 4);
+  b.ln1_slots = cv.take(N * cocodr_ln_bwd_partial_floats((int)M, (int)H) * 4);
+  b.b1_slots = cv.take(N * cocodr_gemm_colsum_partial_floats((int)M, (int)I) * 4);
+  b.bv_slots = cv.take(N * cocodr_gemm_colsum_partial_floats((int)M, (int)H) * 4);
   b.total = cv.off;
   return b;
 }
@@ -228,6 +233,38 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
   // a continuation range (d_in == NULL) picks up the gradient the previous range left in the arena
   const uint16_t* dx = d_in ? d_in : dxb;
   const int NG = layer_hi - layer_lo;  // layers in this range
+
+  // Deferred reductions: the LayerNorm backward and the two GEMMs with fused column sums leave per-layer partial rows
+  // in the arena and ONE batched reduction per group finishes them for the whole range (instead of four short
+  // launches per layer).  Needs the vector gradients of a layer group to sit at one common layer stride (true for the
+  // flat parameter layout); otherwise every call reduces immediately.
+  hipStream_t hst = (hipStream_t)stream;
+  const int P_ln = cocodr_ln_bwd_blocks(M);
+  const size_t ln_slot = (size_t)P_ln * 3 * H;
+  float* ln2_slots = (float*)(bb + bl.ln2_slots);
+  float* ln1_slots = (float*)(bb + bl.ln1_slots);
+  float* b1_slots = (float*)(bb + bl.b1_slots);
+  float* bv_slots = (float*)(bb + bl.bv_slots);
+  long long s_vec = 0;
+  bool defer = NG > 1;
+  if (defer) {
+    const cocodr_layer_grads &x0 = lg[layer_lo], &x1 = lg[layer_lo + 1];
+    s_vec = x1.b2 - x0.b2;
+    defer = (x1.ln2_g - x0.ln2_g == s_vec) && (x1.ln2_b - x0.ln2_b == s_vec) && (x1.ln1_g - x0.ln1_g == s_vec) &&
+            (x1.ln1_b - x0.ln1_b == s_vec) && (x1.bo - x0.bo == s_vec) && (x1.b1 - x0.b1 == s_vec) && (x1.bqkv - x0.bqkv == s_vec);
+    for (int l = layer_lo + 2; defer && l < layer_hi; ++l)
+      defer = (lg[l].ln2_g - lg[l - 1].ln2_g == s_vec) && (lg[l].ln2_b - lg[l - 1].ln2_b == s_vec) &&
+              (lg[l].ln1_g - lg[l - 1].ln1_g == s_vec) && (lg[l].ln1_b - lg[l - 1].ln1_b == s_vec) &&
+              (lg[l].bo - lg[l - 1].bo == s_vec) && (lg[l].b2 - lg[l - 1].b2 == s_vec) && (lg[l].b1 - lg[l - 1].b1 == s_vec) &&
+              (lg[l].bqkv - lg[l - 1].bqkv == s_vec);
+  }
+  int rows_b1 = 0, rows_bv = 0;
+  if (defer) {
+    cocodr_gemm_args q = gemm_base(dy2_all, lp[layer_lo].w2, du_all, M, I, H, H, I, I, 0, 1);
+    rows_b1 = cocodr_gemm_colsum_rows(&q);
+    q = gemm_base(dy1_all, lp[layer_lo].wo, dctx, M, H, H, H, H, H, 0, 1);
+    rows_bv = cocodr_gemm_colsum_rows(&q);
+  }
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const cocodr_layer_params& w = lp[l];
     const cocodr_layer_grads& gr = lg[l];
@@ -249,17 +286,22 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
 
     // bias gradients ride on the kernels that produce the matrices they sum: b2 / bo on the LayerNorm backward, b1 on the
     // GELU' epilogue, and the value bias on the context-gradient GEMM (sum_k dV[k] = sum_q dctx[q]: softmax rows sum to 1)
-    TRY(cocodr_ln_bwd(dx, y2, w.ln2_g, mean2, rstd2, dy2, gr.ln2_g, gr.ln2_b, gr.b2, ln_partial, M, H, stream));
+    const size_t li = (size_t)(l - layer_lo);
+    if (defer) TRY(cocodr_ln_bwd_partials(dx, y2, w.ln2_g, mean2, rstd2, dy2, ln2_slots + li * ln_slot, M, H, 3, hst));
+    else TRY(cocodr_ln_bwd(dx, y2, w.ln2_g, mean2, rstd2, dy2, gr.ln2_g, gr.ln2_b, gr.b2, ln_partial, M, H, stream));
     cocodr_gemm_args g = gemm_base(dy2, w.w2, du, M, I, H, H, I, I, 0, 1);  // dh = dy2 W2, fused with GELU'(u)
     g.epi = COCODR_EPI_DGELU; g.R = u; g.ldr = I;
-    g.colsum = gr.b1; g.colsum_partial = cs_partial;
+    if (rows_b1 > 0) g.colsum_partial = b1_slots + li * rows_b1 * I;
+    else { g.colsum = gr.b1; g.colsum_partial = cs_partial; }
     TRY(cocodr_gemm(&g, stream));
     g = gemm_base(du, w.w1, dxa, M, H, I, I, H, H, 0, 1);  // dx1 = du W1 + dy2 (residual branch)
     g.epi = COCODR_EPI_ADD; g.R = dy2; g.ldr = H;
     TRY(cocodr_gemm(&g, stream));
-    TRY(cocodr_ln_bwd(dxa, y1, w.ln1_g, mean1, rstd1, dy1, gr.ln1_g, gr.ln1_b, gr.bo, ln_partial, M, H, stream));
+    if (defer) TRY(cocodr_ln_bwd_partials(dxa, y1, w.ln1_g, mean1, rstd1, dy1, ln1_slots + li * ln_slot, M, H, 3, hst));
+    else TRY(cocodr_ln_bwd(dxa, y1, w.ln1_g, mean1, rstd1, dy1, gr.ln1_g, gr.ln1_b, gr.bo, ln_partial, M, H, stream));
     g = gemm_base(dy1, w.wo, dctx, M, H, H, H, H, H, 0, 1);  // dctx = dy1 Wo
-    g.colsum = gr.bqkv + 2 * H; g.colsum_partial = cs_partial;
+    if (rows_bv > 0) g.colsum_partial = bv_slots + li * rows_bv * H;
+    else { g.colsum = gr.bqkv + 2 * H; g.colsum_partial = cs_partial; }
     TRY(cocodr_gemm(&g, stream));
     TRY(cocodr_attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, L, c->heads, stream));
     g = gemm_base(dqkv, w.wqkv, dxb, M, H, 3 * H, 3 * H, H, H, 0, 1);  // dx = dqkv Wqkv + dy1 (residual branch)
@@ -291,6 +333,13 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
   g = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
   g.out_f32 = 1; g.batch = NG; g.strideA = sMH; g.strideB = sMI; g.strideC = s_w2;
   TRY(cocodr_gemm(&g, stream));
+  // ---- deferred reductions of the range (LayerNorm weight / bias + the Linear bias in front of it; b1; value bias)
+  if (defer) {
+    TRY(cocodr_reduce_partials(ln2_slots, g0.ln2_g, g0.ln2_b, g0.b2, P_ln, 3, H, NG, s_vec, hst));
+    TRY(cocodr_reduce_partials(ln1_slots, g0.ln1_g, g0.ln1_b, g0.bo, P_ln, 3, H, NG, s_vec, hst));
+    if (rows_b1 > 0) TRY(cocodr_reduce_partials(b1_slots, g0.b1, nullptr, nullptr, rows_b1, 1, I, NG, s_vec, hst));
+    if (rows_bv > 0) TRY(cocodr_reduce_partials(bv_slots, g0.bqkv + 2 * H, nullptr, nullptr, rows_bv, 1, H, NG, s_vec, hst));
+  }
   // ---- the remaining bias gradients (query, key): batched column sums of the first 2H columns of the saved dqkv
   TRY(cocodr_colsum(dqkv_all + l0 * sM3H, g0.bqkv, cs_partial, M, 2 * H, 3 * H, NG, sM3H, s_bqkv, stream));
   return COCODR_OK;

@@ -749,6 +749,44 @@ extern "C" int cocodr_gemm_set_impl(int impl) {
   return COCODR_OK;
 }
 
+namespace {
+// which pipeline a call runs on (see g_gemm_impl); shape-only, so callers can ask before they launch
+int select_impl(const cocodr_gemm_args& a) {
+  // the direct-to-LDS pipeline needs whole 64-wide K-steps for every operand whose contraction index is the
+  // fast axis (ragged K is only zero-filled along rows), and 32-bit byte offsets per batch item
+  const bool k_ok = (a.K % BK == 0) || (a.trans_a && a.trans_b);
+  const bool small = (size_t)(a.trans_a ? a.K : a.M) * a.lda * 2 < (1ull << 32) && (size_t)(a.trans_b ? a.K : a.N) * a.ldb * 2 < (1ull << 32);
+  const int batch = a.batch > 0 ? a.batch : 1;
+  int impl = gemm_impl_override();
+  if (impl == 0) {
+    // auto (measured on MI355X, tools/gemm_bench.py): with >= 1.5 tiles per CU the BK=32 geometry wins because a
+    // second resident workgroup hides prologue/epilogue; with fewer tiles (and for the mid-sized grouped wgrad) the
+    // deeper BK=64 ring with four loader waves wins; below half a wave of 256-row tiles fall back to 128-row tiles to
+    // occupy more CUs.
+    const long long tiles256 = (long long)((a.M + 255) / 256) * (a.N / BN) * batch;
+    const long long tiles128 = (long long)((a.M + 127) / 128) * (a.N / BN) * batch;
+    if (!(k_ok && small)) impl = 1;
+    else if (tiles256 >= 384 && !(a.trans_a && tiles256 < 768)) impl = 5;
+    else if (tiles256 >= 128) impl = 9;
+    else impl = tiles128 >= 512 ? 4 : 2;
+  }
+  if (impl != 1 && !(k_ok && small)) impl = 1;
+  if (impl == 8 && a.N % 192 != 0) impl = 3;  // the 128x192 tile needs N % 192 == 0
+  return impl;
+}
+// row panels of the fused column sums for that pipeline (0: not fused there)
+int colsum_rows(int impl, int M) {
+  if (impl == 1 || impl == 8) return 0;
+  const int bm = (impl == 2 || impl == 4) ? 128 : 256;
+  return (M + bm - 1) / bm;
+}
+}  // namespace
+
+extern "C" int cocodr_gemm_colsum_rows(const cocodr_gemm_args* args) {
+  if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0 || args->N % BN != 0 || args->batch > 1 || args->out_f32) return 0;
+  return colsum_rows(select_impl(*args), args->M);
+}
+
 extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream) {
   CK_ARG(args != nullptr, "gemm: null args");
   cocodr_gemm_args a = *args;
@@ -769,35 +807,18 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   CK_ARG((((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.C2 | (uintptr_t)a.R | (uintptr_t)a.bias) & 15) == 0,
          "gemm: pointers must be 16-byte aligned");
   if (a.epi != COCODR_EPI_ADD && a.epi != COCODR_EPI_DGELU) a.R = nullptr;
-  CK_ARG(!a.colsum || (a.colsum_partial && a.batch == 1 && !a.out_f32), "gemm: colsum needs colsum_partial, batch == 1 and a bf16 output");
+  CK_ARG(!(a.colsum || a.colsum_partial) || (a.colsum_partial && a.batch == 1 && !a.out_f32),
+         "gemm: column sums need colsum_partial, batch == 1 and a bf16 output");
   float* const cs_out = a.colsum;
   float* const cs_part = a.colsum_partial;
-  if (!cs_out) a.colsum_partial = nullptr;
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
   dim3 grid(ntm * ntn, a.batch);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_GEMM, st, 2.0 * a.M * a.N * (double)a.K * a.batch);
-  // the direct-to-LDS pipeline needs whole 64-wide K-steps for every operand whose contraction index is the
-  // fast axis (ragged K is only zero-filled along rows), and 32-bit byte offsets per batch item
-  const bool k_ok = (a.K % BK == 0) || (a.trans_a && a.trans_b);
-  const bool small = (size_t)(a.trans_a ? a.K : a.M) * a.lda * 2 < (1ull << 32) && (size_t)(a.trans_b ? a.K : a.N) * a.ldb * 2 < (1ull << 32);
-  int impl = gemm_impl_override();
-  if (impl == 0) {
-    // auto (measured on MI355X, tools/gemm_bench.py): with >= 1.5 tiles per CU the BK=32 geometry wins because a
-    // second resident workgroup hides prologue/epilogue; with fewer tiles (and for the mid-sized grouped wgrad) the
-    // deeper BK=64 ring with four loader waves wins; below half a wave of 256-row tiles fall back to 128-row tiles to
-    // occupy more CUs.
-    const long long tiles256 = (long long)((a.M + 255) / 256) * (a.N / BN) * a.batch;
-    const long long tiles128 = (long long)((a.M + 127) / 128) * (a.N / BN) * a.batch;
-    if (!(k_ok && small)) impl = 1;
-    else if (tiles256 >= 384 && !(a.trans_a && tiles256 < 768)) impl = 5;
-    else if (tiles256 >= 128) impl = 9;
-    else impl = tiles128 >= 512 ? 4 : 2;
-  }
-  if (impl != 1 && !(k_ok && small)) impl = 1;
-  if (impl == 8 && a.N % 192 != 0) impl = 3;  // the 128x192 tile needs N % 192 == 0
-  const bool fused_colsum = cs_out && impl != 1 && impl != 8;  // the kernels with 128-column tiles reduce in their epilogue
-  if (!fused_colsum) a.colsum_partial = nullptr;
+  const int impl = select_impl(a);
+  const int cs_rows = colsum_rows(impl, a.M);  // the kernels with 128-column tiles reduce in their epilogue
+  CK_ARG(!cs_part || cs_out || cs_rows > 0, "gemm: deferred column sums (colsum == NULL) are not available on this pipeline; ask cocodr_gemm_colsum_rows first");
+  if (cs_rows == 0) a.colsum_partial = nullptr;
   if (impl == 10) launch_glds_any<256, 64, 4, 2, 4>(a, st);
   else if (impl == 9) launch_glds_any<256, 64, 2, 2, 4>(a, st);
   else if (impl == 8) launch_glds_any<128, 64, 2, 3>(a, st);
@@ -812,10 +833,7 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   else launch<1, 1>(a, grid, st);
   CK_LAUNCH("gemm");
   if (cs_out) {
-    if (fused_colsum) {
-      const int bm = (impl == 2 || impl == 4) ? 128 : 256;
-      return cocodr_reduce_partials(cs_part, cs_out, (a.M + bm - 1) / bm, a.N, st);
-    }
+    if (cs_rows > 0) return cocodr_reduce_partials(cs_part, cs_out, nullptr, nullptr, cs_rows, 1, a.N, 1, 0, st);
     return cocodr_colsum((const uint16_t*)a.C, cs_out, cs_part, a.M, a.N, a.ldc, 1, 0, 0, stream);
   }
   return COCODR_OK;

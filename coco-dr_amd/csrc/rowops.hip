@@ -392,9 +392,16 @@ int launch_reduce(const float* partial, float* o0, float* o1, float* o2, int P, 
 bool row_shape_ok(int H) { return H % 4 == 0 && H >= 4 && H <= MAXC * 256; }
 }  // namespace
 
-// out[n] = sum_p partial[p * n_len + n]  (used by the GEMM's fused column sums, csrc/gemm.hip)
-int cocodr_reduce_partials(const float* partial, float* out, int P, int n_len, hipStream_t st) {
-  return launch_reduce(partial, out, nullptr, nullptr, P, 1, n_len, 1, 0, st);
+int cocodr_reduce_partials(const float* partial, float* o0, float* o1, float* o2, int P, int nseg, int n_len, int batch,
+                           long long stride_out, hipStream_t st) {
+  return launch_reduce(partial, o0, o1, o2, P, nseg, n_len, batch, stride_out, st);
+}
+int cocodr_ln_bwd_blocks(int M) { return ln_bwd_blocks(M); }
+int cocodr_ln_bwd_partials(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
+                           uint16_t* dy, float* partial, int M, int H, int nseg, hipStream_t st) {
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_bwd_blocks(M)), dim3(RB_THREADS), 0, st, dout, y, gamma, mean, rstd, dy, partial, M, H, nseg);
+  CK_LAUNCH("ln_bwd");
+  return COCODR_OK;
 }
 
 namespace {

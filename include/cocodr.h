@@ -76,6 +76,11 @@ typedef struct {
   float* colsum_partial;
 } cocodr_gemm_args;
 size_t cocodr_gemm_colsum_partial_floats(int M, int N);
+/* Deferred form: with colsum == NULL and colsum_partial != NULL the call only leaves its per-row-panel sums
+ * [rows][N] in colsum_partial (rows = cocodr_gemm_colsum_rows(args), which is 0 when the call would not run on a
+ * pipeline with fused sums - then the deferred form is refused); the caller adds the panels later, e.g. for
+ * all layers of a backward range in one launch. */
+int cocodr_gemm_colsum_rows(const cocodr_gemm_args* args);
 int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream);
 /* tuning / test hook: 0 = auto, 1 = register-staged pipeline,
  * direct-to-LDS <BM,BK,wave rows/32>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile,
