@@ -19,6 +19,7 @@ extern "C" const char* cocodr_last_error(void) { return g_err; }
 extern "C" const char* cocodr_build_info(void) { return "cocodr_hip gfx950 (MI355X/CDNA4) " __DATE__ " " __TIME__; }
 
 int g_prof_kind = PROF_OFF;
+int g_prof_paused = 0;
 namespace {
 struct ProfState {
   std::vector<hipEvent_t> begin, end;
@@ -49,6 +50,12 @@ extern "C" int cocodr_prof_begin(int kind) {
   g_ps.used = 0;
   g_ps.flops = 0.0;
   g_prof_kind = kind;
+  g_prof_paused = 0;
+  return COCODR_OK;
+}
+
+extern "C" int cocodr_prof_pause(int paused) {
+  g_prof_paused = paused != 0;
   return COCODR_OK;
 }
 

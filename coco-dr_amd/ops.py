@@ -270,6 +270,10 @@ def prof_begin(kind: int) -> None:
     check(lib().cocodr_prof_begin(kind), "prof_begin")
 
 
+def prof_pause(paused: bool) -> None:
+    check(lib().cocodr_prof_pause(int(bool(paused))), "prof_pause")
+
+
 def prof_end():
     n, ms, fl = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
     check(lib().cocodr_prof_end(C.byref(n), C.byref(ms), C.byref(fl)), "prof_end")

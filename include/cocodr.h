@@ -259,6 +259,9 @@ int cocodr_encoder_bwd_range(const cocodr_config* cfg, const cocodr_embed_params
  * on the launch stream.  kind: 0 = off, 1 = GEMM launches, 2 = attention, 3 = score_topk GEMM.
  * ------------------------------------------------------------------------------------------ */
 int cocodr_prof_begin(int kind);
+/* paused != 0: launches are not bracketed until resumed (the events cost ~1.5 us of stream time each, so a bench
+ * samples some of its timed steps instead of all of them); totals keep accumulating */
+int cocodr_prof_pause(int paused);
 /* synchronises, returns launches / summed ms / summed algorithmic FLOPs, and disables profiling */
 int cocodr_prof_end(int* launches, double* total_ms, double* total_flops);
 
