@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256, 2) void score_gemm_kernel(const float* __restr
 
 // ------------------------------------------------------------------ exact top-k per row
 constexpr int TOPK_THREADS = 512;
-constexpr int NREP = 8;        // replicated LDS histograms (lane & 7) to thin same-address atomics
+constexpr int NREP = 4;        // replicated LDS histograms (lane & 3) to thin same-address atomics
 constexpr int NBIN = 2048;
 constexpr int KMAX = 2048;
+constexpr int NCAND = 2048;    // LDS candidate list of the compacted path
 
 // order-preserving map: smaller key <=> larger float  (NaN sorts last)
 __device__ __forceinline__ uint32_t desc_key(float f) {
@@ -113,26 +114,27 @@ struct SelState {
   int count_eq;
 };
 
-// One radix pass: histogram `digit(v)` over the elements with (v & himask) == prefix, pick the
-// smallest digit whose cumulative count reaches st.need.
-template <typename F>
-__device__ __forceinline__ void radix_pass(int n, int shift, int bits, uint32_t himask, SelState& st, uint32_t* hist, int* sh,
-                                           F value_at) {
+// One radix pass over the elements `scan` enumerates: histogram digit(v) of the values val(key, idx, v) accepts whose
+// high bits match the prefix, pick the smallest digit whose cumulative count reaches st.need.
+template <typename Scan, typename Val>
+__device__ __forceinline__ void radix_pass(Scan scan, Val val, int shift, int bits, uint32_t himask, SelState& st, uint32_t* hist,
+                                           int* sh) {
   const int tid = threadIdx.x;
   const int nb = 1 << bits;
   for (int i = tid; i < NREP * NBIN; i += TOPK_THREADS) hist[i] = 0;
   __syncthreads();
   uint32_t* my = hist + (tid & (NREP - 1)) * NBIN;
-  for (int i = tid; i < n; i += TOPK_THREADS) {
+  const uint32_t prefix = st.prefix;
+  scan([&](uint32_t key, uint32_t idx) {
     uint32_t v;
-    if (value_at(i, v) && (v & himask) == st.prefix) atomicAdd(&my[(v >> shift) & (nb - 1)], 1u);
-  }
+    if (val(key, idx, v) && (v & himask) == prefix) atomicAdd(&my[(v >> shift) & (nb - 1)], 1u);
+  });
   __syncthreads();
   for (int b = tid; b < nb; b += TOPK_THREADS) {
-    uint32_t s = 0;
+    uint32_t t = 0;
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) s += hist[r * NBIN + b];
-    hist[b] = s;
+    for (int r = 0; r < NREP; ++r) t += hist[r * NBIN + b];
+    hist[b] = t;
   }
   __syncthreads();
   if (tid == 0) {
@@ -152,11 +154,18 @@ __device__ __forceinline__ void radix_pass(int n, int shift, int bits, uint32_t 
   __syncthreads();
 }
 
+// Exact selection of the k best of one score row.  Pass 1 histograms the top 11 key bits of the whole row (16-byte
+// loads).  When the bin that holds the k-th score is small (the usual case: k << Np and scores spread over a few
+// exponents), ONE more pass over the row moves the sure winners to the output buffer and that bin's members to an LDS
+// candidate list, and the remaining radix / tie-break passes run on the list: 2 trips over the row instead of 4.
+// Otherwise all passes stream the row, as before.  Result and order (score descending, position ascending on ties) are
+// identical on both paths.
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ S, long long lds_s, int np, int k,
                                                             long long id_offset, float* __restrict__ D, long long* __restrict__ I) {
   __shared__ uint32_t hist[NREP * NBIN];
-  __shared__ unsigned long long buf[KMAX];  // (key << 32) | idx : ascending = score desc, idx asc
-  __shared__ int sh[4];
+  __shared__ unsigned long long buf[KMAX];   // (key << 32) | idx : ascending = score desc, idx asc
+  __shared__ unsigned long long cand[NCAND];
+  __shared__ int sh[6];
   const int tid = threadIdx.x;
   const float* row = S + (size_t)blockIdx.x * lds_s;
   float* Drow = D + (size_t)blockIdx.x * k;
@@ -165,32 +174,77 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
   int kpad = 1;
   while (kpad < kk) kpad <<= 1;
   for (int i = tid; i < kpad; i += TOPK_THREADS) buf[i] = ~0ull;
-  if (tid == 0) sh[3] = 0;
+  if (tid == 0) { sh[3] = 0; sh[4] = 0; }
 
-  uint32_t thr = 0xffffffffu;
-  uint32_t ithr = 0xffffffffu;
+  auto scan_row = [&](auto body) {  // rows start 16-byte aligned (workspace leading dimension is a multiple of 4)
+    const int n4 = np >> 2;
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+    for (int i = tid; i < n4; i += TOPK_THREADS) {
+      const float4 v = r4[i];
+      body(desc_key(v.x), (uint32_t)(4 * i));
+      body(desc_key(v.y), (uint32_t)(4 * i + 1));
+      body(desc_key(v.z), (uint32_t)(4 * i + 2));
+      body(desc_key(v.w), (uint32_t)(4 * i + 3));
+    }
+    for (int i = (n4 << 2) + tid; i < np; i += TOPK_THREADS) body(desc_key(row[i]), (uint32_t)i);
+  };
+  auto by_key = [](uint32_t key, uint32_t, uint32_t& v) { v = key; return true; };
+
+  uint32_t thr = 0xffffffffu, ithr = 0xffffffffu;
+  bool compacted = false;
+  int ncand = 0;
   if (kk < np) {
     SelState st{0u, kk, 0};
-    auto keyf = [&](int i, uint32_t& v) { v = desc_key(row[i]); return true; };
-    radix_pass(np, 21, 11, 0x00000000u, st, hist, sh, keyf);
-    radix_pass(np, 10, 11, 0xffe00000u, st, hist, sh, keyf);
-    radix_pass(np, 0, 10, 0xfffffc00u, st, hist, sh, keyf);
-    thr = st.prefix;
-    if (st.count_eq > st.need) {  // exact score ties straddle the cut: keep the lowest positions
-      SelState si{0u, st.need, 0};
-      auto idxf = [&](int i, uint32_t& v) { v = (uint32_t)i; return desc_key(row[i]) == thr; };
-      radix_pass(np, 21, 11, 0x00000000u, si, hist, sh, idxf);
-      radix_pass(np, 10, 11, 0xffe00000u, si, hist, sh, idxf);
-      radix_pass(np, 0, 10, 0xfffffc00u, si, hist, sh, idxf);
-      ithr = si.prefix;
+    radix_pass(scan_row, by_key, 21, 11, 0x00000000u, st, hist, sh);
+    compacted = st.count_eq <= NCAND;  // workgroup-uniform (read from LDS)
+    if (compacted) {
+      const uint32_t bin = st.prefix >> 21;
+      scan_row([&](uint32_t key, uint32_t idx) {
+        const uint32_t top = key >> 21;
+        if (top < bin) buf[atomicAdd(&sh[3], 1)] = ((unsigned long long)key << 32) | idx;
+        else if (top == bin) cand[atomicAdd(&sh[4], 1)] = ((unsigned long long)key << 32) | idx;
+      });
+      __syncthreads();
+      ncand = sh[4];
     }
+    auto scan_cand = [&](auto body) {
+      for (int c = tid; c < ncand; c += TOPK_THREADS) {
+        const unsigned long long e = cand[c];
+        body((uint32_t)(e >> 32), (uint32_t)e);
+      }
+    };
+    auto rest = [&](auto scan) {
+      radix_pass(scan, by_key, 10, 11, 0xffe00000u, st, hist, sh);
+      radix_pass(scan, by_key, 0, 10, 0xfffffc00u, st, hist, sh);
+      thr = st.prefix;
+      if (st.count_eq > st.need) {  // exact score ties straddle the cut: keep the lowest positions
+        SelState si{0u, st.need, 0};
+        const uint32_t t = thr;
+        auto by_idx = [t](uint32_t key, uint32_t idx, uint32_t& v) { v = idx; return key == t; };
+        radix_pass(scan, by_idx, 21, 11, 0x00000000u, si, hist, sh);
+        radix_pass(scan, by_idx, 10, 11, 0xffe00000u, si, hist, sh);
+        radix_pass(scan, by_idx, 0, 10, 0xfffffc00u, si, hist, sh);
+        ithr = si.prefix;
+      }
+    };
+    if (compacted) rest(scan_cand);
+    else rest(scan_row);
   }
   __syncthreads();
-  for (int i = tid; i < np; i += TOPK_THREADS) {
-    const uint32_t key = desc_key(row[i]);
-    if (key < thr || (key == thr && (uint32_t)i <= ithr)) {
-      const int pos = atomicAdd(&sh[3], 1);
-      if (pos < kpad) buf[pos] = ((unsigned long long)key << 32) | (uint32_t)i;
+  {
+    auto take = [&](uint32_t key, uint32_t idx) {
+      if (key < thr || (key == thr && idx <= ithr)) {
+        const int pos = atomicAdd(&sh[3], 1);
+        if (pos < kpad) buf[pos] = ((unsigned long long)key << 32) | idx;
+      }
+    };
+    if (compacted) {
+      for (int c = tid; c < ncand; c += TOPK_THREADS) {
+        const unsigned long long e = cand[c];
+        take((uint32_t)(e >> 32), (uint32_t)e);
+      }
+    } else {
+      scan_row(take);
     }
   }
   __syncthreads();

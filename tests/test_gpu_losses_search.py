@@ -89,3 +89,21 @@ def test_score_topk_exact_ties_prefer_lower_position():
     D, I = ops.score_topk(t(Q), t(P), 50)
     Dr, Ir = O.score_topk(Q, P, 50)
     assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
+
+
+@pytest.mark.parametrize("mode", ["narrow", "ties"])
+def test_score_topk_streams_the_row_when_the_cut_bin_is_crowded(mode):
+    """Both selection paths give the same result: scores packed into one exponent / a couple of mantissa steps (or
+    thousands of exact ties at the cut) overflow the LDS candidate list, so every radix pass streams the row."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    Np, k = 20000, 300
+    if mode == "narrow":  # integer-valued, exact in fp32: scores 1024 + {0..255} -> one 11-bit key bin holds them all
+        Q = np.zeros((3, 8), np.float32); Q[:, 0] = 1.0
+        P = np.zeros((Np, 8), np.float32); P[:, 0] = 1024 + rng.integers(0, 256, Np)
+    else:  # the k-th score is shared by 5000 passages
+        Q = np.ones((3, 4), np.float32)
+        P = rng.integers(0, 4, (Np, 4)).astype(np.float32)
+        P[5000:10000] = 2.0
+    D, I = ops.score_topk(t(Q), t(P), k)
+    Dr, Ir = O.score_topk(Q, P, k)
+    assert np.array_equal(D.cpu().numpy(), Dr) and np.array_equal(I.cpu().numpy(), Ir)
