@@ -109,10 +109,6 @@ class CondenserHead(nn.Module):
             self._shadow_version = self.flat_decay._version
 
 
-def _gelu_grad(x: torch.Tensor) -> torch.Tensor:
-    return 0.5 * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0)))) + x * torch.exp(-0.5 * x * x) * (1.0 / math.sqrt(2.0 * math.pi))
-
-
 class _CondenserStepFn(torch.autograd.Function):
     """(backbone flats, head flats, ids, mask, labels) -> (mlm loss scalar, fp32 [CLS] rows).  The contrastive loss
     is applied on the returned [CLS] rows by the caller (it needs the cross-rank gather)."""
@@ -211,7 +207,7 @@ class _CondenserStepFn(torch.autograd.Function):
             dg, dlnw, dlnb = ops.ln_bwd(dt, g_act, head.hf_view("cls.predictions.transform.LayerNorm.weight"), t_mean, t_rstd)
             gv("cls.predictions.transform.LayerNorm.weight").copy_(dlnw)
             gv("cls.predictions.transform.LayerNorm.bias").copy_(dlnb)
-            da = (dg.float() * _gelu_grad(a_pre.float())).to(torch.bfloat16)
+            da = (dg.float() * a_pre.float()).to(torch.bfloat16)  # a_pre holds GELU'(pre-activation) (EPI_GELU's C2)
             gv("cls.predictions.transform.dense.weight").copy_(ops.gemm(da, xg, trans_a=True, trans_b=True, out_f32=True))
             gv("cls.predictions.transform.dense.bias").copy_(ops.colsum(da))
             wt = head._shadow[: H * H].view(H, H)

@@ -96,6 +96,14 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   erf_pdf_terms(x, er, e);
   return 0.5f * (1.0f + er) + x * 0.3989422804014327f * e;
 }
+// value and derivative from one erf / exp evaluation (the forward saves the derivative for the backward)
+__device__ __forceinline__ void gelu_erf_both(float x, float& g, float& gp) {
+  float er, e;
+  erf_pdf_terms(x, er, e);
+  const float cdf = 0.5f * (1.0f + er);
+  g = x * cdf;
+  gp = cdf + x * 0.3989422804014327f * e;
+}
 
 // ------------------------------------------------------------------ LDS tile addressing
 // [rows][64] bf16 tiles (128-B rows, 8 chunks of 16 B).  The chunk index is XOR-swizzled with a

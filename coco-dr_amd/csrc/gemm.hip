@@ -162,9 +162,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const cocodr_gemm_args p) 
           v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
         if (p.epi == COCODR_EPI_GELU) {
-          *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(v);
+          float gp[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+          for (int j = 0; j < 8; ++j) gelu_erf_both(v[j], v[j], gp[j]);
+          *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(gp);
         } else if (p.epi == COCODR_EPI_ADD) {
           float r[8];
           unpack8(*reinterpret_cast<const uint4*>(R + (size_t)gm * p.ldr + gn), r);
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const cocodr_gemm_args p) 
           float r[8];
           unpack8(*reinterpret_cast<const uint4*>(R + (size_t)gm * p.ldr + gn), r);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(r[j]);
+          for (int j = 0; j < 8; ++j) v[j] *= r[j];
         }
         if (OUT_F32) {
           float* C = reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
@@ -396,9 +397,10 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
   }
   if (p.epi == COCODR_EPI_GELU) {
-    *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(v);
+    float gp[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+    for (int j = 0; j < 8; ++j) gelu_erf_both(v[j], v[j], gp[j]);
+    *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(gp);
   } else if (p.epi == COCODR_EPI_ADD) {
     float r[8];
     unpack8(RPRE ? rpre : *reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
@@ -408,7 +410,7 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
     float r[8];
     unpack8(RPRE ? rpre : *reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(r[j]);
+    for (int j = 0; j < 8; ++j) v[j] *= r[j];
   }
   if (OUT_F32) {
     float* C = reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;

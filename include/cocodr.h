@@ -48,15 +48,16 @@ const char* cocodr_build_info(void);
  *   trans_a = 0: A is [M,K] row-major (lda)        trans_a = 1: A is stored [K,M] (lda)
  *   trans_b = 0: B is [N,K] row-major (ldb) i.e. a torch Linear weight; trans_b = 1: B is [K,N]
  *   forward   Y = X W^T      -> (0,0)      dgrad dX = dY W -> (0,1)     wgrad dW = dY^T X -> (1,1)
- * Epilogues (COCODR_EPI_*): bias add, bias+exact-erf GELU (also emits the pre-activation),
- * residual add, and multiply by GELU'(U) for the FFN backward.
+ * Epilogues (COCODR_EPI_*): bias add, bias+exact-erf GELU (also emits GELU'(pre-activation), bf16, the only
+ * thing the backward needs from the pre-activation), residual add, and the element-wise multiply by that saved
+ * derivative for the FFN backward.
  * Requirements: N % 128 == 0; K % 8 == 0; M % 8 == 0 when trans_a; all leading dims % 8 == 0.
  * ------------------------------------------------------------------------------------------ */
 enum {
   COCODR_EPI_NONE = 0,      /* C = acc (+bias)                                  */
-  COCODR_EPI_GELU = 1,      /* C2 = acc+bias (pre-activation), C = gelu(C2)     */
+  COCODR_EPI_GELU = 1,      /* u = acc+bias: C = gelu(u), C2 = gelu'(u)         */
   COCODR_EPI_ADD = 2,       /* C = acc (+bias) + R                              */
-  COCODR_EPI_DGELU = 3      /* C = acc * gelu'(R)   (R = saved pre-activation)  */
+  COCODR_EPI_DGELU = 3      /* C = acc * R          (R = the C2 of EPI_GELU)    */
 };
 typedef struct {
   const uint16_t* A;

@@ -67,10 +67,13 @@ def test_gemm_nt_bias(M, Nn, K, gemm_impl):
 def test_gemm_nt_gelu_and_residual(gemm_impl):
     M, Nn, K = 384, 512, 128
     a, w, bias, r = rnd(M, K, seed=3), rnd(Nn, K, scale=0.1, seed=4), rnd(Nn, seed=5, dtype=torch.float32), rnd(M, Nn, seed=6)
-    h, u = ops.gemm(a, w, bias=bias, epi=N.EPI_GELU)
-    pre = a.float() @ w.float().T + bias
-    assert rel_l2(u, pre) < 5e-3
-    assert rel_l2(h, torch.nn.functional.gelu(pre)) < 5e-3
+    h, gp = ops.gemm(a, w, bias=bias, epi=N.EPI_GELU)
+    pre = (a.float() @ w.float().T + bias).requires_grad_(True)
+    ref = torch.nn.functional.gelu(pre)
+    assert rel_l2(h, ref) < 5e-3
+    ref.sum().backward()  # second output: GELU'(pre-activation), what the backward multiplies by
+    assert rel_l2(gp, pre.grad) < 5e-3
+    pre = pre.detach()
     out = ops.gemm(a, w, bias=bias, epi=N.EPI_ADD, r=r)
     assert rel_l2(out, pre + r.float()) < 5e-3
 
@@ -80,11 +83,9 @@ def test_gemm_nn_dgrad(M, Nn, K, gemm_impl):
     dy, w = rnd(M, K, seed=7), rnd(K, Nn, scale=0.05, seed=8)  # w stored [K,N] = Linear weight [out=K, in=N]
     out = ops.gemm(dy, w, trans_b=True)
     assert rel_l2(out, dy.float() @ w.float()) < 5e-3
-    u = rnd(M, Nn, seed=9)
-    out = ops.gemm(dy, w, trans_b=True, epi=N.EPI_DGELU, r=u)
-    x = u.float()
-    gp = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
-    assert rel_l2(out, (dy.float() @ w.float()) * gp) < 5e-3
+    gp = rnd(M, Nn, seed=9)  # the saved GELU' values (any bf16 matrix: the epilogue is an element-wise product)
+    out = ops.gemm(dy, w, trans_b=True, epi=N.EPI_DGELU, r=gp)
+    assert rel_l2(out, (dy.float() @ w.float()) * gp.float()) < 5e-3
 
 
 @pytest.mark.parametrize("M,Nn,K", [(200, 256, 384), (8192, 768, 768), (1000, 3072, 768)])
@@ -96,8 +97,7 @@ def test_gemm_fused_column_sums(M, Nn, K, gemm_impl):
     assert torch.equal(out, ops.gemm(dy, w, trans_b=True))
     assert (cs - ref.sum(0)).abs().max() < 2e-3 * float(ref.abs().sum(0).max())
     out, cs = ops.gemm(dy, w, trans_b=True, epi=N.EPI_DGELU, r=u, colsum=True)
-    x = u.float()
-    gp = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    gp = u.float()
     assert (cs - (ref * gp).sum(0)).abs().max() < 2e-3 * float((ref * gp).abs().sum(0).max())
 
 
