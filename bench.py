@@ -144,6 +144,61 @@ def eval_search(dev, nq: int = 2048, npass: int = 125000, dim: int = 1024, k: in
             "workload": f"{nq} queries x {npass} passages x {dim} fp32, k={k}, exact scores + exact top-k, 1 GPU shard of config 5"}
 
 
+def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3):
+    """BASELINE config 4 (ANCE/drivers/run_ann.py:293-356): BERT-large triplet step, 32 rows/GPU = queries [32,64] +
+    positives / negatives [32,128], backward, clip_grad_norm_(1.0), LAMB (the reference's default optimizer), linear
+    schedule.  One training row = 3 sequences."""
+    from cocodr_amd.modeling import BertDotNLL, CocoBertConfig
+    from cocodr_amd.optim import FlatLamb, clip_grad_norm_
+    cfg = CocoBertConfig.large()
+    torch.manual_seed(0)
+    model = BertDotNLL(cfg).to(dev)
+    opt = FlatLamb.for_model(model.bert, lr=5e-6, eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: max(0.0, 1.0 - s / 1000.0))
+    q, qm = synth_batch(0, rows, 64, cfg.vocab_size, dev)
+    a, am = synth_batch(1, rows, 128, cfg.vocab_size, dev)
+    b, bm = synth_batch(2, rows, 128, cfg.vocab_size, dev)
+    flats = [model.bert.flat_decay, model.bert.flat_nodecay]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _acc, _logits = model(q, qm, a, am, b, bm)
+        loss.backward()
+        opt.step(clip=clip_grad_norm_(flats, 1.0))  # norm and coefficient stay on the device
+        sched.step()
+        return loss
+
+    for _ in range(warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"sequences_per_sec": round(3 * rows / dt, 1), "rows_per_sec": round(rows / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+            "loss": round(float(loss.detach()), 4),
+            "scope": f"cocodr-large triplet step, {rows} rows (q L64 + pos/neg L128), bf16, clip_grad_norm_(1.0) + LAMB; BASELINE configs[3]"}
+
+
+def corpus_encode(cfg, dev, n: int = 8192, seq_len: int = 128, batch: int = 512, iters: int = 3):
+    """Inference half of the path (ANCE/drivers/run_ann_data_gen.py:157-212): eval-mode passage embeddings of a token
+    cache resident in HBM, kept on device (retrieval.encode_corpus)."""
+    from cocodr_amd import retrieval
+    from cocodr_amd.modeling import BertDotNLL
+    model = BertDotNLL(cfg).to(dev).eval()
+    ids, mask = synth_batch(0, n, seq_len, cfg.vocab_size, dev)
+    retrieval.encode_corpus(model, ids[:batch], mask[:batch], batch_size=batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        emb, _ = retrieval.encode_corpus(model, ids, mask, batch_size=batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"sequences_per_sec": round(n / dt, 1), "ms": round(dt * 1e3, 2),
+            "workload": f"{n} passages x L{seq_len}, batch {batch}, BertDot_NLL_LN body_emb (last-layer [CLS]), bf16 encoder, eval mode"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +295,8 @@ def main():
     if not args.no_full_step and not use_dist:
         full = full_coco_step(cfg, args, dev, ids, mask)  # second scope: what the reference's step really runs
     search = eval_search(dev) if (not args.no_full_step and not use_dist) else None
+    encode = corpus_encode(cfg, dev, seq_len=args.seq_len) if (not args.no_full_step and not use_dist) else None
+    ance = ance_step(dev) if (not args.no_full_step and not use_dist and args.model == "base") else None
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -268,6 +325,10 @@ def main():
             out["full_coco_step"] = full
         if search is not None:
             out["eval_search"] = search
+        if encode is not None:
+            out["corpus_encode"] = encode
+        if ance is not None:
+            out["ance_triplet_step"] = ance
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

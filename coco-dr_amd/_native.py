@@ -52,6 +52,11 @@ class EncoderLayout(C.Structure):
         "rstd2", "emb_mean", "emb_rstd", "bwd_scratch", "bwd_bytes", "bwd_dx")]
 
 
+class LambPlan(C.Structure):  # mirrors cocodr_lamb_plan
+    _fields_ = [("chunk_start", c_void_p), ("chunk_len", c_void_p), ("chunk_seg", c_void_p), ("seg_chunk_begin", c_void_p),
+                ("nchunk", c_int), ("nseg", c_int)]
+
+
 EPI_NONE, EPI_GELU, EPI_ADD, EPI_DGELU = 0, 1, 2, 3
 
 # name -> (restype, argtypes); every symbol include/cocodr.h declares
@@ -74,7 +79,10 @@ SIGNATURES = {
     "cocodr_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
     "cocodr_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "cocodr_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_float, c_float,
-                                  c_float, c_float, c_int, c_float, c_void_p]),
+                                  c_float, c_float, c_int, c_float, c_void_p, c_void_p]),
+    "cocodr_grad_norm_clip": (c_int, [C.POINTER(c_void_p), C.POINTER(c_size_t), c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "cocodr_lamb_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, C.POINTER(LambPlan), c_float,
+                                 c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_scatter_cls_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cocodr_simce_workspace_floats": (c_size_t, [c_int]),
     "cocodr_simce_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -177,7 +177,7 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     TRY(cocodr_gemm(&g, stream));
     TRY(cocodr_ln_fwd(y1, w.ln1_g, w.ln1_b, x1, mean1, rstd1, nullptr, 0, M, H, c->ln_eps, stream));
     g = gemm_base(x1, w.w1, h, M, I, H, H, H, I, 0, 0);
-    g.bias = w.b1; g.epi = COCODR_EPI_GELU; g.C2 = u;
+    g.bias = w.b1; g.epi = COCODR_EPI_GELU; g.C2 = training ? u : nullptr;  // u: GELU'(pre-activation) for the backward
     TRY(cocodr_gemm(&g, stream));
     g = gemm_base(h, w.w2, y2, M, H, I, I, I, H, 0, 0);
     g.bias = w.b2; g.epi = COCODR_EPI_ADD; g.R = x1; g.ldr = H;

@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const cocodr_gemm_args p) 
           const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
           v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
-        if (p.epi == COCODR_EPI_GELU) {
+        if (p.epi == COCODR_EPI_GELU && p.C2 == nullptr) {  // inference: nobody needs the derivative
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        } else if (p.epi == COCODR_EPI_GELU) {
           float gp[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) gelu_erf_both(v[j], v[j], gp[j]);
@@ -396,7 +399,10 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
     const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
   }
-  if (p.epi == COCODR_EPI_GELU) {
+  if (p.epi == COCODR_EPI_GELU && p.C2 == nullptr) {  // inference: nobody needs the derivative
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+  } else if (p.epi == COCODR_EPI_GELU) {
     float gp[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) gelu_erf_both(v[j], v[j], gp[j]);
@@ -746,7 +752,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG(impl >= 0 && impl <= 10, "gemm_set_impl: impl must be in [0,10]");
+  CK_ARG(impl >= 0 && impl <= 11, "gemm_set_impl: impl must be in [0,11]");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -774,11 +780,12 @@ int select_impl(const cocodr_gemm_args& a) {
   }
   if (impl != 1 && !(k_ok && small)) impl = 1;
   if (impl == 8 && a.N % 192 != 0) impl = 3;  // the 128x192 tile needs N % 192 == 0
+  if (impl == 11 && a.N % 256 != 0) impl = 5;  // the 256x256 tile needs N % 256 == 0
   return impl;
 }
 // row panels of the fused column sums for that pipeline (0: not fused there)
 int colsum_rows(int impl, int M) {
-  if (impl == 1 || impl == 8) return 0;
+  if (impl == 1 || impl == 8 || impl == 11) return 0;
   const int bm = (impl == 2 || impl == 4) ? 128 : 256;
   return (M + bm - 1) / bm;
 }
@@ -804,7 +811,7 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
 #endif
   CK_ARG(!(a.trans_a && !a.trans_b), "gemm: (trans_a=1, trans_b=0) is not used on this path");
   CK_ARG(a.epi >= COCODR_EPI_NONE && a.epi <= COCODR_EPI_DGELU, "gemm: bad epilogue %d", a.epi);
-  CK_ARG(a.epi != COCODR_EPI_GELU || (a.C2 && !a.out_f32), "gemm: EPI_GELU needs C2 and bf16 output");
+  CK_ARG(a.epi != COCODR_EPI_GELU || !a.out_f32, "gemm: EPI_GELU needs a bf16 output");
   CK_ARG((a.epi != COCODR_EPI_ADD && a.epi != COCODR_EPI_DGELU) || (a.R && a.ldr % 8 == 0 && a.ldr >= a.N), "gemm: epilogue needs R");
   CK_ARG((((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.C2 | (uintptr_t)a.R | (uintptr_t)a.bias) & 15) == 0,
          "gemm: pointers must be 16-byte aligned");
@@ -821,7 +828,8 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   const int cs_rows = colsum_rows(impl, a.M);  // the kernels with 128-column tiles reduce in their epilogue
   CK_ARG(!cs_part || cs_out || cs_rows > 0, "gemm: deferred column sums (colsum == NULL) are not available on this pipeline; ask cocodr_gemm_colsum_rows first");
   if (cs_rows == 0) a.colsum_partial = nullptr;
-  if (impl == 10) launch_glds_any<256, 64, 4, 2, 4>(a, st);
+  if (impl == 11) launch_glds_any<256, 32, 2, 4>(a, st);
+  else if (impl == 10) launch_glds_any<256, 64, 4, 2, 4>(a, st);
   else if (impl == 9) launch_glds_any<256, 64, 2, 2, 4>(a, st);
   else if (impl == 8) launch_glds_any<128, 64, 2, 3>(a, st);
   else if (impl == 7) launch_glds_any<256, 64, 4>(a, st);

@@ -508,7 +508,9 @@ namespace {
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, uint16_t* __restrict__ shadow, size_t shadow_begin,
                                                     size_t n4, float lr, float beta1, float beta2, float eps, float wd,
-                                                    float bc1, float bc2_sqrt, float grad_scale) {
+                                                    float bc1, float bc2_sqrt, float grad_scale,
+                                                    const float* __restrict__ grad_scale_dev) {
+  if (grad_scale_dev) grad_scale *= *grad_scale_dev;  // e.g. the clip coefficient cocodr_grad_norm_clip left on the device
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
     const float4 gv = reinterpret_cast<const float4*>(g)[i];
@@ -532,11 +534,162 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (shadow && i * 4 >= shadow_begin) *reinterpret_cast<uint2*>(shadow + (i * 4 - shadow_begin)) = pack4(pa);
   }
 }
+
+// ---- gradient norm / clip coefficient (torch.nn.utils.clip_grad_norm_, ANCE/drivers/run_ann.py:347-352), no host sync
+constexpr int GN_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = x[n4 * 4 + threadIdx.x]; acc += t * t; }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int np, float max_norm, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    out[0] = norm;
+    out[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
+  }
+}
+
+// ---- LAMB (ANCE/utils/lamb.py:61-121): Adam moments without bias correction, per-tensor trust ratio
+// clamp(||w||, 0, 10) / ||m / (sqrt(v) + eps) + wd * w||.  The flat parameter is cut into chunks that never straddle a
+// tensor (host-built plan): pass 1 updates m, v and leaves per-chunk (sum w^2, sum u^2), a small kernel turns them into
+// one trust ratio per tensor (chunks added in a fixed order: deterministic), pass 2 re-forms u and applies the step.
+__device__ __forceinline__ float lamb_u(float w, float m, float v, float eps, float wd) { return m / (sqrtf(v) + eps) + wd * w; }
+
+__global__ __launch_bounds__(256) void lamb_moments_kernel(const float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, const long long* __restrict__ chunk_start,
+                                                           const int* __restrict__ chunk_len, float beta1, float beta2, float eps,
+                                                           float wd, float grad_scale, const float* __restrict__ grad_scale_dev,
+                                                           float* __restrict__ chunk_sums) {
+  __shared__ float red[2][4];
+  if (grad_scale_dev) grad_scale *= *grad_scale_dev;
+  const size_t base = (size_t)chunk_start[blockIdx.x] / 4;
+  const int len4 = chunk_len[blockIdx.x] / 4;
+  float sw = 0.f, su = 0.f;
+  for (int i = threadIdx.x; i < len4; i += 256) {
+    const float4 pv = reinterpret_cast<const float4*>(p)[base + i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[base + i];
+    float4 mv = reinterpret_cast<float4*>(m)[base + i];
+    float4 vv = reinterpret_cast<float4*>(v)[base + i];
+    const float pa[4] = {pv.x, pv.y, pv.z, pv.w};
+    const float ga[4] = {gv.x * grad_scale, gv.y * grad_scale, gv.z * grad_scale, gv.w * grad_scale};
+    float ma[4] = {mv.x, mv.y, mv.z, mv.w};
+    float va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ma[e] = beta1 * ma[e] + (1.0f - beta1) * ga[e];
+      va[e] = beta2 * va[e] + (1.0f - beta2) * ga[e] * ga[e];
+      const float u = lamb_u(pa[e], ma[e], va[e], eps, wd);
+      sw += pa[e] * pa[e];
+      su += u * u;
+    }
+    reinterpret_cast<float4*>(m)[base + i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    reinterpret_cast<float4*>(v)[base + i] = make_float4(va[0], va[1], va[2], va[3]);
+  }
+  sw = wave_sum(sw);
+  su = wave_sum(su);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sw; red[1][threadIdx.x >> 6] = su; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    chunk_sums[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    chunk_sums[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+// one wave per tensor: trust[s] = clamp(||w||, 0, 10) / ||u||  (1 when either norm is 0); stats [s] = (||w|| clamped, ||u||)
+__global__ __launch_bounds__(64) void lamb_trust_kernel(const float* __restrict__ chunk_sums, const int* __restrict__ seg_chunk_begin,
+                                                        float* __restrict__ trust, float* __restrict__ stats) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  float sw = 0.f, su = 0.f;
+  for (int c = seg_chunk_begin[s] + lane; c < seg_chunk_begin[s + 1]; c += 64) { sw += chunk_sums[2 * c]; su += chunk_sums[2 * c + 1]; }
+  sw = wave_sum(sw);
+  su = wave_sum(su);
+  if (lane == 0) {
+    const float wn = fminf(sqrtf(sw), 10.0f), un = sqrtf(su);
+    trust[s] = (wn == 0.f || un == 0.f) ? 1.0f : wn / un;
+    if (stats) { stats[2 * s] = wn; stats[2 * s + 1] = un; }
+  }
+}
+__global__ __launch_bounds__(256) void lamb_apply_kernel(float* __restrict__ p, const float* __restrict__ m, const float* __restrict__ v,
+                                                         uint16_t* __restrict__ shadow, size_t shadow_begin,
+                                                         const long long* __restrict__ chunk_start, const int* __restrict__ chunk_len,
+                                                         const int* __restrict__ chunk_seg, const float* __restrict__ trust, float lr,
+                                                         float eps, float wd) {
+  const size_t base = (size_t)chunk_start[blockIdx.x] / 4;
+  const int len4 = chunk_len[blockIdx.x] / 4;
+  const float step = lr * trust[chunk_seg[blockIdx.x]];
+  for (int i = threadIdx.x; i < len4; i += 256) {
+    float4 pv = reinterpret_cast<float4*>(p)[base + i];
+    const float4 mv = reinterpret_cast<const float4*>(m)[base + i];
+    const float4 vv = reinterpret_cast<const float4*>(v)[base + i];
+    float pa[4] = {pv.x, pv.y, pv.z, pv.w};
+    const float ma[4] = {mv.x, mv.y, mv.z, mv.w};
+    const float va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pa[e] -= step * lamb_u(pa[e], ma[e], va[e], eps, wd);
+    reinterpret_cast<float4*>(p)[base + i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    const size_t el = (base + i) * 4;
+    if (shadow && el >= shadow_begin) *reinterpret_cast<uint2*>(shadow + (el - shadow_begin)) = pack4(pa);
+  }
+}
 }  // namespace
+
+extern "C" int cocodr_grad_norm_clip(const float* const* grads, const size_t* numels, int count, float max_norm, float* partial,
+                                     float* out, cocodr_stream_t stream) {
+  CK_ARG(grads && numels && partial && out && count > 0 && count <= 8, "grad_norm_clip: need 1..8 tensors, workspace and output");
+  hipStream_t st = (hipStream_t)stream;
+  for (int t = 0; t < count; ++t) {
+    CK_ARG(grads[t] && (((uintptr_t)grads[t]) & 15) == 0, "grad_norm_clip: tensor %d must be a 16-byte aligned device pointer", t);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(GN_BLOCKS), dim3(256), 0, st, grads[t], numels[t], partial + (size_t)t * GN_BLOCKS);
+    CK_LAUNCH("grad_norm_clip(sumsq)");
+  }
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, partial, count * GN_BLOCKS, max_norm, out);
+  CK_LAUNCH("grad_norm_clip");
+  return COCODR_OK;
+}
+
+extern "C" int cocodr_lamb_step(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin, size_t n,
+                                const cocodr_lamb_plan* plan, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                float grad_scale, const float* grad_scale_dev, float* workspace, float* stats,
+                                cocodr_stream_t stream) {
+  CK_ARG(p && g && m && v && plan && workspace, "lamb_step: null pointer");
+  CK_ARG(plan->chunk_start && plan->chunk_len && plan->chunk_seg && plan->seg_chunk_begin && plan->nchunk > 0 && plan->nseg > 0,
+         "lamb_step: incomplete plan");
+  CK_ARG(n % 4 == 0 && shadow_begin % 4 == 0, "lamb_step: n and shadow_begin must be multiples of 4");
+  CK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)shadow) & 7) == 0,
+         "lamb_step: pointers must be 16-byte aligned");
+  CK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "lamb_step: bad hyper-parameters");
+  hipStream_t st = (hipStream_t)stream;
+  float* chunk_sums = workspace;                       // [nchunk][2]
+  float* trust = workspace + (size_t)2 * plan->nchunk;  // [nseg]
+  hipLaunchKernelGGL(lamb_moments_kernel, dim3(plan->nchunk), dim3(256), 0, st, p, g, m, v, plan->chunk_start, plan->chunk_len, beta1,
+                     beta2, eps, weight_decay, grad_scale, grad_scale_dev, chunk_sums);
+  CK_LAUNCH("lamb_step(moments)");
+  hipLaunchKernelGGL(lamb_trust_kernel, dim3(plan->nseg), dim3(64), 0, st, chunk_sums, plan->seg_chunk_begin, trust, stats);
+  CK_LAUNCH("lamb_step(trust)");
+  hipLaunchKernelGGL(lamb_apply_kernel, dim3(plan->nchunk), dim3(256), 0, st, p, m, v, shadow, shadow_begin, plan->chunk_start,
+                     plan->chunk_len, plan->chunk_seg, trust, lr, eps, weight_decay);
+  CK_LAUNCH("lamb_step(apply)");
+  return COCODR_OK;
+}
 
 extern "C" int cocodr_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin, size_t n,
                                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                                 cocodr_stream_t stream) {
+                                 const float* grad_scale_dev, cocodr_stream_t stream) {
   CK_ARG(p && g && m && v, "adamw_step: null pointer");
   CK_ARG(n % 4 == 0 && shadow_begin % 4 == 0, "adamw_step: n and shadow_begin must be multiples of 4");
   CK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)shadow) & 7) == 0,
@@ -548,7 +701,7 @@ extern "C" int cocodr_adamw_step(float* p, const float* g, float* m, float* v, u
   const size_t n4 = n / 4;
   const int grid = (int)std::min((size_t)4096, (n4 + 255) / 256);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, shadow_begin, n4, lr, beta1,
-                     beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                     beta2, eps, weight_decay, bc1, bc2, grad_scale, grad_scale_dev);
   CK_LAUNCH("adamw_step");
   return COCODR_OK;
 }

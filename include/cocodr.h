@@ -63,7 +63,7 @@ typedef struct {
   const uint16_t* A;
   const uint16_t* B;
   void* C;            /* bf16 [M,N] (out_f32 = 0) or fp32 [M,N] (out_f32 = 1) */
-  uint16_t* C2;       /* bf16 [M,N], EPI_GELU only */
+  uint16_t* C2;       /* bf16 [M,N], EPI_GELU only; NULL = do not emit the derivative (inference) */
   const float* bias;  /* fp32 [N] or NULL */
   const uint16_t* R;  /* bf16 [M,N], EPI_ADD / EPI_DGELU */
   int M, N, K;
@@ -137,11 +137,40 @@ int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int
 
 /* Fused AdamW over one flat fp32 parameter (torch.optim.AdamW semantics; the reference steps AdamW through the HF
  * Trainer, COCO/trainer.py:66-70, or its own loop, ANCE/drivers/run_ann.py:345-356).  g is multiplied by grad_scale
- * first.  When shadow != NULL the updated values of elements [shadow_begin, n) are also written as bf16 to
+ * (and by *grad_scale_dev when that device pointer is not NULL - the clip coefficient below) first.  When
+ * shadow != NULL the updated values of elements [shadow_begin, n) are also written as bf16 to
  * shadow[0 .. n - shadow_begin) - the weight-matrix shadow the GEMMs read - in the same pass. */
 int cocodr_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin, size_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                      cocodr_stream_t stream);
+                      const float* grad_scale_dev, cocodr_stream_t stream);
+
+/* torch.nn.utils.clip_grad_norm_ (ANCE/drivers/run_ann.py:347-352) without a host round trip: the total L2 norm of
+ * up to 8 gradient tensors goes to out[0] and the coefficient min(1, max_norm / (norm + 1e-6)) to out[1] (device
+ * memory); the optimizer passes multiply the gradient by it (grad_scale_dev).  grads / numels are host arrays;
+ * partial: device workspace of count * 1024 floats. */
+int cocodr_grad_norm_clip(const float* const* grads, const size_t* numels, int count, float max_norm, float* partial,
+                          float* out, cocodr_stream_t stream);
+
+/* LAMB as the reference implements it (ANCE/utils/lamb.py:61-121; ANCE's default optimizer, run_ann.py:128-133):
+ * m, v without bias correction, u = m / (sqrt(v) + eps) + weight_decay * w, and per parameter TENSOR
+ * w -= lr * [clamp(||w||, 0, 10) / ||u||] * u (ratio 1 when either norm is 0).  The tensors live inside one flat
+ * parameter; `plan` (device arrays, built once by the host) cuts it into chunks of at most a few thousand elements
+ * that never straddle a tensor: chunk c = elements [chunk_start[c], chunk_start[c] + chunk_len[c]) (multiples of 4) of
+ * tensor chunk_seg[c]; the chunks of tensor s are seg_chunk_begin[s] .. seg_chunk_begin[s+1]-1.
+ * workspace: 2 * nchunk + nseg floats; stats (NULL or [nseg][2]) receives (weight_norm, adam_norm) per tensor, the
+ * quantities the reference logs (lamb.py:12-22).  The reference loops over ~200 tensors with ~10 torch kernels
+ * each; this is three launches per flat. */
+typedef struct {
+  const long long* chunk_start;
+  const int* chunk_len;
+  const int* chunk_seg;
+  const int* seg_chunk_begin;
+  int nchunk, nseg;
+} cocodr_lamb_plan;
+int cocodr_lamb_step(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin, size_t n,
+                     const cocodr_lamb_plan* plan, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     float grad_scale, const float* grad_scale_dev, float* workspace, float* stats,
+                     cocodr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses

@@ -20,3 +20,4 @@ reference's evaluate/evaluation/msmarco_eval.py).
 from .bert_oracle import *  # noqa: F401,F403
 from .retrieval_oracle import *  # noqa: F401,F403
 from .condenser_oracle import *  # noqa: F401,F403
+from .optim_oracle import *  # noqa: F401,F403

@@ -337,9 +337,51 @@ def golden_token_cache():
     sys.path.pop(0)
 
 
+def golden_lamb():
+    """Three steps of the reference's own ``Lamb`` (ANCE/utils/lamb.py) behind ``torch.nn.utils.clip_grad_norm_`` -
+    the optimizer half of the ANCE step (ANCE/drivers/run_ann.py:345-356).  Harness shim (disclosed): lamb.py imports
+    ``tensorboardX`` at module level only for its logging helper; the package is absent here, so an empty stand-in
+    module with a ``SummaryWriter`` name is registered before the import.  Five tensors exercise the corner cases:
+    a matrix, a vector, an all-zero tensor (trust ratio 1), a tensor with ||w|| > 10 (clamp) and a tiny one."""
+    import types
+    tb = types.ModuleType("tensorboardX")
+    tb.SummaryWriter = object
+    sys.modules.setdefault("tensorboardX", tb)
+    sys.path.insert(0, os.path.join(REF, "ANCE", "utils"))
+    from lamb import Lamb
+    sys.path.pop(0)
+    g = torch.Generator().manual_seed(11)
+    shapes = [(24, 16), (64,), (32,), (40, 8), (4,)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g) * 0.05) for s in shapes]
+    with torch.no_grad():
+        params[2].zero_()
+        params[3].mul_(40.0)  # ||w|| ~ 36 -> clamped to 10
+    out = {f"p0_{i}": p.detach().numpy().copy() for i, p in enumerate(params)}
+    for wd, tag in ((0.0, "wd0"), (0.01, "wd01")):
+        ps = [torch.nn.Parameter(p.detach().clone()) for p in params]
+        opt = Lamb(ps, lr=2e-3, eps=1e-6, weight_decay=wd)
+        gg = torch.Generator().manual_seed(12)
+        for step in range(3):
+            for i, p in enumerate(ps):
+                p.grad = torch.randn(p.shape, generator=gg) * (3.0 if step == 0 else 0.02)  # step 0 is clipped, the others not
+                if i == 2 and step < 2:
+                    p.grad.zero_()  # zero weights AND zero update -> trust ratio 1 branch
+                out[f"{tag}_g{step}_{i}"] = p.grad.numpy().copy()
+            norm = torch.nn.utils.clip_grad_norm_(ps, 1.0)
+            out[f"{tag}_norm{step}"] = np.float64(float(norm))
+            opt.step()
+            for i, p in enumerate(ps):
+                out[f"{tag}_p{step + 1}_{i}"] = p.detach().numpy().copy()
+            out[f"{tag}_trust{step}"] = np.array([float(opt.state[p]["trust_ratio"]) for p in ps])
+    np.savez_compressed(os.path.join(OUT, "lamb_steps.npz"), **out)
+    print("lamb golden: norms", [out[f"wd0_norm{i}"] for i in range(3)], "trust", out["wd0_trust0"])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache"]
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb"]
+    if "lamb" in which:
+        golden_lamb()
     if "cache" in which:
         golden_token_cache()
     if "coco" in which:

@@ -49,7 +49,7 @@ def test_probe_ds_read_tr16_layout():
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10], ids=["regstage", "glds128x64", "glds256x64", "glds128x32", "glds256x32", "glds256x32w4", "glds256x64w4", "glds128x192", "glds256x64ld4", "glds256x64w4ld4"], autouse=False)
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], ids=["regstage", "glds128x64", "glds256x64", "glds128x32", "glds256x32", "glds256x32w4", "glds256x64w4", "glds128x192", "glds256x64ld4", "glds256x64w4ld4", "glds256x256"], autouse=False)
 def gemm_impl(request):
     ops.gemm_set_impl(request.param)
     yield request.param
@@ -248,3 +248,77 @@ def test_flat_adamw_matches_torch_adamw_and_updates_shadow():
     lo = m.layout
     assert torch.equal(m._shadow, m.flat_decay.data[lo.mat_begin:].to(torch.bfloat16))
     assert m._shadow_version == m.flat_decay._version
+
+
+def test_flat_lamb_and_device_clip_match_reference_lamb_golden():
+    """The native LAMB + clip coefficient on a flat parameter holding the golden's five tensors (with alignment padding
+    between them) reproduces three steps of the reference's own Lamb class behind clip_grad_norm_."""
+    import os
+    from cocodr_amd.optim import FlatLamb, clip_grad_norm_
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lamb_steps.npz"))
+    shapes = [z[f"p0_{i}"].shape for i in range(5)]
+    offs, o = [], 0
+    for s in shapes:
+        offs.append(o)
+        o = (o + int(np.prod(s)) + 63) // 64 * 64  # padded like the model's flat layout
+    for wd, tag in ((0.0, "wd0"), (0.01, "wd01")):
+        flat = torch.zeros(o, dtype=torch.float32, device=DEV)
+        for i, s in enumerate(shapes):
+            flat[offs[i]: offs[i] + int(np.prod(s))] = torch.from_numpy(z[f"p0_{i}"].ravel()).to(DEV)
+        p = torch.nn.Parameter(flat)
+        opt = FlatLamb([p], [offs], lr=2e-3, eps=1e-6, weight_decay=wd)
+        for step in range(3):
+            g = torch.zeros(o, dtype=torch.float32, device=DEV)
+            for i, s in enumerate(shapes):
+                g[offs[i]: offs[i] + int(np.prod(s))] = torch.from_numpy(z[f"{tag}_g{step}_{i}"].ravel()).to(DEV)
+            p.grad = g
+            clip = clip_grad_norm_([p], 1.0)
+            opt.step(clip=clip)
+            norm, coef = (float(x) for x in clip)
+            ref_norm = float(z[f"{tag}_norm{step}"])
+            assert abs(norm - ref_norm) <= 1e-5 * ref_norm and abs(coef - min(1.0, 1.0 / (ref_norm + 1e-6))) < 1e-6
+            np.testing.assert_allclose(opt.state[p]["trust_ratio"].cpu().numpy(), z[f"{tag}_trust{step}"], rtol=5e-4)
+            for i, s in enumerate(shapes):
+                got = p.data[offs[i]: offs[i] + int(np.prod(s))].cpu().numpy().reshape(s)
+                np.testing.assert_allclose(got, z[f"{tag}_p{step + 1}_{i}"], rtol=2e-4, atol=5e-7)
+        # padding between the tensors never moves
+        mask = torch.ones(o, dtype=torch.bool, device=DEV)
+        for i, s in enumerate(shapes):
+            mask[offs[i]: offs[i] + int(np.prod(s))] = False
+        assert float(p.data[mask].abs().max()) == 0.0
+
+
+def test_flat_lamb_on_the_model_matches_the_oracle_per_tensor():
+    """FlatLamb.for_model: trust ratios per HF-named tensor inside the two flats, bf16 shadow refreshed in the pass."""
+    import oracle as O
+    from cocodr_amd.modeling import CocoBertConfig, CocoBertModel
+    from cocodr_amd.optim import FlatLamb, clip_grad_norm_
+    cfg = CocoBertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=64)
+    torch.manual_seed(0)
+    m = CocoBertModel(cfg).to(DEV)
+    names = list(m.layout.names)
+    ref = {n: m.hf_view(n).detach().cpu().numpy().astype(np.float64).copy() for n in names}
+    rm = {n: np.zeros_like(v) for n, v in ref.items()}
+    rv = {n: np.zeros_like(v) for n, v in ref.items()}
+    opt = FlatLamb.for_model(m, lr=1e-3, eps=1e-6)
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for step in range(3):
+        grads = {}
+        for p in (m.flat_decay, m.flat_nodecay):
+            p.grad = torch.zeros_like(p)
+        for n in names:
+            gview = m.layout.view((m.flat_decay.grad, m.flat_nodecay.grad), n)
+            gn = torch.randn(gview.shape, generator=gen) * (0.5 if step == 0 else 0.01)
+            gview.copy_(gn.to(DEV))
+            grads[n] = gn.numpy().astype(np.float64)
+        clip = clip_grad_norm_([m.flat_decay, m.flat_nodecay], 1.0)
+        opt.step(clip=clip)
+        norm, coef = O.clip_grad_norm(list(grads.values()), 1.0)
+        assert abs(float(clip[0]) - norm) <= 1e-5 * norm
+        O.lamb_step([ref[n] for n in names], [grads[n] * coef for n in names], [rm[n] for n in names], [rv[n] for n in names],
+                    lr=1e-3, eps=1e-6)
+    for n in names:
+        np.testing.assert_allclose(m.hf_view(n).detach().cpu().numpy(), ref[n], rtol=3e-4, atol=1e-6, err_msg=n)
+    lo = m.layout
+    assert torch.equal(m._shadow, m.flat_decay.data[lo.mat_begin:].to(torch.bfloat16))

@@ -171,3 +171,20 @@ def test_full_condenser_step_matches_reference():
                 continue
             assert _rel(Gh[name], g[key]) < 2e-3, (name, _rel(Gh[name], g[key]))
     assert _rel(G["embeddings.word_embeddings.weight"][:64], g["grad_rows:embeddings.word_embeddings.weight"]) < 2e-3
+
+
+def test_lamb_and_clip_oracle_match_reference_lamb_golden():
+    """oracle.lamb_step / clip_grad_norm vs three steps of the reference's Lamb class (tests/golden/lamb_steps.npz)."""
+    z = load_golden("lamb_steps.npz")
+    for wd, tag in ((0.0, "wd0"), (0.01, "wd01")):
+        ps = [z[f"p0_{i}"].astype(np.float64) for i in range(5)]
+        m = [np.zeros_like(p) for p in ps]
+        v = [np.zeros_like(p) for p in ps]
+        for step in range(3):
+            gs = [z[f"{tag}_g{step}_{i}"].astype(np.float64) for i in range(5)]
+            norm, coef = O.clip_grad_norm(gs, 1.0)
+            assert abs(norm - float(z[f"{tag}_norm{step}"])) <= 1e-5 * norm
+            trust = O.lamb_step(ps, [g * coef for g in gs], m, v, lr=2e-3, eps=1e-6, weight_decay=wd)
+            np.testing.assert_allclose(trust, z[f"{tag}_trust{step}"], rtol=2e-4)
+            for i in range(5):
+                np.testing.assert_allclose(ps[i], z[f"{tag}_p{step + 1}_{i}"], rtol=1e-4, atol=2e-7)

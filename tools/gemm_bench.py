@@ -25,6 +25,11 @@ SHAPES = [  # (name, M, N, K, ta, tb, batch, out_f32)
     ("wgrad ffn2 12x 768x3072x8192", 768, 3072, 8192, 1, 1, 12, 1),
     ("large fwd ffn1 8192x4096x1024", 8192, 4096, 1024, 0, 0, 1, 0),
     ("large fwd qkv 2048x3072x1024", 2048, 3072, 1024, 0, 0, 1, 0),
+    # corpus-encode batch (512 x 128 tokens, forward only)
+    ("enc qkv  65536x2304x768", 65536, 2304, 768, 0, 0, 1, 0),
+    ("enc out  65536x768x768", 65536, 768, 768, 0, 0, 1, 0),
+    ("enc ffn1 65536x3072x768", 65536, 3072, 768, 0, 0, 1, 0),
+    ("enc ffn2 65536x768x3072", 65536, 768, 3072, 0, 0, 1, 0),
     # K sweep at a fixed 8192x3072 output (3 full rounds of 128x128 tiles at 2 WG/CU): time = fixed + per-K-step
     ("ksweep 8192x3072x64", 8192, 3072, 64, 0, 0, 1, 0),
     ("ksweep 8192x3072x128", 8192, 3072, 128, 0, 0, 1, 0),
