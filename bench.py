@@ -176,9 +176,34 @@ def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"sequences_per_sec": round(3 * rows / dt, 1), "rows_per_sec": round(rows / dt, 1), "ms_per_step": round(dt * 1e3, 3),
-            "loss": round(float(loss.detach()), 4),
-            "scope": f"cocodr-large triplet step, {rows} rows (q L64 + pos/neg L128), bf16, clip_grad_norm_(1.0) + LAMB; BASELINE configs[3]"}
+    out = {"sequences_per_sec": round(3 * rows / dt, 1), "rows_per_sec": round(rows / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+           "loss": round(float(loss.detach()), 4),
+           "scope": f"cocodr-large triplet step, {rows} rows (q L64 + pos/neg L128), bf16, clip_grad_norm_(1.0) + LAMB; BASELINE configs[3]"}
+    # the same step with iDRO re-weighting: 50 query clusters, per-group gradients of the last 2 layers
+    import types
+    n_groups = 50
+    model.add_group_loss(args=types.SimpleNamespace(model_size="large"), n_groups=n_groups, dro_type="idro", alpha=0.25, eps=0.01,
+                         ema=0.1, rho=0.05)
+    groups = torch.randint(0, n_groups, (rows,), generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def idro_step():
+        opt.zero_grad(set_to_none=True)
+        robust, _acc, _gl, _gc = model(q, qm, a, am, b, bm, group_ids=groups)
+        robust.backward()
+        opt.step(clip=clip_grad_norm_(flats, 1.0))
+        return robust
+
+    for _ in range(2):
+        idro_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(3, steps // 2)):
+        idro_step()
+    torch.cuda.synchronize()
+    dti = (time.perf_counter() - t0) / max(3, steps // 2)
+    out["idro"] = {"ms_per_step": round(dti * 1e3, 3), "rows_per_sec": round(rows / dti, 1),
+                   "groups_present": int(groups.unique().numel()), "n_groups": n_groups}
+    return out
 
 
 def corpus_encode(cfg, dev, n: int = 8192, seq_len: int = 128, batch: int = 512, iters: int = 3):

@@ -1,0 +1,148 @@
+"""iDRO re-weighting of the ANCE triplet step: ``iDROLoss`` (ANCE/model/dro_loss.py:160-254) behind
+``BertDot_NLL_LN.forward(group_ids=...)`` (ANCE/model/models.py:211-223, 259-273).
+
+Per step: per-row triplet losses -> per-group mean losses L_g; the gradient of every present group's L_g w.r.t. the
+parameters of the last layers (dro_loss.py:177-205: layers 9-11 of a 12-layer model, the last 2 of a large one);
+cross-rank SUM of the [G, D] gradient matrix (:234); cosine gram x (L^alpha outer product) -> multiplicative update of
+the group weights h (:236-252); the step's loss is sum_g h_g L_g with the weights from BEFORE the update (:229).
+
+Native structure: the three encoder passes keep their activation arenas; a group's gradient is ONE partial backward
+(``cocodr_encoder_bwd_range`` over the selected layers only, [CLS] gradient of the group's rows scaled by 1/count_g)
+per pass instead of an autograd.grad through the whole graph, and the gram / weight update are a handful of small
+device ops.  The final backward is the ordinary one with row weights h_{g(i)} / count_{g(i)}.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._native import check, lib, ptr, stream_ptr
+
+__all__ = ["IDROLoss", "idro_triplet_step"]
+
+
+class IDROLoss:
+    """State and update rule of ``iDROLoss`` (hyper-parameters as in ``add_group_loss``, models.py:211-218)."""
+
+    def __init__(self, n_groups: int, alpha: float, eps: float, ema: float = 0.1, rho: float = 0.1, model_size: str = "base",
+                 device=None):
+        self.n_groups, self.alpha, self.eps, self.ema, self.rho = int(n_groups), float(alpha), float(eps), float(ema), float(rho)
+        self.model_size = model_size
+        self.h_fun = torch.ones(self.n_groups, dtype=torch.float32, device=device)  # register_buffer('h_fun', ones), :28
+
+    def selected_layers(self, n_layers: int) -> Tuple[int, int]:
+        """[lo, hi) of the re-weighted layers: the reference matches the names layer.9/10/11 (base) or layer.22/23
+        (large) (:177-181), i.e. the top 3 / top 2 of the stack."""
+        k = 2 if self.model_size == "large" else 3
+        if n_layers < k:
+            raise ValueError("iDRO needs at least %d encoder layers" % k)
+        return n_layers - k, n_layers
+
+    @torch.no_grad()
+    def update(self, group_losses: torch.Tensor, counts: torch.Tensor, all_grads: torch.Tensor) -> None:
+        mask = (counts > 0).to(torch.float32)
+        A = all_grads / (1e-12 + torch.linalg.norm(all_grads, dim=-1, keepdim=True))      # :236-237
+        RTG = A @ A.T                                                                       # :238
+        gl = torch.pow(group_losses.unsqueeze(-1), self.alpha)                              # :240
+        RTG = (gl @ gl.T) * RTG                                                             # :241
+        ex = self.rho * RTG.mean(dim=0) * mask                                              # :242-244
+        ex = ex - ex.max()                                                                  # :246
+        h = torch.pow(self.h_fun, self.ema) * torch.exp(ex) * (counts != 0).to(torch.float32)  # :248-250
+        h = h / h.sum()
+        self.h_fun = torch.clamp(h, min=self.eps)                                           # :252
+
+
+class _IDROStepFn(torch.autograd.Function):
+    """(flat_decay, flat_nodecay) -> robust loss; everything else rides along un-differentiated."""
+
+    @staticmethod
+    def forward(ctx, fd, fn, passes, groups, bert, dro: IDROLoss):
+        # passes: list of (ids int32 [Bp,L], mask int32 [Bp,L]); rows of q / a / b are located by `slots`
+        cfg = bert.config
+        H, NL = cfg.hidden_size, cfg.num_hidden_layers
+        G = dro.n_groups
+        dev = fd.device
+        arenas, cls_rows = [], []
+        for ids, mask in passes:
+            arena, lay = bert._run_forward(ids, mask, True)
+            Bp = ids.shape[0]
+            cls_rows.append(arena[lay.cls_f32: lay.cls_f32 + Bp * H * 4].view(torch.float32).view(Bp, H).clone())
+            arenas.append(arena)
+        q = cls_rows[0]
+        B = q.shape[0]
+        if len(passes) == 2:   # positives and negatives share one pass
+            a, b = cls_rows[1][:B], cls_rows[1][B:]
+        else:
+            a, b = cls_rows[1], cls_rows[2]
+        _mean, rows, logits, dq, da, db = ops.triplet_nll_fwd_bwd(q.contiguous(), a.contiguous(), b.contiguous(), None)
+        dq, da, db = dq * B, da * B, db * B            # d(row loss)/d(q, a, b): the kernel folds in the 1/B of the mean
+        unit = [dq, torch.cat([da, db])] if len(passes) == 2 else [dq, da, db]
+        # ---- group statistics (dro_loss.py:220-229)
+        g = groups.to(torch.int64)
+        counts = torch.zeros(G, dtype=torch.float32, device=dev).scatter_add_(0, g, torch.ones(B, dtype=torch.float32, device=dev))
+        sums = torch.zeros(G, dtype=torch.float32, device=dev).scatter_add_(0, g, rows)
+        group_losses = sums / (counts + (counts == 0).to(torch.float32))
+        h_old = dro.h_fun.clone()
+        robust = (group_losses * h_old).sum()
+        # ---- per-group gradients of the selected layers (dro_loss.py:192-205, 231-234)
+        lo = bert.layout
+        l_lo, l_hi = dro.selected_layers(NL)
+        d0, d1 = lo.mat_begin + l_lo * lo.mat_stride, lo.mat_begin + l_hi * lo.mat_stride
+        n0, n1 = lo.vec_begin + l_lo * lo.vec_stride, lo.vec_begin + l_hi * lo.vec_stride
+        all_grads = torch.zeros((G, (d1 - d0) + (n1 - n0)), dtype=torch.float32, device=dev)
+        sd, sn = torch.empty_like(fd), torch.empty_like(fn)   # scratch gradient flats: only the selected slices are written
+        emb, arr, eg, garr = bert._param_structs((sd, sn))
+        ccfg = bert._c_config()
+        present = torch.nonzero(counts > 0).flatten().tolist()   # one host sync per step (the reference has several)
+        inv = 1.0 / counts.clamp(min=1.0)
+        for gi in present:
+            w = (g == gi).to(torch.float32) * inv[gi]
+            for p, (ids, mask) in enumerate(passes):
+                Bp, L = ids.shape
+                wp = w if Bp == B else torch.cat([w, w])
+                d16 = ops.scatter_cls_grad((unit[p] * wp[:, None]).contiguous(), L)
+                check(lib().cocodr_encoder_bwd_range(C.byref(ccfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d16),
+                                                     Bp, L, ptr(arenas[p]), arenas[p].numel(), l_hi, l_lo, 0, stream_ptr()),
+                      "encoder_bwd_range(idro)")
+                all_grads[gi, : d1 - d0] += sd[d0:d1]
+                all_grads[gi, d1 - d0:] += sn[n0:n1]
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(all_grads)                                                   # :234 (SUM)
+        dro.update(group_losses.detach(), counts, all_grads)
+        # ---- what the ordinary backward needs: row weights h_{g(i)} / count_{g(i)} of the PRE-update weights
+        ctx.bert, ctx.passes, ctx.arenas, ctx.unit = bert, passes, arenas, unit
+        ctx.row_w = (h_old * inv)[g]
+        ctx.B = B
+        ctx.mark_non_differentiable(rows, logits, group_losses, counts)
+        return robust, rows, logits, group_losses, counts
+
+    @staticmethod
+    def backward(ctx, g_robust, *_unused):
+        bert = ctx.bert
+        gd_tot = gn_tot = None
+        for p, (ids, mask) in enumerate(ctx.passes):
+            Bp, L = ids.shape
+            wp = ctx.row_w if Bp == ctx.B else torch.cat([ctx.row_w, ctx.row_w])
+            d16 = ops.scatter_cls_grad((ctx.unit[p] * (wp * g_robust)[:, None]).contiguous(), L)
+            gd, gn = bert._run_backward(ids, mask, d16, ctx.arenas[p])
+            gd_tot = gd if gd_tot is None else gd_tot.add_(gd)
+            gn_tot = gn if gn_tot is None else gn_tot.add_(gn)
+        ctx.arenas = None
+        return gd_tot, gn_tot, None, None, None, None
+
+
+def idro_triplet_step(bert, dro: IDROLoss, query_ids, attention_mask_q, input_ids_a, attention_mask_a, input_ids_b,
+                      attention_mask_b, group_ids):
+    """-> (robust_loss, loss_rows, logits, group_losses, group_counts); ``dro.h_fun`` is updated in place."""
+    q_ids, q_mask, _ = bert._prep(query_ids, attention_mask_q)
+    a_ids, a_mask, _ = bert._prep(input_ids_a, attention_mask_a)
+    b_ids, b_mask, _ = bert._prep(input_ids_b, attention_mask_b)
+    if a_ids.shape == b_ids.shape:
+        passes = [(q_ids, q_mask), (torch.cat([a_ids, b_ids]), torch.cat([a_mask, b_mask]))]
+    else:
+        passes = [(q_ids, q_mask), (a_ids, a_mask), (b_ids, b_mask)]
+    return _IDROStepFn.apply(bert.flat_decay, bert.flat_nodecay, passes, group_ids, bert, dro)

@@ -559,6 +559,19 @@ class BertDotNLL(nn.Module):
         self.config = config
         self.bert = CocoBertModel(config, device=device)
         self.total = 0
+        self.dro_type, self.loss = "erm", None
+
+    def add_group_loss(self, args=None, n_groups: int = 0, dro_type: str = "idro", alpha: float = 0.0, eps: float = 0.1,
+                       ema: float = 0.1, rho: float = 0.1, weight_ema: bool = True):
+        """ANCE/model/models.py:211-223.  ``args.model_size == 'large'`` re-weights the last 2 layers, otherwise the last 3
+        (ANCE/model/dro_loss.py:177-181)."""
+        if dro_type != "idro":
+            raise NotImplementedError("only dro_type='idro' (the COCO-DR fine-tuning recipe, ANCE/README.md:101-112) is built")
+        from .idro import IDROLoss
+        self.dro_type = dro_type
+        self.n_groups = n_groups
+        self.loss = IDROLoss(n_groups, alpha, eps, ema, rho, model_size=getattr(args, "model_size", "base"),
+                             device=self.bert.flat_decay.device)
 
     @classmethod
     def from_pretrained(cls, path, config=None, device=None, **unused):
@@ -580,8 +593,15 @@ class BertDotNLL(nn.Module):
                 attention_mask_b=None, is_query=True, group_ids=None, weights=None):
         if input_ids_b is None:
             return self.query_emb(query_ids, attention_mask_q) if is_query else self.body_emb(query_ids, attention_mask_q)
-        if group_ids is not None:
-            raise NotImplementedError("group-DRO re-weighting (ANCE/model/dro_loss.py) is SURVEY 8(f2) 'next'")
+        if group_ids is not None:  # ANCE/model/models.py:259-273
+            if getattr(self, "loss", None) is None or self.dro_type != "idro":
+                raise NotImplementedError("group_ids need add_group_loss(dro_type='idro') first (dro-greedy is not built)")
+            from .idro import idro_triplet_step
+            robust, rows, logits, group_losses, group_counts = idro_triplet_step(
+                self.bert, self.loss, query_ids, attention_mask_q, input_ids_a, attention_mask_a, input_ids_b, attention_mask_b,
+                group_ids)
+            self.total += rows.shape[0] * (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
+            return robust, torch.argmax(logits, dim=1), group_losses, group_counts
         q = self.query_emb(query_ids, attention_mask_q)
         B = q.shape[0]
         if input_ids_a.shape == input_ids_b.shape:  # one encoder pass for positives and negatives

@@ -21,3 +21,4 @@ from .bert_oracle import *  # noqa: F401,F403
 from .retrieval_oracle import *  # noqa: F401,F403
 from .condenser_oracle import *  # noqa: F401,F403
 from .optim_oracle import *  # noqa: F401,F403
+from .idro_oracle import *  # noqa: F401,F403

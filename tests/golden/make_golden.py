@@ -337,6 +337,60 @@ def golden_token_cache():
     sys.path.pop(0)
 
 
+def golden_idro():
+    """f2: two training steps of the reference's iDRO re-weighting (ANCE/model/dro_loss.py:160-254) driven through
+    BertDot_NLL_LN.forward(group_ids=...) (ANCE/model/models.py:234-273) on a 12-layer toy BERT (iDROLoss selects
+    layer.9-11 by name, :177-189).  1-rank gloo group for its all_reduce.  No shims: the class runs unmodified."""
+    sys.path.insert(0, os.path.join(REF, "ANCE"))
+    import types
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29534", rank=0, world_size=1)
+    from model.models import BertDot_NLL_LN  # reference
+
+    cfg = OracleConfig(vocab_size=400, hidden_size=128, num_hidden_layers=12, num_attention_heads=2,
+                       intermediate_size=256, max_position_embeddings=64)
+    seed = 777
+    P = make_params(cfg, seed, std=STD)
+    torch.manual_seed(0)
+    model = BertDot_NLL_LN(hf_config(cfg))
+    load_into(model.bert, P)
+    model.train()  # iDROLoss.forward only defines its group statistics in training mode (:226); dropout is 0 by config
+    G, alpha, eps, ema, rho = 5, 0.25, 0.01, 0.1, 0.1
+    args = types.SimpleNamespace(model_size="base", local_rank=0)
+    model.add_group_loss(args=args, n_groups=G, dro_type="idro", alpha=alpha, eps=eps, ema=ema, rho=rho, weight_ema=True)
+    rng = np.random.Generator(np.random.PCG64(17))
+    B = 6
+    t = torch.from_numpy
+    out = dict(seed=np.int64(seed), std=np.float64(STD), hyper=np.array([G, alpha, eps, ema, rho]),
+               cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                             cfg.intermediate_size, cfg.max_position_embeddings, cfg.type_vocab_size]))
+    groups = [np.array([0, 2, 2, 4, 0, 2]), np.array([1, 1, 3, 0, 4, 4])]  # group 3 / 1 absent in step 0, 2 in step 1
+    for step in range(2):
+        q_ids, q_mask = synth_batch(rng, B, 16, cfg.vocab_size)
+        a_ids, a_mask = synth_batch(rng, B, 32, cfg.vocab_size)
+        b_ids, b_mask = synth_batch(rng, B, 32, cfg.vocab_size)
+        g = groups[step]
+        model.zero_grad()
+        robust, acc, group_losses, group_counts = model(t(q_ids), t(q_mask), t(a_ids), t(a_mask), t(b_ids), t(b_mask),
+                                                        group_ids=t(g))
+        robust.backward()
+        out.update({f"s{step}_q_ids": q_ids, f"s{step}_q_mask": q_mask, f"s{step}_a_ids": a_ids, f"s{step}_a_mask": a_mask,
+                    f"s{step}_b_ids": b_ids, f"s{step}_b_mask": b_mask, f"s{step}_groups": g,
+                    f"s{step}_robust": np.float64(float(robust)), f"s{step}_group_losses": group_losses.numpy().astype(np.float64),
+                    f"s{step}_group_counts": group_counts.numpy().astype(np.float64),
+                    f"s{step}_h_fun": model.loss.h_fun.detach().numpy().astype(np.float64)})
+        sg = selected_grads(model.named_parameters(), "bert.")
+        out.update({f"s{step}_{k}": v for k, v in sg.items()})
+        for name, p in model.named_parameters():  # a few last-layer gradients as well (the re-weighted layers)
+            if name in ("bert.encoder.layer.11.output.dense.weight", "bert.encoder.layer.9.attention.self.value.weight",
+                        "bert.encoder.layer.10.intermediate.dense.bias"):
+                out[f"s{step}_grad:{name[5:]}"] = p.grad.detach().numpy().copy()
+        print(f"idro golden step {step}: robust {float(robust):.6f} h_fun {model.loss.h_fun.numpy()}")
+    np.savez_compressed(os.path.join(OUT, "idro_steps.npz"), **out)
+    sys.path.pop(0)
+
+
 def golden_lamb():
     """Three steps of the reference's own ``Lamb`` (ANCE/utils/lamb.py) behind ``torch.nn.utils.clip_grad_norm_`` -
     the optimizer half of the ANCE step (ANCE/drivers/run_ann.py:345-356).  Harness shim (disclosed): lamb.py imports
@@ -379,7 +433,9 @@ def golden_lamb():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb"]
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro"]
+    if "idro" in which:
+        golden_idro()
     if "lamb" in which:
         golden_lamb()
     if "cache" in which:

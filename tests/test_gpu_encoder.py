@@ -292,3 +292,44 @@ def test_full_condenser_step_base_size_properties():
     assert np.isfinite(lv) and 2 * np.log(30522) * 0.8 < lv < 2 * np.log(30522) * 1.3 + 60
     for p in list(m.parameters()) + list(model.c_head.parameters()):
         assert torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+
+
+def test_idro_reweighted_triplet_steps_match_reference_golden():
+    """two steps of the reference's iDROLoss behind BertDot_NLL_LN.forward(group_ids=...) on a 12-layer toy
+    model (tests/golden/idro_steps.npz).  Robust loss, group statistics, the multiplicative-weights update of h (driven
+    by the cosine gram of per-group gradients of the last three layers) and the gradient of the re-weighted loss."""
+    import os
+    import types
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "idro_steps.npz"))
+    ocfg = cfg_from_golden(g)
+    cfg = CocoBertConfig(vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
+                         num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
+                         max_position_embeddings=ocfg.max_position_embeddings)
+    model = BertDotNLL(cfg)
+    model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in O.make_params(ocfg, int(g["seed"]), std=float(g["std"])).items()})
+    model.to(DEV)
+    G, alpha, eps, ema, rho = (float(x) for x in g["hyper"])
+    model.add_group_loss(args=types.SimpleNamespace(model_size="base", local_rank=0), n_groups=int(G), dro_type="idro", alpha=alpha,
+                         eps=eps, ema=ema, rho=rho)
+    for step in range(2):
+        t = lambda k: torch.from_numpy(g[f"s{step}_{k}"]).to(DEV)
+        model.bert.zero_grad(set_to_none=True)
+        robust, acc, group_losses, group_counts = model(t("q_ids"), t("q_mask"), t("a_ids"), t("a_mask"), t("b_ids"), t("b_mask"),
+                                                        group_ids=t("groups"))
+        robust.backward()
+        ref_robust = float(g[f"s{step}_robust"])
+        assert abs(float(robust.detach()) - ref_robust) <= 3e-2 * abs(ref_robust), (float(robust.detach()), ref_robust)
+        np.testing.assert_array_equal(group_counts.cpu().numpy(), g[f"s{step}_group_counts"])
+        # logits are O(100) after 12 bf16 layers at this init scale (cf. the ANCE golden: 2-3e-3 relative = 0.2-0.4
+        # absolute), and a row loss moves one-for-one with its logit gap
+        np.testing.assert_allclose(group_losses.cpu().numpy(), g[f"s{step}_group_losses"], rtol=5e-2, atol=0.4)
+        # the weight update sees bf16-level noise in losses and gradient cosines, damped by rho = 0.1 and the EMA power
+        np.testing.assert_allclose(model.loss.h_fun.cpu().numpy(), g[f"s{step}_h_fun"], rtol=3e-2, atol=1e-3)
+        Gr = grads_by_name(model.bert)
+        checked = 0
+        for key in g.files:
+            if key.startswith(f"s{step}_grad:") and not key.endswith("key.bias"):
+                name = key.split(":", 1)[1]
+                assert rel_l2(Gr[name], g[key]) < 0.2, (name, rel_l2(Gr[name], g[key]))
+                checked += 1
+        assert checked >= 10

@@ -188,3 +188,28 @@ def test_lamb_and_clip_oracle_match_reference_lamb_golden():
             np.testing.assert_allclose(trust, z[f"{tag}_trust{step}"], rtol=2e-4)
             for i in range(5):
                 np.testing.assert_allclose(ps[i], z[f"{tag}_p{step + 1}_{i}"], rtol=1e-4, atol=2e-7)
+
+
+def test_idro_oracle_matches_reference_idro_golden():
+    """Two steps of the reference's iDROLoss through BertDot_NLL_LN (tests/golden/idro_steps.npz): robust loss, group
+    statistics, the updated group weights and gradients of the re-weighted loss."""
+    z = load_golden("idro_steps.npz")
+    cfg = cfg_from_golden(z)
+    P = {k: v.astype(np.float64) for k, v in O.make_params(cfg, int(z["seed"]), std=float(z["std"])).items()}
+    G, alpha, eps, ema, rho = (float(x) for x in z["hyper"])
+    G = int(G)
+    h = np.ones(G)
+    for step in range(2):
+        batch = tuple(z[f"s{step}_{k}"] for k in ("q_ids", "q_mask", "a_ids", "a_mask", "b_ids", "b_mask"))
+        robust, gl, cnt, h, grads = O.idro_step(P, cfg, batch, z[f"s{step}_groups"], h, G, alpha, eps, ema, rho)
+        assert abs(robust - float(z[f"s{step}_robust"])) <= 2e-5 * abs(robust)
+        np.testing.assert_allclose(gl, z[f"s{step}_group_losses"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_array_equal(cnt, z[f"s{step}_group_counts"])
+        np.testing.assert_allclose(h, z[f"s{step}_h_fun"], rtol=2e-4, atol=1e-6)
+        for key in z.files:
+            if key.startswith(f"s{step}_grad:"):
+                name = key.split(":", 1)[1]
+                if name.endswith("key.bias"):  # identically zero in exact arithmetic (softmax rows are shift invariant)
+                    assert np.abs(grads[name]).max() < 1e-6 and np.abs(z[key]).max() < 1e-6
+                else:
+                    assert _rel(grads[name], z[key]) < 2e-4, name
