@@ -104,12 +104,19 @@ def full_coco_step(cfg, args, dev, ids, mask, steps: int = 8, warmup: int = 3):
     inp = torch.where(pick, torch.full_like(ids, 103), ids)  # [MASK]
     batch = {"input_ids": inp, "attention_mask": mask}
 
+    from cocodr_amd.optim import clip_grad_norm_
+    head_params = [p for g_ in model.c_head.param_groups(0.01) for p in g_["params"]]
+    all_flats = [bert.flat_decay, bert.flat_nodecay] + head_params
+
     def step():
         opt.zero_grad(set_to_none=True)
         opt_h.zero_grad(set_to_none=True)
         loss = model(batch, labels)
         loss.backward()
-        opt.step()
+        clip = clip_grad_norm_(all_flats, 1.0)  # HF Trainer default max_grad_norm, over backbone + head, on the device
+        opt.step(clip=clip)
+        for p in head_params:
+            p.grad.mul_(clip[1])
         opt_h.step()
         return loss
 
@@ -122,7 +129,7 @@ def full_coco_step(cfg, args, dev, ids, mask, steps: int = 8, warmup: int = 3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"sequences_per_sec": round(ids.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss.detach()), 3),
-            "scope": "backbone + 2 Condenser head layers (skip_from 6) + head & late MLM losses (label-sparse, 15 %) + contrastive + AdamW"}
+            "scope": "backbone + 2 Condenser head layers (skip_from 6) + head & late MLM losses (label-sparse, 15 %) + contrastive + clip_grad_norm_(1.0) + AdamW"}
 
 
 def eval_search(dev, nq: int = 2048, npass: int = 125000, dim: int = 1024, k: int = 1000, iters: int = 3):
@@ -270,11 +277,16 @@ def main():
     ids, mask = synth_batch(rank, args.seq_per_gpu, args.seq_len, cfg.vocab_size, dev)
     batch = {"input_ids": ids, "attention_mask": mask}
 
+    from cocodr_amd.optim import clip_grad_norm_
+    flats = [bert.flat_decay, bert.flat_nodecay]
+
     def step():
         opt.zero_grad(set_to_none=True)
         loss = model(batch, None)
         loss.backward()  # with N > 1 the gradient all-reduce is issued chunk by chunk inside this call
-        opt.step()
+        # HF Trainer clips to max_grad_norm = 1.0 by default before optimizer.step() (COCO/run_coco_pre_training.py drives
+        # the stock training loop); norm and coefficient stay on the device, the AdamW pass applies the coefficient
+        opt.step(clip=clip_grad_norm_(flats, 1.0))
         sched.step()
         return loss
 
@@ -337,7 +349,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"cocodr-{args.model} contrastive step (COCO in-batch negatives), seq_len={args.seq_len}, "
-                                   f"{args.seq_per_gpu} sequences/GPU, bf16 + fp32 accumulate, AdamW; BASELINE configs[1]",
+                                   f"{args.seq_per_gpu} sequences/GPU, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW; BASELINE configs[1]",
                        "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len,
                        "parallelism": f"dp{world}" + (" + RCCL all_gather negatives" if world > 1 else "")},
             "loss": round(final_loss, 4),
