@@ -33,7 +33,7 @@ def build():
         lib = os.path.join(OUT, f"libabl_{name}.so")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                "-DCOCODR_ABL_ALIAS_LD"] + defs + [
-            os.path.join(csrc, "gemm.hip"), os.path.join(csrc, "core.hip"), "-o", lib]
+            os.path.join(csrc, "gemm.hip"), os.path.join(csrc, "core.hip"), os.path.join(csrc, "rowops.hip"), "-o", lib]
         subprocess.run(cmd, check=True)
         print("built", lib)
 
@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--impls", default="3,5")
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--ld64", action="store_true", help="NT shapes only: lda = ldb = 64, i.e. operands alias a ~1 MB L2-resident window")
+    ap.add_argument("--variants", default="", help="comma separated subset of the built variants to time (default: the ablations)")
     ap.add_argument("--timeline", action="store_true", help="per-workgroup phase stamps instead of timings")
     args = ap.parse_args()
     if args.build:
@@ -96,7 +97,7 @@ def main():
     from tools.gemm_bench import SHAPES
     impls = [int(x) for x in args.impls.split(",")]
     libs = {}
-    for name in VARIANTS:
+    for name in (args.variants.split(",") if args.variants else VARIANTS):
         lib = C.CDLL(os.path.join(OUT, f"libabl_{name}.so"))
         lib.cocodr_gemm.argtypes = [C.POINTER(_native.GemmArgs), C.c_void_p]
         lib.cocodr_gemm.restype = C.c_int
@@ -105,7 +106,7 @@ def main():
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     if args.timeline:
         return timeline(args, impls, stream)
-    print(f"{'shape':32s} impl " + " ".join(f"{n:>10s}" for n in VARIANTS) + "   (us per launch)")
+    print(f"{'shape':32s} impl " + " ".join(f"{n:>12s}" for n in libs) + "   (us per launch)")
     for name, M, N, K, ta, tb, nb, f32 in (SHAPES[:4] if args.ld64 else SHAPES[:11]):
         ashape = (nb, K, M) if ta else (nb, M, K)
         bshape = (nb, K, N) if tb else (nb, N, K)
@@ -131,7 +132,7 @@ def main():
                     if r:
                         best = min(best, e0.elapsed_time(e1) / 5 * 1e3)
                 res.append(best)
-            print(f"{name:32s} {impl:4d} " + " ".join(f"{x:10.1f}" for x in res), flush=True)
+            print(f"{name:32s} {impl:4d} " + " ".join(f"{x:12.1f}" for x in res), flush=True)
 
 
 if __name__ == "__main__":
