@@ -130,6 +130,12 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for this path.")
         try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()  # torch's HIP runtime first: a fat binary registered before it leaves launches without a device
+        except ImportError:
+            pass
+        try:
             handle = C.CDLL(LIB_PATH)
         except OSError as e:  # e.g. no ROCm runtime on this machine
             raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
