@@ -21,7 +21,7 @@ import torch
 from . import ops
 from ._native import check, lib, ptr, stream_ptr
 
-__all__ = ["IDROLoss", "idro_triplet_step"]
+__all__ = ["IDROLoss", "DROGreedyLoss", "idro_triplet_step"]
 
 
 class IDROLoss:
@@ -53,6 +53,67 @@ class IDROLoss:
         h = torch.pow(self.h_fun, self.ema) * torch.exp(ex) * (counts != 0).to(torch.float32)  # :248-250
         h = h / h.sum()
         self.h_fun = torch.clamp(h, min=self.eps)                                           # :252
+
+
+class DROGreedyLoss:
+    """``DROGreedyLoss`` (ANCE/model/dro_loss.py:11-126, the driver's default ``--dro_type``): the step's loss is
+    ``sum_i h[g_i] * w_i * loss_i / B`` with the weights of the previous step; afterwards the EMA group losses / counts
+    (gathered over all ranks) choose the worst groups whose cumulative EMA fraction stays below ``alpha``: weight
+    ``1/alpha`` for them, the left-over mass for the next one, ``eps`` for the rest (``update_mw``)."""
+
+    def __init__(self, n_groups: int, alpha: float, eps: float, ema: float = 0.1, weight_ema: bool = False, device=None):
+        self.n_groups, self.alpha, self.eps, self.ema, self.weight_ema = int(n_groups), float(alpha), float(eps), float(ema), bool(weight_ema)
+        self.h_fun = torch.ones(self.n_groups, dtype=torch.float32, device=device)
+        self.sum_losses = torch.zeros(self.n_groups, dtype=torch.float32, device=device)
+        self.count_cat = torch.ones(self.n_groups, dtype=torch.float32, device=device)
+
+    def row_weights(self, groups: torch.Tensor, weights: Optional[torch.Tensor]) -> torch.Tensor:
+        """What ``(loss * row_weights).mean()`` must use so that it equals the robust loss (dro_loss.py:51-60)."""
+        hw = self.h_fun[groups.to(torch.int64)]
+        return hw if weights is None else hw * weights.to(torch.float32)
+
+    @torch.no_grad()
+    def update(self, loss_rows: torch.Tensor, groups: torch.Tensor, weights: Optional[torch.Tensor]):
+        """Post-step bookkeeping (dro_loss.py:62-90).  Returns the LOCAL (group mean losses, group counts)."""
+        import torch.distributed as dist
+        G = self.n_groups
+        g = groups.to(torch.int64)
+        losses = loss_rows if weights is None else loss_rows * weights.to(torch.float32)
+        ga, la = g, losses
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:   # gather_tensors, :128-136
+            W = dist.get_world_size()
+            ga = torch.empty(W * g.numel(), dtype=g.dtype, device=g.device)
+            la = torch.empty(W * losses.numel(), dtype=losses.dtype, device=losses.device)
+            dist.all_gather_into_tensor(ga, g.contiguous())
+            dist.all_gather_into_tensor(la, losses.contiguous())
+        zero = torch.zeros(G, dtype=torch.float32, device=losses.device)
+        cnt_agg = zero.scatter_add(0, ga, torch.ones_like(la))
+        mean_agg = zero.scatter_add(0, ga, la) / (cnt_agg + (cnt_agg == 0).float())
+        valid = cnt_agg > 0
+        self.sum_losses = torch.where(valid, self.sum_losses * (1 - self.ema) + self.ema * mean_agg, self.sum_losses)  # :75
+        self.count_cat = self.count_cat * (1 - self.ema) + self.ema * cnt_agg                                         # :78-79
+        self._update_mw()
+        cnt = zero.scatter_add(0, g, torch.ones_like(losses))
+        return zero.scatter_add(0, g, losses) / (cnt + (cnt == 0).float()), cnt
+
+    def _update_mw(self):  # dro_loss.py:93-126
+        frac = self.count_cat / self.count_cat.sum()
+        _sorted, sort_id = torch.sort(self.sum_losses, descending=True, stable=True)
+        sfrac = frac[sort_id]
+        n = sfrac.numel()
+        cutoff = torch.clamp((torch.cumsum(sfrac, 0) < self.alpha).sum(), max=n - 1)   # device scalar, no host sync
+        pos = torch.arange(n, device=sfrac.device)
+        head = pos < cutoff
+        leftover = 1.0 - (sfrac * head).sum() / self.alpha
+        tie = torch.clamp(leftover / sfrac[cutoff], min=self.eps)
+        vals = torch.where(head, torch.full_like(sfrac, 1.0 / self.alpha), torch.full_like(sfrac, self.eps))
+        vals = torch.where(pos == cutoff, tie, vals)
+        h = torch.empty_like(self.h_fun)
+        h[sort_id] = vals
+        if self.weight_ema:
+            self.h_fun = self.h_fun * (1 - self.ema) + torch.clamp(h, min=self.eps) * self.ema
+        else:
+            self.h_fun = h
 
 
 class _IDROStepFn(torch.autograd.Function):

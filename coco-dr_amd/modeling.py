@@ -565,13 +565,16 @@ class BertDotNLL(nn.Module):
                        ema: float = 0.1, rho: float = 0.1, weight_ema: bool = True):
         """ANCE/model/models.py:211-223.  ``args.model_size == 'large'`` re-weights the last 2 layers, otherwise the last 3
         (ANCE/model/dro_loss.py:177-181)."""
-        if dro_type != "idro":
-            raise NotImplementedError("only dro_type='idro' (the COCO-DR fine-tuning recipe, ANCE/README.md:101-112) is built")
-        from .idro import IDROLoss
+        from .idro import DROGreedyLoss, IDROLoss
+        dev = self.bert.flat_decay.device
+        if dro_type == "idro":
+            self.loss = IDROLoss(n_groups, alpha, eps, ema, rho, model_size=getattr(args, "model_size", "base"), device=dev)
+        elif dro_type == "dro-greedy":
+            self.loss = DROGreedyLoss(n_groups, alpha, eps, ema, weight_ema, device=dev)
+        else:
+            raise ValueError("dro_type must be 'idro' or 'dro-greedy'")
         self.dro_type = dro_type
         self.n_groups = n_groups
-        self.loss = IDROLoss(n_groups, alpha, eps, ema, rho, model_size=getattr(args, "model_size", "base"),
-                             device=self.bert.flat_decay.device)
 
     @classmethod
     def from_pretrained(cls, path, config=None, device=None, **unused):
@@ -593,9 +596,9 @@ class BertDotNLL(nn.Module):
                 attention_mask_b=None, is_query=True, group_ids=None, weights=None):
         if input_ids_b is None:
             return self.query_emb(query_ids, attention_mask_q) if is_query else self.body_emb(query_ids, attention_mask_q)
-        if group_ids is not None:  # ANCE/model/models.py:259-273
-            if getattr(self, "loss", None) is None or self.dro_type != "idro":
-                raise NotImplementedError("group_ids need add_group_loss(dro_type='idro') first (dro-greedy is not built)")
+        if group_ids is not None and getattr(self, "loss", None) is None:
+            raise RuntimeError("group_ids need add_group_loss(...) first (ANCE/drivers/run_ann.py:904-906)")
+        if group_ids is not None and self.dro_type == "idro":  # ANCE/model/models.py:259-273
             from .idro import idro_triplet_step
             robust, rows, logits, group_losses, group_counts = idro_triplet_step(
                 self.bert, self.loss, query_ids, attention_mask_q, input_ids_a, attention_mask_a, input_ids_b, attention_mask_b,
@@ -611,6 +614,11 @@ class BertDotNLL(nn.Module):
             a = self.body_emb(input_ids_a, attention_mask_a)
             b = self.body_emb(input_ids_b, attention_mask_b)
         w = None if weights is None else weights.to(torch.float32).contiguous()
+        if group_ids is not None:  # dro-greedy (ANCE/model/dro_loss.py:50-90): weights of the previous step, then the update
+            loss, rows, logits = _TripletFn.apply(q, a, b, self.loss.row_weights(group_ids, w).contiguous())
+            group_losses, group_counts = self.loss.update(rows, group_ids, w)
+            self.total += B * (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
+            return loss, torch.argmax(logits, dim=1), group_losses, group_counts
         loss, rows, logits = _TripletFn.apply(q, a, b, w)
         self.total += B * (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
         return loss, torch.argmax(logits, dim=1), logits

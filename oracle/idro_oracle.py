@@ -1,6 +1,7 @@
 """CPU restatement of the iDRO re-weighted ANCE step (TEST INFRASTRUCTURE ONLY, see oracle/__init__.py):
 ``iDROLoss.forward`` (ANCE/model/dro_loss.py:160-254) driven by ``BertDot_NLL_LN.forward(group_ids=...)``
-(ANCE/model/models.py:234-273).  Pinned by tests/golden/idro_steps.npz, two steps of the reference's own classes.
+(ANCE/model/models.py:234-273), and of ``DROGreedyLoss`` (:11-126, the driver's default strategy).  Pinned by
+tests/golden/idro_steps.npz and dro_greedy_steps.npz, steps of the reference's own classes.
 """
 from __future__ import annotations
 
@@ -10,7 +11,8 @@ import numpy as np
 
 from .bert_oracle import OracleConfig, cls_embedding, encoder_bwd, encoder_fwd, layer_names, layers_bwd, triplet_nll
 
-__all__ = ["idro_selected_layers", "idro_weights_update", "idro_step"]
+__all__ = ["idro_selected_layers", "idro_weights_update", "idro_step", "DROGreedyState", "dro_greedy_update_mw",
+           "dro_greedy_forward"]
 
 
 def idro_selected_layers(cfg: OracleConfig, model_size: str = "base") -> List[int]:
@@ -92,3 +94,57 @@ def idro_step(P, cfg: OracleConfig, batch, groups: np.ndarray, h_fun: np.ndarray
     new_h = idro_weights_update(h_fun, group_losses, counts, all_grads, alpha, eps, ema, rho)
     grads = backward(h_fun[groups] / counts[groups], False)                           # d robust / d theta
     return robust, group_losses, counts, new_h, grads
+
+
+# ------------------------------------------------------------------------------------------------ DRO-greedy
+class DROGreedyState:
+    """Buffers of ``DROGreedyLoss`` (ANCE/model/dro_loss.py:27-33): h_fun, EMA group losses, EMA group counts."""
+
+    def __init__(self, n_groups: int):
+        self.h_fun = np.ones(n_groups)
+        self.sum_losses = np.zeros(n_groups)
+        self.count_cat = np.ones(n_groups)
+
+
+def dro_greedy_update_mw(st: DROGreedyState, alpha: float, eps: float, ema: float, weight_ema: bool) -> None:
+    """``update_mw`` (dro_loss.py:93-126): groups sorted by EMA loss (descending); the worst ones whose cumulative
+    EMA fraction stays below alpha get weight 1/alpha, the next one the left-over mass, the rest eps."""
+    past_frac = st.count_cat / st.count_cat.sum()
+    sort_id = np.argsort(-st.sum_losses, kind="stable")
+    sorted_frac = past_frac[sort_id]
+    cutoff = int(np.sum(np.cumsum(sorted_frac) < alpha))
+    if cutoff == len(sorted_frac):
+        cutoff = len(sorted_frac) - 1
+    h = np.full_like(st.h_fun, eps)
+    h[sort_id[:cutoff]] = 1.0 / alpha
+    leftover = 1.0 - sorted_frac[:cutoff].sum() / alpha
+    h[sort_id[cutoff]] = max(leftover / sorted_frac[cutoff], eps)
+    if weight_ema:
+        h = np.maximum(h, eps)                       # weight_cutoff clamp, :110-112
+        st.h_fun = st.h_fun * (1 - ema) + h * ema    # :113-114
+    else:
+        st.h_fun = h                                 # :117-121
+
+
+def dro_greedy_forward(st: DROGreedyState, losses: np.ndarray, groups: np.ndarray, weights, n_groups: int, alpha: float,
+                       eps: float, ema: float, weight_ema: bool, all_losses=None, all_groups=None):
+    """``DROGreedyLoss.forward`` (dro_loss.py:50-90), training mode.  ``all_*`` are the cross-rank gathers (default:
+    this rank only).  Returns (robust_loss, row weights the loss gradient carries, group mean losses, group counts)."""
+    if weights is not None:
+        losses = losses * weights                                            # :51-52
+    B = losses.shape[0]
+    gsum = np.zeros(n_groups); np.add.at(gsum, groups, losses)
+    robust = float((gsum * st.h_fun).sum() / B)                              # :59-60, weights of the PREVIOUS step
+    row_w = st.h_fun[groups] * (1.0 if weights is None else weights) / B     # d robust / d (unweighted row loss)
+    la = losses if all_losses is None else all_losses
+    ga = groups if all_groups is None else all_groups
+    cnt_agg = np.zeros(n_groups); np.add.at(cnt_agg, ga, 1.0)                 # :67-69
+    sum_agg = np.zeros(n_groups); np.add.at(sum_agg, ga, la)
+    mean_agg = sum_agg / (cnt_agg + (cnt_agg == 0))                          # :71
+    valid = cnt_agg > 0
+    st.sum_losses[valid] = st.sum_losses[valid] * (1 - ema) + ema * mean_agg[valid]  # :75
+    st.count_cat = st.count_cat * (1 - ema) + ema * cnt_agg                  # :78-79
+    dro_greedy_update_mw(st, alpha, eps, ema, weight_ema)                    # :80
+    cnt = np.zeros(n_groups); np.add.at(cnt, groups, 1.0)                    # :82-86 (local statistics returned)
+    gl = gsum / (cnt + (cnt == 0))
+    return robust, row_w, gl, cnt

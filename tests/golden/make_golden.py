@@ -391,6 +391,67 @@ def golden_idro():
     sys.path.pop(0)
 
 
+def golden_dro_greedy():
+    """f2 (second strategy): three steps of the reference's DROGreedyLoss (ANCE/model/dro_loss.py:11-126, the driver's
+    default --dro_type) through BertDot_NLL_LN.forward(group_ids=..., weights=...), for both h_fun update rules
+    (weight_ema False / True).  2-layer toy BERT, 1-rank gloo group for its all_gather.  Runs unmodified."""
+    sys.path.insert(0, os.path.join(REF, "ANCE"))
+    import types
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29535", rank=0, world_size=1)
+    from model.models import BertDot_NLL_LN  # reference
+
+    cfg = OracleConfig(vocab_size=400, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                       intermediate_size=256, max_position_embeddings=64)
+    seed = 555
+    P = make_params(cfg, seed, std=STD)
+    G, alpha, eps, ema = 4, 0.5, 0.05, 0.3
+    t = torch.from_numpy
+    out = dict(seed=np.int64(seed), std=np.float64(STD), hyper=np.array([G, alpha, eps, ema]),
+               cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                             cfg.intermediate_size, cfg.max_position_embeddings, cfg.type_vocab_size]))
+    B = 6
+    groups = [np.array([0, 2, 2, 3, 0, 2]), np.array([1, 1, 3, 0, 3, 3]), np.array([2, 0, 1, 1, 0, 3])]
+    weights = np.array([1.0, 0.5, 2.0, 1.0, 1.5, 1.0], np.float32)
+    rng = np.random.Generator(np.random.PCG64(23))
+    batches = []
+    for step in range(3):
+        batches.append((synth_batch(rng, B, 16, cfg.vocab_size), synth_batch(rng, B, 32, cfg.vocab_size),
+                        synth_batch(rng, B, 32, cfg.vocab_size)))
+        (q, qm), (a, am), (b, bm) = batches[-1]
+        out.update({f"s{step}_q_ids": q, f"s{step}_q_mask": qm, f"s{step}_a_ids": a, f"s{step}_a_mask": am,
+                    f"s{step}_b_ids": b, f"s{step}_b_mask": bm, f"s{step}_groups": groups[step]})
+    out["weights"] = weights
+    for wema, tag in ((False, "hard"), (True, "ema")):
+        torch.manual_seed(0)
+        model = BertDot_NLL_LN(hf_config(cfg))
+        load_into(model.bert, P)
+        model.train()
+        args = types.SimpleNamespace(model_size="base", local_rank=0)
+        model.add_group_loss(args=args, n_groups=G, dro_type="dro-greedy", alpha=alpha, eps=eps, ema=ema, rho=0.1, weight_ema=wema)
+        for step in range(3):
+            (q, qm), (a, am), (b, bm) = batches[step]
+            model.zero_grad()
+            robust, acc, group_losses, group_counts = model(t(q), t(qm), t(a), t(am), t(b), t(bm), group_ids=t(groups[step]),
+                                                            weights=t(weights))
+            robust.backward()
+            out.update({f"{tag}_s{step}_robust": np.float64(float(robust.detach())),
+                        f"{tag}_s{step}_group_losses": group_losses.numpy().astype(np.float64),
+                        f"{tag}_s{step}_group_counts": group_counts.numpy().astype(np.float64),
+                        f"{tag}_s{step}_h_fun": model.loss.h_fun.detach().numpy().astype(np.float64),
+                        f"{tag}_s{step}_sum_losses": model.loss.sum_losses.detach().numpy().astype(np.float64),
+                        f"{tag}_s{step}_count_cat": model.loss.count_cat.detach().numpy().astype(np.float64)})
+            if step == 1:  # h_fun is no longer uniform here: the gradient shows the re-weighting
+                for name, prm in model.named_parameters():
+                    if name in ("bert.encoder.layer.1.output.dense.weight", "bert.encoder.layer.0.attention.self.value.weight",
+                                "bert.embeddings.LayerNorm.weight"):
+                        out[f"{tag}_s1_grad:{name[5:]}"] = prm.grad.detach().numpy().copy()
+            print(f"dro-greedy golden [{tag}] step {step}: robust {float(robust.detach()):.6f} h_fun {model.loss.h_fun.numpy()}")
+    np.savez_compressed(os.path.join(OUT, "dro_greedy_steps.npz"), **out)
+    sys.path.pop(0)
+
+
 def golden_lamb():
     """Three steps of the reference's own ``Lamb`` (ANCE/utils/lamb.py) behind ``torch.nn.utils.clip_grad_norm_`` -
     the optimizer half of the ANCE step (ANCE/drivers/run_ann.py:345-356).  Harness shim (disclosed): lamb.py imports
@@ -433,7 +494,9 @@ def golden_lamb():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro"]
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy"]
+    if "dro_greedy" in which:
+        golden_dro_greedy()
     if "idro" in which:
         golden_idro()
     if "lamb" in which:

@@ -140,3 +140,41 @@ def test_sharded_search_equals_search_over_merged_corpus(nq, npass, k):
         D, I = res[r]
         np.testing.assert_allclose(D, Dr, rtol=1e-6)
         assert np.array_equal(I, Ir)
+
+
+def _dro_greedy_two_ranks(rank, world, losses, groups, G):
+    """DROGreedyLoss.update in 2 processes: every rank must end with the weights computed from ALL ranks' rows
+    (ANCE/model/dro_loss.py:62-80 gathers group ids and losses before the EMA / weight update)."""
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.idro import DROGreedyLoss
+    m = losses.shape[0] // world
+    dro = DROGreedyLoss(G, alpha=0.5, eps=0.05, ema=0.3, weight_ema=False, device="cpu")
+    out = []
+    for step in range(losses.shape[1]):
+        rows = torch.from_numpy(losses[rank * m:(rank + 1) * m, step].copy())
+        g = torch.from_numpy(groups[rank * m:(rank + 1) * m, step].copy())
+        gl, cnt = dro.update(rows, g, None)
+        out.append((dro.h_fun.numpy().copy(), dro.sum_losses.numpy().copy(), dro.count_cat.numpy().copy(), gl.numpy().copy()))
+    return out
+
+
+def test_dro_greedy_weight_update_aggregates_over_ranks():
+    rng = np.random.Generator(np.random.PCG64(3))
+    G, B, steps = 5, 8, 3
+    losses = rng.random((B, steps)).astype(np.float32) * 3
+    groups = rng.integers(0, G, (B, steps)).astype(np.int64)
+    res = _run(_dro_greedy_two_ranks, 2, losses, groups, G)
+    st = O.DROGreedyState(G)
+    for step in range(steps):
+        for rank in range(2):
+            sl = slice(rank * 4, rank * 4 + 4)
+            st_r = O.DROGreedyState(G)
+            st_r.h_fun, st_r.sum_losses, st_r.count_cat = st.h_fun.copy(), st.sum_losses.copy(), st.count_cat.copy()
+            _rob, _rw, gl, _cnt = O.dro_greedy_forward(st_r, losses[sl, step].astype(np.float64), groups[sl, step], None, G, 0.5, 0.05, 0.3,
+                                                       False, all_losses=losses[:, step].astype(np.float64), all_groups=groups[:, step])
+            h, sl_, cc, gl_got = res[rank][step]
+            np.testing.assert_allclose(h, st_r.h_fun, rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(sl_, st_r.sum_losses, rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(cc, st_r.count_cat, rtol=1e-6)
+            np.testing.assert_allclose(gl_got, gl, rtol=1e-5, atol=1e-6)
+        st = st_r  # both ranks hold the same global state

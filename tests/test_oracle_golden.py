@@ -213,3 +213,45 @@ def test_idro_oracle_matches_reference_idro_golden():
                     assert np.abs(grads[name]).max() < 1e-6 and np.abs(z[key]).max() < 1e-6
                 else:
                     assert _rel(grads[name], z[key]) < 2e-4, name
+
+
+def test_dro_greedy_oracle_matches_reference_golden():
+    """Three steps of the reference's DROGreedyLoss (both h_fun update rules): robust loss, EMA buffers, weights, and the
+    gradient of the re-weighted loss on step 1."""
+    z = load_golden("dro_greedy_steps.npz")
+    cfg = cfg_from_golden(z)
+    P = {k: v.astype(np.float64) for k, v in O.make_params(cfg, int(z["seed"]), std=float(z["std"])).items()}
+    G, alpha, eps, ema = (float(x) for x in z["hyper"])
+    G = int(G)
+    w = z["weights"].astype(np.float64)
+    for wema, tag in ((False, "hard"), (True, "ema")):
+        st = O.DROGreedyState(G)
+        for step in range(3):
+            enc = []
+            for ids, mask in ((z[f"s{step}_q_ids"], z[f"s{step}_q_mask"]), (z[f"s{step}_a_ids"], z[f"s{step}_a_mask"]),
+                              (z[f"s{step}_b_ids"], z[f"s{step}_b_mask"])):
+                hs, cache = O.encoder_fwd(P, cfg, ids, mask, keep_cache=True)
+                enc.append((hs[-1], cache))
+            q, a, b = (O.cls_embedding(e[0]) for e in enc)
+            rows, logits = O.triplet_nll(q, a, b)
+            robust, row_w, gl, cnt = O.dro_greedy_forward(st, rows, z[f"s{step}_groups"], w, G, alpha, eps, ema, wema)
+            assert abs(robust - float(z[f"{tag}_s{step}_robust"])) <= 2e-5 * abs(robust)
+            np.testing.assert_allclose(gl, z[f"{tag}_s{step}_group_losses"], rtol=2e-5, atol=1e-7)
+            np.testing.assert_array_equal(cnt, z[f"{tag}_s{step}_group_counts"])
+            np.testing.assert_allclose(st.h_fun, z[f"{tag}_s{step}_h_fun"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(st.sum_losses, z[f"{tag}_s{step}_sum_losses"], rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(st.count_cat, z[f"{tag}_s{step}_count_cat"], rtol=1e-6)
+            if step == 1:
+                zl = logits - logits.max(1, keepdims=True)
+                p = np.exp(zl) / np.exp(zl).sum(1, keepdims=True)
+                dl = p.copy(); dl[:, 0] -= 1.0
+                dl *= row_w[:, None]
+                dE = (dl[:, :1] * a + dl[:, 1:] * b, dl[:, :1] * q, dl[:, 1:] * q)
+                tot = {}
+                for (last, cache), d in zip(enc, dE):
+                    d_last = np.zeros_like(last); d_last[:, 0] = d
+                    for k, v in O.encoder_bwd(P, cfg, cache, d_last).items():
+                        tot[k] = tot.get(k, 0) + v
+                for key in z.files:
+                    if key.startswith(f"{tag}_s1_grad:"):
+                        assert _rel(tot[key.split(":", 1)[1]], z[key]) < 2e-4, key
