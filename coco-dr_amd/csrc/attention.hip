@@ -366,6 +366,189 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   ATTN_STAMP(5);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256 < L <= 512: the four [L,64] tiles no longer fit the LDS together, so the two phases become two kernels that
+// each keep only the pair of tiles they sweep (K,V for dQ; Q,dO for dK/dV, 128 KiB at L = 512) and fetch the fragments
+// of their own 32 rows straight from global memory.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 frag_rows_global(const uint16_t* base, int ld, int r0, int s, int lane) {
+  return as_bf16x8(*reinterpret_cast<const uint4*>(base + (size_t)(r0 + (lane & 31)) * ld + (2 * s + (lane >> 5)) * 8));
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                             const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
+                                                             const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kt = smem;
+  char* Vt = smem + L * 128;
+  float* madd = reinterpret_cast<float*>(smem + 2 * L * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
+  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
+  const int ld = 3 * H;
+  const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
+  const uint16_t* obase = ctx + (size_t)b * L * H + h * 64;
+  const uint16_t* dobase = dctx + (size_t)b * L * H + h * 64;
+  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
+  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4);
+  for (int i = tid; i < L; i += 256) madd[i] = mask[b * L + i] != 0 ? 0.f : kMaskNeg;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float sl2 = kScale * kLog2e;
+  const int nblk = L / 32;
+  for (int qb = wid; qb < nblk; qb += 4) {
+    bf16x8 qf[4], dof[4];
+    float dpart = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = frag_rows_global(base, ld, qb * 32, s, lane);
+      dof[s] = frag_rows_global(dobase, H, qb * 32, s, lane);
+      const bf16x8 of = frag_rows_global(obase, H, qb * 32, s, lane);
+      float df[8], ofv[8];
+      unpack8(__builtin_bit_cast(uint4, dof[s]), df);
+      unpack8(__builtin_bit_cast(uint4, of), ofv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dpart += df[e] * ofv[e];
+    }
+    const float my_delta = dpart + __shfl_xor(dpart, 32, 64);  // lanes l and l^32 hold the two halves of row l & 31
+    const float my_lse = lse[((size_t)b * heads + h) * L + qb * 32 + (lane & 31)] * kLog2e;
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    for (int kb = 0; kb < nblk; ++kb) {
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, kb * 32, s, lane), qf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vt, kb * 32, s, lane), dof[s], dpacc, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float4 ma = *reinterpret_cast<const float4*>(madd + kb * 32 + 8 * rg + 4 * half);
+        const float mm[4] = {ma.x, ma.y, ma.z, ma.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = rg * 4 + e;
+          const float p = fast_exp2(sacc[r] * sl2 + mm[e] - my_lse);
+          ds[r] = p * (dpacc[r] - my_delta);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 dsf = pack_acc(ds, j);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Kt, kb * 32 + j * 16, dt, lane), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                              const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
+                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qt = smem;
+  char* Dt = smem + L * 128;
+  float* lse2 = reinterpret_cast<float*>(smem + 2 * L * 128);
+  float* delta = lse2 + L;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
+  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
+  const int ld = 3 * H;
+  const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
+  const uint16_t* obase = ctx + (size_t)b * L * H + h * 64;
+  const uint16_t* dobase = dctx + (size_t)b * L * H + h * 64;
+  stage_tile_dma(Qt, base, ld, L, lane, wid, 4);
+  for (int q0 = 0; q0 < L * 8; q0 += 256 * 4) {  // dO through registers (delta = rowsum(dO * O)), four 16-B chunks per thread a round
+    uint4 dreg[4], oreg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = q0 + tid + i * 256, row = q >> 3, ch = q & 7;
+      if (q < L * 8) {  // L * 8 is a multiple of 256: whole waves are in or out
+        dreg[i] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
+        oreg[i] = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = q0 + tid + i * 256, row = q >> 3, ch = q & 7;
+      if (q >= L * 8) continue;
+      *reinterpret_cast<uint4*>(Dt + tile64_off(row, ch)) = dreg[i];
+      float df[8], of[8];
+      unpack8(dreg[i], df);
+      unpack8(oreg[i], of);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += df[e] * of[e];
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64);
+      if (ch == 0) delta[row] = part;
+    }
+  }
+  for (int i = tid; i < L; i += 256) lse2[i] = lse[((size_t)b * heads + h) * L + i] * kLog2e;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float sl2 = kScale * kLog2e;
+  const int nblk = L / 32;
+  for (int kb = wid; kb < nblk; kb += 4) {
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = frag_rows_global(base + H, ld, kb * 32, s, lane);
+      vf[s] = frag_rows_global(base + 2 * H, ld, kb * 32, s, lane);
+    }
+    const float my_madd = mask[b * L + kb * 32 + (lane & 31)] != 0 ? 0.f : kMaskNeg;
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    for (int qb = 0; qb < nblk; ++qb) {
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qt, qb * 32, s, lane), kf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Dt, qb * 32, s, lane), vf[s], dpacc, 0, 0, 0);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float4 l4 = *reinterpret_cast<const float4*>(lse2 + qb * 32 + 8 * rg + 4 * half);
+        const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = rg * 4 + e;
+          p[r] = fast_exp2(sacc[r] * sl2 + my_madd - ll[e]);
+          ds[r] = p[r] * (dpacc[r] - dd[e]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 pf = pack_acc(p, j), dsf = pack_acc(ds, j);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Dt, qb * 32 + j * 16, dt, lane), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Qt, qb * 32 + j * 16, dt, lane), dsf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
+    store_acc_T16(row0 + H, ld, dk, kScale, lane);
+    store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
+  }
+}
+
 }  // namespace
 
 #if defined(COCODR_ABL_TIMELINE)
@@ -397,7 +580,7 @@ extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const u
                                const float* lse, uint16_t* dqkv, int B, int L, int heads, cocodr_stream_t stream) {
   CK_ARG(qkv && mask && ctx && dctx && lse && dqkv, "attn_bwd: null pointer");
   CK_ARG(B > 0 && heads > 0, "attn_bwd: bad shape");
-  CK_ARG(L % 32 == 0 && L >= 32 && L <= 256, "attn_bwd: L=%d must be a multiple of 32 in [32,256]", L);
+  CK_ARG(L % 32 == 0 && L >= 32 && L <= 512, "attn_bwd: L=%d must be a multiple of 32 in [32,512]", L);
   const int H = heads * 64;
   const size_t lds = (size_t)4 * L * 128 + (size_t)3 * L * 4;
   static bool attr_done = false;
@@ -407,6 +590,21 @@ extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const u
   }
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_ATTN, st, 10.0 * B * heads * (double)L * L * 64);
+  if (L > 256) {  // two kernels, each with the pair of [L,64] tiles it sweeps resident
+    static bool split_attr_done = false;
+    if (!split_attr_done) {
+      hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      split_attr_done = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(heads, B), dim3(256), (size_t)2 * L * 128 + (size_t)L * 4, st, qkv, mask, ctx, dctx, lse,
+                       dqkv, L, H);
+    CK_LAUNCH("attn_bwd(dq)");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(heads, B), dim3(256), (size_t)2 * L * 128 + (size_t)2 * L * 4, st, qkv, mask, ctx, dctx,
+                       lse, dqkv, L, H);
+    CK_LAUNCH("attn_bwd(dkv)");
+    return COCODR_OK;
+  }
   static int stagger = -1;  // x 4096 clocks; COCODR_ATTN_STAGGER overrides (0 disables)
   if (stagger < 0) {
     const char* e = getenv("COCODR_ATTN_STAGGER");

@@ -197,7 +197,6 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
   CK_ARG(lp && lg && mask && arena && (!do_embed || (emb && eg && ids)), "encoder_bwd: null pointer");
   CK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= c->layers, "encoder_bwd: bad layer range [%d,%d)", layer_lo, layer_hi);
   CK_ARG(d_in != nullptr || layer_hi < c->layers, "encoder_bwd: the first (top) range needs the upstream gradient d_in");
-  CK_ARG(L <= 256, "encoder_bwd: L=%d > 256 is not supported by the attention backward yet", L);
   if (arena_bytes < lay.total_bytes) {
     cocodr_set_error("encoder_bwd: arena %zu B < required %zu B (was the forward run with training=1?)", arena_bytes, lay.total_bytes);
     return COCODR_ERR_WORKSPACE;

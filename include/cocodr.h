@@ -97,7 +97,8 @@ int cocodr_gemm_set_impl(int impl);
  * ------------------------------------------------------------------------------------------ */
 int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse,
                     int B, int L, int heads, cocodr_stream_t stream);
-/* backward: dqkv [B*L, 3H] (dQ | dK | dV) from dctx; L <= 256 */
+/* backward: dqkv [B*L, 3H] (dQ | dK | dV) from dctx; L <= 512 (one kernel with all four [L,64] tiles of a
+ * (batch, head) in LDS up to L = 256, a dQ kernel + a dK/dV kernel above that) */
 int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
                     const float* lse, uint16_t* dqkv, int B, int L, int heads, cocodr_stream_t stream);
 

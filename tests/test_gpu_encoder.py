@@ -373,3 +373,30 @@ def test_dro_greedy_steps_match_reference_golden(weight_ema, tag):
                 if key.startswith(f"{tag}_s1_grad:"):
                     name = key.split(":", 1)[1]
                     assert rel_l2(Gr[name], g[key]) < 0.15, (name, rel_l2(Gr[name], g[key]))
+
+
+def test_training_step_at_512_tokens_matches_oracle():
+    """ANCE's document setting trains at max_seq_length 512: the attention backward then runs as two kernels (dQ with
+    K/V resident, dK/dV with Q/dO resident).  One layer pair, full forward + backward against the numpy oracle."""
+    ocfg = O.OracleConfig(vocab_size=500, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=512)
+    P = O.make_params(ocfg, 21, std=0.05)
+    m = model_from_oracle(ocfg, P)
+    rng = np.random.Generator(np.random.PCG64(2))
+    B, L = 2, 512
+    ids = rng.integers(5, 500, (B, L))
+    mask = np.ones((B, L), np.int64)
+    mask[1, 400:] = 0
+    out = m(input_ids=torch.from_numpy(ids).to(DEV), attention_mask=torch.from_numpy(mask).to(DEV))
+    dE = rng.standard_normal((B, ocfg.hidden_size)).astype(np.float32)
+    (out.cls_fp32 * torch.from_numpy(dE).to(DEV)).sum().backward()
+    hs, cache = O.encoder_fwd(P, ocfg, ids, mask, keep_cache=True)
+    assert cosine_rows(out.cls_fp32.detach().cpu().numpy(), hs[-1][:, 0]).min() > 0.999
+    d_last = np.zeros_like(hs[-1])
+    d_last[:, 0] = dE
+    G = O.encoder_bwd(P, ocfg, cache, d_last)
+    got = grads_by_name(m)
+    for name in ("encoder.layer.0.attention.self.query.weight", "encoder.layer.0.attention.self.value.weight",
+                 "encoder.layer.1.attention.self.key.weight", "encoder.layer.0.intermediate.dense.weight",
+                 "embeddings.position_embeddings.weight"):
+        assert rel_l2(got[name], G[name]) < 8e-2, (name, rel_l2(got[name], G[name]))

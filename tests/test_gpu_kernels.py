@@ -146,7 +146,7 @@ def test_attention_fwd(B, L, heads):
     assert torch.allclose(lse, rlse, atol=2e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("B,L,heads", [(2, 32, 2), (3, 64, 2), (2, 128, 12), (2, 256, 4)])
+@pytest.mark.parametrize("B,L,heads", [(2, 32, 2), (3, 64, 2), (2, 128, 12), (2, 256, 4), (2, 288, 2), (3, 512, 4)])
 def test_attention_bwd(B, L, heads):
     H = heads * 64
     qkv = rnd(B * L, 3 * H, seed=13)
