@@ -586,6 +586,12 @@ class BertDotNLL(nn.Module):
     def save_pretrained(self, path):
         self.bert.save_pretrained(path)
 
+    def _side_stream(self):
+        s = getattr(self, "_side", None)
+        if s is None or s.device != self.bert.flat_decay.device:
+            s = self._side = torch.cuda.Stream(device=self.bert.flat_decay.device)
+        return s
+
     def query_emb(self, input_ids, attention_mask):
         return self.bert(input_ids=input_ids, attention_mask=attention_mask).cls_fp32
 
@@ -605,7 +611,13 @@ class BertDotNLL(nn.Module):
                 group_ids)
             self.total += rows.shape[0] * (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
             return robust, torch.argmax(logits, dim=1), group_losses, group_counts
-        q = self.query_emb(query_ids, attention_mask_q)
+        # The short query pass (B x 64 tokens) fills a fraction of the CUs; it runs on a side stream next to the passage
+        # pass.  Autograd replays each pass's backward on its forward stream, so the two backward passes overlap as well.
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            q = self.query_emb(query_ids, attention_mask_q)
         B = q.shape[0]
         if input_ids_a.shape == input_ids_b.shape:  # one encoder pass for positives and negatives
             ab = self.body_emb(torch.cat([input_ids_a, input_ids_b]), torch.cat([attention_mask_a, attention_mask_b]))
@@ -613,6 +625,8 @@ class BertDotNLL(nn.Module):
         else:
             a = self.body_emb(input_ids_a, attention_mask_a)
             b = self.body_emb(input_ids_b, attention_mask_b)
+        main.wait_stream(side)
+        q.record_stream(main)
         w = None if weights is None else weights.to(torch.float32).contiguous()
         if group_ids is not None:  # dro-greedy (ANCE/model/dro_loss.py:50-90): weights of the previous step, then the update
             loss, rows, logits = _TripletFn.apply(q, a, b, self.loss.row_weights(group_ids, w).contiguous())
