@@ -93,6 +93,8 @@ SIGNATURES = {
     "cocodr_encoder_layout": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),
     "cocodr_encoder_fwd": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "cocodr_encoder_fwd_range": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), c_void_p, c_void_p,
+                                         c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "cocodr_stack_fwd": (c_int, [C.POINTER(Config), C.POINTER(LayerParams), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                                  c_void_p]),
     "cocodr_ce_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -114,7 +114,7 @@ extern "C" int cocodr_encoder_layout(const cocodr_config* c, int B, int L, int t
 namespace {
 int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp, const int32_t* ids,
                      const int32_t* mask, int B, int L, int training, void* arena, size_t arena_bytes, bool from_hidden,
-                     cocodr_stream_t stream);
+                     cocodr_stream_t stream, int layer_lo = 0, int layer_hi = -1);
 }
 
 extern "C" int cocodr_encoder_fwd(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
@@ -122,6 +122,13 @@ extern "C" int cocodr_encoder_fwd(const cocodr_config* c, const cocodr_embed_par
                                   size_t arena_bytes, cocodr_stream_t stream) {
   CK_ARG(emb && ids, "encoder_fwd: null pointer");
   return encoder_fwd_impl(c, emb, lp, ids, mask, B, L, training, arena, arena_bytes, false, stream);
+}
+
+extern "C" int cocodr_encoder_fwd_range(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
+                                        const int32_t* ids, const int32_t* mask, int B, int L, int training, void* arena,
+                                        size_t arena_bytes, int layer_lo, int layer_hi, cocodr_stream_t stream) {
+  CK_ARG(layer_lo > 0 || (emb && ids), "encoder_fwd_range: the range that starts at layer 0 needs the embedding inputs");
+  return encoder_fwd_impl(c, emb, lp, ids, mask, B, L, training, arena, arena_bytes, false, stream, layer_lo, layer_hi);
 }
 
 extern "C" int cocodr_stack_fwd(const cocodr_config* c, const cocodr_layer_params* lp, const int32_t* mask, int B, int L,
@@ -132,7 +139,7 @@ extern "C" int cocodr_stack_fwd(const cocodr_config* c, const cocodr_layer_param
 namespace {
 int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp, const int32_t* ids,
                      const int32_t* mask, int B, int L, int training, void* arena, size_t arena_bytes, bool from_hidden,
-                     cocodr_stream_t stream) {
+                     cocodr_stream_t stream, int layer_lo, int layer_hi) {
   cocodr_encoder_layout_t lay;
   TRY(cocodr_encoder_layout(c, B, L, training, &lay));
   CK_ARG(lp && mask && arena, "encoder_fwd: null pointer");
@@ -147,10 +154,12 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   uint16_t* hidden = (uint16_t*)(base + lay.hidden);
   float* cls = (float*)(base + lay.cls_f32);
 
-  if (!from_hidden)  // a bare layer stack (Condenser head) starts from hidden slot 0, filled by the caller
+  if (layer_hi < 0) layer_hi = NL;
+  CK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= NL, "encoder_fwd: bad layer range [%d,%d)", layer_lo, layer_hi);
+  if (!from_hidden && layer_lo == 0)  // a bare layer stack (Condenser head) starts from hidden slot 0, filled by the caller
     TRY(cocodr_embed_ln_fwd(ids, emb->word, emb->pos, emb->type0, emb->ln_g, emb->ln_b, hidden, (float*)(base + lay.emb_mean),
                             (float*)(base + lay.emb_rstd), B, L, H, c->vocab, c->ln_eps, stream));
-  for (int l = 0; l < NL; ++l) {
+  for (int l = layer_lo; l < layer_hi; ++l) {
     const cocodr_layer_params& w = lp[l];
     const size_t lo = ls * l;
     uint16_t* x_in = hidden + (size_t)l * M * H;

@@ -255,6 +255,13 @@ int cocodr_encoder_fwd(const cocodr_config* cfg, const cocodr_embed_params* emb,
                        const cocodr_layer_params* layers_host, const int32_t* ids, const int32_t* mask,
                        int B, int L, int training, void* arena, size_t arena_bytes, cocodr_stream_t stream);
 
+/* The same forward for the layers [layer_lo, layer_hi) only (the embedding runs with the range that starts at 0), for
+ * hosts that interleave other work or waits between parts of the stack; consecutive ranges over one arena leave exactly
+ * what the single call leaves. */
+int cocodr_encoder_fwd_range(const cocodr_config* cfg, const cocodr_embed_params* emb, const cocodr_layer_params* layers_host,
+                             const int32_t* ids, const int32_t* mask, int B, int L, int training, void* arena,
+                             size_t arena_bytes, int layer_lo, int layer_hi, cocodr_stream_t stream);
+
 /* A bare stack of BertLayers (no embeddings): the Condenser head of COCO/modeling.py:43-46,73-79,212-220
  * (`c_head`, n_head_layers BertLayers applied to cat(cls, hidden_states[skip_from][:,1:])).  Same arena layout as
  * the encoder with cfg->layers = number of stacked layers; the caller fills hidden slot 0 ([M,H] bf16 at

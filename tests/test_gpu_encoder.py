@@ -400,3 +400,29 @@ def test_training_step_at_512_tokens_matches_oracle():
                  "encoder.layer.1.attention.self.key.weight", "encoder.layer.0.intermediate.dense.weight",
                  "embeddings.position_embeddings.weight"):
         assert rel_l2(got[name], G[name]) < 8e-2, (name, rel_l2(got[name], G[name]))
+
+
+def test_forward_in_layer_ranges_equals_the_single_call():
+    """cocodr_encoder_fwd_range over [0,2), [2,3), [3,5) leaves exactly the arena of one cocodr_encoder_fwd call."""
+    import ctypes as C
+    from cocodr_amd._native import check, lib, ptr, stream_ptr
+    cfg = CocoBertConfig(vocab_size=600, hidden_size=128, num_hidden_layers=5, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=64)
+    torch.manual_seed(0)
+    m = CocoBertModel(cfg).to(DEV)
+    rng = np.random.Generator(np.random.PCG64(4))
+    ids = torch.from_numpy(rng.integers(5, 600, (4, 32))).to(DEV).to(torch.int32)
+    mask = torch.ones_like(ids)
+    mask[1, 17:] = 0
+    _, lay = m._run_forward(ids, mask, True)  # also refreshes the bf16 weight shadow
+    arena_ref = torch.zeros(lay.total_bytes, dtype=torch.uint8, device=DEV)
+    arena = torch.zeros_like(arena_ref)
+    emb, arr, _, _ = m._param_structs()
+    ccfg = m._c_config()
+    check(lib().cocodr_encoder_fwd(C.byref(ccfg), C.byref(emb), arr, ptr(ids), ptr(mask), 4, 32, 1, ptr(arena_ref), arena_ref.numel(),
+                                   stream_ptr()), "encoder_fwd")
+    for lo, hi in ((0, 2), (2, 3), (3, 5)):
+        check(lib().cocodr_encoder_fwd_range(C.byref(ccfg), C.byref(emb), arr, ptr(ids), ptr(mask), 4, 32, 1, ptr(arena), arena.numel(),
+                                             lo, hi, stream_ptr()), "encoder_fwd_range")
+    n = lay.bwd_scratch  # everything the forward writes lies in front of the backward scratch
+    assert torch.equal(arena[:n], arena_ref[:n])
