@@ -322,11 +322,12 @@ def main():
         if n_launch and gemm_ms > 0:
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
             traffic = None  # HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01c_*.md)
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")) as f:
-                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
-            except Exception:
-                pass
+            if args.model == "base" and args.seq_per_gpu == SEQ_PER_GPU and args.seq_len == SEQ_LEN:  # the PMC passes ran on this shape
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")) as f:
+                        traffic = round(json.load(f)["hbm_bytes_per_launch"])
+                except Exception:
+                    pass
             roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                     "kernel": "gemm_glds_kernel (bf16 MFMA 32x32x16, all NT/NN/TN launches)",
@@ -355,7 +356,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"cocodr-{args.model} contrastive step (COCO in-batch negatives), seq_len={args.seq_len}, "
-                                   f"{args.seq_per_gpu} sequences/GPU, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW; BASELINE configs[1]",
+                                   f"{args.seq_per_gpu} sequences/GPU, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW; "
+                                   + ("BASELINE configs[1]" if args.model == "base" and world == 1 else
+                                      "BASELINE configs[2] shape per GPU" if args.model == "base" else "north_star BERT-large target shape"),
                        "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len,
                        "batches": "8 pre-generated synthetic batches per rank, resident in HBM, visited round-robin",
                        "parallelism": f"dp{world}" + (" + RCCL all_gather negatives" if world > 1 else "")},
