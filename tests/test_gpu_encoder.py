@@ -426,3 +426,28 @@ def test_forward_in_layer_ranges_equals_the_single_call():
                                              lo, hi, stream_ptr()), "encoder_fwd_range")
     n = lay.bwd_scratch  # everything the forward writes lies in front of the backward scratch
     assert torch.equal(arena[:n], arena_ref[:n])
+
+
+def test_smallest_shapes_single_sequence_of_32_tokens():
+    """Edge of the supported range: B = 1, L = 32 (one attention block, one GEMM row panel of 32 valid rows)."""
+    ocfg = O.OracleConfig(vocab_size=300, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128,
+                          max_position_embeddings=32)
+    P = O.make_params(ocfg, 5, std=0.05)
+    m = model_from_oracle(ocfg, P)
+    rng = np.random.Generator(np.random.PCG64(8))
+    ids = rng.integers(5, 300, (1, 27))          # padded to 32 internally
+    mask = np.ones((1, 27), np.int64)
+    mask[0, 19:] = 0
+    out = m(input_ids=torch.from_numpy(ids).to(DEV), attention_mask=torch.from_numpy(mask).to(DEV), output_hidden_states=True)
+    assert out.last_hidden_state.shape == (1, 27, 128) and len(out.hidden_states) == 2
+    dE = rng.standard_normal((1, 128)).astype(np.float32)
+    (out.cls_fp32 * torch.from_numpy(dE).to(DEV)).sum().backward()
+    hs, cache = O.encoder_fwd(P, ocfg, ids, mask, keep_cache=True)
+    valid = mask.astype(bool)
+    assert rel_l2(out.last_hidden_state.detach().float().cpu().numpy()[valid], hs[-1][valid]) < 2e-2
+    d_last = np.zeros_like(hs[-1])
+    d_last[:, 0] = dE
+    G = O.encoder_bwd(P, ocfg, cache, d_last)
+    got = grads_by_name(m)
+    for name in ("encoder.layer.0.attention.self.value.weight", "encoder.layer.0.output.dense.weight", "embeddings.LayerNorm.bias"):
+        assert rel_l2(got[name], G[name]) < 6e-2, name

@@ -107,3 +107,14 @@ def test_score_topk_streams_the_row_when_the_cut_bin_is_crowded(mode):
     D, I = ops.score_topk(t(Q), t(P), k)
     Dr, Ir = O.score_topk(Q, P, k)
     assert np.array_equal(D.cpu().numpy(), Dr) and np.array_equal(I.cpu().numpy(), Ir)
+
+
+def test_score_topk_degenerate_sizes():
+    """One query, one passage, k = 1; and k far above the corpus size."""
+    Q = np.array([[1.0, 2.0, 3.0, 4.0]], np.float32)
+    P = np.array([[0.5, 0.5, 0.5, 0.5]], np.float32)
+    D, I = ops.score_topk(t(Q), t(P), 1)
+    assert I.cpu().tolist() == [[0]] and abs(float(D[0, 0]) - 5.0) < 1e-6
+    D, I = ops.score_topk(t(Q), t(np.repeat(P, 3, 0) * np.array([[1.0], [3.0], [2.0]], np.float32)), 7, id_offset=100)
+    assert I.cpu().tolist() == [[101, 102, 100, -1, -1, -1, -1]]
+    assert np.isneginf(D.cpu().numpy()[0, 3:]).all()

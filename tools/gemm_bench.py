@@ -25,6 +25,17 @@ SHAPES = [  # (name, M, N, K, ta, tb, batch, out_f32)
     ("wgrad ffn2 12x 768x3072x8192", 768, 3072, 8192, 1, 1, 12, 1),
     ("large fwd ffn1 8192x4096x1024", 8192, 4096, 1024, 0, 0, 1, 0),
     ("large fwd qkv 2048x3072x1024", 2048, 3072, 1024, 0, 0, 1, 0),
+    # BERT-large (H 1024, I 4096) at 8192 tokens
+    ("L fwd qkv  8192x3072x1024", 8192, 3072, 1024, 0, 0, 1, 0),
+    ("L fwd out  8192x1024x1024", 8192, 1024, 1024, 0, 0, 1, 0),
+    ("L fwd ffn1 8192x4096x1024", 8192, 4096, 1024, 0, 0, 1, 0),
+    ("L fwd ffn2 8192x1024x4096", 8192, 1024, 4096, 0, 0, 1, 0),
+    ("L dgrad ffn2 8192x4096x1024", 8192, 4096, 1024, 0, 1, 1, 0),
+    ("L dgrad ffn1 8192x1024x4096", 8192, 1024, 4096, 0, 1, 1, 0),
+    ("L dgrad qkv 8192x1024x3072", 8192, 1024, 3072, 0, 1, 1, 0),
+    ("L wgrad qkv 24x 3072x1024x8192", 3072, 1024, 8192, 1, 1, 24, 1),
+    ("L wgrad out 24x 1024x1024x8192", 1024, 1024, 8192, 1, 1, 24, 1),
+    ("L wgrad ffn1 24x 4096x1024x8192", 4096, 1024, 8192, 1, 1, 24, 1),
     # corpus-encode batch (512 x 128 tokens, forward only)
     ("enc qkv  65536x2304x768", 65536, 2304, 768, 0, 0, 1, 0),
     ("enc out  65536x768x768", 65536, 768, 768, 0, 0, 1, 0),
