@@ -104,6 +104,8 @@ SIGNATURES = {
     "cocodr_encoder_bwd_range": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams),
                                          C.POINTER(EmbedGrads), C.POINTER(LayerGrads), c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "cocodr_mlm_collate": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_double,
+                                   C.c_ulonglong, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_prof_begin": (c_int, [c_int]),
     "cocodr_prof_pause": (c_int, [c_int]),
     "cocodr_prof_end": (c_int, [C.POINTER(c_int), C.POINTER(c_double), C.POINTER(c_double)]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcocodr_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "loss.hip", "score.hip", "encoder.hip", "probe.hip"]
+SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "loss.hip", "score.hip", "encoder.hip", "collate.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 
 

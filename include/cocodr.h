@@ -293,6 +293,20 @@ int cocodr_encoder_bwd_range(const cocodr_config* cfg, const cocodr_embed_params
                              int layer_lo, int do_embed, cocodr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * On-device Condenser / coCondenser collator (COCO/data.py:24-156): per span a random truncation window of
+ * max_seq_length - 2 tokens (:101-117), the whole-word-mask proxy (:44-55, 68-99: words = a token plus its "##"
+ * continuations, shuffled, taken greedily up to round(len * mlm_probability) tokens), [CLS] .. [SEP] + padding
+ * (:135-144) and the 80 % [MASK] / 10 % random / 10 % keep rule of torch_mask_tokens; labels are -100 off the mask.
+ * tokens: int32, all spans back to back (no special tokens); offsets: int64 [n_spans + 1]; is_subword: uint8 [vocab]
+ * (1 for "##" pieces); outputs int32 [n_spans, max_seq_length].  Randomness is a counter-based hash of
+ * (seed, span_index_base + span, purpose, position) - reproducible, and identical in the oracle.
+ * ------------------------------------------------------------------------------------------ */
+int cocodr_mlm_collate(const int32_t* tokens, const long long* offsets, int n_spans, const uint8_t* is_subword, int vocab,
+                       int max_seq_length, int cls_id, int sep_id, int pad_id, int mask_id, double mlm_probability,
+                       unsigned long long seed, long long span_index_base, int32_t* input_ids, int32_t* labels,
+                       int32_t* attention_mask, cocodr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py roofline): bracket every launch of one kernel class with HIP events
  * on the launch stream.  kind: 0 = off, 1 = GEMM launches, 2 = attention, 3 = score_topk GEMM.
  * ------------------------------------------------------------------------------------------ */

@@ -22,3 +22,4 @@ from .retrieval_oracle import *  # noqa: F401,F403
 from .condenser_oracle import *  # noqa: F401,F403
 from .optim_oracle import *  # noqa: F401,F403
 from .idro_oracle import *  # noqa: F401,F403
+from .collate_oracle import *  # noqa: F401,F403

@@ -452,6 +452,55 @@ def golden_dro_greedy():
     sys.path.pop(0)
 
 
+def golden_collate():
+    """f3: the reference collator's own methods (COCO/data.py:44-55 word grouping, :68-99 whole-word mask, :101-117
+    truncation) called unbound on a stub ``self`` (the class itself cannot be constructed offline: it needs a tokenizer
+    with a vocabulary file, and its ``__call__`` uses the removed ``encode_plus``).  ``random.shuffle`` /
+    ``random.randint`` are replaced by recorded permutations / offsets so the algorithm - not Python's RNG stream - is
+    what the fixture pins."""
+    import types
+    sys.path.insert(0, os.path.join(REF, "COCO"))
+    import data as coco_data  # reference
+    C = coco_data.CondenserCollator
+    rng = np.random.Generator(np.random.PCG64(99))
+    cases = []
+    for case in range(12):
+        n = int(rng.integers(1, 60)) if case else 1
+        sub = rng.random(n) < 0.35
+        sub[0] = bool(case % 2) and n > 1 and case > 6  # a leading "##" piece starts a word of its own (:50)
+        toks = [("##" if s_ else "") + f"w{i}" for i, s_ in enumerate(sub)]
+        stub = types.SimpleNamespace(specials=["[CLS]", "[SEP]", "[PAD]", "[MASK]", "[UNK]"], mlm_probability=0.15 if case % 3 else 0.3)
+        stub._whole_word_cand_indexes_bert = lambda t, stub=stub: C._whole_word_cand_indexes_bert(stub, t)
+        groups = C._whole_word_cand_indexes_bert(stub, toks)
+        order = rng.permutation(len(groups))
+
+        def fake_shuffle(lst, order=order):
+            lst[:] = [lst[i] for i in order]
+        coco_data.random.shuffle = fake_shuffle
+        mask = C._whole_word_mask(stub, toks)
+        cases.append(dict(sub=sub.astype(np.uint8), order=order.astype(np.int64), mask=np.array(mask, np.int64),
+                          prob=np.float64(stub.mlm_probability),
+                          groups_flat=np.array([i for g in groups for i in g], np.int64),
+                          groups_len=np.array([len(g) for g in groups], np.int64)))
+    out = {}
+    for i, c in enumerate(cases):
+        out.update({f"c{i}_{k}": v for k, v in c.items()})
+    out["n_cases"] = np.int64(len(cases))
+    # truncation window
+    import random as _random
+    tstub = types.SimpleNamespace(max_seq_length=16, tokenizer=types.SimpleNamespace(num_special_tokens_to_add=lambda pair: 2))
+    ex = list(range(100, 140))
+    for j, left in enumerate((0, 7, 26)):
+        coco_data.random.randint = lambda a, b, left=left: left
+        out[f"trunc{j}"] = np.array(C._truncate(tstub, list(ex)), np.int64)
+        out[f"trunc{j}_left"] = np.int64(left)
+    out["trunc_short"] = np.array(C._truncate(tstub, ex[:9]), np.int64)
+    coco_data.random.shuffle, coco_data.random.randint = _random.shuffle, _random.randint
+    np.savez_compressed(os.path.join(OUT, "collator_cases.npz"), **out)
+    print("collator golden:", len(cases), "mask cases; truncation", out["trunc1"][:3], "...")
+    sys.path.pop(0)
+
+
 def golden_lamb():
     """Three steps of the reference's own ``Lamb`` (ANCE/utils/lamb.py) behind ``torch.nn.utils.clip_grad_norm_`` -
     the optimizer half of the ANCE step (ANCE/drivers/run_ann.py:345-356).  Harness shim (disclosed): lamb.py imports
@@ -494,7 +543,9 @@ def golden_lamb():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy"]
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate"]
+    if "collate" in which:
+        golden_collate()
     if "dro_greedy" in which:
         golden_dro_greedy()
     if "idro" in which:

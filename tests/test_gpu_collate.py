@@ -1,0 +1,48 @@
+"""the on-device Condenser / coCondenser collator against its oracle (same counter-based generator ->
+bit-exact), including over-long spans (random truncation window), one-token and empty spans, L = 512."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cocodr_amd  # noqa: E402
+from cocodr_amd.collate import CoCondenserCollator, CondenserCollator, subword_flags_from_vocab  # noqa: E402
+import oracle as O  # noqa: E402  (checker only)
+
+
+def _vocab(V, rng):
+    toks = ["[PAD]"] + [f"[unused{i}]" for i in range(1, 100)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    toks += [("##" if rng.random() < 0.3 else "") + f"t{i}" for i in range(len(toks), V)]
+    return toks
+
+
+@pytest.mark.parametrize("L,seed", [(32, 1), (128, 2), (512, 3)])
+def test_collator_matches_oracle_bit_for_bit(L, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    V = 3000
+    flags = subword_flags_from_vocab(_vocab(V, rng))
+    col = CondenserCollator(flags, max_seq_length=L, seed=seed * 11, mlm_probability=0.15)
+    lens = [0, 1, 2, L - 3, L - 2, L - 1, L + 40, 3 * L] + [int(x) for x in rng.integers(1, 2 * L, 40)]
+    spans = [rng.integers(104, V, n).tolist() for n in lens]
+    for rep in range(2):  # the second call continues the span counter
+        base = col.spans_seen
+        out = col([{"text": s} for s in spans])
+        ids, labels, att = (out[k].cpu().numpy() for k in ("input_ids", "labels", "attention_mask"))
+        assert ids.dtype == np.int64 and ids.shape == (len(spans), L)
+        for i, s in enumerate(spans):
+            ri, rl, ra = O.collate_span(s, flags, seed * 11, base + i, L, 101, 102, 0, 103, 0.15)
+            assert np.array_equal(ids[i], ri) and np.array_equal(labels[i], rl) and np.array_equal(att[i], ra), (rep, i, len(s))
+
+
+def test_cocondenser_collator_lays_span_pairs_back_to_back():
+    rng = np.random.Generator(np.random.PCG64(5))
+    flags = subword_flags_from_vocab(_vocab(2000, rng))
+    col = CoCondenserCollator(flags, max_seq_length=64, seed=4)
+    docs = [{"span": [rng.integers(104, 2000, 20).tolist(), rng.integers(104, 2000, 30).tolist()]} for _ in range(5)]
+    out = col(docs)
+    assert out["input_ids"].shape == (10, 64)
+    att = out["attention_mask"].cpu().numpy()
+    assert list(att.sum(1)) == [22, 32] * 5  # rows 2i / 2i+1 are the two spans of document i (COCO/modeling.py:172-177)
+    lab = out["labels"].cpu().numpy()
+    assert ((lab != -100).sum(1) >= 1).all()

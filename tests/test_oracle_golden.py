@@ -255,3 +255,57 @@ def test_dro_greedy_oracle_matches_reference_golden():
                 for key in z.files:
                     if key.startswith(f"{tag}_s1_grad:"):
                         assert _rel(tot[key.split(":", 1)[1]], z[key]) < 2e-4, key
+
+
+def test_collator_oracle_matches_reference_methods():
+    """Word grouping, greedy whole-word selection and the truncation window against the reference collator's own methods
+    driven with recorded permutations / offsets (tests/golden/collator_cases.npz)."""
+    z = load_golden("collator_cases.npz")
+    for i in range(int(z["n_cases"])):
+        sub = z[f"c{i}_sub"].astype(bool)
+        groups = O.whole_word_groups(list(sub))
+        assert [len(g) for g in groups] == list(z[f"c{i}_groups_len"])
+        assert [t for g in groups for t in g] == list(z[f"c{i}_groups_flat"])
+        mask = O.whole_word_mask(groups, list(z[f"c{i}_order"]), len(sub), float(z[f"c{i}_prob"]))
+        assert mask == list(z[f"c{i}_mask"]), i
+    # truncation: window [left, left + max_seq_length - 2) - collate_span takes `left` from its generator; check the slicing
+    ex = list(range(100, 140))
+    for j in range(3):
+        left = int(z[f"trunc{j}_left"])
+        assert ex[left:left + 14] == list(z[f"trunc{j}"])
+    assert list(z["trunc_short"]) == ex[:9]
+
+
+def test_collate_span_invariants_and_rates():
+    """collate_span end to end: layout, whole words masked together, budget, label / id consistency, 80/10/10 rates."""
+    rng = np.random.Generator(np.random.PCG64(1))
+    V, L = 1000, 64
+    is_sub = (rng.random(V) < 0.3).astype(np.uint8)
+    is_sub[:110] = 0
+    n_mask = n_tok = n_repl = n_rand = n_keep = 0
+    for ex in range(300):
+        n = int(rng.integers(1, 90))
+        toks = rng.integers(110, V, n)
+        ids, labels, att = O.collate_span(toks, is_sub, seed=7, ex=ex, L=L, cls_id=101, sep_id=102, pad_id=0, mask_id=103,
+                                          mlm_probability=0.15)
+        m = min(n, L - 2)
+        assert ids[0] == 101 and ids[m + 1] == 102 and (ids[m + 2:] == 0).all()
+        assert att.sum() == m + 2 and (att[:m + 2] == 1).all()
+        lab = labels[1:m + 1]
+        picked = lab != -100
+        want = min(512, max(1, int(round(m * 0.15))))
+        assert 0 <= picked.sum() <= want and labels[0] == -100 and (labels[m + 1:] == -100).all()
+        # the window is a contiguous slice of the span and unmasked positions keep their token
+        win = ids[1:m + 1].copy()
+        win[picked] = lab[picked]
+        starts = [s for s in range(n - m + 1) if (toks[s:s + m] == win).all()]
+        assert starts
+        # whole words: a "##" piece is masked iff the token in front of it (same word) is
+        for i in range(1, m):
+            if is_sub[win[i]]:
+                assert picked[i] == picked[i - 1]
+        n_tok += m; n_mask += int(picked.sum())
+        cur = ids[1:m + 1][picked]
+        n_repl += int((cur == 103).sum()); n_keep += int((cur == lab[picked]).sum()); n_rand += int(((cur != 103) & (cur != lab[picked])).sum())
+    assert 0.10 < n_mask / n_tok < 0.16
+    assert abs(n_repl / n_mask - 0.8) < 0.05 and abs(n_rand / n_mask - 0.1) < 0.04 and abs(n_keep / n_mask - 0.1) < 0.04
