@@ -471,7 +471,12 @@ class CocoBertModel(nn.Module):
             return gd, gn
         import torch.distributed as dist
         nchunk = min(self._dp_chunks, NL)
-        bounds = [round(i * NL / nchunk) for i in range(nchunk + 1)]  # layer boundaries, ascending
+        # layer boundaries, ascending, balanced by gradient BYTES: the range that ends at layer 0 also carries the embedding
+        # tables (its all-reduce is the one nothing can hide), so it gets correspondingly fewer layers
+        emb_units = lo.mat_begin / float(lo.mat_stride)
+        bounds = [0] + [min(NL, max(1, round(i * (NL + emb_units) / nchunk - emb_units))) for i in range(1, nchunk)] + [NL]
+        bounds = sorted(set(bounds))
+        nchunk = len(bounds) - 1
         works = []
         for ci in reversed(range(nchunk)):
             l_lo, l_hi = bounds[ci], bounds[ci + 1]
