@@ -57,6 +57,10 @@ class LambPlan(C.Structure):  # mirrors cocodr_lamb_plan
                 ("nchunk", c_int), ("nseg", c_int)]
 
 
+class EncoderBwdLayout(C.Structure):  # mirrors cocodr_encoder_bwd_layout_t
+    _fields_ = [(n, c_size_t) for n in ("dy2", "du", "dy1", "dqkv", "ln2_partial", "ln1_partial")] + [("ln_blocks", c_int), ("ln_rows", c_int)]
+
+
 EPI_NONE, EPI_GELU, EPI_ADD, EPI_DGELU = 0, 1, 2, 3
 
 # name -> (restype, argtypes); every symbol include/cocodr.h declares
@@ -91,6 +95,7 @@ SIGNATURES = {
     "cocodr_score_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
     "cocodr_encoder_layout": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),
+    "cocodr_encoder_bwd_layout": (c_int, [C.POINTER(Config), c_int, c_int, C.POINTER(EncoderBwdLayout)]),
     "cocodr_encoder_fwd": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "cocodr_encoder_fwd_range": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), c_void_p, c_void_p,

@@ -117,6 +117,20 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
                      cocodr_stream_t stream, int layer_lo = 0, int layer_hi = -1);
 }
 
+extern "C" int cocodr_encoder_bwd_layout(const cocodr_config* c, int B, int L, cocodr_encoder_bwd_layout_t* out) {
+  CK_ARG(out != nullptr, "encoder_bwd_layout: null out");
+  cocodr_encoder_layout_t lay;
+  TRY(cocodr_encoder_layout(c, B, L, 1, &lay));
+  const BwdLayout bl = bwd_layout(c, B, L);
+  const size_t base = lay.bwd_scratch;
+  out->dy2 = base + bl.dy2; out->du = base + bl.du; out->dy1 = base + bl.dy1; out->dqkv = base + bl.dqkv;
+  out->ln2_partial = base + bl.ln2_slots; out->ln1_partial = base + bl.ln1_slots;
+  const int M = B * L;
+  out->ln_blocks = cocodr_ln_bwd_blocks(M);
+  out->ln_rows = (M + out->ln_blocks - 1) / out->ln_blocks;
+  return COCODR_OK;
+}
+
 extern "C" int cocodr_encoder_fwd(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
                                   const int32_t* ids, const int32_t* mask, int B, int L, int training, void* arena,
                                   size_t arena_bytes, cocodr_stream_t stream) {

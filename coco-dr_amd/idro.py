@@ -32,6 +32,8 @@ class IDROLoss:
         self.n_groups, self.alpha, self.eps, self.ema, self.rho = int(n_groups), float(alpha), float(eps), float(ema), float(rho)
         self.model_size = model_size
         self.h_fun = torch.ones(self.n_groups, dtype=torch.float32, device=device)  # register_buffer('h_fun', ones), :28
+        self.per_group_backward = False   # True: one partial backward per present group (the reference's structure)
+        self.last_path = None
 
     def selected_layers(self, n_layers: int) -> Tuple[int, int]:
         """[lo, hi) of the re-weighted layers: the reference matches the names layer.9/10/11 (base) or layer.22/23
@@ -44,8 +46,10 @@ class IDROLoss:
     @torch.no_grad()
     def update(self, group_losses: torch.Tensor, counts: torch.Tensor, all_grads: torch.Tensor) -> None:
         mask = (counts > 0).to(torch.float32)
-        A = all_grads / (1e-12 + torch.linalg.norm(all_grads, dim=-1, keepdim=True))      # :236-237
-        RTG = A @ A.T                                                                       # :238
+        # cosine gram (:236-238) from ONE pass over the [G, D] matrix: raw gram, norms from its diagonal
+        raw = _gram(all_grads)
+        nrm = 1e-12 + torch.sqrt(torch.clamp(torch.diagonal(raw), min=0.0))
+        RTG = raw / (nrm[:, None] * nrm[None, :])
         gl = torch.pow(group_losses.unsqueeze(-1), self.alpha)                              # :240
         RTG = (gl @ gl.T) * RTG                                                             # :241
         ex = self.rho * RTG.mean(dim=0) * mask                                              # :242-244
@@ -53,6 +57,21 @@ class IDROLoss:
         h = torch.pow(self.h_fun, self.ema) * torch.exp(ex) * (counts != 0).to(torch.float32)  # :248-250
         h = h / h.sum()
         self.h_fun = torch.clamp(h, min=self.eps)                                           # :252
+
+
+def _gram(a: torch.Tensor, chunk: int = 1 << 16) -> torch.Tensor:
+    """a @ a.T for a short, very wide fp32 matrix: batched over column chunks (the BLAS kernel picked for one
+    [G, D] x [D, G] product with D ~ 2.5e7 runs at a fraction of the HBM rate)."""
+    G, D = a.shape
+    n = D // chunk
+    out = torch.zeros((G, G), dtype=torch.float32, device=a.device)
+    if n > 0:
+        body = a[:, : n * chunk].view(G, n, chunk).transpose(0, 1)        # [n, G, chunk], strided view
+        out += torch.bmm(body, body.transpose(1, 2)).sum(0)
+    if n * chunk < D:
+        tail = a[:, n * chunk:]
+        out += tail @ tail.T
+    return out
 
 
 class DROGreedyLoss:
@@ -116,6 +135,74 @@ class DROGreedyLoss:
             self.h_fun = h
 
 
+def _per_sequence_group_grads(bert, passes, arenas, unit, g, inv, all_grads, layers, slices, scratch, structs) -> bool:
+    """All group gradients from ONE un-weighted partial backward per encoder pass.  The backward of a sequence depends
+    only on its own upstream gradient (attention and LayerNorm never mix sequences), so a single pass with every row's
+    d(row loss)/d[CLS] leaves, per layer of the range, output-gradient matrices whose rows are each sequence's own
+    flow.  The weight gradient of group g is then sum_{i in g} dY_i^T X_i / count_g: batched per-SEQUENCE weight-gradient
+    GEMMs (batch = sequence, contraction over its L tokens) + an index_add by group; bias / LayerNorm gradients come from
+    per-sequence column sums and from the LayerNorm backward's partial rows (which cover whole fractions of a sequence).
+    Returns False (nothing written) when the partial rows do not align with sequences; the caller then falls back."""
+    from . import _native as N
+    lo, cfg = bert.layout, bert.config
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    l_lo, l_hi = layers
+    d0, d1, n0, n1 = slices
+    if l_hi - l_lo < 2:
+        return False
+    sd, sn = scratch
+    emb, arr, eg, garr, ccfg = structs
+    Dd = d1 - d0
+    lays = []
+    for ids, _mask in passes:
+        Bp, L = ids.shape
+        bl = N.EncoderBwdLayout()
+        check(lib().cocodr_encoder_bwd_layout(C.byref(ccfg), Bp, L, C.byref(bl)), "encoder_bwd_layout")
+        if L % bl.ln_rows != 0 or bl.ln_rows * bl.ln_blocks != Bp * L:
+            return False
+        lays.append(bl)
+    B = g.shape[0]
+    for p, (ids, mask) in enumerate(passes):
+        Bp, L = ids.shape
+        M = Bp * L
+        arena, bl, fl = arenas[p], lays[p], bert._layout_for(Bp, L, True)
+        d16 = ops.scatter_cls_grad(unit[p].contiguous(), L)
+        check(lib().cocodr_encoder_bwd_range(C.byref(ccfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d16), Bp, L,
+                                             ptr(arena), arena.numel(), l_hi, l_lo, 0, stream_ptr()), "encoder_bwd_range(idro)")
+        seq_g = g if Bp == B else torch.cat([g, g])
+
+        def act(off, layer, width):  # bf16 [Bp, L, width] view of a per-layer activation / gradient block
+            b0 = off + layer * M * width * 2
+            return arena[b0: b0 + M * width * 2].view(torch.bfloat16).view(Bp, L, width)
+
+        def add(col0, per_seq):      # all_grads[group, col0 : col0 + n] += per_seq[i] for every sequence i of the group
+            n = per_seq.shape[1]     # (the 1 / count_g of the group MEAN is a row scale: the cosine gram does not see it)
+            all_grads[:, col0: col0 + n].index_add_(0, seq_g, per_seq)
+
+        per = L // bl.ln_rows
+        for l in range(l_lo, l_hi):
+            li = l - l_lo
+            cd, cn = li * lo.mat_stride, Dd + li * lo.vec_stride
+            dqkv, dy1 = act(bl.dqkv, l, 3 * H), act(bl.dy1, l, H)
+            du, dy2 = act(bl.du, l, I), act(bl.dy2, l, H)
+            x_in, ctx = act(fl.hidden, l, H), act(fl.ctx, l, H)
+            x1, hh = act(fl.x1, l, H), act(fl.h, l, I)
+            for col, a_, b_ in ((lo.off_wqkv, dqkv, x_in), (lo.off_wo, dy1, ctx), (lo.off_w1, du, x1), (lo.off_w2, dy2, hh)):
+                gw = ops.gemm(a_, b_, trans_a=True, trans_b=True, out_f32=True)      # [Bp, out, in] fp32, one per sequence
+                add(cd + col, gw.view(Bp, -1))
+                del gw
+            add(cn + lo.off_bqkv, ops.colsum(dqkv))
+            add(cn + lo.off_b1, ops.colsum(du))
+            for off, slot_off, names in ((bl.ln1_partial, li, (lo.off_ln1g, lo.off_ln1b, lo.off_bo)),
+                                         (bl.ln2_partial, li, (lo.off_ln2g, lo.off_ln2b, lo.off_b2))):
+                nfl = bl.ln_blocks * 3 * H
+                b0 = off + slot_off * nfl * 4
+                part = arena[b0: b0 + nfl * 4].view(torch.float32).view(Bp, per, 3, H).sum(1)   # [Bp, 3, H]
+                for k, col in enumerate(names):
+                    add(cn + col, part[:, k].contiguous())
+    return True
+
+
 class _IDROStepFn(torch.autograd.Function):
     """(flat_decay, flat_nodecay) -> robust loss; everything else rides along un-differentiated."""
 
@@ -157,8 +244,11 @@ class _IDROStepFn(torch.autograd.Function):
         sd, sn = torch.empty_like(fd), torch.empty_like(fn)   # scratch gradient flats: only the selected slices are written
         emb, arr, eg, garr = bert._param_structs((sd, sn))
         ccfg = bert._c_config()
-        present = torch.nonzero(counts > 0).flatten().tolist()   # one host sync per step (the reference has several)
         inv = 1.0 / counts.clamp(min=1.0)
+        fast = (not dro.per_group_backward) and _per_sequence_group_grads(
+            bert, passes, arenas, unit, g, inv, all_grads, (l_lo, l_hi), (d0, d1, n0, n1), (sd, sn), (emb, arr, eg, garr, ccfg))
+        dro.last_path = "per-sequence" if fast else "per-group"
+        present = [] if fast else torch.nonzero(counts > 0).flatten().tolist()   # fallback: one partial backward per group
         for gi in present:
             w = (g == gi).to(torch.float32) * inv[gi]
             for p, (ids, mask) in enumerate(passes):

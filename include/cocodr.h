@@ -251,6 +251,19 @@ typedef struct { /* byte offsets into the arena, filled by cocodr_encoder_layout
 /* training = 0 keeps only what inference needs (hidden states + one layer of scratch) */
 int cocodr_encoder_layout(const cocodr_config* cfg, int B, int L, int training, cocodr_encoder_layout_t* out);
 
+/* Where a backward range leaves what it computed besides the parameter gradients (byte offsets from the arena base,
+ * training arenas only): the output gradients of the four Linears of every layer in the range (bf16, [layers][M, .],
+ * indexed by ABSOLUTE layer: dy2 = d(FFN output + residual), du = d(FFN pre-activation), dy1 = d(attention output +
+ * residual), dqkv) and - for ranges of more than one layer - the LayerNorm-backward partial rows of the range
+ * (fp32 [layer - layer_lo][ln_blocks][3][H] = dgamma, dbeta, column sums of dy, over ln_rows consecutive tokens each).
+ * Used by hosts that need per-sequence gradients (iDRO's per-group gradients, coco-dr_amd/idro.py). */
+typedef struct {
+  size_t dy2, du, dy1, dqkv;
+  size_t ln2_partial, ln1_partial;
+  int ln_blocks, ln_rows;
+} cocodr_encoder_bwd_layout_t;
+int cocodr_encoder_bwd_layout(const cocodr_config* cfg, int B, int L, cocodr_encoder_bwd_layout_t* out);
+
 int cocodr_encoder_fwd(const cocodr_config* cfg, const cocodr_embed_params* emb,
                        const cocodr_layer_params* layers_host, const int32_t* ids, const int32_t* mask,
                        int B, int L, int training, void* arena, size_t arena_bytes, cocodr_stream_t stream);

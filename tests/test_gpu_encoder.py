@@ -451,3 +451,28 @@ def test_smallest_shapes_single_sequence_of_32_tokens():
     got = grads_by_name(m)
     for name in ("encoder.layer.0.attention.self.value.weight", "encoder.layer.0.output.dense.weight", "embeddings.LayerNorm.bias"):
         assert rel_l2(got[name], G[name]) < 6e-2, name
+
+
+def test_idro_single_pass_group_gradients_equal_the_per_group_backwards():
+    """The per-sequence route (one un-weighted partial backward + per-sequence weight-gradient GEMMs) and the
+    reference-shaped route (one partial backward per group) update the group weights identically."""
+    import types
+    cfg = CocoBertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=12, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=64)
+    rng = np.random.Generator(np.random.PCG64(31))
+    B = 8
+    mk = lambda L: (torch.from_numpy(rng.integers(5, 500, (B, L))).to(DEV), torch.ones(B, L, dtype=torch.int64, device=DEV))
+    (q, qm), (a, am), (b, bm) = mk(32), mk(64), mk(64)
+    groups = torch.tensor([0, 3, 3, 1, 0, 5, 5, 5], device=DEV)
+    hs = {}
+    for per_group in (False, True):
+        torch.manual_seed(0)
+        model = BertDotNLL(cfg).to(DEV)
+        model.add_group_loss(args=types.SimpleNamespace(model_size="base"), n_groups=6, dro_type="idro", alpha=0.25, eps=0.01, ema=0.1,
+                             rho=2.0)  # a large rho makes the update sensitive to the gradient cosines
+        model.loss.per_group_backward = per_group
+        for _ in range(2):
+            robust, *_ = model(q, qm, a, am, b, bm, group_ids=groups)
+        assert model.loss.last_path == ("per-group" if per_group else "per-sequence")
+        hs[per_group] = model.loss.h_fun.cpu().numpy()
+    np.testing.assert_allclose(hs[False], hs[True], rtol=2e-3, atol=1e-5)
