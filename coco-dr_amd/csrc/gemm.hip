@@ -641,7 +641,13 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD>::NTHREADS), (Geom<BMv
           }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if defined(COCODR_ABL_TIMELINE)
+    if (tid == 0 && h == 0) tl[5] = wall_clock64();  // own LDS writes done
+#endif
     __builtin_amdgcn_s_barrier();
+#if defined(COCODR_ABL_TIMELINE)
+    if (tid == 0 && h == 0) tl[6] = wall_clock64();  // everybody's LDS writes done
+#endif
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * G::CTHREADS;

@@ -65,15 +65,18 @@ def timeline(args, impls, stream):
             st = stamps.cpu().numpy()
             st = st[st[:, 0] > 0]
             print("   HW_REG_LDS_ALLOC values:", sorted(set(hex(int(x)) for x in st[:, 4]))[:8])
+            ex = (st[:, :8].astype(np.float64) - st[:, 0].min()) / 100.0
             st = st[:, :4].astype(np.float64)
             t0 = st[:, 0].min()
             st = (st - t0) / 100.0  # us
             order = np.argsort(st[:, 0])
             st = st[order]
+            ex = ex[order]
             n = len(st)
             print(f"== {name} impl {impl}: {n} workgroups, kernel span {st[:, 3].max():.1f} us")
             pro, loop, epi = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
-            for lbl, v in (("start", st[:, 0]), ("prologue", pro), ("main loop", loop), ("epilogue", epi)):
+            for lbl, v in (("start", st[:, 0]), ("prologue", pro), ("main loop", loop), ("epilogue", epi),
+                           ("  epi: LDS write", ex[:, 5] - st[:, 2]), ("  epi: barrier", ex[:, 6] - ex[:, 5]), ("  epi: copy-out", st[:, 3] - ex[:, 6])):
                 print(f"   {lbl:10s} min {v.min():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  "
                       f"p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f}")
             # waves of dispatch: start-time histogram in 2-us bins
