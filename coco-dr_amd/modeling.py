@@ -470,6 +470,7 @@ class CocoBertModel(nn.Module):
                                            B, L, ptr(arena), arena.numel(), stream_ptr()), "encoder_bwd")
             return gd, gn
         import torch.distributed as dist
+        avg_native = dist.get_backend(self._dp_group) == "nccl"
         nchunk = min(self._dp_chunks, NL)
         # layer boundaries, ascending, balanced by gradient BYTES: the range that ends at layer 0 also carries the embedding
         # tables (its all-reduce is the one nothing can hide), so it gets correspondingly fewer layers
@@ -490,9 +491,14 @@ class CocoBertModel(nn.Module):
             n0 = lo.vec_begin + l_lo * lo.vec_stride if l_lo > 0 else 0
             n1 = lo.vec_begin + l_hi * lo.vec_stride
             for t in (gd[d0:d1], gn[n0:n1]):
-                works.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self._dp_group, async_op=True))
+                works.append(dist.all_reduce(t, op=dist.ReduceOp.AVG if avg_native else dist.ReduceOp.SUM, group=self._dp_group,
+                                             async_op=True))
         for w in works:
             w.wait()  # stream-level: the current stream waits for the collectives, the host does not
+        if not avg_native:  # gloo (used by the 2-process single-GPU test) has no AVG
+            W = dist.get_world_size(self._dp_group)
+            gd.div_(W)
+            gn.div_(W)
         return gd, gn
 
     # ---------------------------------------------------------------- public forward
