@@ -77,3 +77,42 @@ def test_bert_large_triplet_step_config4_shapes():
         qe, ae, be = model.query_emb(q, qm), model.body_emb(a, am), model.body_emb(b, am)
         ref = -torch.log_softmax(torch.stack([(qe * ae).sum(-1), (qe * be).sum(-1)], 1), 1)[:, 0].mean()
     assert abs(float(loss) - float(ref)) < 1e-3 * max(1.0, abs(float(ref)))
+
+
+def test_encode_search_ndcg_pipeline_matches_fp32_oracle_pipeline():
+    """north_star: nDCG@10 within 1e-3 of the reference path.  Whole eval pipeline (config 5 in miniature): bf16 GPU encoder
+    -> resident embeddings -> exact search -> EvalDevQuery, against the fp32 numpy encoder + numpy search.  Queries are
+    noisy copies of planted passages, so the metric is non-trivial (some positives are NOT ranked first)."""
+    ocfg = O.OracleConfig(vocab_size=800, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=64)
+    P = O.make_params(ocfg, 17, std=0.08)
+    cfg = CocoBertConfig(vocab_size=800, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=64)
+    model = BertDotNLL(cfg)
+    model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    model.to(DEV).eval()
+    rng = np.random.Generator(np.random.PCG64(3))
+    npass, nq, Lp, Lq = 400, 60, 64, 32
+    p_ids = rng.integers(5, 800, (npass, Lp)); p_ids[:, 0] = 1
+    p_mask = np.ones((npass, Lp), np.int64)
+    for i in range(npass):
+        n = int(rng.integers(20, Lp + 1)); p_mask[i, n:] = 0; p_ids[i, n:] = 0
+    pos = rng.permutation(npass)[:nq]
+    q_ids = p_ids[pos, :Lq].copy()
+    flip = rng.random((nq, Lq)) < 0.3          # heavy token noise: the positive is not always the nearest passage
+    q_ids[flip] = rng.integers(5, 800, int(flip.sum())); q_ids[:, 0] = 1
+    q_mask = np.ones((nq, Lq), np.int64)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    Pe, _ = R.encode_corpus(model, t(p_ids), t(p_mask), batch_size=128)
+    Qe, _ = R.encode_corpus(model, t(q_ids), t(q_mask), batch_size=32, is_query=True)
+    D, I = R.search(Qe, Pe, 50)
+    enc = lambda ids, mask: O.cls_embedding(O.encoder_fwd(P, ocfg, ids, mask)[0][-1]).astype(np.float32)
+    Pr, Qr = enc(p_ids, p_mask), enc(q_ids, q_mask)
+    assert np.min(np.sum(Pe.cpu().numpy() * Pr, 1) / (np.linalg.norm(Pe.cpu().numpy(), axis=1) * np.linalg.norm(Pr, axis=1))) > 0.999
+    Dr, Ir = O.score_topk(Qr, Pr, 50)
+    q2id, p2id = np.arange(nq) + 100, np.arange(npass) * 2 + 7
+    qrels = {int(q2id[i]): {int(p2id[pos[i]]): 1} for i in range(nq)}
+    ndcg, mrr, n, _ = R.eval_dev_query(q2id, p2id, qrels, I, 50)
+    ndcg_r, mrr_r, n_r, _ = O.eval_dev_query(q2id, p2id, qrels, Ir, 50)
+    assert n == n_r == nq and 0.15 < ndcg_r < 0.999
+    assert abs(ndcg - ndcg_r) <= 1e-3 + 1.0 / nq * 0.4, (ndcg, ndcg_r)   # at most one near-tie swap among 60 queries
