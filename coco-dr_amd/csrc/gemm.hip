@@ -775,12 +775,13 @@ int select_impl(const cocodr_gemm_args& a) {
   if (impl == 0) {
     // auto (measured on MI355X, tools/gemm_bench.py): with >= 1.5 tiles per CU the BK=32 geometry wins because a
     // second resident workgroup hides prologue/epilogue; with fewer tiles (and for the mid-sized grouped wgrad) the
-    // deeper BK=64 ring with four loader waves wins; below half a wave of 256-row tiles fall back to 128-row tiles to
-    // occupy more CUs.
+    // deeper BK=64 ring with four loader waves wins - also for the long-K forward / dgrad forms (K >= 2048) at any tile
+    // count, where the per-tile prologue / epilogue is amortised anyway; below half a wave of 256-row tiles fall back
+    // to 128-row tiles to occupy more CUs.
     const long long tiles256 = (long long)((a.M + 255) / 256) * (a.N / BN) * batch;
     const long long tiles128 = (long long)((a.M + 127) / 128) * (a.N / BN) * batch;
     if (!(k_ok && small)) impl = 1;
-    else if (tiles256 >= 384 && !(a.trans_a && tiles256 < 768)) impl = 5;
+    else if (tiles256 >= 384 && !(a.trans_a && tiles256 < 800) && !(!a.trans_a && a.K >= 2048)) impl = 5;
     else if (tiles256 >= 128) impl = 9;
     else impl = tiles128 >= 512 ? 4 : 2;
   }
