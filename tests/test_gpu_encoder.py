@@ -511,3 +511,37 @@ def test_contrastive_training_learns_span_pairs():
     assert all(np.isfinite(losses))
     chance = float(np.log(2 * docs - 1))
     assert losses[0] > 0.5 * chance and np.mean(losses[-10:]) < 0.35 * chance, (losses[0], np.mean(losses[-10:]))
+
+
+def test_huggingface_checkpoint_interchange(tmp_path):
+    """Drop-in boundary: a checkpoint written by transformers' own BertModel.save_pretrained loads with
+    CocoBertModel.from_pretrained and gives the same hidden states as the HF eager model (fp32 CPU); the native model's
+    save_pretrained output loads back into transformers."""
+    transformers = pytest.importorskip("transformers")
+    hf_cfg = transformers.BertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                     max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                     attn_implementation="eager")
+    torch.manual_seed(3)
+    hf = transformers.BertModel(hf_cfg, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.mul_(3.0)          # the default 0.02 init gives nearly input-independent hidden states
+    d1 = tmp_path / "hf"
+    hf.save_pretrained(str(d1))
+    m = CocoBertModel.from_pretrained(str(d1)).to(DEV)
+    rng = np.random.Generator(np.random.PCG64(4))
+    ids = torch.from_numpy(rng.integers(5, 500, (3, 40)))
+    mask = torch.ones(3, 40, dtype=torch.int64)
+    mask[1, 25:] = 0
+    with torch.no_grad():
+        ref = hf(input_ids=ids, attention_mask=mask).last_hidden_state.numpy()
+        out = m(input_ids=ids.to(DEV), attention_mask=mask.to(DEV))
+    got = out.last_hidden_state.float().cpu().numpy()
+    valid = mask.numpy().astype(bool)
+    assert rel_l2(got[valid], ref[valid]) < 2e-2 and cosine_rows(got[:, 0], ref[:, 0]).min() > 0.999
+    d2 = tmp_path / "native"
+    m.save_pretrained(str(d2))
+    hf2 = transformers.BertModel.from_pretrained(str(d2), add_pooling_layer=False, attn_implementation="eager").eval()
+    with torch.no_grad():
+        ref2 = hf2(input_ids=ids, attention_mask=mask).last_hidden_state.numpy()
+    np.testing.assert_allclose(ref2, ref, rtol=1e-5, atol=1e-5)
