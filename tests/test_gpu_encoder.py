@@ -545,3 +545,27 @@ def test_huggingface_checkpoint_interchange(tmp_path):
     with torch.no_grad():
         ref2 = hf2(input_ids=ids, attention_mask=mask).last_hidden_state.numpy()
     np.testing.assert_allclose(ref2, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_ance_wrapper_loads_a_sequence_classification_checkpoint(tmp_path):
+    """ANCE builds BertDot_NLL_LN by from_pretrained on a BertForSequenceClassification-shaped checkpoint
+    (ANCE/drivers/run_ann.py:896-901): keys carry a 'bert.' prefix and there are head tensors the encoder does not own."""
+    transformers = pytest.importorskip("transformers")
+    hf_cfg = transformers.BertConfig(vocab_size=400, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                     max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                     attn_implementation="eager", num_labels=2)
+    torch.manual_seed(5)
+    hf = transformers.BertForSequenceClassification(hf_cfg).eval()
+    with torch.no_grad():
+        for p in hf.bert.parameters():
+            p.mul_(3.0)
+    hf.save_pretrained(str(tmp_path))
+    model = BertDotNLL.from_pretrained(str(tmp_path)).to(DEV).eval()
+    ids = torch.randint(5, 400, (4, 32), generator=torch.Generator().manual_seed(1))
+    mask = torch.ones_like(ids)
+    with torch.no_grad():
+        ref = hf.bert(input_ids=ids, attention_mask=mask)[0][:, 0].numpy()   # ANCE/model/models.py:225-229
+        got = model.query_emb(ids.to(DEV), mask.to(DEV)).cpu().numpy()
+    assert cosine_rows(got, ref).min() > 0.999 and rel_l2(got, ref) < 2e-2
+    sd = model.bert.state_dict()
+    assert any(k.startswith("classifier.") or k.startswith("pooler.") or "classifier" in k for k in sd), list(sd)[-4:]
