@@ -374,10 +374,13 @@ class CocoBertModel(nn.Module):
         model.load_state_dict(sd, strict=False)
         return model
 
-    def save_pretrained(self, path: str) -> None:
+    def save_pretrained(self, path: str, prefix: str = "") -> None:
+        """``prefix`` ("bert.") writes the encoder tensors under the base-model name a head-carrying HF class expects
+        (BertForMaskedLM / BertForSequenceClassification); tensors this model only carries along keep their names."""
         from safetensors.torch import save_file
         self.config.save_pretrained(path)
-        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        own = {name for name, _ in self.hf_named_parameters()}
+        sd = {(prefix + k if k in own else k): v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
         save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
 
     def resize_token_embeddings(self, n: int):
@@ -710,16 +713,27 @@ class CoCondenserForPretraining(nn.Module):
     @classmethod
     def from_pretrained(cls, model_args, data_args, train_args, path, **kw):
         model = cls(CocoBertModel.from_pretrained(path, **kw), model_args, data_args, train_args)
-        extra = os.path.join(path, "model.pt")  # head weights saved next to the HF checkpoint (COCO/modeling.py:103-107)
-        if model.c_head is not None and os.path.exists(extra):
-            sd = torch.load(extra, map_location="cpu", weights_only=True)
+        if model.c_head is not None:
+            # the reference keeps the MLM head (cls.predictions.*) inside the HF checkpoint (AutoModelForMaskedLM) and the
+            # Condenser layers (c_head.*) in model.pt next to it (COCO/modeling.py:103-107, 123-131)
+            sd = {k: v for k, v in model.lm._extra_state.items() if k.startswith("cls.predictions.")}
+            extra = os.path.join(path, "model.pt")
+            if os.path.exists(extra):
+                sd.update(torch.load(extra, map_location="cpu", weights_only=True))
             model.c_head.load_state_dict(sd, strict=False)
         return model
 
     def save_pretrained(self, output_dir: str):
-        self.lm.save_pretrained(output_dir)
         if self.c_head is not None:
-            torch.save({k: v.cpu() for k, v in self.c_head.state_dict().items()}, os.path.join(output_dir, "model.pt"))
+            head = {k: v.detach().cpu() for k, v in self.c_head.state_dict().items()}
+            for k, v in head.items():  # MLM head into the HF checkpoint
+                if k.startswith("cls.predictions."):
+                    self.lm._extra_state[k] = v
+            for k in ("cls.predictions.decoder.weight", "cls.predictions.decoder.bias"):
+                self.lm._extra_state.pop(k, None)  # tied to the word embeddings / cls.predictions.bias: transformers re-ties on load
+        self.lm.save_pretrained(output_dir, prefix="bert." if self.c_head is not None else "")
+        if self.c_head is not None:
+            torch.save({k: v for k, v in head.items() if k.startswith("c_head.")}, os.path.join(output_dir, "model.pt"))
 
     def param_groups(self, weight_decay: float = 0.0):
         groups = self.lm.param_groups(weight_decay)

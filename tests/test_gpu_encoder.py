@@ -569,3 +569,41 @@ def test_ance_wrapper_loads_a_sequence_classification_checkpoint(tmp_path):
     assert cosine_rows(got, ref).min() > 0.999 and rel_l2(got, ref) < 2e-2
     sd = model.bert.state_dict()
     assert any(k.startswith("classifier.") or k.startswith("pooler.") or "classifier" in k for k in sd), list(sd)[-4:]
+
+
+def test_cocondenser_checkpoint_layout_matches_the_reference(tmp_path):
+    """COCO/modeling.py:96-131: the reference's checkpoint is an AutoModelForMaskedLM directory (encoder under 'bert.',
+    MLM head under 'cls.predictions.') plus model.pt holding the wrapper's non-lm tensors (c_head.{i}.*).  Such a
+    directory loads into the native wrapper, and what the native wrapper writes loads back into transformers."""
+    import types
+    transformers = pytest.importorskip("transformers")
+    hf_cfg = transformers.BertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                     max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                     attn_implementation="eager")
+    torch.manual_seed(11)
+    hf = transformers.BertForMaskedLM(hf_cfg).eval()
+    with torch.no_grad():
+        hf.cls.predictions.bias.normal_()
+        hf.cls.predictions.transform.LayerNorm.bias.normal_()
+    d1 = tmp_path / "ref"
+    hf.save_pretrained(str(d1))
+    head_layers = [transformers.models.bert.modeling_bert.BertLayer(hf_cfg) for _ in range(2)]
+    c_head = {f"c_head.{i}.{k}": v.detach().clone() for i, l in enumerate(head_layers) for k, v in l.state_dict().items()}
+    torch.save({**c_head, "co_target": torch.arange(8)}, str(d1 / "model.pt"))   # the reference registers this buffer (:172-176)
+    margs = types.SimpleNamespace(n_head_layers=2, skip_from=1, late_mlm=False)
+    model = CoCondenserForPretraining.from_pretrained(margs, None, None, str(d1))
+    got = {k: v.detach().float().cpu() for k, v in model.c_head.state_dict().items()}
+    for k, v in c_head.items():
+        torch.testing.assert_close(got[k], v, rtol=0, atol=0)
+    hf_sd = hf.state_dict()
+    for k in ("cls.predictions.bias", "cls.predictions.transform.dense.weight", "cls.predictions.transform.dense.bias",
+              "cls.predictions.transform.LayerNorm.weight", "cls.predictions.transform.LayerNorm.bias"):
+        torch.testing.assert_close(got[k], hf_sd[k], rtol=0, atol=0)
+    d2 = tmp_path / "native"
+    model.to(DEV).save_pretrained(str(d2))
+    assert sorted(torch.load(str(d2 / "model.pt"), weights_only=True)) == sorted(c_head)
+    hf2, info = transformers.BertForMaskedLM.from_pretrained(str(d2), attn_implementation="eager", output_loading_info=True)
+    assert not info["missing_keys"] and not info["mismatched_keys"], info
+    sd2 = hf2.state_dict()
+    for k, v in hf_sd.items():
+        torch.testing.assert_close(sd2[k], v, rtol=0, atol=0, msg=k)
