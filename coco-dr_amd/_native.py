@@ -70,7 +70,7 @@ SIGNATURES = {
     "cocodr_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
     "cocodr_gemm_set_impl": (c_int, [c_int]),
     "cocodr_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "cocodr_attn_bwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
+    "cocodr_attn_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     "cocodr_embed_ln_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "cocodr_embed_bwd_partial_floats": (c_size_t, [c_int, c_int]),
     "cocodr_embed_ln_bwd": (c_int, [c_void_p] * 14 + [c_int, c_int, c_int, c_int, c_void_p]),

@@ -193,17 +193,72 @@ __device__ unsigned long long* g_attn_tl = nullptr;
 #endif
 
 // Backward.  All four [L][64] tiles of one (batch, head) live in LDS (L <= 256 -> 128 KiB).
+// Column sums of a transposed [32 rows x 64 columns] fp32 accumulator tile (the query / key bias gradient).  A lane holds
+// 32 columns of one row.  Per 16-column group the lanes of a 16-lane row pair up (lane ^ 8, then 7 - lane within 8 lanes):
+// both partners get the pair sums and keep the half of the value list their own lane bit selects; the quads then sum
+// their four remaining entries and each lane keeps one.  All of it is DPP operands of v_add_f32 - no LDS traffic - and
+// one cross-row add (lane ^ 16) finishes a group, after which lane l owns the sum of ONE column: list index
+// c = l & 31 (bit 4 = group) -> column qk_col(l).
+#ifdef COCODR_ABL_QK_NOSUM
+constexpr bool QK_ABL_NOSUM = true;
+#else
+constexpr bool QK_ABL_NOSUM = false;
+#endif
+// r = own + partner's value of the same list entry, where the quads in bank mask LO take entry a and the quads in HI take
+// entry b: two DPP adds whose bank masks do the selecting (hipcc does not fold a bank-masked update_dpp into the add, and
+// inline asm is invisible to its hazard recognizer: the s_nop covers the two wait states between a VALU write and a DPP read)
+#define COLSUM_PAIR(r, a, b, CTRL, LO, HI)                                                   \
+  asm volatile("s_nop 1\n\t"                                                                 \
+               "v_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" LO "\n\t"           \
+               "v_add_f32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:" HI                  \
+               : "=&v"(r) : "v"(a), "v"(b))
+#define COLSUM_QUAD(x, CTRL) \
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(x))
+__device__ __forceinline__ float acc_colsum32(const f32x16 (&o)[2], float mul, int lane) {
+  float out[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    float v[8], w[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)  // partner lane ^ 8; lanes 8..15 of a row (quads 2, 3) keep the upper half of the list
+      COLSUM_PAIR(v[i], o[dt][i], o[dt][i + 8], "row_ror:8", "0x3", "0xc");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // partner 7 - lane within 8 lanes (flips bit 2); quads 1, 3 keep the upper half
+      COLSUM_PAIR(w[i], v[i], v[i + 4], "row_half_mirror", "0x5", "0xa");
+    // the four lanes of a quad now hold the same four columns: full quad sums, then every lane keeps column (lane & 3)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      COLSUM_QUAD(w[i], "quad_perm:[1,0,3,2]");
+      COLSUM_QUAD(w[i], "quad_perm:[2,3,0,1]");
+    }
+    const float a = (lane & 1) ? w[1] : w[0], c = (lane & 1) ? w[3] : w[2];
+    const float q = (lane & 2) ? c : a;
+    out[dt] = q + __shfl_xor(q, 16, 64);
+  }
+  return ((lane & 16) ? out[1] : out[0]) * mul;
+}
+__device__ __forceinline__ int qk_col(int lane) {  // list index dt*16 + rg*4 + e of half (lane >> 5) -> d = dt*32 + 8*rg + 4*half + e
+  const int c = lane & 31;
+  return (c >> 4) * 32 + ((c >> 2) & 3) * 8 + 4 * (lane >> 5) + (c & 3);
+}
+// every wave leaves its own row: partial is [B][4 waves][2H] floats (query half | key half), no LDS pass and no barrier at
+// the end of the workgroup; a wave without a block of its own writes zeros
+__device__ __forceinline__ void qk_bias_store(float* partial, float acc, int which, int b, int h, int H, int tid) {
+  partial[((size_t)(b * 4 + (tid >> 6)) * 2 + which) * H + h * 64 + qk_col(tid & 63)] = acc;
+}
 //  phase A: wave <-> 32 queries,  S^T/dP^T layout (lane = query):  dQ^T += K^T dS^T
 //  phase B: wave <-> 32 keys,     S / dP layout   (lane = key):    dV^T += dO^T P,  dK^T += Q^T dS
+template <bool QKSUM>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                           const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
                                                           const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L,
-                                                          int H, int stagger) {
+                                                          int H, int stagger, float* __restrict__ qk_partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qt = smem;
   char* Kt = smem + L * 128;
   char* Vt = smem + 2 * L * 128;
   char* Dt = smem + 3 * L * 128;
+  float qacc = 0.f, kacc = 0.f;
   float* madd = reinterpret_cast<float*>(smem + 4 * L * 128);
   float* lse2 = madd + L;
   float* delta = lse2 + L;
@@ -308,8 +363,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     }
     ATTN_STAMP(2);
     store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
+    if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale, lane);
   }
   ATTN_STAMP(3);
+  if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, 0, b, h, H, tid);
 
   // ---------------- phase B: dK, dV
   for (int kb = wid; kb < nblk; kb += 4) {
@@ -362,8 +419,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
     store_acc_T16(row0 + H, ld, dk, kScale, lane);
     store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
+    if constexpr (QKSUM && !QK_ABL_NOSUM) kacc += acc_colsum32(dk, kScale, lane);
   }
   ATTN_STAMP(5);
+  if constexpr (QKSUM) qk_bias_store(qk_partial, kacc, 1, b, h, H, tid);
 }
 
 
@@ -376,10 +435,13 @@ __device__ __forceinline__ bf16x8 frag_rows_global(const uint16_t* base, int ld,
   return as_bf16x8(*reinterpret_cast<const uint4*>(base + (size_t)(r0 + (lane & 31)) * ld + (2 * s + (lane >> 5)) * 8));
 }
 
+template <bool QKSUM>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                              const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
-                                                             const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H) {
+                                                             const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H,
+                                                             float* __restrict__ qk_partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float qacc = 0.f;
   char* Kt = smem;
   char* Vt = smem + L * 128;
   float* madd = reinterpret_cast<float*>(smem + 2 * L * 128);
@@ -447,13 +509,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
       }
     }
     store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
+    if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale, lane);
   }
+  if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, 0, b, h, H, tid);
 }
 
+template <bool QKSUM>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                               const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
-                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H) {
+                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H,
+                                                              float* __restrict__ qk_partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float kacc = 0.f;
   char* Qt = smem;
   char* Dt = smem + L * 128;
   float* lse2 = reinterpret_cast<float*>(smem + 2 * L * 128);
@@ -546,7 +613,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
     uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
     store_acc_T16(row0 + H, ld, dk, kScale, lane);
     store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
+    if constexpr (QKSUM && !QK_ABL_NOSUM) kacc += acc_colsum32(dk, kScale, lane);
   }
+  if constexpr (QKSUM) qk_bias_store(qk_partial, kacc, 1, b, h, H, tid);
 }
 
 }  // namespace
@@ -577,7 +646,8 @@ extern "C" int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_
 }
 
 extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
-                               const float* lse, uint16_t* dqkv, int B, int L, int heads, cocodr_stream_t stream) {
+                               const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
+                               cocodr_stream_t stream) {
   CK_ARG(qkv && mask && ctx && dctx && lse && dqkv, "attn_bwd: null pointer");
   CK_ARG(B > 0 && heads > 0, "attn_bwd: bad shape");
   CK_ARG(L % 32 == 0 && L >= 32 && L <= 512, "attn_bwd: L=%d must be a multiple of 32 in [32,512]", L);
@@ -585,23 +655,24 @@ extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const u
   const size_t lds = (size_t)4 * L * 128 + (size_t)3 * L * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_ATTN, st, 10.0 * B * heads * (double)L * L * 64);
+  const bool qks = qk_bias_partial != nullptr;
   if (L > 256) {  // two kernels, each with the pair of [L,64] tiles it sweeps resident
-    static bool split_attr_done = false;
-    if (!split_attr_done) {
-      hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      split_attr_done = true;
-    }
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(heads, B), dim3(256), (size_t)2 * L * 128 + (size_t)L * 4, st, qkv, mask, ctx, dctx, lse,
-                       dqkv, L, H);
+    const size_t lds_q = (size_t)2 * L * 128 + (size_t)L * 4, lds_kv = (size_t)2 * L * 128 + (size_t)2 * L * 4;
+    hipLaunchKernelGGL(qks ? attn_bwd_dq_kernel<true> : attn_bwd_dq_kernel<false>, dim3(heads, B), dim3(256), lds_q, st, qkv, mask, ctx,
+                       dctx, lse, dqkv, L, H, qk_bias_partial);
     CK_LAUNCH("attn_bwd(dq)");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(heads, B), dim3(256), (size_t)2 * L * 128 + (size_t)2 * L * 4, st, qkv, mask, ctx, dctx,
-                       lse, dqkv, L, H);
+    hipLaunchKernelGGL(qks ? attn_bwd_dkv_kernel<true> : attn_bwd_dkv_kernel<false>, dim3(heads, B), dim3(256), lds_kv, st, qkv, mask, ctx,
+                       dctx, lse, dqkv, L, H, qk_bias_partial);
     CK_LAUNCH("attn_bwd(dkv)");
     return COCODR_OK;
   }
@@ -610,8 +681,8 @@ extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const u
     const char* e = getenv("COCODR_ATTN_STAGGER");
     stagger = e ? atoi(e) : 2;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(256), lds, st, qkv, mask, ctx, dctx, lse, dqkv, L, H,
-                     2 * lds <= 160 * 1024 && heads * B > 512 ? stagger : 0);
+  hipLaunchKernelGGL(qks ? attn_bwd_kernel<true> : attn_bwd_kernel<false>, dim3(heads, B), dim3(256), lds, st, qkv, mask, ctx, dctx, lse,
+                     dqkv, L, H, 2 * lds <= 160 * 1024 && heads * B > 512 ? stagger : 0, qk_bias_partial);
   CK_LAUNCH("attn_bwd");
   return COCODR_OK;
 }

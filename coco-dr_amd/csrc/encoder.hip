@@ -29,7 +29,7 @@ struct BwdLayout {
   size_t dy2, du, dy1, dqkv;  // bf16 [layers][M,*]
   size_t dxa, dxb, dctx;      // bf16 [M,H]
   size_t ln_partial, colsum_partial, emb_partial;  // fp32
-  size_t ln2_slots, ln1_slots, b1_slots, bv_slots;  // fp32 per-layer partial rows of the deferred reductions
+  size_t ln2_slots, ln1_slots, b1_slots, bv_slots, bqk_slots;  // fp32 per-layer partial rows of the deferred reductions
   size_t total;
 };
 
@@ -52,6 +52,7 @@ BwdLayout bwd_layout(const cocodr_config* c, int B, int L) {
   b.ln1_slots = cv.take(N * cocodr_ln_bwd_partial_floats((int)M, (int)H) * 4);
   b.b1_slots = cv.take(N * cocodr_gemm_colsum_partial_floats((int)M, (int)I) * 4);
   b.bv_slots = cv.take(N * cocodr_gemm_colsum_partial_floats((int)M, (int)H) * 4);
+  b.bqk_slots = cv.take(N * (size_t)4 * B * 2 * H * 4);  // attention backward: 4 B partial rows of dQ | dK column sums
   b.total = cv.off;
   return b;
 }
@@ -267,6 +268,8 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
   float* ln1_slots = (float*)(bb + bl.ln1_slots);
   float* b1_slots = (float*)(bb + bl.b1_slots);
   float* bv_slots = (float*)(bb + bl.bv_slots);
+  float* bqk_slots = (float*)(bb + bl.bqk_slots);
+  const size_t bqk_slot = (size_t)4 * B * 2 * H;
   long long s_vec = 0;
   bool defer = NG > 1;
   if (defer) {
@@ -325,7 +328,9 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
     if (rows_bv > 0) g.colsum_partial = bv_slots + li * rows_bv * H;
     else { g.colsum = gr.bqkv + 2 * H; g.colsum_partial = cs_partial; }
     TRY(cocodr_gemm(&g, stream));
-    TRY(cocodr_attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, L, c->heads, stream));
+    // the query / key bias gradients are column sums of dQ | dK: the attention backward leaves four partial rows per sequence
+    TRY(cocodr_attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, B, L, c->heads, stream));
+    if (!defer) TRY(cocodr_reduce_partials(bqk_slots + li * bqk_slot, gr.bqkv, nullptr, nullptr, 4 * B, 1, 2 * H, 1, 0, hst));
     g = gemm_base(dqkv, w.wqkv, dxb, M, H, 3 * H, 3 * H, H, H, 0, 1);  // dx = dqkv Wqkv + dy1 (residual branch)
     g.epi = COCODR_EPI_ADD; g.R = dy1; g.ldr = H;
     TRY(cocodr_gemm(&g, stream));
@@ -361,9 +366,8 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
     TRY(cocodr_reduce_partials(ln1_slots, g0.ln1_g, g0.ln1_b, g0.bo, P_ln, 3, H, NG, s_vec, hst));
     if (rows_b1 > 0) TRY(cocodr_reduce_partials(b1_slots, g0.b1, nullptr, nullptr, rows_b1, 1, I, NG, s_vec, hst));
     if (rows_bv > 0) TRY(cocodr_reduce_partials(bv_slots, g0.bqkv + 2 * H, nullptr, nullptr, rows_bv, 1, H, NG, s_vec, hst));
+    TRY(cocodr_reduce_partials(bqk_slots, g0.bqkv, nullptr, nullptr, 4 * B, 1, 2 * H, NG, s_vec, hst));
   }
-  // ---- the remaining bias gradients (query, key): batched column sums of the first 2H columns of the saved dqkv
-  TRY(cocodr_colsum(dqkv_all + l0 * sM3H, g0.bqkv, cs_partial, M, 2 * H, 3 * H, NG, sM3H, s_bqkv, stream));
   return COCODR_OK;
 }
 

@@ -109,16 +109,19 @@ def attn_fwd(qkv: torch.Tensor, mask: torch.Tensor, B: int, L: int, heads: int) 
     return ctx, lse
 
 
-def attn_bwd(qkv, mask, ctx, dctx, lse, B: int, L: int, heads: int) -> torch.Tensor:
+def attn_bwd(qkv, mask, ctx, dctx, lse, B: int, L: int, heads: int, qk_bias: bool = False):
+    """``qk_bias=True`` also returns the [4 B, 2H] fp32 partial column sums of dQ | dK (four rows per sequence; their sum over
+    all rows is the query / key bias gradient)."""
     H = heads * 64
     _req(qkv, BF16, "qkv", 2); _req(mask, I32, "mask", 2); _req(ctx, BF16, "ctx", 2); _req(dctx, BF16, "dctx", 2)
     _req(lse, F32, "lse", 3)
     if tuple(qkv.shape) != (B * L, 3 * H) or tuple(ctx.shape) != (B * L, H) or tuple(dctx.shape) != (B * L, H):
         raise ValueError("attn_bwd: shape mismatch")
     dqkv = torch.empty_like(qkv)
-    check(lib().cocodr_attn_bwd(ptr(qkv), ptr(mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), B, L, heads, stream_ptr()),
-          "attn_bwd")
-    return dqkv
+    part = torch.empty((4 * B, 2 * H), dtype=F32, device=qkv.device) if qk_bias else None
+    check(lib().cocodr_attn_bwd(ptr(qkv), ptr(mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(part) if qk_bias else None,
+                                B, L, heads, stream_ptr()), "attn_bwd")
+    return (dqkv, part) if qk_bias else dqkv
 
 
 # ----------------------------------------------------------------------------------------------- row kernels

@@ -98,9 +98,14 @@ int cocodr_gemm_set_impl(int impl);
 int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse,
                     int B, int L, int heads, cocodr_stream_t stream);
 /* backward: dqkv [B*L, 3H] (dQ | dK | dV) from dctx; L <= 512 (one kernel with all four [L,64] tiles of a
- * (batch, head) in LDS up to L = 256, a dQ kernel + a dK/dV kernel above that) */
+ * (batch, head) in LDS up to L = 256, a dQ kernel + a dK/dV kernel above that).
+ * qk_bias_partial (or NULL): [4 B, 2H] fp32 partial column sums of dQ | dK from the fp32 accumulators (rows 4b .. 4b+3
+ * together cover the L rows of sequence b; one row per wave of the workgroup) - summed over all 4 B rows they are the
+ * query / key bias gradients (hf BertSelfAttention's nn.Linear biases), so the 2H dQ | dK columns need not be read
+ * again for them. */
 int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
-                    const float* lse, uint16_t* dqkv, int B, int L, int heads, cocodr_stream_t stream);
+                    const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
+                    cocodr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row kernels (HBM bound)

@@ -153,10 +153,20 @@ def test_attention_bwd(B, L, heads):
     mask = make_mask(B, L, seed=L + 1)
     dctx = rnd(B * L, H, seed=14)
     ctx, lse = ops.attn_fwd(qkv, mask, B, L, heads)
-    dqkv = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, heads)
+    dqkv, part = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, heads, qk_bias=True)
+    plain = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, heads)
+    assert torch.equal(plain, dqkv)
     q = qkv.float().clone().requires_grad_(True)
     rctx, _ = ref_attention(q, mask, B, L, heads)
     rctx.backward(dctx.float())
+    # fused query / key bias partials: column sums of dQ | dK (four partial rows per sequence), taken from the fp32 accumulators (the stored
+    # values are their bf16 roundings); the key half is pure rounding noise around an exact zero (softmax shift invariance)
+    part = part.view(B, 4, 2 * H).sum(1)
+    stored = dqkv[:, :2 * H].float().view(B, L, 2 * H).sum(1)
+    want = q.grad[:, :2 * H].view(B, L, 2 * H).sum(1)
+    scale = float(want[:, :H].abs().max())
+    assert rel_l2(part[:, :H], want[:, :H]) < 2e-2
+    assert float((part - stored).abs().max()) < 2e-2 * scale and float(part[:, H:].abs().max()) < 2e-2 * scale
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
         assert rel_l2(dqkv[:, sl], q.grad[:, sl]) < 2e-2, name
 

@@ -46,7 +46,7 @@ def main():
     assert lib.cocodr_attn_fwd(p(qkv), p(mask), p(ctx), p(lse), B, L, heads, st) == 0
     for _ in range(3):
         stamps.zero_()
-        assert lib.cocodr_attn_bwd(p(qkv), p(mask), p(ctx), p(dctx), p(lse), p(dqkv), B, L, heads, st) == 0
+        assert lib.cocodr_attn_bwd(p(qkv), p(mask), p(ctx), p(dctx), p(lse), p(dqkv), None, B, L, heads, st) == 0
         torch.cuda.synchronize()
     s = stamps.cpu().numpy().astype(np.float64)
     t0 = s[:, 0].min()
