@@ -265,10 +265,10 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int BMv, int BKv, int WTM, int WTN, int LD = 0>
+template <int BMv, int BKv, int WTM, int WTN, int LD = 0, int WC = 2>
 struct Geom {
-  static constexpr int BNv = 64 * WTN;  // two wave columns of 32*WTN
-  static constexpr int NWAVES = (BMv / (32 * WTM)) * 2;  // MFMA waves
+  static constexpr int BNv = 32 * WTN * WC;  // WC wave columns of 32*WTN
+  static constexpr int NWAVES = (BMv / (32 * WTM)) * WC;  // MFMA waves
   static constexpr int NLOAD = LD;                       // dedicated loader waves (0: the MFMA waves issue the DMA themselves)
   static constexpr int NISSUE = LD ? LD : NWAVES;        // waves that issue DMA pieces
   static constexpr int NTHREADS = (NWAVES + NLOAD) * 64;
@@ -303,9 +303,10 @@ __device__ __forceinline__ int tile_rows_off(int row, int ch) {
 // chunk swizzle of a [k][COLS] tile read with ds_read_b64_tr_b16 (4 rows x 64 B per 32 lanes): rows r..r+3 must fall
 // into the four 64-B windows of a 256-B bank row.  256-B / 512-B rows: XOR the chunk with (row & 3) << 2; 384-B rows
 // (COLS = 192) already alternate 128-B halves, so only bit 2 is flipped on rows 2,3 (keeps chunk < 24).
+// 192-B rows (COLS = 96) step through the four windows by themselves (0, 192, 128, 64 mod 256): no swizzle.
 template <int COLS>
 __device__ __forceinline__ int swz_cols(int row) {
-  return COLS == 192 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
+  return COLS == 96 ? 0 : (COLS == 192 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2));
 }
 
 // byte offset (relative to the matrix base) of the 16-B chunk that must land at linear LDS chunk p of a tile
@@ -428,16 +429,16 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
   }
 }
 
-template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, bool OUT_F32>
-__global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD>::NTHREADS), (Geom<BMv, BKv, WTM, WTN, LD>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
+template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, bool OUT_F32, int WC = 2>
+__global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC>::NTHREADS), (Geom<BMv, BKv, WTM, WTN, LD, WC>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
     const cocodr_gemm_args p, const int stagger) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type only exists in the device pass; the host pass just needs the stub
-  using G = Geom<BMv, BKv, WTM, WTN, LD>;
+  using G = Geom<BMv, BKv, WTM, WTN, LD, WC>;
   constexpr int BNv = G::BNv;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WC, wn = wid % WC;
   const int ntn = p.N / BNv, ntm = (p.M + BMv - 1) / BMv;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   int tm_, tn_;
@@ -702,16 +703,16 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD>::NTHREADS), (Geom<BMv
 #endif
 }
 
-template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB>
+template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, int WC = 2>
 void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
-  using G = Geom<BMv, BKv, WTM, WTN, LD>;
+  using G = Geom<BMv, BKv, WTM, WTN, LD, WC>;
   const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / G::BNv;
   dim3 grid(ntm * ntn, a.batch);
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   static int stagger = -1;  // x 4096 clocks; COCODR_GEMM_STAGGER overrides (0 disables)
@@ -721,16 +722,16 @@ void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
   }
   const int sg = (int)(grid.x * grid.y) > 256 * G::WG_PER_CU / 2 ? stagger : 0;
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true>), grid, dim3(G::NTHREADS), lds, st, a, sg);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true, WC>), grid, dim3(G::NTHREADS), lds, st, a, sg);
   else
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false>), grid, dim3(G::NTHREADS), lds, st, a, sg);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false, WC>), grid, dim3(G::NTHREADS), lds, st, a, sg);
 }
 
-template <int BMv, int BKv, int WTM, int WTN = 2, int LD = 0>
+template <int BMv, int BKv, int WTM, int WTN = 2, int LD = 0, int WC = 2>
 void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
-  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 0>(a, st);
-  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 1>(a, st);
-  else launch_glds<BMv, BKv, WTM, WTN, LD, 1, 1>(a, st);
+  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 0, WC>(a, st);
+  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 1, WC>(a, st);
+  else launch_glds<BMv, BKv, WTM, WTN, LD, 1, 1, WC>(a, st);
 }
 
 }  // namespace cocodr_gemm_v2
@@ -738,7 +739,7 @@ using cocodr_gemm_v2::launch_glds_any;
 
 namespace {
 
-int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, direct-to-LDS <BM,BK,WTM>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile <128,64,2> with 64x96 wave tiles, 9 = <256,64,2> + 4 loader waves, 10 = <256,64,4> + 4 loader waves
+int g_gemm_impl = -1;  // 0 = auto, 1 = register-staged v1, direct-to-LDS <BM,BK,WTM>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile <128,64,2> with 64x96 wave tiles, 9 = <256,64,2> + 4 loader waves, 10 = <256,64,4> + 4 loader waves, 11 = 256x256 tile, 12 = 256x96 tile: 4x3 waves of 64x32 + 4 loader waves
 int gemm_impl_override() {
   if (g_gemm_impl < 0) {
     const char* e = getenv("COCODR_GEMM_IMPL");
@@ -758,7 +759,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG(impl >= 0 && impl <= 11, "gemm_set_impl: impl must be in [0,11]");
+  CK_ARG(impl >= 0 && impl <= 12, "gemm_set_impl: impl must be in [0,12]");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -780,7 +781,14 @@ int select_impl(const cocodr_gemm_args& a) {
     // to 128-row tiles to occupy more CUs.
     const long long tiles256 = (long long)((a.M + 255) / 256) * (a.N / BN) * batch;
     const long long tiles128 = (long long)((a.M + 127) / 128) * (a.N / BN) * batch;
+    // 256x96 tiles (no fused column sums there): when they need fewer rounds of the 256 CUs even at 3/4 of a tile's work
+    // each - the N = 768 GEMMs of 8192 tokens become exactly one tile per CU instead of 192 tiles, QKV 3 rounds of
+    // smaller tiles instead of 2.25 (measured 2-8 % on those shapes; the long-K wgrads lose 10-60 % and stay out)
+    const long long tiles96 = a.N % 96 == 0 ? (long long)((a.M + 255) / 256) * (a.N / 96) * batch : 0;
+    static const bool no96 = getenv("COCODR_GEMM_NO96") != nullptr;  // A/B switch of this rule
+    const bool fewer_rounds = !no96 && tiles96 > 0 && ((tiles96 + 255) / 256) * 3 < ((tiles256 + 255) / 256) * 4;
     if (!(k_ok && small)) impl = 1;
+    else if (fewer_rounds && !a.trans_a && tiles256 >= 128 && !a.colsum && !a.colsum_partial) impl = 12;
     else if (tiles256 >= 384 && !(a.trans_a && tiles256 < 800) && !(!a.trans_a && a.K >= 2048)) impl = 5;
     else if (tiles256 >= 128) impl = 9;
     else impl = tiles128 >= 512 ? 4 : 2;
@@ -788,11 +796,12 @@ int select_impl(const cocodr_gemm_args& a) {
   if (impl != 1 && !(k_ok && small)) impl = 1;
   if (impl == 8 && a.N % 192 != 0) impl = 3;  // the 128x192 tile needs N % 192 == 0
   if (impl == 11 && a.N % 256 != 0) impl = 5;  // the 256x256 tile needs N % 256 == 0
+  if (impl == 12 && a.N % 96 != 0) impl = 9;   // the 256x96 tile needs N % 96 == 0
   return impl;
 }
 // row panels of the fused column sums for that pipeline (0: not fused there)
 int colsum_rows(int impl, int M) {
-  if (impl == 1 || impl == 8 || impl == 11) return 0;
+  if (impl == 1 || impl == 8 || impl == 11 || impl == 12) return 0;
   const int bm = (impl == 2 || impl == 4) ? 128 : 256;
   return (M + bm - 1) / bm;
 }
@@ -800,7 +809,10 @@ int colsum_rows(int impl, int M) {
 
 extern "C" int cocodr_gemm_colsum_rows(const cocodr_gemm_args* args) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0 || args->N % BN != 0 || args->batch > 1 || args->out_f32) return 0;
-  return colsum_rows(select_impl(*args), args->M);
+  cocodr_gemm_args q = *args;
+  static float dummy;
+  if (!q.colsum_partial) q.colsum_partial = &dummy;  // "which pipeline would this call run on with column sums requested"
+  return colsum_rows(select_impl(q), q.M);
 }
 
 extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream) {
@@ -835,7 +847,8 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   const int cs_rows = colsum_rows(impl, a.M);  // the kernels with 128-column tiles reduce in their epilogue
   CK_ARG(!cs_part || cs_out || cs_rows > 0, "gemm: deferred column sums (colsum == NULL) are not available on this pipeline; ask cocodr_gemm_colsum_rows first");
   if (cs_rows == 0) a.colsum_partial = nullptr;
-  if (impl == 11) launch_glds_any<256, 32, 2, 4>(a, st);
+  if (impl == 12) launch_glds_any<256, 64, 2, 1, 4, 3>(a, st);
+  else if (impl == 11) launch_glds_any<256, 32, 2, 4>(a, st);
   else if (impl == 10) launch_glds_any<256, 64, 4, 2, 4>(a, st);
   else if (impl == 9) launch_glds_any<256, 64, 2, 2, 4>(a, st);
   else if (impl == 8) launch_glds_any<128, 64, 2, 3>(a, st);

@@ -85,7 +85,8 @@ int cocodr_gemm_colsum_rows(const cocodr_gemm_args* args);
 int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream);
 /* tuning / test hook: 0 = auto, 1 = register-staged pipeline,
  * direct-to-LDS <BM,BK,wave rows/32>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile,
- * 9 / 10 = 3 / 7 with four dedicated loader waves per workgroup
+ * 9 / 10 = 3 / 7 with four dedicated loader waves per workgroup, 11 = 256x256 tile, 12 = 256x96 tile (4x3 MFMA waves of
+ * 64x32 + four loader waves; N % 96 == 0, makes the N = 768 GEMMs of 8192 tokens exactly one tile per CU)
  * (also settable through the COCODR_GEMM_IMPL environment variable) */
 int cocodr_gemm_set_impl(int impl);
 
