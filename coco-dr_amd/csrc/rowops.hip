@@ -11,9 +11,11 @@ namespace {
 
 constexpr int MAXC = 4;  // chunks per lane -> H <= 1024
 
-struct RowVec {
-  float v[MAXC][4];
+template <int NC>
+struct RowVecT {
+  float v[NC][4];
 };
+using RowVec = RowVecT<MAXC>;
 
 __device__ __forceinline__ void load_bf16_row(const uint16_t* row, int nch, int lane, RowVec& r) {
 #pragma unroll
@@ -33,9 +35,10 @@ __device__ __forceinline__ void load_f32_row(const float* row, int nch, int lane
     } else r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
   }
 }
-__device__ __forceinline__ void store_bf16_row(uint16_t* row, int nch, int lane, const RowVec& r) {
+template <int NC>
+__device__ __forceinline__ void store_bf16_row(uint16_t* row, int nch, int lane, const RowVecT<NC>& r) {
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) *reinterpret_cast<uint2*>(row + c * 4) = pack4(r.v[i]);
   }
@@ -138,12 +141,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const uint16_t* __restrict_
 // LayerNorm backward core for one row held in registers:
 //   in : d = upstream gradient, x = LN input (pre-normalisation)
 //   out: d <- gradient w.r.t. the LN input; dg/db accumulate the gamma/beta gradients.
-__device__ __forceinline__ void ln_bwd_row(RowVec& d, const RowVec& x, const float* gamma, int nch, int lane, int H, float mean,
-                                           float rstd, RowVec& dg, RowVec& db) {
-  RowVec xh;
+template <int NC>
+__device__ __forceinline__ void ln_bwd_row(RowVecT<NC>& d, const RowVecT<NC>& x, const float* gamma, int nch, int lane, int H, float mean,
+                                           float rstd, RowVecT<NC>& dg, RowVecT<NC>& db) {
+  RowVecT<NC> xh;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
       const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * 4);
@@ -165,7 +169,7 @@ __device__ __forceinline__ void ln_bwd_row(RowVec& d, const RowVec& x, const flo
   s1 = wave_sum(s1) / (float)H;
   s2 = wave_sum(s2) / (float)H;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i)
+  for (int i = 0; i < NC; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) d.v[i][e] = rstd * (d.v[i][e] - s1 - xh.v[i][e] * s2);
 }
@@ -191,40 +195,116 @@ __device__ __forceinline__ void block_reduce_store(const RowVec& acc, float* lds
   }
 }
 
-__device__ __forceinline__ void zero_row(RowVec& r) {
+template <int NC>
+__device__ __forceinline__ void zero_row(RowVecT<NC>& r) {
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
+  for (int i = 0; i < NC; ++i) r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
 }
 
+// all `nseg` accumulator rows of the workgroup in as few LDS passes as the 160 KiB allow (three rows of H = 768 at once,
+// two of H = 1024): every wave writes its rows, one barrier, then nseg x H/4 threads each add the NW waves' float4 in wave
+// order (deterministic) and store the partial row.  red: [rows in pass][NW][H] floats.
+template <int NC>
+__device__ __forceinline__ void lds_put_row(const RowVecT<NC>& a, float* dst, int nch, int lane) {
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) *reinterpret_cast<float4*>(dst + c * 4) = make_float4(a.v[i][0], a.v[i][1], a.v[i][2], a.v[i][3]);
+  }
+}
+template <int NC>
+__device__ __forceinline__ void block_reduce_store_rows(const RowVecT<NC>& a0, const RowVecT<NC>& a1, const RowVecT<NC>& a2, int nseg, int per_pass,
+                                                        float* red, float* prow, int H, int nch, int tid) {
+  const int lane = tid & 63, wid = tid >> 6;
+  for (int s0 = 0; s0 < nseg; s0 += per_pass) {
+    const int ns = min(per_pass, nseg - s0);
+    if (s0 > 0) __syncthreads();
+    // the accumulators stay in registers: no indexing by a run-time row number
+    if (0 >= s0 && 0 < s0 + ns) lds_put_row(a0, red + ((size_t)(0 - s0) * NW + wid) * H, nch, lane);
+    if (1 >= s0 && 1 < s0 + ns) lds_put_row(a1, red + ((size_t)(1 - s0) * NW + wid) * H, nch, lane);
+    if (2 >= s0 && 2 < s0 + ns && nseg > 2) lds_put_row(a2, red + ((size_t)(2 - s0) * NW + wid) * H, nch, lane);
+    __syncthreads();
+    for (int t = tid; t < ns * nch; t += RB_THREADS) {
+      const int sgm = t / nch, c = t - sgm * nch;
+      const float* src = red + (size_t)sgm * NW * H + c * 4;
+      float4 acc = *reinterpret_cast<const float4*>(src);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)w * H);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(prow + (size_t)(s0 + sgm) * H + c * 4) = acc;
+    }
+  }
+}
+
+template <int NC>
+struct RawRow {
+  uint2 v[NC];
+};
+template <int NC>
+__device__ __forceinline__ void load_raw_row(const uint16_t* row, int nch, int lane, RawRow<NC>& r) {
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    r.v[i] = c < nch ? *reinterpret_cast<const uint2*>(row + c * 4) : make_uint2(0u, 0u);
+  }
+}
+template <int NC>
+__device__ __forceinline__ void unpack_raw_row(const RawRow<NC>& r, RowVecT<NC>& o) {
+#pragma unroll
+  for (int i = 0; i < NC; ++i) unpack4(r.v[i], o.v[i]);
+}
+
+// NC = 16-B fp32 chunks per lane: 3 covers H <= 768 (a quarter fewer registers than the general 4: no spills at 4 waves / SIMD)
+template <int NC, bool PREFETCH>
 __global__ __launch_bounds__(RB_THREADS) void ln_bwd_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, uint16_t* __restrict__ dy,
-                                                     float* __restrict__ partial, int M, int H, int nseg) {
-  __shared__ __attribute__((aligned(16))) float red[NW * MAXC * 256];
+                                                     float* __restrict__ partial, int M, int H, int nseg, int per_pass) {
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
   const int rows_per = (M + gridDim.x - 1) / gridDim.x;
   const int r_begin = blockIdx.x * rows_per, r_end = min(M, r_begin + rows_per);
-  RowVec dg, db, dxs;  // dxs: column sums of the input gradient = bias gradient of the Linear that feeds this LayerNorm
+  RowVecT<NC> dg, db, dxs;  // dxs: column sums of the input gradient = bias gradient of the Linear that feeds this LayerNorm
   zero_row(dg);
   zero_row(db);
   zero_row(dxs);
-  for (int row = r_begin + wid; row < r_end; row += NW) {
-    RowVec d, x;
-    load_bf16_row(dout + (size_t)row * H, nch, lane, d);
-    load_bf16_row(y + (size_t)row * H, nch, lane, x);
-    ln_bwd_row(d, x, gamma, nch, lane, H, mean_i[row], rstd_i[row], dg, db);
+  // the next row's loads are in flight while this row is reduced and stored
+  int row = r_begin + wid;
+  RawRow<NC> nd, nx;
+  float nmean = 0.f, nrstd = 0.f;
+  if (row < r_end) {
+    load_raw_row(dout + (size_t)row * H, nch, lane, nd);
+    load_raw_row(y + (size_t)row * H, nch, lane, nx);
+    nmean = mean_i[row]; nrstd = rstd_i[row];
+  }
+  for (; row < r_end; row += NW) {
+    RowVecT<NC> d, x;
+    unpack_raw_row(nd, d);
+    unpack_raw_row(nx, x);
+    const float mean = nmean, rstd = nrstd;
+    const int nrow = row + NW;
+    if (PREFETCH && nrow < r_end) {
+      load_raw_row(dout + (size_t)nrow * H, nch, lane, nd);
+      load_raw_row(y + (size_t)nrow * H, nch, lane, nx);
+      nmean = mean_i[nrow]; nrstd = rstd_i[nrow];
+    }
+    ln_bwd_row(d, x, gamma, nch, lane, H, mean, rstd, dg, db);
     store_bf16_row(dy + (size_t)row * H, nch, lane, d);
     if (nseg == 3) {
 #pragma unroll
-      for (int i = 0; i < MAXC; ++i)
+      for (int i = 0; i < NC; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dxs.v[i][e] += d.v[i][e];
     }
+    if (!PREFETCH && nrow < r_end) {  // H = 1024: the extra row in registers would spill at 4 waves / SIMD
+      load_raw_row(dout + (size_t)nrow * H, nch, lane, nd);
+      load_raw_row(y + (size_t)nrow * H, nch, lane, nx);
+      nmean = mean_i[nrow]; nrstd = rstd_i[nrow];
+    }
   }
-  float* prow = partial + (size_t)blockIdx.x * nseg * H;
-  block_reduce_store(dg, red, prow, nch, tid);
-  block_reduce_store(db, red, prow + H, nch, tid);
-  if (nseg == 3) block_reduce_store(dxs, red, prow + 2 * H, nch, tid);
+  block_reduce_store_rows(dg, db, dxs, nseg, per_pass, red_dyn, partial + (size_t)blockIdx.x * nseg * H, H, nch, tid);
 }
 
 // grid.x = L (one workgroup per position): the position-embedding gradient row is a plain sum over
@@ -378,6 +458,23 @@ __global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restric
 int colsum_splits(int M) { return M >= 4096 ? 32 : (M >= 512 ? 8 : 1); }
 int ln_bwd_blocks(int M) { return M >= 256 * NW ? 256 : (M + NW - 1) / NW; }
 
+int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd, uint16_t* dy,
+                  float* partial, int M, int H, int nseg, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const size_t row_bytes = (size_t)NW * H * 4;  // one accumulator row of every wave
+  const int per_pass = std::max(1, std::min(nseg, (int)((160 * 1024) / row_bytes)));
+  auto kern = H <= 768 ? ln_bwd_kernel<3, true> : ln_bwd_kernel<MAXC, false>;
+  hipLaunchKernelGGL(kern, dim3(ln_bwd_blocks(M)), dim3(RB_THREADS), per_pass * row_bytes, st, dout, y, gamma, mean, rstd, dy, partial, M, H,
+                     nseg, per_pass);
+  CK_LAUNCH("ln_bwd");
+  return COCODR_OK;
+}
+
 int launch_reduce(const float* partial, float* o0, float* o1, float* o2, int P, int nseg, int n_len, int batch, long long stride_out,
                   hipStream_t st) {
   ReduceArgs a;
@@ -399,9 +496,7 @@ int cocodr_reduce_partials(const float* partial, float* o0, float* o1, float* o2
 int cocodr_ln_bwd_blocks(int M) { return ln_bwd_blocks(M); }
 int cocodr_ln_bwd_partials(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
                            uint16_t* dy, float* partial, int M, int H, int nseg, hipStream_t st) {
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_bwd_blocks(M)), dim3(RB_THREADS), 0, st, dout, y, gamma, mean, rstd, dy, partial, M, H, nseg);
-  CK_LAUNCH("ln_bwd");
-  return COCODR_OK;
+  return launch_ln_bwd(dout, y, gamma, mean, rstd, dy, partial, M, H, nseg, st);
 }
 
 namespace {
@@ -462,8 +557,7 @@ extern "C" int cocodr_ln_bwd(const uint16_t* dout, const uint16_t* y, const floa
   hipStream_t st = (hipStream_t)stream;
   const int P = ln_bwd_blocks(M);
   const int nseg = dy_colsum ? 3 : 2;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(P), dim3(RB_THREADS), 0, st, dout, y, gamma, mean, rstd, dy, partial, M, H, nseg);
-  CK_LAUNCH("ln_bwd");
+  if (int rc = launch_ln_bwd(dout, y, gamma, mean, rstd, dy, partial, M, H, nseg, st)) return rc;
   return launch_reduce(partial, dgamma, dbeta, dy_colsum, P, nseg, H, 1, 0, st);
 }
 
