@@ -242,7 +242,11 @@ __device__ __forceinline__ int qk_col(int lane) {  // list index dt*16 + rg*4 + 
   return (c >> 4) * 32 + ((c >> 2) & 3) * 8 + 4 * (lane >> 5) + (c & 3);
 }
 // every wave leaves its own row: partial is [B][4 waves][2H] floats (query half | key half), no LDS pass and no barrier at
-// the end of the workgroup; a wave without a block of its own writes zeros
+// the end of the workgroup; a wave without a block of its own writes zeros.
+// The key half is written as exact zeros: sum_k dK[k] = scale * sum_q Q[q] * (sum_k dS[q][k]) and every row of dS sums to
+// P.dP - delta * sum(P) = 0 (softmax shift invariance: the scores do not depend on the key bias).  The fp32 reference gets
+// rounding noise ~1e-7 of the other gradients there, far below Adam's eps; summing the bf16 pipeline's dK would instead
+// hand the optimizer noise it treats as a gradient.
 __device__ __forceinline__ void qk_bias_store(float* partial, float acc, int which, int b, int h, int H, int tid) {
   partial[((size_t)(b * 4 + (tid >> 6)) * 2 + which) * H + h * 64 + qk_col(tid & 63)] = acc;
 }
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   char* Kt = smem + L * 128;
   char* Vt = smem + 2 * L * 128;
   char* Dt = smem + 3 * L * 128;
-  float qacc = 0.f, kacc = 0.f;
+  float qacc = 0.f;
   float* madd = reinterpret_cast<float*>(smem + 4 * L * 128);
   float* lse2 = madd + L;
   float* delta = lse2 + L;
@@ -419,10 +423,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
     store_acc_T16(row0 + H, ld, dk, kScale, lane);
     store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
-    if constexpr (QKSUM && !QK_ABL_NOSUM) kacc += acc_colsum32(dk, kScale, lane);
   }
   ATTN_STAMP(5);
-  if constexpr (QKSUM) qk_bias_store(qk_partial, kacc, 1, b, h, H, tid);
+  if constexpr (QKSUM) qk_bias_store(qk_partial, 0.f, 1, b, h, H, tid);  // key half: see qk_bias_store
 }
 
 
@@ -520,7 +523,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
                                                               const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H,
                                                               float* __restrict__ qk_partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float kacc = 0.f;
   char* Qt = smem;
   char* Dt = smem + L * 128;
   float* lse2 = reinterpret_cast<float*>(smem + 2 * L * 128);
@@ -613,9 +615,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
     uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
     store_acc_T16(row0 + H, ld, dk, kScale, lane);
     store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
-    if constexpr (QKSUM && !QK_ABL_NOSUM) kacc += acc_colsum32(dk, kScale, lane);
   }
-  if constexpr (QKSUM) qk_bias_store(qk_partial, kacc, 1, b, h, H, tid);
+  if constexpr (QKSUM) qk_bias_store(qk_partial, 0.f, 1, b, h, H, tid);  // key half: see qk_bias_store
 }
 
 }  // namespace

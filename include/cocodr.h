@@ -103,7 +103,8 @@ int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, flo
  * qk_bias_partial (or NULL): [4 B, 2H] fp32 partial column sums of dQ | dK from the fp32 accumulators (rows 4b .. 4b+3
  * together cover the L rows of sequence b; one row per wave of the workgroup) - summed over all 4 B rows they are the
  * query / key bias gradients (hf BertSelfAttention's nn.Linear biases), so the 2H dQ | dK columns need not be read
- * again for them. */
+ * again for them.  The key half is exact zeros: the rows of dS sum to zero, so the key-bias gradient vanishes identically
+ * (the fp32 reference produces rounding noise ~1e-7 of the other gradients there). */
 int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
                     const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
                     cocodr_stream_t stream);
