@@ -228,6 +228,17 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// "all but the k most recently issued stages (NP loads each) have landed", k wave-uniform in [0, KMAX]
+template <int NP, int KMAX, int K = 0>
+__device__ __forceinline__ void wait_vmcnt_stages(int k) {
+  static_assert(NP * KMAX <= 63, "vmcnt is a 6-bit counter");
+  if constexpr (K >= KMAX) {
+    wait_vmcnt<NP * KMAX>();
+  } else {
+    if (k == K) wait_vmcnt<NP * K>();
+    else wait_vmcnt_stages<NP, KMAX, K + 1>(k);
+  }
+}
 template <int N>
 __device__ __forceinline__ void wait_lgkmcnt() {
   __builtin_amdgcn_sched_barrier(0);
@@ -265,7 +276,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int BMv, int BKv, int WTM, int WTN, int LD = 0, int WC = 2>
+template <int BMv, int BKv, int WTM, int WTN, int LD = 0, int WC = 2, int NS = 3>
 struct Geom {
   static constexpr int BNv = 32 * WTN * WC;  // WC wave columns of 32*WTN
   static constexpr int NWAVES = (BMv / (32 * WTM)) * WC;  // MFMA waves
@@ -280,7 +291,9 @@ struct Geom {
   static constexpr int GA = (A_BYTES / 1024) / NISSUE;  // wave-level 1 KiB loads per stage and issuing wave
   static constexpr int GB = (B_BYTES / 1024) / NISSUE;
   static_assert(GA * NISSUE * 1024 == A_BYTES && GB * NISSUE * 1024 == B_BYTES, "operand tiles must split evenly over the issuing waves");
-  static constexpr int NSTAGE = 3;
+  static constexpr int NSTAGE = NS;  // ring depth: NS - 1 stages are in flight or landed ahead of the one being read.  Six 24-KiB
+                                     // stages (BK = 32) instead of three 48-KiB ones measured 10-20 % SLOWER on every encoder shape
+                                     // (profiles/r01k_gemm_ring_depth.txt): a K-step costs ~0.17 us of hand-off however short it is
   static constexpr int KS = BKv / 16;  // MFMA K-sub-steps per stage
   static constexpr int WG_PER_CU = (160 * 1024) / (NSTAGE * STAGE);
   static constexpr int MIN_WAVES_PER_SIMD = (WG_PER_CU * (NWAVES + NLOAD) + 3) / 4;
@@ -429,11 +442,11 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
   }
 }
 
-template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, bool OUT_F32, int WC = 2>
-__global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC>::NTHREADS), (Geom<BMv, BKv, WTM, WTN, LD, WC>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
+template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, bool OUT_F32, int WC = 2, int NS = 3>
+__global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC, NS>::NTHREADS), (Geom<BMv, BKv, WTM, WTN, LD, WC, NS>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
     const cocodr_gemm_args p, const int stagger) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type only exists in the device pass; the host pass just needs the stub
-  using G = Geom<BMv, BKv, WTM, WTN, LD, WC>;
+  using G = Geom<BMv, BKv, WTM, WTN, LD, WC, NS>;
   constexpr int BNv = G::BNv;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -515,24 +528,22 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC>::NTHREADS), (Geom
   // sub-step's MFMAs, and the next stage's first fragments are requested right behind it: the barrier wait and that
   // read latency are covered by the MFMAs still executing, instead of opening a bubble at every K-step boundary.
   const int nt = (p.K + BKv - 1) / BKv;
+  constexpr int D = G::NSTAGE - 1;  // prefetch distance: stage t + D is requested once stage t - 1 has been released
   if (SELF_ISSUE || is_loader) {
-    static_for<0, NP>([&](auto jc) { issue_piece(jc, 0); });
-    if (nt > 1) {
-      static_for<0, NP>([&](auto jc) { issue_piece(jc, 1); });
-      wait_vmcnt<NP>();
-    } else {
-      wait_vmcnt<0>();
-    }
+    static_for<0, D>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      if (d < nt) static_for<0, NP>([&](auto jc) { issue_piece(jc, d); });
+    });
+    wait_vmcnt_stages<NP, D - 1>(min(nt, D) - 1);
   }
   __builtin_amdgcn_s_barrier();  // barrier 0: stage 0 complete
   if (is_loader) {
-    // loader wave: after barrier t every MFMA wave has finished reading stage t-1 = (t+2) % 3 -> refill it, then hand
-    // over stage t+1 (own pieces landed) at barrier t+1.  Same barrier sequence as the MFMA waves below.
+    // loader wave: after barrier t every MFMA wave has finished reading stage t-1 -> refill its slot with stage t+D, then
+    // hand over stage t+1 (own pieces landed) at barrier t+1.  Same barrier sequence as the MFMA waves below.
     for (int t = 0; t < nt; ++t) {
-      if (t + 2 < nt) static_for<0, NP>([&](auto jc) { issue_piece(jc, t + 2); });
+      if (t + D < nt) static_for<0, NP>([&](auto jc) { issue_piece(jc, t + D); });
       if (t + 1 < nt) {
-        if (t + 2 < nt) wait_vmcnt<NP>();
-        else wait_vmcnt<0>();
+        wait_vmcnt_stages<NP, D - 1>(min(nt - 1, t + D) - (t + 1));  // stages requested beyond t + 1 may stay in flight
         __builtin_amdgcn_s_barrier();
       }
     }
@@ -553,33 +564,30 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC>::NTHREADS), (Geom
 #endif
   constexpr int SLOTS = G::KS - 1;  // DMA issue slots per K-step (in front of the MFMAs of sub-steps 0 .. KS-2)
   for (int t = 0; t < nt; ++t) {
-    const bool more = SELF_ISSUE && t + 2 < nt;  // every wave is past barrier t: stage (t+2) % 3 == (t-1) % 3 is free
+    const bool more = SELF_ISSUE && t + D < nt;  // every wave is past barrier t: the slot of stage t-1 is free
     frags_issue<TA, BMv, BKv, WTM, 1>(curA, fa1); frags_issue<TB, BNv, BKv, WTN, 1>(curB, fb1);
 #if !defined(COCODR_ABL_NO_DMA)  // ablation builds (tools/gemm_ablate.py) only; never defined in the product library
-    if (more) static_for<0, NP / SLOTS>([&](auto jc) { issue_piece(jc, t + 2); });
+    if (more) static_for<0, NP / SLOTS>([&](auto jc) { issue_piece(jc, t + D); });
 #endif
     wait_lgkmcnt<R>();
     mfma_step<TA, TB, WTM, WTN>(fa0, fb0, acc);
     if constexpr (G::KS == 4) {
       frags_issue<TA, BMv, BKv, WTM, 2>(curA, fa0); frags_issue<TB, BNv, BKv, WTN, 2>(curB, fb0);
 #if !defined(COCODR_ABL_NO_DMA)
-      if (more) static_for<NP / SLOTS, 2 * NP / SLOTS>([&](auto jc) { issue_piece(jc, t + 2); });
+      if (more) static_for<NP / SLOTS, 2 * NP / SLOTS>([&](auto jc) { issue_piece(jc, t + D); });
 #endif
       wait_lgkmcnt<R>();
       mfma_step<TA, TB, WTM, WTN>(fa1, fb1, acc);
       frags_issue<TA, BMv, BKv, WTM, 3>(curA, fa1); frags_issue<TB, BNv, BKv, WTN, 3>(curB, fb1);
 #if !defined(COCODR_ABL_NO_DMA)
-      if (more) static_for<2 * NP / SLOTS, NP>([&](auto jc) { issue_piece(jc, t + 2); });
+      if (more) static_for<2 * NP / SLOTS, NP>([&](auto jc) { issue_piece(jc, t + D); });
 #endif
       wait_lgkmcnt<R>();
       mfma_step<TA, TB, WTM, WTN>(fa0, fb0, acc);
     }
     wait_lgkmcnt<0>();  // this wave is done reading stage t
     if (t + 1 < nt) {
-      if (SELF_ISSUE) {
-        if (more) wait_vmcnt<NP>();
-        else wait_vmcnt<0>();
-      }
+      if (SELF_ISSUE) wait_vmcnt_stages<NP, D - 1>(min(nt - 1, t + D) - (t + 1));
       __builtin_amdgcn_s_barrier();  // barrier t+1: stage t+1 complete, stage t released
       const uint32_t sb = lds_base + (uint32_t)(((t + 1) % G::NSTAGE) * G::STAGE);
 #pragma unroll
@@ -703,16 +711,16 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC>::NTHREADS), (Geom
 #endif
 }
 
-template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, int WC = 2>
+template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, int WC = 2, int NS = 3>
 void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
-  using G = Geom<BMv, BKv, WTM, WTN, LD, WC>;
+  using G = Geom<BMv, BKv, WTM, WTN, LD, WC, NS>;
   const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / G::BNv;
   dim3 grid(ntm * ntn, a.batch);
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   static int stagger = -1;  // x 4096 clocks; COCODR_GEMM_STAGGER overrides (0 disables)
@@ -722,16 +730,16 @@ void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
   }
   const int sg = (int)(grid.x * grid.y) > 256 * G::WG_PER_CU / 2 ? stagger : 0;
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true, WC>), grid, dim3(G::NTHREADS), lds, st, a, sg);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true, WC, NS>), grid, dim3(G::NTHREADS), lds, st, a, sg);
   else
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false, WC>), grid, dim3(G::NTHREADS), lds, st, a, sg);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false, WC, NS>), grid, dim3(G::NTHREADS), lds, st, a, sg);
 }
 
-template <int BMv, int BKv, int WTM, int WTN = 2, int LD = 0, int WC = 2>
+template <int BMv, int BKv, int WTM, int WTN = 2, int LD = 0, int WC = 2, int NS = 3>
 void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
-  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 0, WC>(a, st);
-  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 1, WC>(a, st);
-  else launch_glds<BMv, BKv, WTM, WTN, LD, 1, 1, WC>(a, st);
+  if (!a.trans_a && !a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 0, WC, NS>(a, st);
+  else if (!a.trans_a && a.trans_b) launch_glds<BMv, BKv, WTM, WTN, LD, 0, 1, WC, NS>(a, st);
+  else launch_glds<BMv, BKv, WTM, WTN, LD, 1, 1, WC, NS>(a, st);
 }
 
 }  // namespace cocodr_gemm_v2
