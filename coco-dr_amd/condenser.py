@@ -200,7 +200,8 @@ class _CondenserStepFn(torch.autograd.Function):
         if g_mlm is not None:
             dlog = dlogits.mul_(g_mlm.to(dlogits.dtype))  # upstream scale (1.0 in the reference step); no host sync
             # decoder (tied to the word embeddings) and its bias
-            dt = ops.gemm(dlog, word16, trans_b=True)                                   # [n2,H]   dlogits . Word
+            # [n2,H] = dlogits . Word: 120 output tiles of 128 rows over K = 30 592: two K slices in one launch fill the CUs
+            dt = ops.gemm(dlog, word16, trans_b=True, split_k=2 if head.vpad % 128 == 0 else 1)
             dword_mlm = ops.gemm(dlog, t, trans_a=True, trans_b=True, out_f32=True)       # [vpad,H] dlogits^T . t
             gv("cls.predictions.bias").copy_(ops.colsum(dlog)[:V])
             # transform: LayerNorm, erf-GELU, dense

@@ -35,9 +35,14 @@ def build_info() -> str:
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          bias: Optional[torch.Tensor] = None, epi: int = N.EPI_NONE, r: Optional[torch.Tensor] = None,
-         out_f32: bool = False, out: Optional[torch.Tensor] = None, colsum: bool = False):
+         out_f32: bool = False, out: Optional[torch.Tensor] = None, colsum: bool = False, split_k: int = 1):
     """C = epi(op(a) @ op(b)); a, b bf16 2-D (or 3-D batched with equal batch).  See cocodr_gemm.
-    colsum=True (unbatched) also returns the fp32 column sums of C as the last element of the result tuple."""
+    colsum=True (unbatched) also returns the fp32 column sums of C as the last element of the result tuple.
+    split_k > 1 (plain 2-D product, trans_a=False): the contraction is cut into split_k slices that run as the batch items of
+    ONE launch (fp32 partial products, summed afterwards) - for few-tile outputs over a very long K, which would otherwise
+    leave most CUs idle."""
+    if split_k > 1:
+        return _gemm_split_k(a, b, trans_b, out_f32, split_k)
     batched = a.dim() == 3
     _req(a, BF16, "a", 3 if batched else 2)
     _req(b, BF16, "b", 3 if batched else 2)
@@ -90,6 +95,27 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
     if colsum:
         res = res + (cs,)
     return res if len(res) > 1 else res[0]
+
+
+def _gemm_split_k(a, b, trans_b: bool, out_f32: bool, s: int):
+    _req(a, BF16, "a", 2)
+    _req(b, BF16, "b", 2)
+    M, K = a.shape
+    Nn, Kb = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if K != Kb or K % (64 * s) != 0:
+        raise ValueError(f"gemm(split_k={s}): K={K} must match and be a multiple of {64 * s}")
+    Ks = K // s
+    part = torch.empty((s, M, Nn), dtype=F32, device=a.device)
+    g = N.GemmArgs()
+    g.A, g.B, g.C = a.data_ptr(), b.data_ptr(), part.data_ptr()
+    g.M, g.N, g.K = M, Nn, Ks
+    g.lda, g.ldb, g.ldc = K, b.shape[1], Nn
+    g.trans_a, g.trans_b, g.epi, g.out_f32 = 0, int(trans_b), N.EPI_NONE, 1
+    g.batch = s
+    g.strideA, g.strideB, g.strideC = Ks, (Ks * Nn if trans_b else Ks), M * Nn  # slice z: columns z*Ks.. of a, rows / columns of b
+    check(lib().cocodr_gemm(C.byref(g), stream_ptr()), "gemm(split_k)")
+    out = part.sum(0)
+    return out if out_f32 else out.to(BF16)
 
 
 def gemm_set_impl(impl: int) -> None:

@@ -109,6 +109,19 @@ def test_gemm_tn_wgrad_batched_fp32(nb, Mtok, No, Ni, gemm_impl):
     assert out.dtype == torch.float32 and rel_l2(out, ref) < 1e-4  # fp32 out: accumulate-order noise only
 
 
+def test_gemm_split_k_matches_the_single_pass():
+    """the decoder-gradient shape of the MLM head: few output tiles, very long K, cut into batch items of one launch"""
+    dy, w = rnd(512, 3072, seed=41), rnd(3072, 256, scale=0.05, seed=42)
+    ref = dy.float() @ w.float()
+    for s in (2, 4):
+        assert rel_l2(ops.gemm(dy, w, trans_b=True, split_k=s), ref) < 5e-3
+        assert rel_l2(ops.gemm(dy, w, trans_b=True, split_k=s, out_f32=True), ref) < 1e-4
+    wt = w.t().contiguous()
+    assert rel_l2(ops.gemm(dy, wt, split_k=2, out_f32=True), ref) < 1e-4
+    with pytest.raises(ValueError):
+        ops.gemm(dy, w, trans_b=True, split_k=5)
+
+
 def test_gemm_rejects_bad_shapes():
     with pytest.raises(ValueError):
         ops.gemm(rnd(64, 64), rnd(100, 64))  # N not a multiple of 128
