@@ -144,7 +144,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const uint16_t* __restrict_
 template <int NC>
 __device__ __forceinline__ void ln_bwd_row(RowVecT<NC>& d, const RowVecT<NC>& x, const float* gamma, int nch, int lane, int H, float mean,
                                            float rstd, RowVecT<NC>& dg, RowVecT<NC>& db) {
-  RowVecT<NC> xh;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
@@ -154,24 +153,23 @@ __device__ __forceinline__ void ln_bwd_row(RowVecT<NC>& d, const RowVecT<NC>& x,
       const float g[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        xh.v[i][e] = (x.v[i][e] - mean) * rstd;
-        dg.v[i][e] += d.v[i][e] * xh.v[i][e];
+        const float xh = (x.v[i][e] - mean) * rstd;
+        dg.v[i][e] += d.v[i][e] * xh;
         db.v[i][e] += d.v[i][e];
         d.v[i][e] *= g[e];  // dxhat
         s1 += d.v[i][e];
-        s2 += d.v[i][e] * xh.v[i][e];
+        s2 += d.v[i][e] * xh;
       }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) xh.v[i][e] = 0.f;
     }
   }
   s1 = wave_sum(s1) / (float)H;
   s2 = wave_sum(s2) / (float)H;
+  // xhat is recomputed instead of kept: 4 NC fewer live registers across the two wave reductions (padded chunks hold
+  // d = 0, x = 0 and are never stored)
 #pragma unroll
   for (int i = 0; i < NC; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) d.v[i][e] = rstd * (d.v[i][e] - s1 - xh.v[i][e] * s2);
+    for (int e = 0; e < 4; ++e) d.v[i][e] = rstd * (d.v[i][e] - s1 - (x.v[i][e] - mean) * rstd * s2);
 }
 
 // reduce the NW waves' per-lane accumulators through LDS and write one partial row [H]

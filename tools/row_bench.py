@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cocodr_amd  # noqa
 from cocodr_amd import ops
 
-M, H = 8192, 768
+M, H = 8192, (int(sys.argv[1]) if len(sys.argv) > 1 else 768)
 y = torch.randn(M, H, device="cuda").to(torch.bfloat16)
 d = torch.randn(M, H, device="cuda").to(torch.bfloat16)
 g = torch.ones(H, device="cuda"); b = torch.zeros(H, device="cuda")
