@@ -604,10 +604,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     const float* __restrict__ grad_scale_dev) {
   if (grad_scale_dev) grad_scale *= *grad_scale_dev;  // e.g. the clip coefficient cocodr_grad_norm_clip left on the device
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    float4 pv = reinterpret_cast<float4*>(p)[i];
-    const float4 gv = reinterpret_cast<const float4*>(g)[i];
-    float4 mv = reinterpret_cast<float4*>(m)[i];
-    float4 vv = reinterpret_cast<float4*>(v)[i];
+    // one pass over 30 B / parameter that nothing re-reads soon: non-temporal loads and stores (kernel -10 %)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v pq = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p) + i), gq = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(g) + i);
+    const f4v mq = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m) + i), vq = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v) + i);
+    float4 pv = make_float4(pq.x, pq.y, pq.z, pq.w); const float4 gv = make_float4(gq.x, gq.y, gq.z, gq.w);
+    float4 mv = make_float4(mq.x, mq.y, mq.z, mq.w); float4 vv = make_float4(vq.x, vq.y, vq.z, vq.w);
     float pa[4] = {pv.x, pv.y, pv.z, pv.w};
     const float ga[4] = {gv.x * grad_scale, gv.y * grad_scale, gv.z * grad_scale, gv.w * grad_scale};
     float ma[4] = {mv.x, mv.y, mv.z, mv.w};
@@ -620,9 +622,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       const float denom = sqrtf(va[e]) / bc2_sqrt + eps;
       pa[e] -= (lr / bc1) * (ma[e] / denom);
     }
-    reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
-    reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
-    reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
+    { f4v t = {pa[0], pa[1], pa[2], pa[3]}; __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p) + i); }
+    { f4v t = {ma[0], ma[1], ma[2], ma[3]}; __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(m) + i); }
+    { f4v t = {va[0], va[1], va[2], va[3]}; __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(v) + i); }
     if (shadow && i * 4 >= shadow_begin) *reinterpret_cast<uint2*>(shadow + (i * 4 - shadow_begin)) = pack4(pa);
   }
 }
