@@ -49,13 +49,6 @@ __device__ __forceinline__ bf16x8 pack_acc(const float* p, int j) {
   return as_bf16x8(pack8(t));
 }
 
-__device__ __forceinline__ void stage_tile(char* dst, const uint16_t* src, int ld, int L, int tid, int nthreads) {
-  for (int q = tid; q < L * 8; q += nthreads) {
-    const int row = q >> 3, ch = q & 7;
-    *reinterpret_cast<uint4*>(dst + tile64_off(row, ch)) = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
-  }
-}
-
 // Same tile, fetched with the LDS DMA (buffer_load ... lds, 1 KiB = 8 rows per wave instruction, no VGPR round trip).
 // The DMA writes lane-linear, so the chunk swizzle is applied to the per-lane SOURCE address (the XOR is an involution).
 // Wave `wid` of `nw` issues pieces wid, wid + nw, ...; completion = s_waitcnt vmcnt(0) + barrier by the caller.
@@ -91,19 +84,6 @@ __device__ __forceinline__ void store_acc_T16(uint16_t* dst, int ld, const f32x1
       const int d = dt * 32 + 8 * (2 * rp + half);  // columns d .. d+7: half-0 lane owns d..d+3, half-1 lane d+4..d+7
       const uint4 v = half == 0 ? make_uint4(keep.x, keep.y, got.x, got.y) : make_uint4(got.x, got.y, keep.x, keep.y);
       *reinterpret_cast<uint4*>(dst + (size_t)(lane & 31) * ld + d) = v;
-    }
-}
-
-__device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane) {
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      float t[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = o[dt][rg * 4 + e] * mul;
-      const int d = dt * 32 + 8 * rg + 4 * (lane >> 5);
-      *reinterpret_cast<uint2*>(dst + (size_t)(lane & 31) * ld + d) = pack4(t);
     }
 }
 
@@ -193,6 +173,20 @@ __device__ unsigned long long* g_attn_tl = nullptr;
 #endif
 
 // Backward.  All four [L][64] tiles of one (batch, head) live in LDS (L <= 256 -> 128 KiB).
+// 8-byte store form (the forward: the 16-byte form costs it a wave of occupancy, 152 vs 94 registers, and measures slower)
+__device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = o[dt][rg * 4 + e] * mul;
+      const int d = dt * 32 + 8 * rg + 4 * (lane >> 5);
+      *reinterpret_cast<uint2*>(dst + (size_t)(lane & 31) * ld + d) = pack4(t);
+    }
+}
+
 // Column sums of a transposed [32 rows x 64 columns] fp32 accumulator tile (the query / key bias gradient).  A lane holds
 // 32 columns of one row.  Per 16-column group the lanes of a 16-lane row pair up (lane ^ 8, then 7 - lane within 8 lanes):
 // both partners get the pair sums and keep the half of the value list their own lane bit selects; the quads then sum
@@ -242,13 +236,15 @@ __device__ __forceinline__ int qk_col(int lane) {  // list index dt*16 + rg*4 + 
   return (c >> 4) * 32 + ((c >> 2) & 3) * 8 + 4 * (lane >> 5) + (c & 3);
 }
 // every wave leaves its own row: partial is [B][4 waves][2H] floats (query half | key half), no LDS pass and no barrier at
-// the end of the workgroup; a wave without a block of its own writes zeros.
+// the end of the workgroup; a wave without a query block of its own writes zeros.
 // The key half is written as exact zeros: sum_k dK[k] = scale * sum_q Q[q] * (sum_k dS[q][k]) and every row of dS sums to
 // P.dP - delta * sum(P) = 0 (softmax shift invariance: the scores do not depend on the key bias).  The fp32 reference gets
 // rounding noise ~1e-7 of the other gradients there, far below Adam's eps; summing the bf16 pipeline's dK would instead
 // hand the optimizer noise it treats as a gradient.
-__device__ __forceinline__ void qk_bias_store(float* partial, float acc, int which, int b, int h, int H, int tid) {
-  partial[((size_t)(b * 4 + (tid >> 6)) * 2 + which) * H + h * 64 + qk_col(tid & 63)] = acc;
+__device__ __forceinline__ void qk_bias_store(float* partial, float qacc, int b, int h, int H, int tid) {
+  float* row = partial + (size_t)(b * 4 + (tid >> 6)) * 2 * H + h * 64 + qk_col(tid & 63);
+  row[0] = qacc;
+  row[H] = 0.f;
 }
 //  phase A: wave <-> 32 queries,  S^T/dP^T layout (lane = query):  dQ^T += K^T dS^T
 //  phase B: wave <-> 32 keys,     S / dP layout   (lane = key):    dV^T += dO^T P,  dK^T += Q^T dS
@@ -366,11 +362,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       }
     }
     ATTN_STAMP(2);
-    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
+    // (in front of the store: behind it hipcc interleaves the two and spills 72 SGPRs of lane masks instead of 9)
     if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale, lane);
+    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
   }
   ATTN_STAMP(3);
-  if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, 0, b, h, H, tid);
+  if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
 
   // ---------------- phase B: dK, dV
   for (int kb = wid; kb < nblk; kb += 4) {
@@ -425,7 +422,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
   }
   ATTN_STAMP(5);
-  if constexpr (QKSUM) qk_bias_store(qk_partial, 0.f, 1, b, h, H, tid);  // key half: see qk_bias_store
 }
 
 
@@ -511,17 +507,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Kt, kb * 32 + j * 16, dt, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
     if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale, lane);
+    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
   }
-  if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, 0, b, h, H, tid);
+  if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
 }
 
-template <bool QKSUM>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                               const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
-                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H,
-                                                              float* __restrict__ qk_partial) {
+                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qt = smem;
   char* Dt = smem + L * 128;
@@ -616,7 +610,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
     store_acc_T16(row0 + H, ld, dk, kScale, lane);
     store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
   }
-  if constexpr (QKSUM) qk_bias_store(qk_partial, 0.f, 1, b, h, H, tid);  // key half: see qk_bias_store
 }
 
 }  // namespace
@@ -660,8 +653,7 @@ extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const u
     hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -672,8 +664,7 @@ extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const u
     hipLaunchKernelGGL(qks ? attn_bwd_dq_kernel<true> : attn_bwd_dq_kernel<false>, dim3(heads, B), dim3(256), lds_q, st, qkv, mask, ctx,
                        dctx, lse, dqkv, L, H, qk_bias_partial);
     CK_LAUNCH("attn_bwd(dq)");
-    hipLaunchKernelGGL(qks ? attn_bwd_dkv_kernel<true> : attn_bwd_dkv_kernel<false>, dim3(heads, B), dim3(256), lds_kv, st, qkv, mask, ctx,
-                       dctx, lse, dqkv, L, H, qk_bias_partial);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(heads, B), dim3(256), lds_kv, st, qkv, mask, ctx, dctx, lse, dqkv, L, H);
     CK_LAUNCH("attn_bwd(dkv)");
     return COCODR_OK;
   }
