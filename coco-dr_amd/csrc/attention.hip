@@ -87,6 +87,20 @@ __device__ __forceinline__ void store_acc_T16(uint16_t* dst, int ld, const f32x1
     }
 }
 
+// 8-byte store form (the forward: the 16-byte form costs it a wave of occupancy, 152 vs 94 registers, and measures slower)
+__device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = o[dt][rg * 4 + e] * mul;
+      const int d = dt * 32 + 8 * rg + 4 * (lane >> 5);
+      *reinterpret_cast<uint2*>(dst + (size_t)(lane & 31) * ld + d) = pack4(t);
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                        uint16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -173,20 +187,6 @@ __device__ unsigned long long* g_attn_tl = nullptr;
 #endif
 
 // Backward.  All four [L][64] tiles of one (batch, head) live in LDS (L <= 256 -> 128 KiB).
-// 8-byte store form (the forward: the 16-byte form costs it a wave of occupancy, 152 vs 94 registers, and measures slower)
-__device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane) {
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      float t[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = o[dt][rg * 4 + e] * mul;
-      const int d = dt * 32 + 8 * rg + 4 * (lane >> 5);
-      *reinterpret_cast<uint2*>(dst + (size_t)(lane & 31) * ld + d) = pack4(t);
-    }
-}
-
 // Column sums of a transposed [32 rows x 64 columns] fp32 accumulator tile (the query / key bias gradient).  A lane holds
 // 32 columns of one row.  Per 16-column group the lanes of a 16-lane row pair up (lane ^ 8, then 7 - lane within 8 lanes):
 // both partners get the pair sums and keep the half of the value list their own lane bit selects; the quads then sum

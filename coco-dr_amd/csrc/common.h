@@ -74,35 +74,37 @@ __device__ __forceinline__ float wave_max(float v) {
 // ------------------------------------------------------------------ math
 // exact-erf GELU (hidden_act="gelu").  erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the
 // bf16 output rounding of 2^-9 relative): one v_exp + one v_rcp + 5 FMAs; exp(-x^2/2) is shared with the
-// Gaussian pdf term of the derivative.
-__device__ __forceinline__ void erf_pdf_terms(float x, float& erf_v, float& e) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-  e = __expf(-z * z);  // = exp(-x^2 / 2)
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float r = 1.0f - p * t * e;
-  erf_v = copysignf(r, x);
+// Gaussian pdf term of the derivative.  The epilogue that evaluates this is VALU-bound (about as many VALU cycles per
+// tile as the main loop has MFMA cycles), so every operation counts.
+// q = (1 - erf(|x| / sqrt 2)) / 2 = the Gaussian tail probability, e = exp(-x^2 / 2); the constants of 7.1.26 carry the
+// 1/sqrt 2 of the argument and the 1/2 of the cdf, so the cdf is 1 - q (x >= 0) or q (x < 0) without further scaling
+__device__ __forceinline__ void gauss_tail_terms(float x, float& q, float& e) {
+  const float t = __frcp_rn(fmaf(0.23164189f, fabsf(x), 1.0f));   // 0.3275911 / sqrt 2
+  e = __builtin_amdgcn_exp2f(x * x * -0.72134752f);                // exp(-x^2 / 2) = 2^(-x^2 log2(e) / 2)
+  float p = fmaf(0.5307027145f, t, -0.7265760135f);                // the 7.1.26 coefficients, halved
+  p = fmaf(p, t, 0.7107068705f);
+  p = fmaf(p, t, -0.142248368f);
+  p = fmaf(p, t, 0.127414796f);
+  q = p * t * e;
 }
+__device__ __forceinline__ float gauss_cdf(float x, float q) { return x >= 0.f ? 1.0f - q : q; }
 __device__ __forceinline__ float gelu_erf(float x) {
-  float er, e;
-  erf_pdf_terms(x, er, e);
-  return 0.5f * x * (1.0f + er);
+  float q, e;
+  gauss_tail_terms(x, q, e);
+  return x * gauss_cdf(x, q);
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  float er, e;
-  erf_pdf_terms(x, er, e);
-  return 0.5f * (1.0f + er) + x * 0.3989422804014327f * e;
+  float q, e;
+  gauss_tail_terms(x, q, e);
+  return fmaf(x * 0.3989422804014327f, e, gauss_cdf(x, q));
 }
 // value and derivative from one erf / exp evaluation (the forward saves the derivative for the backward)
 __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& gp) {
-  float er, e;
-  erf_pdf_terms(x, er, e);
-  const float cdf = 0.5f * (1.0f + er);
+  float q, e;
+  gauss_tail_terms(x, q, e);
+  const float cdf = gauss_cdf(x, q);
   g = x * cdf;
-  gp = cdf + x * 0.3989422804014327f * e;
+  gp = fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 // ------------------------------------------------------------------ LDS tile addressing
