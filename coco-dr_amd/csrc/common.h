@@ -36,14 +36,16 @@ void cocodr_set_error(const char* fmt, ...);
 
 // ------------------------------------------------------------------ bf16 <-> f32
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f) {  // round to nearest even
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
+// fp32 -> bf16, round to nearest even: gfx950 converts a pair per instruction (v_cvt_pk_bf16_f32); the integer form
+// (add 0x7fff + lsb, shift) costs ~7 VALU operations per pair, which the VALU-bound epilogues and the attention inner
+// loops feel
+typedef __bf16 cocodr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float cocodr_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const cocodr_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, cocodr_bf16x2));
 }
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
   f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
