@@ -62,15 +62,30 @@ __device__ __forceinline__ void unpack4(const uint2& v, float* f) {
 __device__ __forceinline__ uint2 pack4(const float* f) { return make_uint2(pack2bf(f[0], f[1]), pack2bf(f[2], f[3])); }
 
 // ------------------------------------------------------------------ wave64 reductions
+// Within a 16-lane row the partner values arrive as DPP operands of the VALU instruction (lane ^ 1, lane ^ 2, the mirrored
+// lane of the 8-lane half, the mirrored lane of the row); the four row totals are then read as scalars.  No LDS round trips:
+// the six dependent ds_bpermute of a __shfl_xor ladder cost ~0.4 us per reduction, which the one-row-per-wave LayerNorm
+// kernels (two reductions each) are made of.  Every lane returns the same value; the order of the additions is fixed.
+template <int CTRL>
+__device__ __forceinline__ float dpp_partner(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_partner<0xB1>(v);   // quad_perm 1,0,3,2
+  v += dpp_partner<0x4E>(v);   // quad_perm 2,3,0,1
+  v += dpp_partner<0x141>(v);  // row_half_mirror
+  v += dpp_partner<0x140>(v);  // row_mirror
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_partner<0xB1>(v));
+  v = fmaxf(v, dpp_partner<0x4E>(v));
+  v = fmaxf(v, dpp_partner<0x141>(v));
+  v = fmaxf(v, dpp_partner<0x140>(v));
+  return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // ------------------------------------------------------------------ math

