@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       part += __shfl_xor(part, 1, 64);
       part += __shfl_xor(part, 2, 64);
       part += __shfl_xor(part, 4, 64);
-      if (ch == 0) delta[row] = part;
+      if (ch == 0) delta[row] = -part;  // negated: it seeds the dP accumulators below
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       dof[s] = frag_rows(Dt, qb * 32, s, lane);
     }
     const float my_lse = lse2[qb * 32 + (lane & 31)];
-    const float my_delta = delta[qb * 32 + (lane & 31)];
+    const float my_ndelta = delta[qb * 32 + (lane & 31)];  // -delta of this lane's query
     f32x16 dq[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     for (int kb = 0; kb < nblk; ++kb) {
       f32x16 sacc, dpacc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = my_ndelta; }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, kb * 32, s, lane), qf[s], sacc, 0, 0, 0);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
         for (int e = 0; e < 4; ++e) {
           const int r = rg * 4 + e;
           const float p = fast_exp2(sacc[r] * sl2 + mm[e] - my_lse);
-          ds[r] = p * (dpacc[r] - my_delta);
+          ds[r] = p * dpacc[r];  // dpacc was seeded with -delta
         }
       }
 #pragma unroll
@@ -386,7 +386,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     for (int qb = 0; qb < nblk; ++qb) {
       f32x16 sacc, dpacc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {  // dP accumulators start at -delta of their query rows
+        const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
+        dpacc[rg * 4 + 0] = d4.x; dpacc[rg * 4 + 1] = d4.y; dpacc[rg * 4 + 2] = d4.z; dpacc[rg * 4 + 3] = d4.w;
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qt, qb * 32, s, lane), kf[s], sacc, 0, 0, 0);
@@ -396,14 +401,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const float4 l4 = *reinterpret_cast<const float4*>(lse2 + qb * 32 + 8 * rg + 4 * half);
-        const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
         const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
-        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = rg * 4 + e;
           p[r] = fast_exp2(sacc[r] * sl2 + my_madd - ll[e]);
-          ds[r] = p[r] * (dpacc[r] - dd[e]);
+          ds[r] = p[r] * dpacc[r];  // dpacc was seeded with -delta
         }
       }
 #pragma unroll
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
       for (int e = 0; e < 8; ++e) dpart += df[e] * ofv[e];
     }
-    const float my_delta = dpart + __shfl_xor(dpart, 32, 64);  // lanes l and l^32 hold the two halves of row l & 31
+    const float my_ndelta = -(dpart + __shfl_xor(dpart, 32, 64));  // lanes l and l^32 hold the two halves of row l & 31
     const float my_lse = lse[((size_t)b * heads + h) * L + qb * 32 + (lane & 31)] * kLog2e;
     f32x16 dq[2];
 #pragma unroll
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     for (int kb = 0; kb < nblk; ++kb) {
       f32x16 sacc, dpacc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = my_ndelta; }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, kb * 32, s, lane), qf[s], sacc, 0, 0, 0);
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
         for (int e = 0; e < 4; ++e) {
           const int r = rg * 4 + e;
           const float p = fast_exp2(sacc[r] * sl2 + mm[e] - my_lse);
-          ds[r] = p * (dpacc[r] - my_delta);
+          ds[r] = p * dpacc[r];  // dpacc was seeded with -delta
         }
       }
 #pragma unroll
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
       part += __shfl_xor(part, 1, 64);
       part += __shfl_xor(part, 2, 64);
       part += __shfl_xor(part, 4, 64);
-      if (ch == 0) delta[row] = part;
+      if (ch == 0) delta[row] = -part;  // negated: it seeds the dP accumulators below
     }
   }
   for (int i = tid; i < L; i += 256) lse2[i] = lse[((size_t)b * heads + h) * L + i] * kLog2e;
@@ -576,7 +579,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
     for (int qb = 0; qb < nblk; ++qb) {
       f32x16 sacc, dpacc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {  // dP accumulators start at -delta of their query rows
+        const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
+        dpacc[rg * 4 + 0] = d4.x; dpacc[rg * 4 + 1] = d4.y; dpacc[rg * 4 + 2] = d4.z; dpacc[rg * 4 + 3] = d4.w;
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qt, qb * 32, s, lane), kf[s], sacc, 0, 0, 0);
@@ -586,14 +594,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const float4 l4 = *reinterpret_cast<const float4*>(lse2 + qb * 32 + 8 * rg + 4 * half);
-        const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
         const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
-        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = rg * 4 + e;
           p[r] = fast_exp2(sacc[r] * sl2 + my_madd - ll[e]);
-          ds[r] = p[r] * (dpacc[r] - dd[e]);
+          ds[r] = p[r] * dpacc[r];  // dpacc was seeded with -delta
         }
       }
 #pragma unroll
