@@ -113,7 +113,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
   stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
   stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4);
-  for (int i = tid; i < L; i += 256) madd[i] = mask[b * L + i] != 0 ? 0.f : kMaskNeg;
+  // additive key mask in units of the raw q.k scores; it seeds the S accumulators, so no add per element later.  -2e5 raw
+  // = -3.6e4 in the exponent: exp2 underflows to an exact 0 against any real score, and a row whose keys are ALL masked
+  // still gets a finite softmax over its raw scores (what adding finfo.min to every key gives the reference); a seed
+  // of -1e30 would leave the fma below with a rounding residue of ~1e22 there.
+  for (int i = tid; i < L; i += 256) madd[i] = mask[b * L + i] != 0 ? 0.f : -2.0e5f;
   const int q0 = blockIdx.z * 128 + wid * 32;
   const int half = lane >> 5;
   bf16x8 qf[4];
@@ -137,23 +141,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   for (int kb = 0; kb < L / 32; ++kb) {
     f32x16 sacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    for (int rg = 0; rg < 4; ++rg) {  // S starts at the key mask: the MFMAs add K.Q on top
+      const float4 ma = *reinterpret_cast<const float4*>(madd + kb * 32 + 8 * rg + 4 * half);
+      sacc[rg * 4 + 0] = ma.x; sacc[rg * 4 + 1] = ma.y; sacc[rg * 4 + 2] = ma.z; sacc[rg * 4 + 3] = ma.w;
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Kt, kb * 32, s, lane), qf[s], sacc, 0, 0, 0);
     float p[16];
-    float bmax = kMaskNeg;
+    float bmax = sacc[0];  // block maximum on the raw scores (the scale is positive), one multiply per row afterwards
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 ma = *reinterpret_cast<const float4*>(madd + kb * 32 + 8 * rg + 4 * half);
-      p[rg * 4 + 0] = sacc[rg * 4 + 0] * sl2 + ma.x;
-      p[rg * 4 + 1] = sacc[rg * 4 + 1] * sl2 + ma.y;
-      p[rg * 4 + 2] = sacc[rg * 4 + 2] * sl2 + ma.z;
-      p[rg * 4 + 3] = sacc[rg * 4 + 3] * sl2 + ma.w;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, p[r]);
+    for (int r = 1; r < 16; ++r) bmax = fmaxf(bmax, sacc[r]);
     bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
-    const float mnew = fmaxf(m, bmax);
+    const float mnew = fmaxf(m, bmax * sl2);
     const float alpha = fast_exp2(m - mnew);
     m = mnew;
     lsum *= alpha;
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
       for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      p[r] = fast_exp2(p[r] - mnew);
+      p[r] = fast_exp2(fmaf(sacc[r], sl2, -mnew));
       lsum += p[r];
     }
 #pragma unroll
