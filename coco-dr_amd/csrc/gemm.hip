@@ -404,11 +404,14 @@ __device__ __forceinline__ void mfma_step(const FragSet<TA, WTM>& fa, const Frag
 }
 
 // one 8-column slice of an output row: bias / GELU / residual / GELU' and the store
-template <bool OUT_F32, bool RPRE = false>
+template <bool OUT_F32, bool RPRE = false, bool BPRE = false>
 __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z, const float* __restrict__ bias,
                                                 const uint16_t* __restrict__ R_, int gm, int gn, float (&v)[8],
-                                                uint4 rpre = make_uint4(0, 0, 0, 0)) {
-  if (bias) {
+                                                uint4 rpre = make_uint4(0, 0, 0, 0), const float* bpre = nullptr) {
+  if constexpr (BPRE) {  // the caller's chunks all sit in the same 8 columns: their bias was fetched once (zeros without a bias)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += bpre[j];
+  } else if (bias) {
     const float4 b0 = *reinterpret_cast<const float4*>(bias + gn);
     const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
@@ -617,6 +620,19 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC, NS>::NTHREADS), (
     }
   };
   fetch_r(0, rcur);
+  // a thread's copy-out chunks all lie in the same 8 columns when CTHREADS % CPRW == 0: one bias fetch per tile instead of
+  // two 16-B loads per chunk inside the store-bound copy-out loop
+#if defined(COCODR_ABL_NO_BIAS_HOIST)
+  constexpr bool COLS_FIXED = false;
+#else
+  constexpr bool COLS_FIXED = (G::CTHREADS % CPRW) == 0;
+#endif
+  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (COLS_FIXED && bias != nullptr && !is_loader) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + n0 + ((tid % CPRW) << 3));
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + n0 + ((tid % CPRW) << 3) + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
   __syncthreads();
 #if defined(COCODR_ABL_TIMELINE)
   if (tid == 0) tl[2] = wall_clock64();
@@ -668,7 +684,7 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC, NS>::NTHREADS), (
         const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CLD + c8);
         const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CLD + c8 + 4);
         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-        epilogue_store8<OUT_F32, PREFETCH_R>(p, z, bias, R_, gm, gn, v, rcur[PREFETCH_R ? i : 0]);
+        epilogue_store8<OUT_F32, PREFETCH_R, COLS_FIXED>(p, z, bias, R_, gm, gn, v, rcur[PREFETCH_R ? i : 0], bias8);
         if (do_colsum) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) csum[j] += v[j];
