@@ -165,6 +165,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // internal (csrc/rowops.hip), used by the GEMM's fused column sums and the encoder backward's deferred reductions:
 // out_s[z * stride_out + n] = sum_p partial[((z * P + p) * nseg + s) * n_len + n],  s < nseg <= 3
+struct cocodr_reduce_job {  // one cocodr_reduce_partials call
+  const float* partial;
+  float *o0, *o1, *o2;
+  int P, nseg, n_len, batch;
+  long long stride_out;
+};
+int cocodr_reduce_partials_multi(const cocodr_reduce_job* jobs, int njobs, hipStream_t st);
 int cocodr_reduce_partials(const float* partial, float* o0, float* o1, float* o2, int P, int nseg, int n_len, int batch,
                            long long stride_out, hipStream_t st);
 // LayerNorm backward without the final reduction: partial [ln_bwd_blocks(M)][nseg][H] (dgamma, dbeta[, dy column sums])

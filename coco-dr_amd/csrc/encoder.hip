@@ -362,11 +362,14 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
   TRY(cocodr_gemm(&g, stream));
   // ---- deferred reductions of the range (LayerNorm weight / bias + the Linear bias in front of it; b1; value bias)
   if (defer) {
-    TRY(cocodr_reduce_partials(ln2_slots, g0.ln2_g, g0.ln2_b, g0.b2, P_ln, 3, H, NG, s_vec, hst));
-    TRY(cocodr_reduce_partials(ln1_slots, g0.ln1_g, g0.ln1_b, g0.bo, P_ln, 3, H, NG, s_vec, hst));
-    if (rows_b1 > 0) TRY(cocodr_reduce_partials(b1_slots, g0.b1, nullptr, nullptr, rows_b1, 1, I, NG, s_vec, hst));
-    if (rows_bv > 0) TRY(cocodr_reduce_partials(bv_slots, g0.bqkv + 2 * H, nullptr, nullptr, rows_bv, 1, H, NG, s_vec, hst));
-    TRY(cocodr_reduce_partials(bqk_slots, g0.bqkv, nullptr, nullptr, 4 * B, 1, 2 * H, NG, s_vec, hst));
+    cocodr_reduce_job jobs[5];  // one launch for all of them
+    int nj = 0;
+    jobs[nj++] = {ln2_slots, g0.ln2_g, g0.ln2_b, g0.b2, P_ln, 3, H, NG, s_vec};
+    jobs[nj++] = {ln1_slots, g0.ln1_g, g0.ln1_b, g0.bo, P_ln, 3, H, NG, s_vec};
+    if (rows_b1 > 0) jobs[nj++] = {b1_slots, g0.b1, nullptr, nullptr, rows_b1, 1, I, NG, s_vec};
+    if (rows_bv > 0) jobs[nj++] = {bv_slots, g0.bqkv + 2 * H, nullptr, nullptr, rows_bv, 1, H, NG, s_vec};
+    jobs[nj++] = {bqk_slots, g0.bqkv, nullptr, nullptr, 4 * B, 1, 2 * H, NG, s_vec};
+    TRY(cocodr_reduce_partials_multi(jobs, nj, hst));
   }
   return COCODR_OK;
 }

@@ -400,6 +400,43 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
   if (rg == 0 && n < a.n_len) a.out[s][(size_t)z * a.stride_out + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// several independent reductions of that kind in ONE launch (the deferred reductions at the end of a backward range are
+// five ~5 us kernels otherwise): blockIdx.z walks the concatenated batch items of the jobs
+constexpr int REDUCE_MAX_JOBS = 6;
+struct ReduceJobs {
+  ReduceArgs job[REDUCE_MAX_JOBS];
+  int z_end[REDUCE_MAX_JOBS];  // exclusive prefix of the batch counts
+  int njobs;
+};
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J) {
+  __shared__ float red[4][64];
+  int j = 0;
+  while (j + 1 < J.njobs && (int)blockIdx.z >= J.z_end[j]) ++j;
+  const ReduceArgs& a = J.job[j];
+  const int z = blockIdx.z - (j > 0 ? J.z_end[j - 1] : 0);
+  const int s = blockIdx.y;
+  if (s >= a.nseg || (int)blockIdx.x * 64 >= a.n_len) return;  // workgroup-uniform
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  float acc = 0.f;
+  if (n < a.n_len) {
+    const size_t step = (size_t)a.nseg * a.n_len;
+    const float* p = a.partial + ((size_t)z * a.P * a.nseg + s) * a.n_len + n;
+    int i = rg;
+    for (; i + 28 < a.P; i += 32) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(i + 4 * u) * step];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; i < a.P; i += 4) acc += p[(size_t)i * step];
+  }
+  red[rg][c] = acc;
+  __syncthreads();
+  if (rg == 0 && n < a.n_len) a.out[s][(size_t)z * a.stride_out + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 // column sums: workgroup = 256-column strip x row range; a lane owns 4 adjacent columns
 __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ X, float* __restrict__ partial, int M, int N,
                                                      int ldx, long long strideX, int S) {
@@ -490,6 +527,28 @@ bool row_shape_ok(int H) { return H % 4 == 0 && H >= 4 && H <= MAXC * 256; }
 int cocodr_reduce_partials(const float* partial, float* o0, float* o1, float* o2, int P, int nseg, int n_len, int batch,
                            long long stride_out, hipStream_t st) {
   return launch_reduce(partial, o0, o1, o2, P, nseg, n_len, batch, stride_out, st);
+}
+// up to REDUCE_MAX_JOBS reductions (same argument meaning as cocodr_reduce_partials, one array entry each) in one launch
+int cocodr_reduce_partials_multi(const cocodr_reduce_job* jobs, int njobs, hipStream_t st) {
+  if (njobs <= 0) return COCODR_OK;
+  CK_ARG(jobs && njobs <= REDUCE_MAX_JOBS, "reduce_partials_multi: 1..%d jobs", REDUCE_MAX_JOBS);
+  ReduceJobs J;
+  int gx = 1, gy = 1, gz = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const cocodr_reduce_job& q = jobs[j];
+    ReduceArgs& a = J.job[j];
+    a.partial = q.partial;
+    a.out[0] = q.o0; a.out[1] = q.o1; a.out[2] = q.o2;
+    a.P = q.P; a.nseg = q.nseg; a.n_len = q.n_len; a.batch = q.batch; a.stride_out = q.stride_out;
+    gx = std::max(gx, (q.n_len + 63) / 64);
+    gy = std::max(gy, q.nseg);
+    gz += q.batch;
+    J.z_end[j] = gz;
+  }
+  J.njobs = njobs;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(gx, gy, gz), dim3(256), 0, st, J);
+  CK_LAUNCH("reduce_partials_multi");
+  return COCODR_OK;
 }
 int cocodr_ln_bwd_blocks(int M) { return ln_bwd_blocks(M); }
 int cocodr_ln_bwd_partials(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
