@@ -96,7 +96,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // q = (1 - erf(|x| / sqrt 2)) / 2 = the Gaussian tail probability, e = exp(-x^2 / 2); the constants of 7.1.26 carry the
 // 1/sqrt 2 of the argument and the 1/2 of the cdf, so the cdf is 1 - q (x >= 0) or q (x < 0) without further scaling
 __device__ __forceinline__ void gauss_tail_terms(float x, float& q, float& e) {
-  const float t = __frcp_rn(fmaf(0.23164189f, fabsf(x), 1.0f));   // 0.3275911 / sqrt 2
+  // v_rcp_f32 (1 ulp): __frcp_rn / 1.0f / x expand to the ten-instruction IEEE division sequence, per element, in a
+  // VALU-bound epilogue; the approximation itself is good to 1.5e-7
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));   // 0.3275911 / sqrt 2
   e = __builtin_amdgcn_exp2f(x * x * -0.72134752f);                // exp(-x^2 / 2) = 2^(-x^2 log2(e) / 2)
   float p = fmaf(0.5307027145f, t, -0.7265760135f);                // the 7.1.26 coefficients, halved
   p = fmaf(p, t, 0.7107068705f);
