@@ -76,8 +76,11 @@ __device__ __forceinline__ void store_acc_T16(uint16_t* dst, int ld, const f32x1
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) mine[g][e] = o[dt][(2 * rp + g) * 4 + e] * mul;
-      const uint2 keep = pack4(mine[half]);        // my 4 columns of the group I store
-      const uint2 give = pack4(mine[half ^ 1]);    // my 4 columns of the group the partner stores
+      // both groups are packed with static indices and the packed words selected by lane half: indexing mine[half]
+      // turns into an eight-way select chain per element (hipcc cannot index registers by a per-lane value)
+      const uint2 g0 = pack4(mine[0]), g1 = pack4(mine[1]);
+      const uint2 keep = half ? g1 : g0;           // my 4 columns of the group I store
+      const uint2 give = half ? g0 : g1;           // my 4 columns of the group the partner stores
       uint2 got;
       got.x = __shfl_xor((int)give.x, 32, 64);
       got.y = __shfl_xor((int)give.y, 32, 64);
