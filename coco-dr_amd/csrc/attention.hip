@@ -104,7 +104,9 @@ __device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 
     }
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+// three waves per SIMD (168 registers): at the default bound hipcc parks the O accumulators in AGPRs and pays an
+// accvgpr read + write per element for every online-softmax rescale
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                        uint16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
