@@ -308,9 +308,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       float part = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) part += df[e] * of[e];
-      part += __shfl_xor(part, 1, 64);
-      part += __shfl_xor(part, 2, 64);
-      part += __shfl_xor(part, 4, 64);
+      part += dpp_partner<0xB1>(part);   // lane ^ 1
+      part += dpp_partner<0x4E>(part);   // lane ^ 2
+      part += dpp_partner<0x141>(part);  // the other quad of the 8 lanes that hold a row (DPP operands, no LDS round trip)
       if (ch == 0) delta[row] = -part;  // negated: it seeds the dP accumulators below
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -556,9 +556,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
       float part = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) part += df[e] * of[e];
-      part += __shfl_xor(part, 1, 64);
-      part += __shfl_xor(part, 2, 64);
-      part += __shfl_xor(part, 4, 64);
+      part += dpp_partner<0xB1>(part);   // lane ^ 1
+      part += dpp_partner<0x4E>(part);   // lane ^ 2
+      part += dpp_partner<0x141>(part);  // the other quad of the 8 lanes that hold a row (DPP operands, no LDS round trip)
       if (ch == 0) delta[row] = -part;  // negated: it seeds the dP accumulators below
     }
   }
