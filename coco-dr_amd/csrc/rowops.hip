@@ -255,13 +255,14 @@ __device__ __forceinline__ void unpack_raw_row(const RawRow<NC>& r, RowVecT<NC>&
 }
 
 // NC = 16-B fp32 chunks per lane: 3 covers H <= 768 (a quarter fewer registers than the general 4: no spills at 4 waves / SIMD)
-template <int NC, bool PREFETCH>
+// FULL: H == 256 NC (768 / 1024) - every lane owns all NC chunks, so the per-chunk guards fold away
+template <int NC, bool PREFETCH, bool FULL>
 __global__ __launch_bounds__(RB_THREADS) void ln_bwd_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, uint16_t* __restrict__ dy,
                                                      float* __restrict__ partial, int M, int H, int nseg, int per_pass) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = FULL ? 64 * NC : (H >> 2);
   const int rows_per = (M + gridDim.x - 1) / gridDim.x;
   const int r_begin = blockIdx.x * rows_per, r_end = min(M, r_begin + rows_per);
   RowVecT<NC> dg, db, dxs;  // dxs: column sums of the input gradient = bias gradient of the Linear that feeds this LayerNorm
@@ -497,13 +498,15 @@ int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, c
                   float* partial, int M, int H, int nseg, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const size_t row_bytes = (size_t)NW * H * 4;  // one accumulator row of every wave
   const int per_pass = std::max(1, std::min(nseg, (int)((160 * 1024) / row_bytes)));
-  auto kern = H <= 768 ? ln_bwd_kernel<3, true> : ln_bwd_kernel<MAXC, false>;
+  auto kern = H == 768 ? ln_bwd_kernel<3, true, true> : (H < 768 ? ln_bwd_kernel<3, true, false> : (H == 1024 ? ln_bwd_kernel<MAXC, false, true> : ln_bwd_kernel<MAXC, false, false>));
   hipLaunchKernelGGL(kern, dim3(ln_bwd_blocks(M)), dim3(RB_THREADS), per_pass * row_bytes, st, dout, y, gamma, mean, rstd, dy, partial, M, H,
                      nseg, per_pass);
   CK_LAUNCH("ln_bwd");
