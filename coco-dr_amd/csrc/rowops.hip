@@ -17,9 +17,10 @@ struct RowVecT {
 };
 using RowVec = RowVecT<MAXC>;
 
-__device__ __forceinline__ void load_bf16_row(const uint16_t* row, int nch, int lane, RowVec& r) {
+template <int NC>
+__device__ __forceinline__ void load_bf16_row(const uint16_t* row, int nch, int lane, RowVecT<NC>& r) {
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) unpack4(*reinterpret_cast<const uint2*>(row + c * 4), r.v[i]);
     else r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
@@ -43,19 +44,21 @@ __device__ __forceinline__ void store_bf16_row(uint16_t* row, int nch, int lane,
     if (c < nch) *reinterpret_cast<uint2*>(row + c * 4) = pack4(r.v[i]);
   }
 }
-__device__ __forceinline__ float row_sum(const RowVec& r) {
+template <int NC>
+__device__ __forceinline__ float row_sum(const RowVecT<NC>& r) {
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
+  for (int i = 0; i < NC; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
   return wave_sum(s);
 }
 
 // mean / rstd of a row held in registers (two-pass, biased variance; padded chunks hold zeros)
-__device__ __forceinline__ void row_stats(const RowVec& r, int nch, int lane, int H, float eps, float& mean, float& rstd) {
+template <int NC>
+__device__ __forceinline__ void row_stats(const RowVecT<NC>& r, int nch, int lane, int H, float eps, float& mean, float& rstd) {
   mean = row_sum(r) / (float)H;
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i)
+  for (int i = 0; i < NC; ++i)
     if (lane + 64 * i < nch) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float d = r.v[i][e] - mean; s += d * d; }
@@ -63,9 +66,10 @@ __device__ __forceinline__ void row_stats(const RowVec& r, int nch, int lane, in
   rstd = rsqrtf(wave_sum(s) / (float)H + eps);
 }
 
-__device__ __forceinline__ void ln_apply(RowVec& r, const float* gamma, const float* beta, int nch, int lane, float mean, float rstd) {
+template <int NC>
+__device__ __forceinline__ void ln_apply(RowVecT<NC>& r, const float* gamma, const float* beta, int nch, int lane, float mean, float rstd) {
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
@@ -114,13 +118,15 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int32_t* __rest
   }
 }
 
+// NC chunks per lane (3 for H <= 768); FULL: H == 256 NC, the per-chunk guards fold away
+template <int NC, bool FULL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const uint16_t* __restrict__ y, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, uint16_t* __restrict__ out,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                      float* __restrict__ cls_out, int cls_stride, int M, int H, float eps) {
-  const int lane = threadIdx.x & 63, nch = H >> 2;
+  const int lane = threadIdx.x & 63, nch = FULL ? 64 * NC : (H >> 2);
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
-    RowVec r;
+    RowVecT<NC> r;
     load_bf16_row(y + (size_t)row * H, nch, lane, r);
     float mean, rstd;
     row_stats(r, nch, lane, H, eps, mean, rstd);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const uint16_t* __restrict_
     if (cls_out && row % cls_stride == 0) {
       float* dst = cls_out + (size_t)(row / cls_stride) * H;
 #pragma unroll
-      for (int i = 0; i < MAXC; ++i) {
+      for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) *reinterpret_cast<float4*>(dst + c * 4) = make_float4(r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]);
       }
@@ -601,7 +607,8 @@ extern "C" int cocodr_ln_fwd(const uint16_t* y, const float* gamma, const float*
   CK_ARG(y && gamma && beta && out && mean && rstd, "ln_fwd: null pointer");
   CK_ARG(M > 0 && row_shape_ok(H), "ln_fwd: bad shape M=%d H=%d", M, H);
   CK_ARG(!cls_out || cls_stride > 0, "ln_fwd: cls_stride must be positive");
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, (hipStream_t)stream, y, gamma, beta, out, mean, rstd, cls_out,
+  auto kern = H == 768 ? ln_fwd_kernel<3, true> : (H < 768 ? ln_fwd_kernel<3, false> : (H == 1024 ? ln_fwd_kernel<MAXC, true> : ln_fwd_kernel<MAXC, false>));
+  hipLaunchKernelGGL(kern, dim3(row_grid(M)), dim3(256), 0, (hipStream_t)stream, y, gamma, beta, out, mean, rstd, cls_out,
                      cls_stride > 0 ? cls_stride : 1, M, H, eps);
   CK_LAUNCH("ln_fwd");
   return COCODR_OK;
