@@ -21,7 +21,7 @@ import torch
 from . import ops
 
 __all__ = ["shard_indices", "merged_order", "encode_corpus", "search", "sharded_search", "merge_topk", "eval_dev_query",
-           "generate_negatives", "ndcg_at_10", "mrr_at_10"]
+           "EvalDevQuery", "generate_negatives", "ndcg_at_10", "map_at_10", "recall_at", "mrr_at_10"]
 
 
 # ----------------------------------------------------------------------------------------------- sharding
@@ -163,15 +163,92 @@ def eval_dev_query(query_embedding2id, passage_embedding2id, dev_query_positive_
     return (nd / n if n else 0.0), (rr / n if n else 0.0), n, prediction
 
 
+def map_at_10(ranked: Sequence[int], qrel: Dict[int, int]) -> float:
+    """trec_eval ``map_cut_10``: precision at every relevant document ranked <= 10, over all relevant documents."""
+    n_rel = sum(1 for v in qrel.values() if v > 0)
+    hits, acc = 0, 0.0
+    for r, p in enumerate(ranked[:10], start=1):
+        if qrel.get(int(p), 0) > 0:
+            hits += 1
+            acc += hits / r
+    return acc / n_rel if n_rel else 0.0
+
+
+def recall_at(ranked: Sequence[int], qrel: Dict[int, int], k: int) -> float:
+    """trec_eval ``recall_k``."""
+    n_rel = sum(1 for v in qrel.values() if v > 0)
+    return sum(1 for p in ranked[:k] if qrel.get(int(p), 0) > 0) / n_rel if n_rel else 0.0
+
+
+def EvalDevQuery(query_embedding2id, passage_embedding2id, dev_query_positive_id: Dict[int, Dict[int, int]], I_nearest_neighbor,
+                 topN: int, offset2qchar: Optional[dict] = None, offset2pchar: Optional[dict] = None):
+    """The BEIR script's ``EvalDevQuery`` with its full return tuple (evaluate/evaluation/evaluate_beir.py:105-194):
+    ``(ndcg@10, n_queries, map@10, mrr, recall@topN, hole_rate, ms_mrr, Ahole_rate, result, prediction, mrrs, ndcgs)``.
+    ``result[qid]`` holds the per-query ``ndcg_cut_10 / map_cut_10 / recip_rank / recall_topN`` the script reads from
+    pytrec_eval; the hole rates are the share of unjudged passages among the first ten / all de-duplicated ranks; ``ms_mrr``
+    is ``msmarco_eval.compute_metrics`` (``{"MRR @10", "QueriesRanked"}``) over the 1000-slot candidate lists.  The two module
+    globals the script reads (``offset2qchar`` / ``offset2pchar``, ArguAna's query == document check) are arguments."""
+    I = np.asarray(I_nearest_neighbor.cpu() if isinstance(I_nearest_neighbor, torch.Tensor) else I_nearest_neighbor)
+    q2id = np.asarray(query_embedding2id)
+    p2id = np.asarray(passage_embedding2id)
+    off_q, off_p = offset2qchar or {}, offset2pchar or {}
+    prediction: Dict[int, Dict[int, int]] = {}
+    ranked_1000: Dict[int, List[int]] = {}
+    total = labeled = atotal = alabeled = 0
+    for qi in range(I.shape[0]):
+        qid = int(q2id[qi])
+        qrel = dev_query_positive_id[qid]  # KeyError for an unjudged query, as in the script (:137)
+        docs: Dict[int, int] = {}
+        slots = ranked_1000.setdefault(qid, [0] * 1000)
+        seen = set()
+        rank = 0
+        pos = I[qi, :topN]
+        for pid in p2id[pos[pos >= 0]].tolist():
+            if pid in seen:
+                continue
+            slots[rank] = pid
+            hole = pid not in qrel
+            atotal += 1
+            alabeled += hole
+            if rank < 10:
+                total += 1
+                labeled += hole
+            rank += 1
+            if qid in off_q and pid in off_p and off_p[pid] == off_q[qid]:
+                continue  # counted and listed, but neither scored nor marked seen
+            docs[pid] = -rank
+            seen.add(pid)
+        prediction[qid] = docs
+    result: Dict[int, Dict[str, float]] = {}
+    for qid, docs in prediction.items():
+        qrel = dev_query_positive_id[qid]
+        ranked = list(docs.keys())  # insertion order == descending score
+        hit = [i for i, pid in enumerate(ranked) if qrel.get(pid, 0) > 0]
+        result[qid] = {"ndcg_cut_10": ndcg_at_10(ranked, qrel), "map_cut_10": map_at_10(ranked, qrel),
+                       "recip_rank": 1.0 / (hit[0] + 1) if hit else 0.0, f"recall_{topN}": recall_at(ranked, qrel, topN)}
+    n = len(result)
+    mean = lambda key: sum(r[key] for r in result.values()) / n if n else 0.0
+    relevant = {int(q): [pid for pid in rel if pid > 0] for q, rel in dev_query_positive_id.items()}
+    ms_mrr = {"MRR @10": mrr_at_10(relevant, ranked_1000), "QueriesRanked": len(ranked_1000)}
+    return (mean("ndcg_cut_10"), n, mean("map_cut_10"), mean("recip_rank"), mean(f"recall_{topN}"),
+            labeled / total if total else 0.0, ms_mrr, alabeled / atotal if atotal else 0.0, result, prediction,
+            [r["recip_rank"] for r in result.values()], [r["ndcg_cut_10"] for r in result.values()])
+
+
 def generate_negatives(query_embedding2id, passage_embedding2id, training_query_positive_id: Dict[int, int],
-                       I_nearest_neighbor, negative_sample: int, effective_q_id: Optional[Iterable[int]] = None):
-    """``GenerateNegativePassaageID`` with ``--ann_measure_topk_mrr`` (run_ann_data_gen.py:497-570): the first
-    ``negative_sample + 1`` retrieved passages minus the positive minus duplicates, at most ``negative_sample``;
-    plus the reciprocal rank of the positive over the whole retrieved list."""
+                       I_nearest_neighbor, negative_sample: int, effective_q_id: Optional[Iterable[int]] = None,
+                       ann_measure_topk_mrr: bool = False, shuffle: Optional[Callable[[list], None]] = None):
+    """``GenerateNegativePassaageID`` (ANCE/drivers/run_ann_data_gen.py:497-570).  Default (as in the driver): the whole
+    retrieved list is walked in a shuffled order - ``shuffle`` permutes ``list(range(k))`` in place, default Python's
+    ``random.shuffle`` (the driver seeds ``random`` in ``set_seed``, so the same seed gives the same negatives);
+    ``ann_measure_topk_mrr=True`` walks the first ``negative_sample + 1`` instead.  Skip the positive, skip duplicates,
+    keep ``negative_sample``.  Also returns the reciprocal rank of the positive over the whole retrieved list."""
+    import random
     I = np.asarray(I_nearest_neighbor.cpu() if isinstance(I_nearest_neighbor, torch.Tensor) else I_nearest_neighbor)
     q2id = np.asarray(query_embedding2id)
     p2id = np.asarray(passage_embedding2id)
     eff = None if effective_q_id is None else {int(x) for x in effective_q_id}
+    shuffle = shuffle or random.shuffle
     negatives: Dict[int, List[int]] = {}
     rr: List[float] = []
     for qi in range(I.shape[0]):
@@ -182,7 +259,12 @@ def generate_negatives(query_embedding2id, passage_embedding2id, training_query_
         pids = p2id[I[qi]]
         where = np.nonzero(pids == pos)[0]
         rr.append(1.0 / (int(where[0]) + 1) if where.size else 0.0)
-        window = pids[:negative_sample + 1]
+        if ann_measure_topk_mrr:
+            window = pids[:negative_sample + 1]
+        else:
+            order = list(range(I.shape[1]))
+            shuffle(order)
+            window = pids[np.asarray(order, dtype=np.int64)]
         window = window[window != pos]
         _, first = np.unique(window, return_index=True)
         negatives[qid] = window[np.sort(first)][:negative_sample].tolist()

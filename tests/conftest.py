@@ -26,6 +26,21 @@ def cfg_from_golden(g):
                         intermediate_size=v[4], max_position_embeddings=v[5], type_vocab_size=v[6])
 
 
+def params_from_golden(g, dtype=np.float32):
+    """The seeded parameters a fixture was generated with (tests/golden/make_golden.py): oracle.make_params(seed, std),
+    and - for the triplet / DRO fixtures - the last LayerNorm's gain and bias scaled by ``final_ln_scale`` so that the
+    dot-product logits are O(5) instead of O(H)."""
+    from oracle import make_params
+    cfg = cfg_from_golden(g)
+    P = make_params(cfg, int(g["seed"]), std=float(g["std"]))
+    if "final_ln_scale" in g.files:
+        s = float(g["final_ln_scale"])
+        last = f"encoder.layer.{cfg.num_hidden_layers - 1}.output.LayerNorm."
+        for k in (last + "weight", last + "bias"):
+            P[k] = (P[k] * s).astype(P[k].dtype)
+    return {k: v.astype(dtype) for k, v in P.items()}
+
+
 @pytest.fixture(scope="session")
 def golden_coco():
     return load_golden("coco_contrastive_tiny.npz")

@@ -31,6 +31,17 @@ from oracle import OracleConfig, make_params  # noqa: E402
 REF = "/root/reference"
 OUT = os.path.dirname(os.path.abspath(__file__))
 STD = 0.08  # larger than HF's 0.02 so that [CLS] rows differ visibly between inputs
+# The [CLS] embedding is a LayerNorm output: |q|^2 ~ H whatever the weight scale, so raw dot-product logits sit near 130
+# at H = 128 and a bf16-vs-fp32 comparison of them says little about the loss.  The triplet / DRO fixtures therefore
+# shrink the LAST LayerNorm (gain and bias x 0.2): logits O(5), logit gaps O(0.1-1), a loss that reacts to errors.
+FINAL_LN_SCALE = 0.2
+
+
+def scale_final_ln(P, cfg, s=FINAL_LN_SCALE):
+    last = f"encoder.layer.{cfg.num_hidden_layers - 1}.output.LayerNorm."
+    P[last + "weight"] = (P[last + "weight"] * s).astype(P[last + "weight"].dtype)
+    P[last + "bias"] = (P[last + "bias"] * s).astype(P[last + "bias"].dtype)
+    return P
 
 
 def hf_config(cfg: OracleConfig):
@@ -168,7 +179,7 @@ def golden_ance():
     cfg = OracleConfig(vocab_size=800, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
                        intermediate_size=256, max_position_embeddings=64)
     seed = 4321
-    P = make_params(cfg, seed, std=STD)
+    P = scale_final_ln(make_params(cfg, seed, std=STD), cfg)
     torch.manual_seed(0)
     model = BertDot_NLL_LN(hf_config(cfg))
     load_into(model.bert, P)
@@ -189,7 +200,8 @@ def golden_ance():
         ae = model.body_emb(t(a_ids), t(a_mask)).numpy()
         be = model.body_emb(t(b_ids), t(b_mask)).numpy()
     out = dict(q_ids=q_ids, q_mask=q_mask, a_ids=a_ids, a_mask=a_mask, b_ids=b_ids, b_mask=b_mask,
-               weights=weights, seed=np.int64(seed), std=np.float64(STD), loss=np.float64(float(loss)), logits=logits.detach().numpy(),
+               weights=weights, seed=np.int64(seed), std=np.float64(STD), final_ln_scale=np.float64(FINAL_LN_SCALE),
+               loss=np.float64(float(loss)), logits=logits.detach().numpy(),
                acc=acc.numpy(), q_emb=qe, a_emb=ae, b_emb=be,
                cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
                              cfg.intermediate_size, cfg.max_position_embeddings, cfg.type_vocab_size]))
@@ -351,7 +363,7 @@ def golden_idro():
     cfg = OracleConfig(vocab_size=400, hidden_size=128, num_hidden_layers=12, num_attention_heads=2,
                        intermediate_size=256, max_position_embeddings=64)
     seed = 777
-    P = make_params(cfg, seed, std=STD)
+    P = scale_final_ln(make_params(cfg, seed, std=STD), cfg)
     torch.manual_seed(0)
     model = BertDot_NLL_LN(hf_config(cfg))
     load_into(model.bert, P)
@@ -362,7 +374,7 @@ def golden_idro():
     rng = np.random.Generator(np.random.PCG64(17))
     B = 6
     t = torch.from_numpy
-    out = dict(seed=np.int64(seed), std=np.float64(STD), hyper=np.array([G, alpha, eps, ema, rho]),
+    out = dict(seed=np.int64(seed), std=np.float64(STD), final_ln_scale=np.float64(FINAL_LN_SCALE), hyper=np.array([G, alpha, eps, ema, rho]),
                cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
                              cfg.intermediate_size, cfg.max_position_embeddings, cfg.type_vocab_size]))
     groups = [np.array([0, 2, 2, 4, 0, 2]), np.array([1, 1, 3, 0, 4, 4])]  # group 3 / 1 absent in step 0, 2 in step 1
@@ -405,10 +417,10 @@ def golden_dro_greedy():
     cfg = OracleConfig(vocab_size=400, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
                        intermediate_size=256, max_position_embeddings=64)
     seed = 555
-    P = make_params(cfg, seed, std=STD)
+    P = scale_final_ln(make_params(cfg, seed, std=STD), cfg)
     G, alpha, eps, ema = 4, 0.5, 0.05, 0.3
     t = torch.from_numpy
-    out = dict(seed=np.int64(seed), std=np.float64(STD), hyper=np.array([G, alpha, eps, ema]),
+    out = dict(seed=np.int64(seed), std=np.float64(STD), final_ln_scale=np.float64(FINAL_LN_SCALE), hyper=np.array([G, alpha, eps, ema]),
                cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
                              cfg.intermediate_size, cfg.max_position_embeddings, cfg.type_vocab_size]))
     B = 6
@@ -508,8 +520,10 @@ def golden_lamb():
     module with a ``SummaryWriter`` name is registered before the import.  Five tensors exercise the corner cases:
     a matrix, a vector, an all-zero tensor (trust ratio 1), a tensor with ||w|| > 10 (clamp) and a tiny one."""
     import types
+    import importlib.machinery
     tb = types.ModuleType("tensorboardX")
     tb.SummaryWriter = object
+    tb.__spec__ = importlib.machinery.ModuleSpec("tensorboardX", None)  # transformers probes find_spec() of optional packages
     sys.modules.setdefault("tensorboardX", tb)
     sys.path.insert(0, os.path.join(REF, "ANCE", "utils"))
     from lamb import Lamb
@@ -541,9 +555,104 @@ def golden_lamb():
     print("lamb golden: norms", [out[f"wd0_norm{i}"] for i in range(3)], "trust", out["wd0_trust0"])
 
 
+def _reference_functions(path, names, namespace):
+    """Compile selected top-level function definitions of a reference script that cannot be imported whole (it parses
+    sys.argv, opens data files and imports faiss / pytrec_eval at module level) into ``namespace`` - the reference's own
+    code objects, executed here only; nothing of their text is stored."""
+    import ast
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in keep} == set(names), (names, [n.name for n in keep])
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), namespace)
+    return namespace
+
+
+def golden_evaldev():
+    """a18: the BEIR script's own ``EvalDevQuery`` + ``convert_to_string_id`` (evaluate/evaluation/evaluate_beir.py:89-194)
+    on a seeded synthetic run with duplicated pids, unjudged passages and two ArguAna-style self matches; MS MARCO MRR from
+    the reference's msmarco_eval.compute_metrics.  Harness shim (disclosed): pytrec_eval is absent, so the evaluator object
+    is ``oracle.TrecEvaluatorStandIn`` - the prediction dictionary, hole rates, eval_query_cnt and ms_mrr stored here are
+    reference outputs; the four trec_eval means are the stand-in's and are stored only as a cross-check."""
+    from oracle import TrecEvaluatorStandIn
+    sys.path.insert(0, os.path.join(REF, "evaluate", "evaluation"))
+    import msmarco_eval  # reference, pure stdlib
+    rng = np.random.Generator(np.random.PCG64(31))
+    nq, npass, k, topN = 24, 400, 120, 100
+    q2id = rng.permutation(5000)[:nq] + 1
+    p2id = rng.integers(1, 260, npass)  # several vectors per document
+    I = np.stack([rng.permutation(npass)[:k] for _ in range(nq)])
+    qrels = {}
+    for i, q in enumerate(q2id):
+        walked = p2id[I[i, :topN]]
+        rel = {int(p): int(rng.integers(0, 3)) for p in rng.choice(walked, 3)}  # some judged with rel 0
+        rel.update({int(p): 1 for p in rng.integers(1, 260, 2)})
+        qrels[int(q)] = rel
+    off_q = {int(q2id[0]): "doc-a", int(q2id[1]): "doc-b"}
+    off_p = {int(p2id[I[0, 0]]): "doc-a", int(p2id[I[1, 4]]): "doc-b", int(p2id[I[2, 1]]): "doc-zzz"}
+    ns = {"pytrec_eval": types.SimpleNamespace(RelevanceEvaluator=TrecEvaluatorStandIn), "compute_metrics": msmarco_eval.compute_metrics,
+          "offset2qchar": off_q, "offset2pchar": off_p}
+    _reference_functions(os.path.join(REF, "evaluate", "evaluation", "evaluate_beir.py"), ["EvalDevQuery", "convert_to_string_id"], ns)
+    (ndcg, cnt, Map, mrr, recall, hole, ms_mrr, ahole, result, prediction, mrrs, ndcgs) = ns["EvalDevQuery"](
+        [int(x) for x in q2id], [int(x) for x in p2id], qrels, I, topN)
+    pred_q, pred_p, pred_s = [], [], []
+    for q, docs in prediction.items():
+        for pid, sc in docs.items():
+            pred_q.append(q); pred_p.append(pid); pred_s.append(sc)
+    qr = [(q, p_, r) for q, d in qrels.items() for p_, r in d.items()]
+    np.savez_compressed(os.path.join(OUT, "evaldev_beir.npz"), q2id=q2id, p2id=p2id, I=I, topN=np.int64(topN),
+                        qrels=np.array(qr, np.int64), off_q=np.array(sorted(off_q), np.int64), off_q_char=np.array([off_q[k_] for k_ in sorted(off_q)]),
+                        off_p=np.array(sorted(off_p), np.int64), off_p_char=np.array([off_p[k_] for k_ in sorted(off_p)]),
+                        pred=np.array([pred_q, pred_p, pred_s], np.int64), n_queries=np.int64(cnt), hole_rate=np.float64(hole),
+                        ahole_rate=np.float64(ahole), ms_mrr10=np.float64(ms_mrr["MRR @10"]), ms_ranked=np.int64(ms_mrr["QueriesRanked"]),
+                        standin_means=np.array([ndcg, Map, mrr, recall]))
+    print("evaldev golden:", cnt, "queries; hole", hole, ahole, "ms_mrr", ms_mrr, "stand-in ndcg/map/mrr/recall", ndcg, Map, mrr, recall)
+    sys.path.pop(0)
+
+
+def golden_negatives():
+    """a19: the ANCE driver's own ``GenerateNegativePassaageID`` (ANCE/drivers/run_ann_data_gen.py:497-570), both branches:
+    ``--ann_measure_topk_mrr`` and the default shuffled walk.  ``random.shuffle`` is replaced by recorded permutations (as
+    for the collator fixture) so the selection rule - not Python's RNG stream - is what the fixture pins; ``trange`` is
+    ``range``."""
+    rng = np.random.Generator(np.random.PCG64(41))
+    nq, npass, k, n_neg = 30, 500, 60, 7
+    q2id = rng.permutation(9000)[:nq]
+    p2id = rng.integers(0, 300, npass)
+    I = np.stack([rng.permutation(npass)[:k] for _ in range(nq)])
+    pos = {int(q): (int(p2id[I[i, int(rng.integers(0, k))]]) if i % 5 else 100000 + i) for i, q in enumerate(q2id)}  # every 5th positive is not retrieved
+    eff = set(int(q) for i, q in enumerate(q2id) if i % 3 != 1)
+    perms = [rng.permutation(k) for _ in range(nq)]
+    state = {"j": 0}
+
+    def fake_shuffle(lst):
+        lst[:] = [int(x) for x in perms[state["j"]]]
+        state["j"] += 1
+
+    ns = {"np": np, "trange": range, "random": types.SimpleNamespace(shuffle=fake_shuffle), "print": lambda *a, **k_: None}
+    _reference_functions(os.path.join(REF, "ANCE", "drivers", "run_ann_data_gen.py"), ["GenerateNegativePassaageID"], ns)
+    out = dict(q2id=q2id, p2id=p2id, I=I, pos=np.array([[q, p_] for q, p_ in pos.items()], np.int64), eff=np.array(sorted(eff), np.int64),
+               negative_sample=np.int64(n_neg), perms=np.stack(perms))
+    for topk, tag in ((True, "topk"), (False, "shuffle")):
+        state["j"] = 0
+        args = types.SimpleNamespace(ann_measure_topk_mrr=topk, negative_sample=n_neg, rank=0)
+        negs, rr = ns["GenerateNegativePassaageID"](args, [int(x) for x in q2id], [int(x) for x in p2id], pos, I, eff)
+        qs = list(negs.keys())
+        out[f"{tag}_qids"] = np.array(qs, np.int64)
+        out[f"{tag}_negs"] = np.array([negs[q] + [-1] * (n_neg - len(negs[q])) for q in qs], np.int64)
+        out[f"{tag}_rr"] = np.asarray(rr, np.float64)
+        out[f"{tag}_nperm"] = np.int64(state["j"])
+    np.savez_compressed(os.path.join(OUT, "hard_negatives.npz"), **out)
+    print("negatives golden:", len(out["topk_qids"]), "queries;", out["shuffle_negs"][0], out["shuffle_nperm"])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate"]
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate", "evaldev", "negatives"]
+    if "evaldev" in which:
+        golden_evaldev()
+    if "negatives" in which:
+        golden_negatives()
     if "collate" in which:
         golden_collate()
     if "dro_greedy" in which:

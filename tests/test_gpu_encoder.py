@@ -14,7 +14,7 @@ import cocodr_amd  # noqa: E402
 from cocodr_amd import ops  # noqa: E402
 from cocodr_amd.modeling import BertDotNLL, CoCondenserForPretraining, CocoBertConfig, CocoBertModel  # noqa: E402
 import oracle as O  # noqa: E402  (checker only)
-from conftest import cfg_from_golden  # noqa: E402
+from conftest import cfg_from_golden, params_from_golden  # noqa: E402
 
 DEV = "cuda"
 
@@ -81,20 +81,24 @@ def test_coco_contrastive_step_matches_reference_golden(golden_coco):
 
 
 def test_ance_triplet_step_matches_reference_golden(golden_ance):
+    """BertDot_NLL_LN.forward + backward against the reference's own class (ANCE/model/models.py:97-106,225-262).  The
+    fixture shrinks the last LayerNorm so the logits are O(5) and the loss reacts to errors (make_golden.py): the loss is
+    asserted at SURVEY 8(d)'s 1e-2 relative, logits at 2e-2 absolute (bf16 hidden states under an fp32 LayerNorm),
+    parameter gradients at 8e-2 rel-L2."""
     g = golden_ance
     ocfg = cfg_from_golden(g)
     cfg = CocoBertConfig(vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
                          num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
                          max_position_embeddings=ocfg.max_position_embeddings)
     model = BertDotNLL(cfg)
-    P = O.make_params(ocfg, int(g["seed"]), std=float(g["std"]))
-    model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in params_from_golden(g).items()})
     model.to(DEV)
     t = lambda k: torch.from_numpy(g[k]).to(DEV)
     loss, acc, logits = model(t("q_ids"), t("q_mask"), t("a_ids"), t("a_mask"), t("b_ids"), t("b_mask"), weights=t("weights"))
     loss.backward()
-    # logits ~130 from bf16 hidden states: absolute error ~0.1 -> compare logits at 2e-3 relative, loss loosely
-    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=3e-3)
+    ref_loss = float(g["loss"])
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-2 * abs(ref_loss), (float(loss.detach()), ref_loss)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], atol=2e-2, rtol=0)
     with torch.no_grad():
         q = model.query_emb(t("q_ids"), t("q_mask")).cpu().numpy()
     assert cosine_rows(q, g["q_emb"]).min() > 0.999 and rel_l2(q, g["q_emb"]) < 2e-2
@@ -102,7 +106,7 @@ def test_ance_triplet_step_matches_reference_golden(golden_ance):
     checked = 0
     for key in g.files:
         if key.startswith("grad:") and not key.endswith("key.bias"):
-            assert rel_l2(G[key[5:]], g[key]) < 0.15, (key, rel_l2(G[key[5:]], g[key]))  # loss gradient amplifies the logit error
+            assert rel_l2(G[key[5:]], g[key]) < 8e-2, (key, rel_l2(G[key[5:]], g[key]))
             checked += 1
     assert checked >= 10
 
@@ -306,7 +310,7 @@ def test_idro_reweighted_triplet_steps_match_reference_golden():
                          num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
                          max_position_embeddings=ocfg.max_position_embeddings)
     model = BertDotNLL(cfg)
-    model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in O.make_params(ocfg, int(g["seed"]), std=float(g["std"])).items()})
+    model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in params_from_golden(g).items()})
     model.to(DEV)
     G, alpha, eps, ema, rho = (float(x) for x in g["hyper"])
     model.add_group_loss(args=types.SimpleNamespace(model_size="base", local_rank=0), n_groups=int(G), dro_type="idro", alpha=alpha,
@@ -318,11 +322,10 @@ def test_idro_reweighted_triplet_steps_match_reference_golden():
                                                         group_ids=t("groups"))
         robust.backward()
         ref_robust = float(g[f"s{step}_robust"])
-        assert abs(float(robust.detach()) - ref_robust) <= 3e-2 * abs(ref_robust), (float(robust.detach()), ref_robust)
+        assert abs(float(robust.detach()) - ref_robust) <= 1e-2 * abs(ref_robust), (float(robust.detach()), ref_robust)
         np.testing.assert_array_equal(group_counts.cpu().numpy(), g[f"s{step}_group_counts"])
-        # logits are O(100) after 12 bf16 layers at this init scale (cf. the ANCE golden: 2-3e-3 relative = 0.2-0.4
-        # absolute), and a row loss moves one-for-one with its logit gap
-        np.testing.assert_allclose(group_losses.cpu().numpy(), g[f"s{step}_group_losses"], rtol=5e-2, atol=0.4)
+        # logits are O(5) in this fixture (last LayerNorm shrunk, make_golden.py); a row loss moves one-for-one with its logit gap
+        np.testing.assert_allclose(group_losses.cpu().numpy(), g[f"s{step}_group_losses"], rtol=1e-2, atol=1e-2)
         # the weight update sees bf16-level noise in losses and gradient cosines, damped by rho = 0.1 and the EMA power
         np.testing.assert_allclose(model.loss.h_fun.cpu().numpy(), g[f"s{step}_h_fun"], rtol=3e-2, atol=1e-3)
         Gr = grads_by_name(model.bert)
@@ -330,7 +333,7 @@ def test_idro_reweighted_triplet_steps_match_reference_golden():
         for key in g.files:
             if key.startswith(f"s{step}_grad:") and not key.endswith("key.bias"):
                 name = key.split(":", 1)[1]
-                assert rel_l2(Gr[name], g[key]) < 0.2, (name, rel_l2(Gr[name], g[key]))
+                assert rel_l2(Gr[name], g[key]) < 8e-2, (name, rel_l2(Gr[name], g[key]))
                 checked += 1
         assert checked >= 10
 
@@ -347,7 +350,7 @@ def test_dro_greedy_steps_match_reference_golden(weight_ema, tag):
                          num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
                          max_position_embeddings=ocfg.max_position_embeddings)
     model = BertDotNLL(cfg)
-    model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in O.make_params(ocfg, int(g["seed"]), std=float(g["std"])).items()})
+    model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in params_from_golden(g).items()})
     model.to(DEV)
     G, alpha, eps, ema = (float(x) for x in g["hyper"])
     model.add_group_loss(args=types.SimpleNamespace(model_size="base", local_rank=0), n_groups=int(G), dro_type="dro-greedy",
@@ -360,11 +363,11 @@ def test_dro_greedy_steps_match_reference_golden(weight_ema, tag):
                                                         group_ids=t("groups"), weights=w)
         robust.backward()
         ref = float(g[f"{tag}_s{step}_robust"])
-        assert abs(float(robust.detach()) - ref) <= 3e-2 * abs(ref) + 2e-3, (float(robust.detach()), ref)
+        assert abs(float(robust.detach()) - ref) <= 1e-2 * abs(ref), (float(robust.detach()), ref)
         np.testing.assert_array_equal(group_counts.cpu().numpy(), g[f"{tag}_s{step}_group_counts"])
-        np.testing.assert_allclose(group_losses.cpu().numpy(), g[f"{tag}_s{step}_group_losses"], rtol=5e-2, atol=5e-2)
+        np.testing.assert_allclose(group_losses.cpu().numpy(), g[f"{tag}_s{step}_group_losses"], rtol=1e-2, atol=5e-3)
         np.testing.assert_allclose(model.loss.count_cat.cpu().numpy(), g[f"{tag}_s{step}_count_cat"], rtol=1e-5)
-        np.testing.assert_allclose(model.loss.sum_losses.cpu().numpy(), g[f"{tag}_s{step}_sum_losses"], rtol=5e-2, atol=3e-2)
+        np.testing.assert_allclose(model.loss.sum_losses.cpu().numpy(), g[f"{tag}_s{step}_sum_losses"], rtol=1e-2, atol=5e-3)
         # the weights are a sort-and-cut function of the EMA losses: identical unless bf16 noise flips the order of two groups
         np.testing.assert_allclose(model.loss.h_fun.cpu().numpy(), g[f"{tag}_s{step}_h_fun"], rtol=3e-2, atol=2e-2)
         if step == 1:
@@ -372,7 +375,7 @@ def test_dro_greedy_steps_match_reference_golden(weight_ema, tag):
             for key in g.files:
                 if key.startswith(f"{tag}_s1_grad:"):
                     name = key.split(":", 1)[1]
-                    assert rel_l2(Gr[name], g[key]) < 0.15, (name, rel_l2(Gr[name], g[key]))
+                    assert rel_l2(Gr[name], g[key]) < 8e-2, (name, rel_l2(Gr[name], g[key]))
 
 
 def test_training_step_at_512_tokens_matches_oracle():

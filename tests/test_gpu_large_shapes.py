@@ -1,0 +1,144 @@
+"""Numeric parity at the shapes of BASELINE.json configs 1, 4, 5 and of the north-star target (BERT-large: H = 1024,
+16 heads, I = 4096; config 1: BERT-base 12 layers, 8 x 64 tokens).  All calls go through the C ABI.
+
+GEMM: every pipeline geometry (`cocodr_gemm_set_impl`) at the (M, N, K) triples a BERT-large step launches, against
+fp32 torch on the same bf16-rounded operands.  Tolerances: bf16 output = rounding of an fp32 accumulator -> rel-L2
+<= 5e-3; fp32 output (weight gradients) -> accumulate-order noise only, <= 1e-4.
+Encoder: forward + InfoNCE + backward against the numpy oracle (SURVEY 8d tolerances: loss <= 1e-2 relative,
+[CLS] cosine >= 0.999, parameter gradients rel-L2 <= 8e-2 per tensor)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cocodr_amd  # noqa: E402
+from cocodr_amd import ops  # noqa: E402
+from cocodr_amd import _native as N  # noqa: E402
+from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertConfig, CocoBertModel  # noqa: E402
+import oracle as O  # noqa: E402  (checker only)
+
+DEV = "cuda"
+IMPLS = list(range(1, 13))
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(params=IMPLS, ids=[f"impl{i}" for i in IMPLS])
+def gemm_impl(request):
+    ops.gemm_set_impl(request.param)
+    yield request.param
+    ops.gemm_set_impl(0)
+
+
+# the projections of one BERT-large layer at 64 x 128 tokens (and at the 16 x 128-token query pass of config 4)
+LARGE_MNK = [(8192, 1024, 1024), (8192, 3072, 1024), (8192, 4096, 1024), (8192, 1024, 4096), (2048, 1024, 1024)]
+
+
+@pytest.mark.parametrize("M,Nn,K", LARGE_MNK)
+def test_gemm_large_forward_forms(M, Nn, K, gemm_impl):
+    a, w = rnd(M, K, seed=3), rnd(Nn, K, scale=0.03, seed=4)
+    bias, r = rnd(Nn, seed=5, dtype=torch.float32), rnd(M, Nn, seed=6)
+    pre = a.float() @ w.float().T + bias
+    assert rel_l2(ops.gemm(a, w, bias=bias), pre) < 5e-3
+    assert rel_l2(ops.gemm(a, w, bias=bias, epi=N.EPI_ADD, r=r), pre + r.float()) < 5e-3
+    if Nn == 4096:  # FFN1: GELU value and saved derivative
+        h, gp = ops.gemm(a, w, bias=bias, epi=N.EPI_GELU)
+        x = pre.clone().requires_grad_(True)
+        ref = torch.nn.functional.gelu(x)
+        ref.sum().backward()
+        assert rel_l2(h, ref) < 5e-3 and rel_l2(gp, x.grad) < 5e-3
+
+
+@pytest.mark.parametrize("M,Nn,K", LARGE_MNK)
+def test_gemm_large_dgrad_forms(M, Nn, K, gemm_impl):
+    dy, w = rnd(M, K, seed=7), rnd(K, Nn, scale=0.03, seed=8)  # Linear weight [out = K, in = N]
+    ref = dy.float() @ w.float()
+    out, cs = ops.gemm(dy, w, trans_b=True, colsum=True)
+    assert rel_l2(out, ref) < 5e-3
+    assert (cs - ref.sum(0)).abs().max() < 2e-3 * float(ref.abs().sum(0).max())
+    if Nn == 4096:  # dgrad of FFN2 times the saved GELU'
+        gp = rnd(M, Nn, seed=9)
+        out, cs = ops.gemm(dy, w, trans_b=True, epi=N.EPI_DGELU, r=gp, colsum=True)
+        assert rel_l2(out, ref * gp.float()) < 5e-3
+        assert (cs - (ref * gp.float()).sum(0)).abs().max() < 2e-3 * float((ref * gp.float()).abs().sum(0).max())
+
+
+@pytest.mark.parametrize("nb,Mtok,No,Ni", [(24, 2048, 1024, 1024), (4, 8192, 4096, 1024), (4, 8192, 1024, 4096), (3, 8192, 3072, 1024)])
+def test_gemm_large_grouped_wgrad(nb, Mtok, No, Ni, gemm_impl):
+    """dW_l = dY_l^T X_l for a group of layers in one launch (24 = every layer of BERT-large), fp32 result"""
+    dy, x = rnd(nb, Mtok, No, seed=10), rnd(nb, Mtok, Ni, seed=11)
+    out = ops.gemm(dy, x, trans_a=True, trans_b=True, out_f32=True)
+    ref = torch.einsum("bmo,bmi->boi", dy.float(), x.float())
+    assert out.dtype == torch.float32 and rel_l2(out, ref) < 1e-4
+
+
+def _model_from_oracle(ocfg, P):
+    cfg = CocoBertConfig(vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
+                         num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
+                         max_position_embeddings=ocfg.max_position_embeddings, type_vocab_size=ocfg.type_vocab_size)
+    m = CocoBertModel(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    return m.to(DEV)
+
+
+def _np_rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _contrastive_step_vs_oracle(ocfg, P, B, L, seed, grad_tol):
+    m = _model_from_oracle(ocfg, P)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ids = rng.integers(5, ocfg.vocab_size, (B, L))
+    mask = np.ones((B, L), np.int64)
+    for b in range(1, B):
+        mask[b, int(rng.integers(8, L + 1)):] = 0
+    ids = ids * mask
+    hs, cache = O.encoder_fwd(P, ocfg, ids, mask, keep_cache=True)
+    E = O.cls_embedding(hs[-1])
+    ref_loss, dE = O.contrastive_loss_grad(E.copy(), 1)
+    d_last = np.zeros_like(hs[-1])
+    d_last[:, 0] = dE
+    Gref = O.encoder_bwd(P, ocfg, cache, d_last)
+    tids, tmask = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    with torch.no_grad():
+        out = m(input_ids=tids, attention_mask=tmask, output_hidden_states=True)
+    valid = mask.astype(bool)
+    for i, h in enumerate(out.hidden_states):
+        assert _np_rel(h.float().cpu().numpy()[valid], hs[i][valid]) < 2e-2, i
+    cls = out.cls_fp32.cpu().numpy().astype(np.float64)
+    cos = (cls * E).sum(-1) / (np.linalg.norm(cls, axis=-1) * np.linalg.norm(E, axis=-1))
+    assert cos.min() > 0.999
+    model = CoCondenserForPretraining(m)
+    loss = model({"input_ids": tids, "attention_mask": tmask}, None)
+    loss.backward()
+    assert abs(float(loss) - ref_loss) < 1e-2 * abs(ref_loss) + 1e-3, (float(loss), ref_loss)
+    G = {k: v.detach().float().cpu().numpy() for k, v in m.hf_named_grads()}
+    bad = {n: _np_rel(G[n], Gref[n]) for n in Gref if not n.endswith("key.bias") and _np_rel(G[n], Gref[n]) > grad_tol}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("B,L", [(4, 128), (4, 64)])
+def test_bert_large_two_layers_vs_oracle(B, L):
+    """the BERT-large layer (H = 1024, 16 heads, I = 4096: its own GEMM geometries and LayerNorm instantiation) at both
+    sequence lengths of configs 4 / 5, forward + InfoNCE + backward"""
+    ocfg = O.OracleConfig(vocab_size=2000, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                          max_position_embeddings=128)
+    _contrastive_step_vs_oracle(ocfg, O.make_params(ocfg, 21, std=0.04), B, L, seed=6, grad_tol=8e-2)
+
+
+def test_config1_real_shape_vs_oracle():
+    """BASELINE.json configs[0] at its real shape: BERT-base, 12 layers, 8 sequences x 64 tokens (the oracle is the CPU
+    path that config is defined on)"""
+    ocfg = O.OracleConfig(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                          max_position_embeddings=512)
+    _contrastive_step_vs_oracle(ocfg, O.make_params(ocfg, 0, std=0.03), 8, 64, seed=7, grad_tol=1e-1)

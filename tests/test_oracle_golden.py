@@ -2,7 +2,7 @@
 (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 
-from conftest import cfg_from_golden, load_golden
+from conftest import cfg_from_golden, load_golden, params_from_golden
 import oracle as O
 
 
@@ -76,7 +76,7 @@ def test_coco_loss_and_grads_through_encoder(golden_coco):
 def test_ance_triplet_matches_reference(golden_ance):
     g = golden_ance
     cfg = cfg_from_golden(g)
-    P = O.make_params(cfg, int(g["seed"]), std=float(g["std"]))
+    P = params_from_golden(g)
     embs, caches = [], []
     for ids, mask in ((g["q_ids"], g["q_mask"]), (g["a_ids"], g["a_mask"]), (g["b_ids"], g["b_mask"])):
         hs, cache = O.encoder_fwd(P, cfg, ids, mask, keep_cache=True)
@@ -195,7 +195,7 @@ def test_idro_oracle_matches_reference_idro_golden():
     statistics, the updated group weights and gradients of the re-weighted loss."""
     z = load_golden("idro_steps.npz")
     cfg = cfg_from_golden(z)
-    P = {k: v.astype(np.float64) for k, v in O.make_params(cfg, int(z["seed"]), std=float(z["std"])).items()}
+    P = params_from_golden(z, np.float64)
     G, alpha, eps, ema, rho = (float(x) for x in z["hyper"])
     G = int(G)
     h = np.ones(G)
@@ -220,7 +220,7 @@ def test_dro_greedy_oracle_matches_reference_golden():
     gradient of the re-weighted loss on step 1."""
     z = load_golden("dro_greedy_steps.npz")
     cfg = cfg_from_golden(z)
-    P = {k: v.astype(np.float64) for k, v in O.make_params(cfg, int(z["seed"]), std=float(z["std"])).items()}
+    P = params_from_golden(z, np.float64)
     G, alpha, eps, ema = (float(x) for x in z["hyper"])
     G = int(G)
     w = z["weights"].astype(np.float64)
