@@ -13,9 +13,14 @@ from ._native import check, lib, ptr, stream_ptr
 __all__ = ["CondenserCollator", "CoCondenserCollator", "subword_flags_from_vocab"]
 
 
-def subword_flags_from_vocab(tokens: Sequence[str]) -> np.ndarray:
-    """uint8 [V]: 1 where the WordPiece token continues a word (``token.startswith('##')``, COCO/data.py:50)."""
-    return np.fromiter((1 if t.startswith("##") else 0 for t in tokens), dtype=np.uint8, count=len(tokens))
+BERT_SPECIALS = ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]")  # BertTokenizer.all_special_tokens
+
+
+def subword_flags_from_vocab(tokens: Sequence[str], specials: Optional[Sequence[str]] = BERT_SPECIALS) -> np.ndarray:
+    """uint8 [V] vocabulary classes: 1 where the WordPiece token continues a word (``token.startswith('##')``,
+    COCO/data.py:50), 2 for the tokenizer's special tokens (skipped by the word grouping, never masked, :47-48), else 0."""
+    sp = set(specials or ())
+    return np.fromiter((2 if t in sp else (1 if t.startswith("##") else 0) for t in tokens), dtype=np.uint8, count=len(tokens))
 
 
 class CondenserCollator:
@@ -36,7 +41,7 @@ class CondenserCollator:
     @classmethod
     def from_tokenizer(cls, tokenizer, **kw):
         vocab = [tokenizer.convert_ids_to_tokens(i) for i in range(len(tokenizer))]
-        return cls(subword_flags_from_vocab(vocab), cls_id=tokenizer.cls_token_id, sep_id=tokenizer.sep_token_id,
+        return cls(subword_flags_from_vocab(vocab, tokenizer.all_special_tokens), cls_id=tokenizer.cls_token_id, sep_id=tokenizer.sep_token_id,
                    pad_id=tokenizer.pad_token_id, mask_id=tokenizer.mask_token_id, **kw)
 
     def collate_spans(self, spans: Sequence[Sequence[int]]) -> Dict[str, torch.Tensor]:

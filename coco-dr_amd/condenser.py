@@ -100,10 +100,14 @@ class CondenserHead(nn.Module):
         self._shadow_version = -1
         return torch.nn.modules.module._IncompatibleKeys(missing, [])
 
-    def _refresh_shadow(self):
+    def _shadow_target(self):
         if self._shadow is None or self._shadow.device != self.flat_decay.device:
             self._shadow = torch.empty(self.layout.decay_numel, dtype=torch.bfloat16, device=self.flat_decay.device)
             self._shadow_version = -1
+        return self._shadow, 0
+
+    def _refresh_shadow(self):
+        self._shadow_target()
         if self._shadow_version != self.flat_decay._version:
             ops.cast_f32_bf16(self.flat_decay.data, self._shadow)
             self._shadow_version = self.flat_decay._version

@@ -31,8 +31,9 @@ __global__ __launch_bounds__(64) void collate_kernel(const int32_t* __restrict__
                                                      long long ex_base, int32_t* __restrict__ input_ids, int32_t* __restrict__ labels,
                                                      int32_t* __restrict__ attn) {
   __shared__ int tok[CL_MAX];
-  __shared__ int word_of[CL_MAX];                 // word index of each token
-  __shared__ int word_start[CL_MAX], word_len[CL_MAX];
+  __shared__ int word_of[CL_MAX];                 // word index of each token (-1: a special token, part of no word)
+  __shared__ int word_len[CL_MAX];
+  __shared__ unsigned char chosen[CL_MAX];        // per word: selected for masking
   __shared__ unsigned long long key[CL_MAX];      // (random key << 32) | word index, padded with ~0 for the bitonic sort
   __shared__ unsigned char masked[CL_MAX];
   __shared__ int s_nwords;
@@ -48,19 +49,24 @@ __global__ __launch_bounds__(64) void collate_kernel(const int32_t* __restrict__
     left = (int)(collate_rand(seed, exg, RS_TRUNC, 0) % (uint32_t)(trunc + 1));
     n = tgt;
   }
-  // ---- tokens and word structure (data.py:44-55): a "##" piece joins the word in front of it
+  // ---- tokens and word structure (data.py:44-55): a "##" piece joins the word in front of it; a special token inside
+  // the span ([UNK], a stray [SEP] ...: vocabulary class 2) is skipped - it belongs to no word and is never masked, and a
+  // "##" piece behind it still joins the last word that was opened
   for (int i = lane; i < n; i += 64) {
     int t = tokens[o0 + left + i];
     t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
     tok[i] = t;
     masked[i] = 0;
+    chosen[i] = 0;
   }
   __syncthreads();
   if (lane == 0) {                                 // n <= 510: a short serial scan
     int nw = 0;
     for (int i = 0; i < n; ++i) {
-      const bool cont = nw >= 1 && is_subword[tok[i]] != 0;
-      if (!cont) { word_start[nw] = i; word_len[nw] = 0; ++nw; }
+      const int cls = is_subword[tok[i]];
+      if (cls == 2) { word_of[i] = -1; continue; }
+      const bool cont = nw >= 1 && cls == 1;
+      if (!cont) { word_len[nw] = 0; ++nw; }
       word_of[i] = nw - 1;
       word_len[nw - 1]++;
     }
@@ -94,10 +100,12 @@ __global__ __launch_bounds__(64) void collate_kernel(const int32_t* __restrict__
       if (taken >= want) break;
       const int w = (int)(key[j] & 0xffffffffu);
       if (taken + word_len[w] > want) continue;
-      for (int i = word_start[w]; i < word_start[w] + word_len[w]; ++i) masked[i] = 1;
+      chosen[w] = 1;
       taken += word_len[w];
     }
   }
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) masked[i] = word_of[i] >= 0 && chosen[word_of[i]];
   __syncthreads();
   // ---- [CLS] tokens [SEP] pad (data.py:135-144) + 80 / 10 / 10 (torch_mask_tokens)
   int32_t* ids_row = input_ids + ex * L;

@@ -98,6 +98,7 @@ constexpr int NCAND = 2048;    // LDS candidate list of the compacted path
 
 // order-preserving map: smaller key <=> larger float  (NaN sorts last)
 __device__ __forceinline__ uint32_t desc_key(float f) {
+  if (f != f) return 0xffffffffu;  // every NaN behind -inf (key_to_float gives a NaN back)
   uint32_t u = __float_as_uint(f);
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending in f
   return ~u;

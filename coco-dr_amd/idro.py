@@ -24,14 +24,16 @@ from ._native import check, lib, ptr, stream_ptr
 __all__ = ["IDROLoss", "DROGreedyLoss", "idro_triplet_step"]
 
 
-class IDROLoss:
-    """State and update rule of ``iDROLoss`` (hyper-parameters as in ``add_group_loss``, models.py:211-218)."""
+class IDROLoss(torch.nn.Module):
+    """State and update rule of ``iDROLoss`` (hyper-parameters as in ``add_group_loss``, models.py:211-218).  A module with
+    the reference's buffer name, so ``state_dict()`` of the wrapping model carries ``loss.h_fun`` across checkpoints."""
 
     def __init__(self, n_groups: int, alpha: float, eps: float, ema: float = 0.1, rho: float = 0.1, model_size: str = "base",
                  device=None):
+        super().__init__()
         self.n_groups, self.alpha, self.eps, self.ema, self.rho = int(n_groups), float(alpha), float(eps), float(ema), float(rho)
         self.model_size = model_size
-        self.h_fun = torch.ones(self.n_groups, dtype=torch.float32, device=device)  # register_buffer('h_fun', ones), :28
+        self.register_buffer("h_fun", torch.ones(self.n_groups, dtype=torch.float32, device=device))  # dro_loss.py:28
         self.per_group_backward = False   # True: one partial backward per present group (the reference's structure)
         self.last_path = None
 
@@ -74,17 +76,18 @@ def _gram(a: torch.Tensor, chunk: int = 1 << 16) -> torch.Tensor:
     return out
 
 
-class DROGreedyLoss:
+class DROGreedyLoss(torch.nn.Module):
     """``DROGreedyLoss`` (ANCE/model/dro_loss.py:11-126, the driver's default ``--dro_type``): the step's loss is
     ``sum_i h[g_i] * w_i * loss_i / B`` with the weights of the previous step; afterwards the EMA group losses / counts
     (gathered over all ranks) choose the worst groups whose cumulative EMA fraction stays below ``alpha``: weight
     ``1/alpha`` for them, the left-over mass for the next one, ``eps`` for the rest (``update_mw``)."""
 
     def __init__(self, n_groups: int, alpha: float, eps: float, ema: float = 0.1, weight_ema: bool = False, device=None):
+        super().__init__()
         self.n_groups, self.alpha, self.eps, self.ema, self.weight_ema = int(n_groups), float(alpha), float(eps), float(ema), bool(weight_ema)
-        self.h_fun = torch.ones(self.n_groups, dtype=torch.float32, device=device)
-        self.sum_losses = torch.zeros(self.n_groups, dtype=torch.float32, device=device)
-        self.count_cat = torch.ones(self.n_groups, dtype=torch.float32, device=device)
+        self.register_buffer("h_fun", torch.ones(self.n_groups, dtype=torch.float32, device=device))        # dro_loss.py:28-30
+        self.register_buffer("sum_losses", torch.zeros(self.n_groups, dtype=torch.float32, device=device))
+        self.register_buffer("count_cat", torch.ones(self.n_groups, dtype=torch.float32, device=device))
 
     def row_weights(self, groups: torch.Tensor, weights: Optional[torch.Tensor]) -> torch.Tensor:
         """What ``(loss * row_weights).mean()`` must use so that it equals the robust loss (dro_loss.py:51-60)."""
@@ -176,7 +179,7 @@ def _per_sequence_group_grads(bert, passes, arenas, unit, g, inv, all_grads, lay
             return arena[b0: b0 + M * width * 2].view(torch.bfloat16).view(Bp, L, width)
 
         def add(col0, per_seq):      # all_grads[group, col0 : col0 + n] += per_seq[i] for every sequence i of the group
-            n = per_seq.shape[1]     # (the 1 / count_g of the group MEAN is a row scale: the cosine gram does not see it)
+            n = per_seq.shape[1]     # (SUMS; the caller applies the 1 / count_g of the group MEAN once, before the cross-rank sum)
             all_grads[:, col0: col0 + n].index_add_(0, seq_g, per_seq)
 
         per = L // bl.ln_rows
@@ -248,6 +251,10 @@ class _IDROStepFn(torch.autograd.Function):
         fast = (not dro.per_group_backward) and _per_sequence_group_grads(
             bert, passes, arenas, unit, g, inv, all_grads, (l_lo, l_hi), (d0, d1, n0, n1), (sd, sn), (emb, arr, eg, garr, ccfg))
         dro.last_path = "per-sequence" if fast else "per-group"
+        if fast:
+            # per-rank group MEAN gradients, as the reference forms them (dro_loss.py:192-205): on one rank the cosine gram
+            # ignores a row scale, but the cross-rank SUM below (:234) mixes ranks whose counts of a group differ
+            all_grads.mul_(inv[:, None])
         present = [] if fast else torch.nonzero(counts > 0).flatten().tolist()   # fallback: one partial backward per group
         for gi in present:
             w = (g == gi).to(torch.float32) * inv[gi]

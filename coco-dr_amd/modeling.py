@@ -407,6 +407,11 @@ class CocoBertModel(nn.Module):
             self._shadow = torch.empty(n, dtype=torch.bfloat16, device=self.flat_decay.device)
             self._shadow_version = -1
 
+    def _shadow_target(self):
+        """(bf16 shadow, first element of flat_decay it mirrors) - what an optimizer pass writes next to the fp32 master"""
+        self._ensure_shadow()
+        return self._shadow, self.layout.mat_begin
+
     def _refresh_shadow(self):
         lo = self.layout
         self._ensure_shadow()
@@ -629,6 +634,9 @@ class BertDotNLL(nn.Module):
         # pass.  Autograd replays each pass's backward on its forward stream, so the two backward passes overlap as well.
         main = torch.cuda.current_stream()
         side = self._side_stream()
+        # the bf16 weight shadow both passes read is brought up to date HERE, on the main stream: refreshed inside the query
+        # pass it would be written on the side stream while the passage pass (main stream) already believes it fresh
+        self.bert._refresh_shadow()
         side.wait_stream(main)
         with torch.cuda.stream(side):
             q = self.query_emb(query_ids, attention_mask_q)

@@ -52,19 +52,39 @@ def lamb_plan(offsets: Sequence[int], numel: int, chunk: int = 4096) -> Tuple[np
     return (np.asarray(start, np.int64), np.asarray(length, np.int32), np.asarray(seg, np.int32), np.asarray(seg_begin, np.int32))
 
 
+def _shadow_owners(model) -> dict:
+    """id(flat_decay) -> the module that keeps a bf16 shadow of it (CocoBertModel, CondenserHead), for ``model`` and all
+    of its sub-modules."""
+    owners = {}
+    for m in model.modules():
+        if hasattr(m, "_shadow_target") and hasattr(m, "flat_decay"):
+            owners[id(m.flat_decay)] = m
+    return owners
+
+
+def _after_native_update(p: torch.Tensor, owner, shadow_written: bool) -> None:
+    """The kernels write the parameter through a raw pointer, which torch's version counter does not see; the bf16 shadows
+    decide on that counter whether they are stale.  Bump it, and mark the shadow fresh only if this pass wrote it."""
+    torch.autograd.graph.increment_version(p)
+    if owner is not None and shadow_written:
+        owner._shadow_version = p._version
+
+
 class FlatAdamW(torch.optim.Optimizer):
     """``FlatAdamW(model.param_groups(weight_decay), lr=...)`` or ``FlatAdamW.for_model(model, ...)``.
 
-    The latter also keeps the model's bf16 shadow in sync inside the optimizer pass."""
+    ``for_model`` accepts anything with ``param_groups()`` (CocoBertModel, BertDotNLL.bert, CoCondenserForPretraining with
+    its Condenser head) and refreshes every bf16 weight shadow inside the optimizer pass; the plain constructor leaves the
+    shadows to the next forward (one extra cast pass), never stale."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._model = None
+        self._owners = {}
 
     @classmethod
     def for_model(cls, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         opt = cls(model.param_groups(weight_decay), lr=lr, betas=betas, eps=eps)
-        opt._model = model
+        opt._owners = _shadow_owners(model)
         return opt
 
     @torch.no_grad()
@@ -88,16 +108,14 @@ class FlatAdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
                 shadow, begin = None, 0
-                m = self._model
-                if m is not None and p is m.flat_decay:
-                    m._ensure_shadow()
-                    shadow, begin = m._shadow, m.layout.mat_begin
+                m = self._owners.get(id(p))
+                if m is not None:
+                    shadow, begin = m._shadow_target()
                 check(lib().cocodr_adamw_step(ptr(p), ptr(p.grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(shadow), begin,
                                               p.numel(), float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                                               st["step"], grad_scale, None if clip is None else clip.data_ptr() + 4,
                                               stream_ptr()), "adamw_step")
-                if shadow is not None:
-                    m._shadow_version = p._version  # the shadow already holds the updated weights
+                _after_native_update(p, m, shadow is not None)  # the shadow already holds the updated weights
         return loss
 
 
@@ -111,7 +129,7 @@ class FlatLamb(torch.optim.Optimizer):
     def __init__(self, params, segments: List[Sequence[int]], lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._segments = segments  # per parameter (in param_groups order): sorted tensor start offsets
-        self._model = None
+        self._owners = {}
         self._plans = {}
 
     @classmethod
@@ -127,7 +145,7 @@ class FlatLamb(torch.optim.Optimizer):
         opt = cls(groups, segs, lr=lr, betas=betas, eps=eps, weight_decay=0.0)
         for g, src in zip(opt.param_groups, groups):
             g["weight_decay"] = src.get("weight_decay", 0.0) if weight_decay else 0.0
-        opt._model = model
+        opt._owners = _shadow_owners(model)
         return opt
 
     def _plan(self, p, offs):
@@ -165,16 +183,14 @@ class FlatLamb(torch.optim.Optimizer):
                 st["step"] += 1
                 plan, _keep, ws, stats = self._plan(p, offs)
                 shadow, begin = None, 0
-                m = self._model
-                if m is not None and p is m.flat_decay:
-                    m._ensure_shadow()
-                    shadow, begin = m._shadow, m.layout.mat_begin
+                m = self._owners.get(id(p))
+                if m is not None:
+                    shadow, begin = m._shadow_target()
                 check(lib().cocodr_lamb_step(ptr(p), ptr(p.grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(shadow), begin,
                                              p.numel(), C.byref(plan), float(group["lr"]), b1, b2, group["eps"],
                                              group["weight_decay"], grad_scale, None if clip is None else clip.data_ptr() + 4,
                                              ptr(ws), ptr(stats), stream_ptr()), "lamb_step")
                 st["weight_norm"], st["adam_norm"] = stats[:, 0], stats[:, 1]
                 st["trust_ratio"] = ws[2 * plan.nchunk:]
-                if shadow is not None:
-                    m._shadow_version = p._version
+                _after_native_update(p, m, shadow is not None)
         return loss

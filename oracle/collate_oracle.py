@@ -32,10 +32,13 @@ def _uniform(r: int) -> np.float32:
     return np.float32(r >> 8) * np.float32(1.0 / 16777216.0)
 
 
-def whole_word_groups(is_subword_of_token: Sequence[bool]) -> List[List[int]]:
-    """data.py:44-55 (no special tokens inside a raw span): a "##" piece joins the previous word."""
+def whole_word_groups(is_subword_of_token: Sequence[bool], is_special_of_token: Sequence[bool] = None) -> List[List[int]]:
+    """data.py:44-55: a "##" piece joins the previous word; a special token ([UNK], a stray [SEP] ... inside the span) is
+    skipped (:47-48) - it joins no word and a "##" piece behind it still attaches to the last word opened."""
     cand: List[List[int]] = []
     for i, sub in enumerate(is_subword_of_token):
+        if is_special_of_token is not None and is_special_of_token[i]:
+            continue
         if len(cand) >= 1 and sub:
             cand[-1].append(i)
         else:
@@ -65,7 +68,8 @@ def whole_word_mask(groups: List[List[int]], order: Sequence[int], n_tokens: int
 
 def collate_span(tokens: Sequence[int], is_subword: np.ndarray, seed: int, ex: int, L: int, cls_id: int, sep_id: int, pad_id: int,
                  mask_id: int, mlm_probability: float) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """One row of the batch: (input_ids, labels, attention_mask), int64 [L]."""
+    """One row of the batch: (input_ids, labels, attention_mask), int64 [L].  ``is_subword`` is the per-vocabulary class the
+    kernel takes: 0 starts a word, 1 continues one ("##"), 2 is a special token."""
     V = len(is_subword)
     toks = list(tokens)
     tgt = L - 2
@@ -75,7 +79,7 @@ def collate_span(tokens: Sequence[int], is_subword: np.ndarray, seed: int, ex: i
         toks = toks[left:left + tgt]
     toks = [min(max(int(t), 0), V - 1) for t in toks]
     n = len(toks)
-    groups = whole_word_groups([bool(is_subword[t]) for t in toks])
+    groups = whole_word_groups([is_subword[t] == 1 for t in toks], [is_subword[t] == 2 for t in toks])  # vocabulary classes
     order = sorted(range(len(groups)), key=lambda w: (collate_rand(seed, ex, RS_SHUFFLE, w), w))
     m = whole_word_mask(groups, order, n, mlm_probability) if n > 0 else []
     ids = np.full(L, pad_id, np.int64)

@@ -24,7 +24,8 @@ def test_collator_matches_oracle_bit_for_bit(L, seed):
     flags = subword_flags_from_vocab(_vocab(V, rng))
     col = CondenserCollator(flags, max_seq_length=L, seed=seed * 11, mlm_probability=0.15)
     lens = [0, 1, 2, L - 3, L - 2, L - 1, L + 40, 3 * L] + [int(x) for x in rng.integers(1, 2 * L, 40)]
-    spans = [rng.integers(104, V, n).tolist() for n in lens]
+    spans = [rng.integers(100, V, n).tolist() for n in lens]  # ids 100-103: [UNK] / [CLS] / [SEP] / [MASK] occur INSIDE spans
+    assert (flags[100:104] == 2).all() and any(t < 104 for s in spans for t in s)
     for rep in range(2):  # the second call continues the span counter
         base = col.spans_seen
         out = col([{"text": s} for s in spans])
@@ -33,6 +34,10 @@ def test_collator_matches_oracle_bit_for_bit(L, seed):
         for i, s in enumerate(spans):
             ri, rl, ra = O.collate_span(s, flags, seed * 11, base + i, L, 101, 102, 0, 103, 0.15)
             assert np.array_equal(ids[i], ri) and np.array_equal(labels[i], rl) and np.array_equal(att[i], ra), (rep, i, len(s))
+            m = min(len(s), L - 2)
+            inside = np.asarray(ri[1:m + 1])
+            assert (rl[1:m + 1][(inside >= 100) & (inside < 104) & (rl[1:m + 1] == -100)] == -100).all()
+            assert not any(100 <= int(x) < 104 for x in rl[1:m + 1] if x != -100)  # a special token is never a prediction target
 
 
 def test_cocondenser_collator_lays_span_pairs_back_to_back():
