@@ -224,6 +224,8 @@ class _CondenserStepFn(torch.autograd.Function):
         harr, hgarr = hlo.layer_structs(head._shadow.data_ptr(), 0, head.flat_nodecay.data_ptr(), (ghd.data_ptr(), ghn.data_ptr()))
         check(lib().cocodr_encoder_bwd_range(C.byref(ctx.hcfg), None, harr, None, hgarr, None, ptr(ctx.mask), ptr(d_head_out), B, L,
                                              ptr(ctx.harena), ctx.harena.numel(), nh, 0, 0, stream_ptr()), "encoder_bwd_range(head)")
+        dp = getattr(bert, "_dp_enabled", False) and bert._dp_fwd_live == 1
+        works = bert._dp_reduce_async([ghd, ghn]) if dp else []  # the head's gradients travel under the whole backbone backward
         d_hin = ctx.harena[ctx.hlay.bwd_dx: ctx.hlay.bwd_dx + M * H * 2].view(torch.bfloat16).view(B, L, H)
         d_last.view(B, L, H)[:, 0] += d_hin[:, 0].float()
         if d_cls is not None:
@@ -244,14 +246,27 @@ class _CondenserStepFn(torch.autograd.Function):
                                                  ptr(d_in) if d_in is not None else None, B, L, ptr(ctx.arena), ctx.arena.numel(),
                                                  hi, lo_, int(do_embed), stream_ptr()), "encoder_bwd_range")
 
-        if skip_from >= NL:       # head reads the last layer itself: its gradient simply adds to d_last
-            bwd_range(NL, 0, (d_last.view(B, L, H) + d_skip.float()).to(torch.bfloat16).view(M, H), True)
+        if skip_from >= NL or skip_from == 0:  # the head reads the last layer / the embedding output: one range
+            if skip_from >= NL:
+                bwd_range(NL, 0, (d_last.view(B, L, H) + d_skip.float()).to(torch.bfloat16).view(M, H), True)
+            else:
+                bwd_range(NL, 0, d_last16, False)
+                dx_view += d_skip
+                bwd_range(0, 0, None, True)
+            lower = (0, NL)
         else:
             bwd_range(NL, skip_from, d_last16, False)
+            if dp:  # layers [skip_from, NL) are final: reduced while the lower range computes
+                works += bert._dp_reduce_async(bert._grad_range(bgd, bgn, skip_from, NL))
             dx_view += d_skip
             bwd_range(skip_from, 0, None, True)
+            lower = (0, skip_from)
         if dword_mlm is not None:
             bgd[: V * H].view(V, H).add_(dword_mlm[:V])
+        if dp:
+            works += bert._dp_reduce_async(bert._grad_range(bgd, bgn, *lower))
+            bert._dp_finish(works)
+            bert._dp_skip_hooks = 2
         ctx.arena = ctx.harena = None
         ctx.saved = None
         return bgd, bgn, ghd, ghn, None, None, None, None, None, None, None

@@ -446,6 +446,8 @@ class CocoBertModel(nn.Module):
             raise RuntimeError("CocoBertModel runs on an MI355X only: move it with .to('cuda') (there is no CPU fallback)")
         B, L = ids.shape
         self._refresh_shadow()
+        if training and getattr(self, "_dp_enabled", False):
+            self._dp_fwd_live += 1
         lay = self._layout_for(B, L, training)
         arena = torch.empty(lay.total_bytes, dtype=torch.uint8, device=ids.device)
         emb, arr, _, _ = self._param_structs()
@@ -455,13 +457,65 @@ class CocoBertModel(nn.Module):
         return arena, lay
 
     def enable_grad_allreduce(self, group=None, chunks: int = 4) -> None:
-        """Data-parallel gradient averaging folded into the backward: the layer stack is walked in ``chunks`` ranges
-        (top-down); as soon as a range's kernels are enqueued its slice of the two flat gradient tensors is
-        all-reduced asynchronously (RCCL over xGMI, on the process group's stream) while the next range computes.
-        Replaces DDP's bucketing (ANCE/drivers/run_ann.py:177-184, HF Trainer for COCO) for this model."""
+        """Data-parallel gradient averaging without DDP (ANCE/drivers/run_ann.py:177-184, HF Trainer for COCO).
+
+        * ONE encoder pass in the step (the COCO contrastive step): the backward walks the layer stack in ``chunks``
+          ranges (top-down); as soon as a range's kernels are enqueued its slice of the two flat gradient tensors is
+          all-reduced asynchronously (RCCL over xGMI, on the process group's stream) while the next range computes.
+        * SEVERAL passes through the same weights (ANCE: query pass + passage pass, iDRO: up to three): every pass runs its
+          plain backward, autograd sums the passes, and the summed gradient is reduced ONCE from a post-accumulate hook -
+          never one all-reduce of the whole model per pass.
+        * the full coCondenser step reduces the head's gradients under the backbone's backward and the upper backbone range
+          under the lower one (condenser._CondenserStepFn.backward).
+        ``no_sync()`` suspends all of it for gradient-accumulation micro-steps."""
         self._dp_group = group
         self._dp_chunks = max(1, int(chunks))
         self._dp_enabled = True
+        self._dp_fwd_live = 0     # training forwards since the last completed backward
+        self._dp_skip_hooks = 0   # hook calls to skip because the backward already reduced in flight
+        if not getattr(self, "_dp_hooks", None):
+            self._dp_hooks = [p.register_post_accumulate_grad_hook(self._dp_post_accumulate)
+                              for p in (self.flat_decay, self.flat_nodecay)]
+
+    def no_sync(self):
+        """Context manager: gradients accumulate locally (DDP's ``no_sync`` for accumulation micro-steps)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            was = getattr(self, "_dp_enabled", False)
+            self._dp_enabled = False
+            try:
+                yield
+            finally:
+                self._dp_enabled = was
+        return ctx()
+
+    def _dp_reduce_async(self, tensors):
+        import torch.distributed as dist
+        native = dist.get_backend(self._dp_group) == "nccl"
+        op = dist.ReduceOp.AVG if native else dist.ReduceOp.SUM  # gloo (CPU tests, two ranks on one GPU) has no AVG
+        return [(dist.all_reduce(t, op=op, group=self._dp_group, async_op=True), t, native) for t in tensors if t.numel()]
+
+    def _dp_finish(self, works) -> None:
+        import torch.distributed as dist
+        for w, _t, _n in works:
+            w.wait()  # stream-level: the current stream waits for the collective, the host does not
+        W = dist.get_world_size(self._dp_group)
+        for _w, t, native in works:
+            if not native:
+                t.div_(W)
+
+    def _dp_post_accumulate(self, p) -> None:
+        if not getattr(self, "_dp_enabled", False) or p.grad is None:
+            return
+        self._dp_fwd_live = 0
+        if self._dp_skip_hooks > 0:
+            self._dp_skip_hooks -= 1
+            return
+        n, k = p.grad.numel(), self._dp_chunks
+        step = (n // k + 1023) // 1024 * 1024 if k > 1 else n
+        self._dp_finish(self._dp_reduce_async([p.grad[a:a + step] for a in range(0, n, max(step, 1))]))
 
     def _run_backward(self, ids, mask, d_last16, arena):
         B, L = ids.shape
@@ -473,12 +527,10 @@ class CocoBertModel(nn.Module):
         emb, arr, eg, garr = self._param_structs((gd, gn))
         cfg = self._c_config()
         dp = getattr(self, "_dp_enabled", False)
-        if not dp:
+        if not dp or self._dp_fwd_live != 1:  # several passes share the weights: reduced once, from the hook
             check(lib().cocodr_encoder_bwd(C.byref(cfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d_last16),
                                            B, L, ptr(arena), arena.numel(), stream_ptr()), "encoder_bwd")
             return gd, gn
-        import torch.distributed as dist
-        avg_native = dist.get_backend(self._dp_group) == "nccl"
         nchunk = min(self._dp_chunks, NL)
         # layer boundaries, ascending, balanced by gradient BYTES: the range that ends at layer 0 also carries the embedding
         # tables (its all-reduce is the one nothing can hide), so it gets correspondingly fewer layers
@@ -493,21 +545,17 @@ class CocoBertModel(nn.Module):
             check(lib().cocodr_encoder_bwd_range(C.byref(cfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask),
                                                  ptr(d_last16) if top else None, B, L, ptr(arena), arena.numel(), l_hi, l_lo,
                                                  int(l_lo == 0), stream_ptr()), "encoder_bwd_range")
-            # this range's gradients: [l_lo, l_hi) layer blocks of both flats (+ the embedding blocks with the last range)
-            d0 = lo.mat_begin + l_lo * lo.mat_stride if l_lo > 0 else 0
-            d1 = lo.mat_begin + l_hi * lo.mat_stride
-            n0 = lo.vec_begin + l_lo * lo.vec_stride if l_lo > 0 else 0
-            n1 = lo.vec_begin + l_hi * lo.vec_stride
-            for t in (gd[d0:d1], gn[n0:n1]):
-                works.append(dist.all_reduce(t, op=dist.ReduceOp.AVG if avg_native else dist.ReduceOp.SUM, group=self._dp_group,
-                                             async_op=True))
-        for w in works:
-            w.wait()  # stream-level: the current stream waits for the collectives, the host does not
-        if not avg_native:  # gloo (used by the 2-process single-GPU test) has no AVG
-            W = dist.get_world_size(self._dp_group)
-            gd.div_(W)
-            gn.div_(W)
+            works += self._dp_reduce_async(self._grad_range(gd, gn, l_lo, l_hi))
+        self._dp_finish(works)
+        self._dp_skip_hooks = 2
         return gd, gn
+
+    def _grad_range(self, gd, gn, l_lo: int, l_hi: int):
+        """the slices of the two flat gradients that layers [l_lo, l_hi) own (+ the embedding blocks when l_lo == 0)"""
+        lo = self.layout
+        d0 = lo.mat_begin + l_lo * lo.mat_stride if l_lo > 0 else 0
+        n0 = lo.vec_begin + l_lo * lo.vec_stride if l_lo > 0 else 0
+        return [gd[d0:lo.mat_begin + l_hi * lo.mat_stride], gn[n0:lo.vec_begin + l_hi * lo.vec_stride]]
 
     # ---------------------------------------------------------------- public forward
     @staticmethod

@@ -83,3 +83,227 @@ def test_two_rank_coco_step_equals_single_process_on_the_full_batch():
         assert abs(o[1] - 2.0 * float(loss.detach())) < 2e-3 * abs(2.0 * float(loss.detach()))
     rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
     assert rel(out[0][2], gd) < 2e-2 and rel(out[0][3], gn) < 2e-2, (rel(out[0][2], gd), rel(out[0][3], gn))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# generic 2-rank harness for the tests below: fn(rank, world, *args) -> picklable result
+def _entry2(fn, rank, world, port, backend, q, args):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        res = fn(rank, world, *args)
+        torch.cuda.synchronize()
+        q.put((rank, res))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+
+
+def _spawn(fn, world, backend, *args):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_entry2, args=(fn, r, world, port, backend, q, args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    errs = [o for o in out if isinstance(o, str)]
+    assert not errs, errs
+    return dict(out)
+
+
+_rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _small_cfg(layers=4):
+    from cocodr_amd.modeling import CocoBertConfig
+    return CocoBertConfig(vocab_size=700, hidden_size=128, num_hidden_layers=layers, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=64)
+
+
+def _triplet_batch(seed, B):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mk = lambda L: (rng.integers(5, 700, (B, L)), np.ones((B, L), np.int64))
+    (q, qm), (a, am), (b, bm) = mk(32), mk(64), mk(64)
+    am[1, 40:] = 0
+    bm[B - 1, 11:] = 0
+    return q, qm, a, am, b, bm
+
+
+def _ance_rank(rank, world, batch):
+    """BertDot_NLL_LN step on this rank's rows with the data-parallel reduction enabled; counts the all-reduce calls."""
+    import torch.distributed as dist
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.modeling import BertDotNLL
+    torch.manual_seed(0)
+    model = BertDotNLL(_small_cfg()).to("cuda")
+    model.bert.enable_grad_allreduce(chunks=2)
+    n = batch[0].shape[0] // world
+    t = [torch.from_numpy(x[rank * n:(rank + 1) * n]).cuda() for x in batch]
+    calls = {"n": 0, "numel": 0}
+    real = dist.all_reduce
+
+    def counting(tensor, *a, **k):
+        calls["n"] += 1
+        calls["numel"] += tensor.numel()
+        return real(tensor, *a, **k)
+
+    dist.all_reduce = counting
+    try:
+        loss, _acc, _logits = model(*t)
+        loss.backward()
+    finally:
+        dist.all_reduce = real
+    bert = model.bert
+    return float(loss.detach()), bert.flat_decay.grad.cpu().numpy(), bert.flat_nodecay.grad.cpu().numpy(), calls["n"], calls["numel"], \
+        bert.flat_decay.numel() + bert.flat_nodecay.numel()
+
+
+def test_two_rank_ance_step_reduces_the_summed_gradient_once():
+    """ANCE/drivers/run_ann.py:177-184 (DDP) for the two-pass triplet step: both ranks end with the mean of their gradients =
+    the single-process gradient of the whole batch, and every gradient element crosses the wire exactly once (the query
+    pass and the passage pass are summed locally first)."""
+    batch = _triplet_batch(3, 8)
+    out = _spawn(_ance_rank, 2, "gloo", batch)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    for r in (0, 1):
+        assert out[r][4] == out[r][5], (out[r][3], out[r][4], out[r][5])  # every gradient element exactly once
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.modeling import BertDotNLL
+    torch.manual_seed(0)
+    model = BertDotNLL(_small_cfg()).to("cuda")
+    loss, _a, _l = model(*[torch.from_numpy(x).cuda() for x in batch])
+    loss.backward()
+    gd, gn = model.bert.flat_decay.grad.cpu().numpy(), model.bert.flat_nodecay.grad.cpu().numpy()
+    assert abs(0.5 * (out[0][0] + out[1][0]) - float(loss.detach())) < 2e-3 * abs(float(loss.detach()))
+    assert _rel(out[0][1], gd) < 2e-2 and _rel(out[0][2], gn) < 2e-2, (_rel(out[0][1], gd), _rel(out[0][2], gn))
+
+
+def _condenser_rank(rank, world, ids, mask, labels):
+    import types
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
+    torch.manual_seed(0)
+    bert = CocoBertModel(_small_cfg()).to("cuda")
+    model = CoCondenserForPretraining(bert, types.SimpleNamespace(n_head_layers=2, skip_from=2, late_mlm=True)).to("cuda")
+    bert.enable_grad_allreduce(chunks=2)
+    n = ids.shape[0] // world
+    sl = slice(rank * n, (rank + 1) * n)
+    t = lambda x: torch.from_numpy(x[sl]).cuda()
+    loss = model({"input_ids": t(ids), "attention_mask": t(mask)}, t(labels))
+    loss.backward()
+    return [p.grad.cpu().numpy() for p in (bert.flat_decay, bert.flat_nodecay, model.c_head.flat_decay, model.c_head.flat_nodecay)]
+
+
+def test_two_rank_full_cocondenser_step_averages_backbone_and_head_gradients():
+    """The overlapped reduction of the full coCondenser step (head gradients under the backbone backward, upper backbone
+    range under the lower one): both ranks end with identical gradients = the mean of the two ranks' local gradients."""
+    import types
+    rng = np.random.Generator(np.random.PCG64(9))
+    ids = rng.integers(5, 700, (8, 32))
+    mask = np.ones((8, 32), np.int64)
+    mask[3, 17:] = 0
+    labels = np.full((8, 32), -100, np.int64)
+    pick = (rng.random((8, 32)) < 0.2) & (mask > 0)
+    pick[:, 0] = False
+    pick[:, 1] = True
+    labels[pick] = ids[pick]
+    out = _spawn(_condenser_rank, 2, "gloo", ids, mask, labels)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    # the mean of the two ranks' LOCAL gradients, each computed by a plain single-process run on that rank's rows with the
+    # loss scale a 2-rank job applies to the contrastive part (COCO/modeling.py:247)
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel, _SimCEFn
+    local = []
+    for r in range(2):
+        torch.manual_seed(0)
+        bert = CocoBertModel(_small_cfg()).to("cuda")
+        model = CoCondenserForPretraining(bert, types.SimpleNamespace(n_head_layers=2, skip_from=2, late_mlm=True)).to("cuda")
+        from cocodr_amd.condenser import condenser_step
+        t = lambda x: torch.from_numpy(x).cuda()
+        mlm, cls = condenser_step(bert, model.c_head, t(ids[4 * r:4 * r + 4]), t(mask[4 * r:4 * r + 4]), t(labels[4 * r:4 * r + 4]), 2, True)
+        with torch.no_grad():  # the other rank's rows enter as constants, exactly what the gather hands over
+            tb = CocoBertModel(_small_cfg()).to("cuda")
+            tb.load_state_dict(bert.state_dict())
+            other = tb.encode_cls(t(ids[4 * (1 - r):4 * (1 - r) + 4]), t(mask[4 * (1 - r):4 * (1 - r) + 4]))
+        E = torch.cat([cls, other] if r == 0 else [other, cls])
+        loss, _rows = _SimCEFn.apply(E, 2, 4 * r, 4)
+        (loss + mlm).backward()
+        local.append([p.grad.cpu().numpy() for p in (bert.flat_decay, bert.flat_nodecay, model.c_head.flat_decay, model.c_head.flat_nodecay)])
+    for k in range(4):
+        want = 0.5 * (local[0][k].astype(np.float64) + local[1][k])
+        assert _rel(out[0][k], want) < 2e-2, (k, _rel(out[0][k], want))
+
+
+def _idro_rank(rank, world, batch, groups, per_group):
+    import types
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.modeling import BertDotNLL
+    torch.manual_seed(0)
+    model = BertDotNLL(_small_cfg(layers=4)).to("cuda")
+    model.add_group_loss(args=types.SimpleNamespace(model_size="base"), n_groups=3, dro_type="idro", alpha=0.25, eps=0.01, ema=0.1, rho=0.5)
+    model.loss.per_group_backward = per_group
+    n = batch[0].shape[0] // world
+    t = [torch.from_numpy(x[rank * n:(rank + 1) * n]).cuda() for x in batch]
+    g = torch.from_numpy(groups[rank * n:(rank + 1) * n]).cuda()
+    robust, _acc, gl, gc = model(*t, group_ids=g)
+    return model.loss.h_fun.cpu().numpy(), model.loss.last_path
+
+
+def test_two_rank_idro_weights_with_unequal_group_counts_match_on_both_paths():
+    """ANCE/model/dro_loss.py:192-205,234: the cross-rank SUM adds per-rank group-MEAN gradients.  With group counts that
+    differ between the ranks (rank 0: 3/1/0 rows of groups 0/1/2, rank 1: 1/1/2) the one-backward fast path must give the
+    same updated weights as the per-group path that follows the reference's structure."""
+    batch = _triplet_batch(5, 8)
+    groups = np.array([0, 0, 0, 1, 0, 1, 2, 2])
+    fast = _spawn(_idro_rank, 2, "gloo", batch, groups, False)
+    slow = _spawn(_idro_rank, 2, "gloo", batch, groups, True)
+    assert fast[0][1] == "per-sequence" and slow[0][1] == "per-group"
+    assert np.array_equal(fast[0][0], fast[1][0]) and np.array_equal(slow[0][0], slow[1][0])
+    np.testing.assert_allclose(fast[0][0], slow[0][0], rtol=2e-2, atol=1e-4)
+    assert np.ptp(slow[0][0]) > 1e-3  # the update moved the weights apart: the comparison is not vacuous
+
+
+def _nccl_one_rank(rank, world, ids, mask):
+    import torch.distributed as dist
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
+    os.environ["COCODR_FORCE_DIST"] = "1"  # take the N > 1 code path with one rank: gather + ranged all-reduce run on RCCL
+    torch.manual_seed(0)
+    bert = CocoBertModel(_small_cfg()).to("cuda")
+    model = CoCondenserForPretraining(bert)
+    bert.enable_grad_allreduce(chunks=2)
+    assert dist.get_backend() == "nccl"
+    loss = model({"input_ids": torch.from_numpy(ids).cuda(), "attention_mask": torch.from_numpy(mask).cuda()}, None)
+    loss.backward()
+    return float(loss.detach()), bert.flat_decay.grad.cpu().numpy(), bert.flat_nodecay.grad.cpu().numpy()
+
+
+def test_one_rank_rccl_step_equals_the_plain_step():
+    """`all_gather_into_tensor` of the [CLS] rows and the per-range gradient all-reduce (AVG) over the `nccl` backend (= RCCL)
+    with a 1-rank group: same loss and bit-identical gradients as the step without a process group."""
+    rng = np.random.Generator(np.random.PCG64(12))
+    ids = rng.integers(5, 700, (8, 32))
+    mask = np.ones((8, 32), np.int64)
+    mask[2, 21:] = 0
+    out = _spawn(_nccl_one_rank, 1, "nccl", ids, mask)[0]
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
+    torch.manual_seed(0)
+    bert = CocoBertModel(_small_cfg()).to("cuda")
+    loss = CoCondenserForPretraining(bert)({"input_ids": torch.from_numpy(ids).cuda(), "attention_mask": torch.from_numpy(mask).cuda()}, None)
+    loss.backward()
+    assert abs(out[0] - float(loss.detach())) < 1e-6
+    assert np.array_equal(out[1], bert.flat_decay.grad.cpu().numpy()) and np.array_equal(out[2], bert.flat_nodecay.grad.cpu().numpy())
