@@ -2,18 +2,22 @@
 """bench.py - contrastive-step throughput of the native MI355X hot path (BASELINE.json metric 1).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...                  (re-launches itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one full COCO contrastive training step on one batch of synthetic MS MARCO-shaped spans
 (BASELINE.json configs[1]: cocodr-base / BERT-base-uncased shape, seq_len 128, 64 sequences per GPU, bf16
 activations with fp32 accumulation, in-batch negatives): encoder forward -> last-layer [CLS] ->
-(all-gather over ranks) -> span-pair InfoNCE -> encoder backward -> gradient all-reduce -> AdamW + linear
+(all-gather over ranks) -> span-pair InfoNCE -> encoder backward -> gradient all-reduce -> clip + AdamW + linear
 warm-up schedule.  Inputs are resident in HBM before the timed region.  Weak scaling: 64 sequences per GPU.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events bracketing every launch of the
-dominant kernel class (the bf16 MFMA GEMM, coco-dr_amd/csrc/gemm.hip) inside the timed region;
-`cpu_baseline` times the numpy oracle (the CPU port of the same step, fwd+loss+bwd) on a bounded sample.
+dominant kernel class (the bf16 MFMA GEMM, coco-dr_amd/csrc/gemm.hip) inside the timed region.  At N = 1 the line also
+carries `north_star_large_step` (the BERT-large seq-128 contrastive step the north star names, with its own roofline
+block), `eval_search` (BASELINE.json's second metric at the real config-5 shard, with its fp32-MFMA roofline) and
+`cpu_baseline` (the same step on the host cores: torch-CPU HuggingFace BertModel + restated loss + AdamW, and the
+numpy oracle as a second number).
 """
 import argparse
 import json
@@ -30,16 +34,19 @@ import torch  # noqa: E402
 
 PROF_EVERY = 5  # timed steps between roofline samples
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3    # fp32-input MFMA peak (v_mfma_f32_32x32x2_f32), same guide
 SEQ_PER_GPU = 64
 SEQ_LEN = 128
 
 
-def synth_batch(rank: int, n_seq: int, L: int, vocab: int, device):
-    """ids ~ U{1000..V-1}, seed 1234+rank, lengths ~ clip(round(N(76,30)), 8, L), [CLS]=101 first,
-    [SEP]=102 last, [PAD]=0 after."""
+def synth_batch(rank: int, n_seq: int, L: int, vocab: int, device, dense: bool = False):
+    """ids ~ U{1000..V-1}, seed 1234+rank, lengths ~ clip(round(N(76,30)), 8, L) (MS MARCO-shaped; (24, 8)
+    at L <= 64), [CLS]=101 first, [SEP]=102 last, [PAD]=0 after.  ``dense``: every sequence fills L (the variant SURVEY
+    8(d) prescribes for roofline fractions; the kernels do not skip masked work, so the FLOPs are the same either way)."""
     rng = np.random.Generator(np.random.PCG64(1234 + rank))
     ids = rng.integers(1000, vocab, (n_seq, L))
-    lens = np.clip(np.rint(rng.normal(76, 30, n_seq)), 8, L).astype(np.int64)
+    mu, sd = (76, 30) if L > 64 else (24, 8)
+    lens = np.full(n_seq, L, np.int64) if dense else np.clip(np.rint(rng.normal(mu, sd, n_seq)), 8, L).astype(np.int64)
     mask = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
     ids = ids * mask
     ids[:, 0] = 101
@@ -53,7 +60,30 @@ def train_flops_per_seq(cfg, L: int) -> float:
     return 3.0 * L * N * (24.0 * H * H + 4.0 * L * H)
 
 
-def cpu_baseline(n_seq: int = 8, L: int = SEQ_LEN, steps: int = 2):
+# ---------------------------------------------------------------------------------------------------------- CPU baselines
+def _cpu_model_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _physical_cores() -> int:
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline_numpy(n_seq: int = 8, L: int = SEQ_LEN, steps: int = 2):
     """The oracle (numpy port of the same contrastive step: encoder fwd + InfoNCE + encoder bwd, fp32) timed on the
     host cores of this box.  Checker/baseline only - never on the product path."""
     import oracle as O
@@ -80,44 +110,103 @@ def cpu_baseline(n_seq: int = 8, L: int = SEQ_LEN, steps: int = 2):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
     except Exception:
         cores = os.cpu_count() or 1
-    return {"value": n_seq / dt, "unit": "sequences/sec", "cores": int(cores), "kind": "port",
+    return {"value": round(n_seq / dt, 3), "unit": "sequences/sec", "cores": int(cores),
             "sample": f"{steps} steps of {n_seq} sequences x L{L}, BERT-base, numpy fp32 oracle fwd+loss+bwd (no optimizer)"}
 
 
-def full_coco_step(cfg, args, dev, ids, mask, steps: int = 8, warmup: int = 3):
+def _best_thread_count(n_seq: int, L: int) -> int:
+    """a 8 x 64-token step does not scale to every core of a 2-socket box: take the fastest of a few thread counts"""
+    phys = _physical_cores()
+    cands = sorted({t for t in (8, 16, 32, 64, phys) if t <= phys})
+    best, best_t = cands[-1], float("inf")
+    for t in cands:
+        r = cpu_baseline_torch(n_seq, L, warmup=1, steps=2, threads=t)
+        if r["s_per_step"] < best_t:
+            best, best_t = t, r["s_per_step"]
+    return best
+
+
+def cpu_baseline_torch(n_seq: int, L: int, warmup: int = 3, steps: int = 10, threads: int = 0):
+    """The step the reference runs on a CPU: the encoder arithmetic of the reference IS transformers'
+    BertModel (COCO/modeling.py:199, ANCE/model/models.py:226), here in fp32, eager attention, eval mode (COCO keeps the
+    backbone in eval, :198), random-init BERT-base; on top of it the restated span-pair InfoNCE (COCO/modeling.py:244-248,
+    oracle-checked) and torch AdamW with HF Trainer's clip_grad_norm_(1.0).  Median step time after warm-up."""
+    from transformers import BertConfig, BertModel
+    threads = threads or _physical_cores()
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(0)
+        model = BertModel(BertConfig(attn_implementation="eager"), add_pooling_layer=False).eval()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)
+        ids, mask = synth_batch(0, n_seq, L, 30522, "cpu")
+        target = torch.arange(n_seq).view(-1, 2).flip(1).flatten()  # co_target, COCO/modeling.py:172-177
+        times = []
+        for i in range(warmup + steps):
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            hs = model(input_ids=ids, attention_mask=mask, output_hidden_states=True, return_dict=True).hidden_states
+            E = hs[-1][:, 0]
+            S = E @ E.T
+            S.fill_diagonal_(float("-inf"))
+            loss = torch.nn.functional.cross_entropy(S, target, reduction="none").mean()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            if i >= warmup:
+                times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+    finally:
+        torch.set_num_threads(old)
+    return {"value": round(n_seq / med, 3), "unit": "sequences/sec", "cores": int(threads), "s_per_step": round(med, 4),
+            "sample": f"median of {steps} steps (after {warmup} warm-up) of {n_seq} sequences x L{L}: transformers BertModel (BERT-base, "
+                      f"fp32, eager attention) fwd + span-pair InfoNCE + bwd + clip_grad_norm_(1.0) + torch AdamW"}
+
+
+def cpu_baseline():
+    """`value`: a bounded sample of the headline workload (configs[1]: L 128; 8 of its 64 sequences per step) on the host
+    cores.  `config1`: BASELINE.json configs[0] at its exact shape (8 sequences x L 64; BASELINE.md measured the reference's
+    full coCondenser step at 6.4 sequences/s on 8 threads there - this scope has no Condenser head / MLM decoders).
+    `port`: the numpy oracle."""
+    out = {"kind": "port", "cpu": _cpu_model_name()}
+    try:
+        thr = _best_thread_count(8, 64)
+        out.update(cpu_baseline_torch(8, SEQ_LEN, threads=thr))
+        out["config1"] = cpu_baseline_torch(8, 64, threads=thr)
+        out["threads_tried"] = "fastest of 8 / 16 / 32 / 64 / all physical cores on the config-1 shape"
+        out["port"] = cpu_baseline_numpy()
+    except Exception as e:  # transformers missing on the box: the numpy port alone
+        out.update(cpu_baseline_numpy())
+        out["note"] = f"torch-CPU HuggingFace baseline unavailable ({type(e).__name__}: {e}); numpy oracle only"
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------- side legs
+def full_coco_step(cfg, dev, ids, mask, steps: int = 8, warmup: int = 3):
     """The reference's whole pre-training step (COCO/modeling.py:192-235 with COCO/README.md:49 settings: 2 Condenser
     head layers, skip_from 6, late MLM): backbone + head + two label-sparse MLM losses + contrastive + AdamW.
     Reported next to the headline metric, never instead of it."""
     import types
     from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
-    from cocodr_amd.optim import FlatAdamW
+    from cocodr_amd.optim import FlatAdamW, clip_grad_norm_
     torch.manual_seed(0)
     bert = CocoBertModel(cfg).to(dev)
     margs = types.SimpleNamespace(n_head_layers=2, skip_from=min(6, cfg.num_hidden_layers), late_mlm=True)
     model = CoCondenserForPretraining(bert, margs).to(dev)
-    opt = FlatAdamW.for_model(bert, lr=1e-4, weight_decay=0.01)
-    opt_h = torch.optim.AdamW(model.c_head.param_groups(0.01), lr=1e-4, fused=True)
+    opt = FlatAdamW.for_model(model, lr=1e-4, weight_decay=0.01)  # backbone + head flats, all four shadows kept in the pass
     g = torch.Generator().manual_seed(5)
     pick = (torch.rand(ids.shape, generator=g) < 0.15).to(dev) & (mask > 0)
     pick[:, 0] = False
     labels = torch.where(pick, ids, torch.full_like(ids, -100))
     inp = torch.where(pick, torch.full_like(ids, 103), ids)  # [MASK]
     batch = {"input_ids": inp, "attention_mask": mask}
-
-    from cocodr_amd.optim import clip_grad_norm_
-    head_params = [p for g_ in model.c_head.param_groups(0.01) for p in g_["params"]]
-    all_flats = [bert.flat_decay, bert.flat_nodecay] + head_params
+    all_flats = [bert.flat_decay, bert.flat_nodecay, model.c_head.flat_decay, model.c_head.flat_nodecay]
 
     def step():
         opt.zero_grad(set_to_none=True)
-        opt_h.zero_grad(set_to_none=True)
         loss = model(batch, labels)
         loss.backward()
-        clip = clip_grad_norm_(all_flats, 1.0)  # HF Trainer default max_grad_norm, over backbone + head, on the device
-        opt.step(clip=clip)
-        for p in head_params:
-            p.grad.mul_(clip[1])
-        opt_h.step()
+        opt.step(clip=clip_grad_norm_(all_flats, 1.0))  # HF Trainer default max_grad_norm, over backbone + head, on the device
         return loss
 
     for _ in range(warmup):
@@ -132,9 +221,11 @@ def full_coco_step(cfg, args, dev, ids, mask, steps: int = 8, warmup: int = 3):
             "scope": "backbone + 2 Condenser head layers (skip_from 6) + head & late MLM losses (label-sparse, 15 %) + contrastive + clip_grad_norm_(1.0) + AdamW"}
 
 
-def eval_search(dev, nq: int = 2048, npass: int = 125000, dim: int = 1024, k: int = 1000, iters: int = 3):
-    """BASELINE.json's second metric on one shard of config 5 (cocodr-large width, 125 k passages per GPU, k = 1000):
-    query x passage dot-products/sec = Nq*Np / wall time of (exact fp32 score + exact top-k), embeddings resident in HBM."""
+def eval_search(dev, nq: int = 10000, npass: int = 125000, dim: int = 1024, k: int = 1000, iters: int = 3):
+    """BASELINE.json's second metric on one GPU's shard of config 5 at its real size (cocodr-large width, 10 000 queries x
+    125 000 passages per GPU, k = 1000): query x passage dot-products/sec = Nq*Np / wall time of (exact fp32 score + exact
+    top-k), embeddings resident in HBM.  Roofline: the score GEMM runs on the exact-fp32 MFMA (157.3 TFLOP/s peak); its
+    time is bracketed with HIP events on the launch stream in a separate pass."""
     from cocodr_amd import ops
     g = torch.Generator().manual_seed(7)
     Q = (torch.randn(nq, dim, generator=g) / dim ** 0.5).to(dev)
@@ -147,8 +238,21 @@ def eval_search(dev, nq: int = 2048, npass: int = 125000, dim: int = 1024, k: in
         ops.score_topk(Q, P, k, workspace=ws)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    return {"dot_products_per_sec": round(nq * npass / dt), "ms": round(dt * 1e3, 2),
-            "workload": f"{nq} queries x {npass} passages x {dim} fp32, k={k}, exact scores + exact top-k, 1 GPU shard of config 5"}
+    out = {"dot_products_per_sec": round(nq * npass / dt), "ms": round(dt * 1e3, 2),
+           "workload": f"{nq} queries x {npass} passages x {dim} fp32, k={k}, exact scores + exact top-k, one GPU's shard of config 5"}
+    ops.prof_begin(3)
+    ops.score_topk(Q, P, k, workspace=ws)
+    torch.cuda.synchronize()
+    n_launch, ms, flops = ops.prof_end()
+    whole = 2.0 * nq * npass * dim / dt / 1e12
+    out["roofline"] = {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "dtype": "f32",
+                       "achieved": round(whole, 2), "frac": round(whole / MFMA_F32_PEAK_TFLOPS, 4),
+                       "note": "whole search (score + selection) against the fp32-MFMA peak: 2*Nq*Np*H FLOP / wall time"}
+    if n_launch and ms > 0:
+        ach = flops / (ms * 1e-3) / 1e12
+        out["roofline"].update({"score_kernel_achieved": round(ach, 2), "score_kernel_frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                                "score_kernel_launches": n_launch, "score_kernel_share_of_search": round(ms / (dt * 1e3), 3)})
+    return out
 
 
 def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3):
@@ -231,57 +335,42 @@ def corpus_encode(cfg, dev, n: int = 8192, seq_len: int = 128, batch: int = 512,
             "workload": f"{n} passages x L{seq_len}, batch {batch}, BertDot_NLL_LN body_emb (last-layer [CLS]), bf16 encoder, eval mode"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="base", choices=["base", "large"])
-    ap.add_argument("--seq-per-gpu", type=int, default=SEQ_PER_GPU)
-    ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-full-step", action="store_true", help="skip the extra full-coCondenser-step and eval-search measurements")
-    ap.add_argument("--dp-chunks", type=int, default=2, help="layer ranges whose gradient all-reduce overlaps the backward")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------- the timed step
+def _traffic_for(model_name: str, seq_per_gpu: int, seq_len: int):
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
+    corrected as MI355X_MICROARCH.md prescribes) of THIS workload shape, with the file it came from; None when no pass was
+    taken on the shape."""
+    path = os.path.join(ROOT, "profiles", f"r02_gemm_pmc_{model_name}_{seq_per_gpu}x{seq_len}.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return round(d["hbm_bytes_per_launch"]), {"file": os.path.relpath(path, ROOT), "commit": d.get("commit"), "launches": d.get("launches")}
+    except Exception:
+        return None, None
 
+
+def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int, warmup: int, dev, rank: int, world: int, use_dist: bool,
+                    dp_chunks: int, roofline: bool, dense: bool = False):
+    """Build the model, run `warmup` untimed + exactly `steps` timed contrastive steps between two fences; returns
+    (seconds over the timed steps on this rank, final loss, roofline dict or None, cfg, one batch)."""
     import torch.distributed as dist
-    import cocodr_amd  # noqa: F401
     from cocodr_amd import ops
     from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertConfig, CocoBertModel
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or bool(os.environ.get("COCODR_FORCE_DIST"))  # FORCE: exercise the N>1 path on one GPU
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
-    cfg = CocoBertConfig.base() if args.model == "base" else CocoBertConfig.large()
+    from cocodr_amd.optim import FlatAdamW, clip_grad_norm_
+    cfg = CocoBertConfig.base() if model_name == "base" else CocoBertConfig.large()
     torch.manual_seed(0)  # identical random-init weights on every rank
     bert = CocoBertModel(cfg).to(dev)
     model = CoCondenserForPretraining(bert)
     if use_dist:
-        bert.enable_grad_allreduce(chunks=args.dp_chunks)  # averaged inside the backward, overlapped with it
-    from cocodr_amd.optim import FlatAdamW
+        bert.enable_grad_allreduce(chunks=dp_chunks)  # averaged inside the backward, overlapped with it
     opt = FlatAdamW.for_model(bert, lr=1e-4, weight_decay=0.01)  # torch.optim.AdamW semantics, one native pass per flat
-    total = args.steps + args.warmup
+    total = steps + warmup
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / max(1, int(0.1 * total))))
     # a small pool of different synthetic batches, resident in HBM before the timed region, visited round-robin (one
     # repeated batch is memorised within a few steps and the loss saturates at 0)
-    pool = [synth_batch(rank + 10007 * i, args.seq_per_gpu, args.seq_len, cfg.vocab_size, dev) for i in range(8)]
-    ids, mask = pool[0]
+    pool = [synth_batch(rank + 10007 * i, seq_per_gpu, seq_len, cfg.vocab_size, dev, dense) for i in range(8)]
     batches = [{"input_ids": i_, "attention_mask": m_} for i_, m_ in pool]
     step_no = [0]
-
-    from cocodr_amd.optim import clip_grad_norm_
     flats = [bert.flat_decay, bert.flat_nodecay]
 
     def step():
@@ -302,55 +391,135 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    loss = None
+    for _ in range(warmup):
         loss = step()
     fence()
-    if not args.no_roofline and rank == 0:
+    prof = roofline and rank == 0
+    if prof:
         ops.prof_begin(1)  # HIP events around every GEMM launch, on the launch stream
     # the event pairs cost stream time (~7 % of the step when every GEMM launch of every step carries one), so the
     # roofline leg brackets the GEMM launches of every PROF_EVERY-th timed step only
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        if not args.no_roofline and rank == 0:
+    for i in range(steps):
+        if prof:
             ops.prof_pause(i % PROF_EVERY != 0)
         loss = step()
     fence()
     dt = time.perf_counter() - t0
     roof = None
-    if not args.no_roofline and rank == 0:
+    if prof:
         n_launch, gemm_ms, gemm_flops = ops.prof_end()
         if n_launch and gemm_ms > 0:
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
-            traffic = None  # HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01c_*.md)
-            if args.model == "base" and args.seq_per_gpu == SEQ_PER_GPU and args.seq_len == SEQ_LEN:  # the PMC passes ran on this shape
-                try:
-                    with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")) as f:
-                        traffic = round(json.load(f)["hbm_bytes_per_launch"])
-                except Exception:
-                    pass
+            sampled = len(range(0, steps, PROF_EVERY))
+            traffic, src = _traffic_for(model_name, seq_per_gpu, seq_len)
             roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "gemm_glds_kernel (bf16 MFMA 32x32x16, all NT/NN/TN launches)",
-                    "launches_per_step": n_launch // max(1, len(range(0, args.steps, PROF_EVERY))),
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+                    "kernel": "bf16 MFMA GEMM class of coco-dr_amd/csrc/gemm.hip (all NT / NN / TN launches of the step)",
+                    "launches_per_step": n_launch // max(1, sampled),
                     "sampled": f"every GEMM launch of every {PROF_EVERY}th timed step ({n_launch} launches)",
                     "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
-                    "gemm_share_of_step": round(gemm_ms / len(range(0, args.steps, PROF_EVERY)) / (dt / args.steps * 1e3), 3)}
-    full = None
-    if not args.no_full_step and not use_dist:
-        full = full_coco_step(cfg, args, dev, ids, mask)  # second scope: what the reference's step really runs
-    search = eval_search(dev) if (not args.no_full_step and not use_dist) else None
-    encode = corpus_encode(cfg, dev, seq_len=args.seq_len) if (not args.no_full_step and not use_dist) else None
-    ance = ance_step(dev) if (not args.no_full_step and not use_dist and args.model == "base") else None
+                    "gemm_share_of_step": round(gemm_ms / sampled / (dt / steps * 1e3), 3),
+                    "batches": "fully dense (every sequence fills L)" if dense else
+                               "MS MARCO-shaped lengths, padded to L; the kernels do not skip masked work, so FLOPs = the dense count"}
+    del opt, model, bert
+    torch.cuda.empty_cache()
+    return dt, float(loss.detach()), roof, cfg, pool[0]
+
+
+def _self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="base", choices=["base", "large"])
+    ap.add_argument("--seq-per-gpu", type=int, default=SEQ_PER_GPU)
+    ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
+    ap.add_argument("--dense", action="store_true", help="every synthetic sequence fills seq_len (SURVEY 8d's roofline variant)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-full-step", action="store_true", help="skip the extra legs (north-star large step, full coCondenser step, search, encode, ANCE)")
+    ap.add_argument("--dp-chunks", type=int, default=2, help="layer ranges whose gradient all-reduce overlaps the backward")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(_self_launch(args))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch.distributed as dist
+    import cocodr_amd  # noqa: F401
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    shared = world > n_dev  # fewer GPUs than ranks (a 1-GPU box running the N > 1 code path): ranks share devices
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    use_dist = world > 1 or bool(os.environ.get("COCODR_FORCE_DIST"))  # FORCE: exercise the N>1 path on one GPU
+    backend = None
     if use_dist:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "gloo" if shared else "nccl"  # RCCL needs one device per rank; gloo moves the tensors through the host
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    solo = not use_dist
+    dt, final_loss, roof, cfg, (ids, mask) = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, rank,
+                                                            world, use_dist, args.dp_chunks, not args.no_roofline, args.dense)
+    extras = {}
+    if solo and not args.no_full_step and rank == 0:
+        # the north-star target shape (BASELINE.json north_star: ">= 50 % MFMA roofline on BERT-large seq128 contrastive step
+        # at 1 GPU"): cocodr-large at this line's 64 sequences and at COCO/README.md:59-63's per-GPU batch for the large
+        # model (100 documents = 200 spans), each with its own HIP-event roofline block
+        large = {}
+        for n_seq, k_steps in ((64, 10), (200, 6)):
+            ldt, lloss, lroof, lcfg, _ = contrastive_leg("large", n_seq, SEQ_LEN, k_steps, 3, dev, 0, 1, False, args.dp_chunks,
+                                                         not args.no_roofline, args.dense)
+            v = n_seq * k_steps / ldt
+            tf = v * train_flops_per_seq(lcfg, SEQ_LEN) / 1e12
+            large[f"{n_seq}_sequences"] = {"sequences_per_sec": round(v, 1), "ms_per_step": round(ldt / k_steps * 1e3, 3), "steps": k_steps,
+                                           "loss": round(lloss, 4), "algorithmic_tflops_whole_step": round(tf, 1),
+                                           "whole_step_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "roofline": lroof}
+        large["workload"] = "cocodr-large (BERT-large, 24 x 1024) contrastive step, seq_len 128, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW, 1 GPU"
+        extras["north_star_large_step"] = large
+        if args.model == "base":
+            extras["full_coco_step"] = full_coco_step(cfg, dev, ids, mask)  # second scope (SURVEY 8d): what the reference's step really runs
+            extras["ance_triplet_step"] = ance_step(dev)
+        extras["corpus_encode"] = corpus_encode(cfg, dev, seq_len=args.seq_len)
+        extras["eval_search"] = eval_search(dev)
+    if use_dist:
+        tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    final_loss = float(loss.detach())
 
     if rank == 0:
         n_seq = args.seq_per_gpu * world * args.steps
         value = n_seq / dt
         step_tflops = value * train_flops_per_seq(cfg, args.seq_len) / 1e12
+        par = f"dp{world}"
+        if world > 1:
+            par += " + RCCL all_gather negatives" if backend == "nccl" else f" over gloo ({world} ranks sharing {n_dev} GPU(s): code-path check, not a scaling number)"
         out = {
             "metric": "contrastive-step sequences/sec", "value": round(value, 2), "unit": "sequences/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -361,21 +530,14 @@ def main():
                                       "BASELINE configs[2] shape per GPU" if args.model == "base" else "north_star BERT-large target shape"),
                        "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len,
                        "batches": "8 pre-generated synthetic batches per rank, resident in HBM, visited round-robin",
-                       "parallelism": f"dp{world}" + (" + RCCL all_gather negatives" if world > 1 else "")},
+                       "parallelism": par},
             "loss": round(final_loss, 4),
             "algorithmic_tflops_whole_step": round(step_tflops, 1),
             "whole_step_frac_of_mfma_peak": round(step_tflops / (MFMA_BF16_PEAK_TFLOPS * world), 4),
         }
         if roof is not None:
             out["roofline"] = roof
-        if full is not None:
-            out["full_coco_step"] = full
-        if search is not None:
-            out["eval_search"] = search
-        if encode is not None:
-            out["corpus_encode"] = encode
-        if ance is not None:
-            out["ance_triplet_step"] = ance
+        out.update(extras)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

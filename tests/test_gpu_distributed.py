@@ -271,9 +271,11 @@ def test_two_rank_idro_weights_with_unequal_group_counts_match_on_both_paths():
     fast = _spawn(_idro_rank, 2, "gloo", batch, groups, False)
     slow = _spawn(_idro_rank, 2, "gloo", batch, groups, True)
     assert fast[0][1] == "per-sequence" and slow[0][1] == "per-group"
-    assert np.array_equal(fast[0][0], fast[1][0]) and np.array_equal(slow[0][0], slow[1][0])
-    np.testing.assert_allclose(fast[0][0], slow[0][0], rtol=2e-2, atol=1e-4)
-    assert np.ptp(slow[0][0]) > 1e-3  # the update moved the weights apart: the comparison is not vacuous
+    # group losses, counts and masks stay LOCAL in the reference (only the gradient matrix is summed, :234), so the two
+    # ranks legitimately end with different weights; the two paths must agree rank by rank
+    for r in (0, 1):
+        np.testing.assert_allclose(fast[r][0], slow[r][0], rtol=2e-2, atol=1e-4)
+        assert np.ptp(slow[r][0]) > 1e-3  # the update moved the weights apart: the comparison is not vacuous
 
 
 def _nccl_one_rank(rank, world, ids, mask):
