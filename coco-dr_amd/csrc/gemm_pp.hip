@@ -1,0 +1,395 @@
+// "Ping-pong" bf16 MFMA GEMM for gfx950: 256 x (128 NB) x 64 tile, eight waves in two groups that alternate, on every
+// SIMD, between an MFMA segment and a load segment.
+//
+// Why a second pipeline: in gemm.hip's one-barrier-per-K-step loop all eight waves of a workgroup do the same thing at the
+// same time, so the MFMA pipe, the LDS and the address unit that feeds the LDS-DMA are each ~50 % busy and their times add
+// (profiles/r01f_*).  Here the waves with wr = 0 (one per SIMD) and the waves with wr = 1 (their SIMD partners) run the same
+// program one barrier apart: while one group issues its 8 MFMAs of a phase (256 pipe cycles), the other group issues the LDS
+// fragment reads of ITS next phase and its share of the operand DMA.  The matrix pipe of a SIMD is handed from one wave to
+// the other at every barrier and never waits for a load.  (CDNA "8-phase" schedule; hardware facts in
+// /opt/skills/guides/MI355X_MICROARCH.md "Two waves per SIMD".)
+//
+// Wave (wr, wc) of the 2 x 4 grid owns rows wr*128 .. +127 and columns wc*(32 NB) .. of the tile: 4 x NB MFMA 32x32x16
+// blocks, walked per 64-deep K-tile as quadrant phases  (A-sub a: 64 rows) x (B-sub b: 32 columns) = 8 MFMAs each:
+//     NB = 2:  (0,0) (0,1) (1,1) (1,0)      NB = 1:  (0,0) (1,0)
+// so every operand sub-tile is read from LDS exactly ONCE per K-tile (24 / 20 ds_read_b128 per 32 / 16 MFMAs) and kept in
+// registers across the phases that reuse it.
+//
+// LDS: two K-tile buffers, each cut into 16-KiB "half-tiles" = the [128][64] image of one A-sub (both wave rows) or one
+// B-sub (all four wave columns).  One half-tile is requested per phase, one K-tile ahead (buffer_load_dwordx4 ... lds, two
+// 1-KiB pieces per wave), so two to three half-tiles are always in flight behind a counted vmcnt; a half-tile is waited for
+// one phase before the phase that reads it and restaged four phases after its last read (both margins include the
+// one-barrier lag of the second group).
+//
+// Forms, epilogues and the C ABI are those of gemm.hip (cocodr_gemm with impl 13 / 14).
+#include <stdlib.h>
+
+#include "common.h"
+#include "gemm_tile.h"
+
+namespace cocodr_gemm_pp {
+using namespace cocodr_gemm_v2;
+
+constexpr int BM = 256, BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;  // 16 KiB: [128 rows][64 k] (or [64 k][128 columns]) bf16
+constexpr int NTHREADS = 512;
+
+template <int NB>
+struct Shape {
+  static constexpr int BN = 128 * NB;
+  static constexpr int NTYPE = 2 + NB;              // half-tiles per K-tile
+  static constexpr int NPHASE = 2 * NB;             // phases per K-tile
+  static constexpr int KT_BYTES = NTYPE * HALF_BYTES;
+  static constexpr int RING_BYTES = 2 * KT_BYTES;
+  static constexpr int CT_LD = BN + 4;              // fp32 epilogue tile leading dimension
+  static constexpr int EPI_BYTES = 128 * CT_LD * 4 + 8 * BN * 4;  // one 128-row pass + one column-sum row per wave
+  static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+};
+
+// ---- half-tile "types": which rows / columns of the workgroup tile a half-tile image holds
+// NB = 2 (staging order A0 B0 B1 A1):  type 0 = A-sub 0, 1 = B-sub 0, 2 = B-sub 1, 3 = A-sub 1
+// NB = 1 (staging order A0 B0 A1):     type 0 = A-sub 0, 1 = B-sub 0, 2 = A-sub 1
+template <int NB>
+__device__ __forceinline__ constexpr bool type_is_a(int ty) { return NB == 2 ? (ty == 0 || ty == 3) : (ty == 0 || ty == 2); }
+template <int NB>
+__device__ __forceinline__ constexpr int type_sub(int ty) { return NB == 2 ? (ty >= 2 ? 1 : 0) : (ty == 2 ? 1 : 0); }
+
+// local row / column r (0..127) of a half-tile image -> row / column of the workgroup tile
+template <int NB>
+__device__ __forceinline__ int a_tile_row(int r, int sub) { return (r >> 6) * 128 + sub * 64 + (r & 63); }
+template <int NB>
+__device__ __forceinline__ int b_tile_col(int c, int sub) { return (c >> 5) * (32 * NB) + sub * 32 + (c & 31); }
+
+// byte offset (from the operand's batch base) of the 16-B chunk that must land at linear chunk p of a half-tile image
+template <int TR, int NB, bool IS_A>
+__device__ __forceinline__ uint32_t src_off(int p, int sub, int r0, int ld) {
+  if (TR == 0) {  // image [128 rows][64 k], 8 chunks per row
+    const int row = p >> 3, ch = (p & 7) ^ swz_rows<BK>(row);
+    const int g = r0 + (IS_A ? a_tile_row<NB>(row, sub) : b_tile_col<NB>(row, sub));
+    return (uint32_t)((g * ld + ch * 8) * 2);
+  } else {        // image [64 k][128 columns], 16 chunks per k row
+    const int row = p >> 4, ch = (p & 15) ^ swz_cols<128>(row);
+    const int lc = ch * 8;  // 8 consecutive columns never straddle a 32- or 64-column group
+    const int g = r0 + (IS_A ? a_tile_row<NB>(lc, sub) : b_tile_col<NB>(lc, sub));
+    return (uint32_t)((row * ld + g) * 2);
+  }
+}
+
+// LDS fragment reads of one K-sub-step with an extra immediate offset (the half-tile's place in the K-tile buffer)
+template <int TR, int NF, int S, int OFF, int A = 0>
+__device__ __forceinline__ void pp_frags_issue(const uint32_t (&cur)[4], FragSet<TR, NF>& f) {
+  if constexpr (A < NF) {
+    if constexpr (TR == 0) {
+      asm_ds_read_b128<OFF + A * 32 * BK * 2>(f.q[A], cur[S]);
+    } else {
+      constexpr int o = OFF + S * 16 * 128 * 2;
+      asm_ds_read_tr16<o>(f.lo[A], cur[A]);
+      asm_ds_read_tr16<o + 4 * 128 * 2>(f.hi[A], cur[A]);
+    }
+    pp_frags_issue<TR, NF, S, OFF, A + 1>(cur, f);
+  }
+}
+template <int TR, int NF, int OFF>
+__device__ __forceinline__ void pp_read_sub(const uint32_t (&cur)[4], FragSet<TR, NF> (&f)[4]) {
+#if defined(COCODR_ABL_NO_LDSREAD)
+  return;
+#endif
+  pp_frags_issue<TR, NF, 0, OFF>(cur, f[0]);
+  pp_frags_issue<TR, NF, 1, OFF>(cur, f[1]);
+  pp_frags_issue<TR, NF, 2, OFF>(cur, f[2]);
+  pp_frags_issue<TR, NF, 3, OFF>(cur, f[3]);
+}
+
+// 8 MFMAs of one quadrant phase: acc[2 asub + i][bsub] += A-sub(i, ks) x B-sub(ks); operands swapped so that a lane ends
+// with 4 consecutive output columns of one row (the epilogue's layout, as in gemm.hip)
+template <int TA, int TB, class MID>
+__device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const FragSet<TB, 1> (&fb)[4], f32x16& c0, f32x16& c1, MID&& mid) {
+#if defined(COCODR_ABL_NO_MFMA)
+  mid();
+  return;
+#endif
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const bf16x8 b = frag_get<TB, 1>(fb[ks], 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, frag_get<TA, 2>(fa[ks], 0), c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, frag_get<TA, 2>(fa[ks], 1), c1, 0, 0, 0);
+    if (ks == 0) mid();
+  }
+}
+
+// VAR (experiment builds, -DCOCODR_PP_VARIANTS, tools/gemm_bench.py --impls 13,15,16): 0 = DMA pieces requested in the load
+// segment behind the fragment reads; 2 = as 0 without s_setprio (-15 %); 3 = requested in front of the fragment reads (=).
+// Requesting them inside the MFMA segment instead cost 10-14 % (profiles/r02_gemm_pp_variants.txt).
+template <int NB, int TA, int TB, bool OUT_F32, int VAR = 0>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using S = Shape<NB>;
+  constexpr int BN = S::BN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;  // waves 0-3 (one per SIMD) form group 0, waves 4-7 group 1
+  const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tm_, tn_;
+  if (TA == 0) grouped_tile(tile, ntm, ntn, 4, tm_, tn_);
+  else { tm_ = tile / ntn; tn_ = tile % ntn; }
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
+  const int z = blockIdx.y;
+  const uint16_t* A = p.A + (size_t)z * p.strideA;
+  const uint16_t* B = p.B + (size_t)z * p.strideB;
+  const uint32_t a_bytes = (uint32_t)((size_t)(TA ? p.K : p.M) * p.lda * 2);
+  const uint32_t b_bytes = (uint32_t)((size_t)(TB ? p.K : p.N) * p.ldb * 2);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+
+  // per-lane DMA source offsets of this wave's two 1-KiB pieces (chunks (2 wid + jj) * 64 + lane) of every half-tile type
+  uint32_t off[S::NTYPE][2];
+#pragma unroll
+  for (int ty = 0; ty < S::NTYPE; ++ty)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int pch = (wid * 2 + jj) * 64 + lane;
+      off[ty][jj] = type_is_a<NB>(ty) ? src_off<TA, NB, true>(pch, type_sub<NB>(ty), m0, p.lda)
+                                      : src_off<TB, NB, false>(pch, type_sub<NB>(ty), n0, p.ldb);
+    }
+  const uint32_t stepa = TA ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
+  const uint32_t stepb = TB ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
+  const int nt = (p.K + BK - 1) / BK;
+
+  auto stage = [&](auto tyc, int t) {  // request half-tile `ty` of K-tile t
+    constexpr int ty = decltype(tyc)::value;
+#if defined(COCODR_ABL_NO_DMA)
+    if (t > 0) return;
+#endif
+    char* dst = smem + (t & 1) * S::KT_BYTES + ty * HALF_BYTES + wid * 2048;
+    if constexpr (type_is_a<NB>(ty)) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))dst, 16, off[ty][0] + t * stepa, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + t * stepa, 0, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))dst, 16, off[ty][0] + t * stepb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + t * stepb, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][NB];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+  uint32_t adA[4], adB[4];
+  frag_addrs<TA, 128, BK, 2>(wr * 64, lane, adA);
+  frag_addrs<TB, 128, BK, 1>(wc * 32, lane, adB);
+
+  // ---- prologue: the half-tiles 0 .. LOOK-1 of the request sequence (K-tile 0 and the first two of K-tile 1); phase 0 needs
+  // A0 and B0 of K-tile 0, everything behind them may stay in flight
+  static_for<0, S::NTYPE>([&](auto tyc) { stage(tyc, 0); });
+  if (nt > 1) {
+    stage(std::integral_constant<int, 0>{}, 1);
+    stage(std::integral_constant<int, 1>{}, 1);
+    wait_vmcnt<8>();
+  } else {
+    wait_vmcnt<4>();
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0 from here on
+
+#if defined(COCODR_ABL_NO_LDSREAD)
+  FragSet<TA, 2> fa[4] = {};
+  FragSet<TB, 1> fb0[4] = {}, fb1[4] = {};
+#else
+  FragSet<TA, 2> fa[4];
+  FragSet<TB, 1> fb0[4], fb1[4];
+#endif
+  uint32_t curA[4], curB[4];
+#if defined(COCODR_ABL_TIMELINE)  // per-workgroup stamps (100 MHz wall clock) into C2: [start, loop entry, loop exit, end]
+  unsigned long long* tl = reinterpret_cast<unsigned long long*>(p.C2) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+  if (tid == 0) { tl[0] = wall_clock64(); tl[1] = wall_clock64(); }
+#endif
+
+  // Request sequence s = 4 t + j in the order A0 B0 B1 A1 of every K-tile; phase p = 4 t + j requests s = p + 6 (the buffer it
+  // lands in was last read at phase p - 2 or earlier) and retires s = p + 2, which is first read at phase p + 1 or later: four
+  // half-tiles (64 KiB per CU) stay in flight, five to six phases (~1.5 K-tiles) between request and first use.  With only
+  // two half-tiles in flight the operand stream ran at ~50 GB/s per CU - the latency of a loaded L2 times the bytes in
+  // flight - and bounded the whole loop (DMA-only ablation, profiles/r02_gemm_pp_ablation.txt).
+  // rem = K-tiles left including this one: the request exists while its K-tile does; the wait count shrinks with the queue.
+  auto request = [&](auto jc, int t, int rem) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < 2) { if (rem >= 2) stage(std::integral_constant<int, j + 2>{}, t + 1); }
+    else { if (rem >= 3) stage(std::integral_constant<int, j - 2>{}, t + 2); }
+  };
+  auto wait_stage = [&](auto jc, int rem) {
+    constexpr int j = decltype(jc)::value;
+    if (rem >= 3) wait_vmcnt<8>();
+    else if (rem == 2) wait_vmcnt<(j < 2 ? 8 : (j == 2 ? 6 : 4))>();
+    else wait_vmcnt<(j == 0 ? 2 : 0)>();
+  };
+
+  for (int t = 0; t < nt; ++t) {
+    const int rem = nt - t;
+    const uint32_t kb = lds_base + (uint32_t)((t & 1) * S::KT_BYTES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + kb; curB[i] = adB[i] + kb; }
+    // one phase; RD: this phase's fragment reads, TY: the half-tile type requested for K-tile t + 1
+    auto phase = [&](auto tyc, auto&& reads, const FragSet<TB, 1> (&fb)[4], f32x16& c0, f32x16& c1) {
+      auto req = [&]() { request(tyc, t, rem); };
+      auto none = []() {};
+      if constexpr (VAR == 3) req();
+      reads();
+      if constexpr (VAR == 0 || VAR == 2) req();
+      wait_stage(tyc, rem);
+      __builtin_amdgcn_s_barrier();
+      wait_lgkmcnt<0>();
+      if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(1);
+      pp_mfma<TA, TB>(fa, fb, c0, c1, none);
+      if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    if constexpr (NB == 2) {
+      phase(std::integral_constant<int, 0>{}, [&]() { pp_read_sub<TA, 2, 0 * HALF_BYTES>(curA, fa); pp_read_sub<TB, 1, 1 * HALF_BYTES>(curB, fb0); },
+            fb0, acc[0][0], acc[1][0]);                                                                  // (A0, B0)
+      phase(std::integral_constant<int, 1>{}, [&]() { pp_read_sub<TB, 1, 2 * HALF_BYTES>(curB, fb1); }, fb1, acc[0][1], acc[1][1]);  // (A0, B1)
+      phase(std::integral_constant<int, 2>{}, [&]() { pp_read_sub<TA, 2, 3 * HALF_BYTES>(curA, fa); }, fb1, acc[2][1], acc[3][1]);   // (A1, B1)
+      phase(std::integral_constant<int, 3>{}, [&]() {}, fb0, acc[2][0], acc[3][0]);                      // (A1, B0): all in registers
+    }
+  }
+#if defined(COCODR_ABL_TIMELINE)
+  if (tid == 0) tl[2] = wall_clock64();
+#endif
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 catches up with group 1's last barrier
+
+  // ---- epilogue (gemm.hip's, for this geometry): two 128-row passes of the fp32 tile through LDS, row-major 16-B stores
+  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
+  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
+  constexpr int CPRW = BN / 8;                 // 8-column chunks per output row
+  constexpr int RP = 128;                      // rows per pass = one wave row
+  constexpr int NCH = RP * CPRW / NTHREADS;    // chunks per thread and pass (4 / 8); CPRW divides NTHREADS: fixed columns
+  const bool need_r = R_ != nullptr && (p.epi == COCODR_EPI_ADD || p.epi == COCODR_EPI_DGELU);
+  uint4 rcur[NCH];
+  auto fetch_r = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * NTHREADS;
+      const int gm = m0 + h * RP + c / CPRW;
+      rcur[i] = make_uint4(0, 0, 0, 0);
+      if (need_r && gm < p.M) rcur[i] = *reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + n0 + ((c % CPRW) << 3));
+    }
+  };
+  fetch_r(0);
+  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (bias != nullptr) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + n0 + ((tid % CPRW) << 3));
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + n0 + ((tid % CPRW) << 3) + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+  __syncthreads();
+  float* ct = reinterpret_cast<float*>(smem);
+  constexpr int CLD = S::CT_LD;
+  const bool do_colsum = p.colsum_partial != nullptr;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (wr == h) {
+#pragma unroll
+      for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int row = ai * 32 + (lane & 31);
+            const int col = wc * 32 * NB + b * 32 + 8 * rg + 4 * (lane >> 5);
+            *reinterpret_cast<float4*>(ct + row * CLD + col) =
+                make_float4(acc[ai][b][rg * 4 + 0], acc[ai][b][rg * 4 + 1], acc[ai][b][rg * 4 + 2], acc[ai][b][rg * 4 + 3]);
+          }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * NTHREADS;
+      const int row = c / CPRW, c8 = (c % CPRW) << 3;
+      const int gm = m0 + h * RP + row;
+      const int gn = n0 + c8;
+      if (gm < p.M) {
+        float v[8];
+        const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CLD + c8);
+        const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CLD + c8 + 4);
+        v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+        epilogue_store8<OUT_F32, true, true>(p, z, bias, R_, gm, gn, v, rcur[i], bias8);
+        if (do_colsum) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) csum[j] += v[j];
+        }
+      }
+    }
+    if (h == 0) {
+      fetch_r(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  if (do_colsum) {  // workgroup-uniform: lanes that differ by a multiple of CPRW hold the same 8 columns
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (CPRW <= 16) csum[j] += __shfl_xor(csum[j], 16, 64);
+      csum[j] += __shfl_xor(csum[j], 32, 64);
+    }
+    float* cred = ct + RP * CLD;
+    if (lane < CPRW) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cred[wid * BN + lane * 8 + j] = csum[j];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < BN) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += cred[w * BN + tid];
+      p.colsum_partial[(size_t)tm_ * p.N + n0 + tid] = t;
+    }
+  }
+#if defined(COCODR_ABL_TIMELINE)
+  if (tid == 0) tl[3] = wall_clock64();
+#endif
+#endif
+}
+
+template <int NB, int TA, int TB, int VAR = 0>
+void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
+  using S = Shape<NB>;
+  const int ntm = (a.M + BM - 1) / BM, ntn = a.N / S::BN;
+  dim3 grid(ntm * ntn, a.batch);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, true, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (a.out_f32)
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a);
+  else
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a);
+}
+
+}  // namespace cocodr_gemm_pp
+
+// nb = 2: 256 x 256 tile (N % 256 == 0), nb = 1: 256 x 128 tile; the caller has validated the arguments (cocodr_gemm)
+template <int VAR>
+static void launch_any(const cocodr_gemm_args& a, hipStream_t st) {
+  using namespace cocodr_gemm_pp;
+  if (!a.trans_a && !a.trans_b) launch_form<2, 0, 0, VAR>(a, st);
+  else if (!a.trans_a && a.trans_b) launch_form<2, 0, 1, VAR>(a, st);
+  else launch_form<2, 1, 1, VAR>(a, st);
+}
+void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st) {
+  if (nb == 2) launch_any<0>(a, st);
+#if defined(COCODR_PP_VARIANTS)
+  else if (nb == 102) launch_any<2>(a, st);
+  else if (nb == 103) launch_any<3>(a, st);
+#endif
+  else launch_any<0>(a, st);
+}

@@ -295,7 +295,8 @@ def _nccl_one_rank(rank, world, ids, mask):
 
 def test_one_rank_rccl_step_equals_the_plain_step():
     """`all_gather_into_tensor` of the [CLS] rows and the per-range gradient all-reduce (AVG) over the `nccl` backend (= RCCL)
-    with a 1-rank group: same loss and bit-identical gradients as the step without a process group."""
+    with a 1-rank group: same loss and the same gradients as the step without a process group (up to fp32 summation order:
+    the ranged backward groups the weight-gradient launches per range and the word-embedding rows are fp32 atomics)."""
     rng = np.random.Generator(np.random.PCG64(12))
     ids = rng.integers(5, 700, (8, 32))
     mask = np.ones((8, 32), np.int64)
@@ -308,4 +309,4 @@ def test_one_rank_rccl_step_equals_the_plain_step():
     loss = CoCondenserForPretraining(bert)({"input_ids": torch.from_numpy(ids).cuda(), "attention_mask": torch.from_numpy(mask).cuda()}, None)
     loss.backward()
     assert abs(out[0] - float(loss.detach())) < 1e-6
-    assert np.array_equal(out[1], bert.flat_decay.grad.cpu().numpy()) and np.array_equal(out[2], bert.flat_nodecay.grad.cpu().numpy())
+    assert _rel(out[1], bert.flat_decay.grad.cpu().numpy()) < 1e-5 and _rel(out[2], bert.flat_nodecay.grad.cpu().numpy()) < 1e-5

@@ -49,14 +49,14 @@ def test_probe_ds_read_tr16_layout():
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12], ids=["regstage", "glds128x64", "glds256x64", "glds128x32", "glds256x32", "glds256x32w4", "glds256x64w4", "glds128x192", "glds256x64ld4", "glds256x64w4ld4", "glds256x256", "glds256x96ld4"], autouse=False)
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13], ids=["regstage", "glds128x64", "glds256x64", "glds128x32", "glds256x32", "glds256x32w4", "glds256x64w4", "glds128x192", "glds256x64ld4", "glds256x64w4ld4", "glds256x256", "glds256x96ld4", "pingpong256x256"], autouse=False)
 def gemm_impl(request):
     ops.gemm_set_impl(request.param)
     yield request.param
     ops.gemm_set_impl(0)
 
 
-@pytest.mark.parametrize("M,Nn,K", [(256, 128, 64), (192, 384, 128), (8192, 768, 768), (1000, 256, 200)])
+@pytest.mark.parametrize("M,Nn,K", [(256, 128, 64), (192, 384, 128), (8192, 768, 768), (1000, 256, 200), (1000, 512, 64), (300, 256, 192)])
 def test_gemm_nt_bias(M, Nn, K, gemm_impl):
     a, w, bias = rnd(M, K, seed=3), rnd(Nn, K, scale=0.05, seed=4), rnd(Nn, seed=5, dtype=torch.float32)
     out = ops.gemm(a, w, bias=bias)

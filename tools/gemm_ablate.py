@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "tools", "_abl")
+OUT = os.path.join(ROOT, "build", "abl")  # git-ignored, but travels to the GPU box
 VARIANTS = {
     "full": [],
     "no_mfma": ["-DCOCODR_ABL_NO_MFMA"],
@@ -33,7 +33,7 @@ def build():
         lib = os.path.join(OUT, f"libabl_{name}.so")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                "-DCOCODR_ABL_ALIAS_LD"] + defs + [
-            os.path.join(csrc, "gemm.hip"), os.path.join(csrc, "core.hip"), os.path.join(csrc, "rowops.hip"), "-o", lib]
+            os.path.join(csrc, "gemm.hip"), os.path.join(csrc, "gemm_pp.hip"), os.path.join(csrc, "core.hip"), os.path.join(csrc, "rowops.hip"), "-o", lib]
         subprocess.run(cmd, check=True)
         print("built", lib)
 
@@ -46,7 +46,7 @@ def timeline(args, impls, stream):
     lib = C.CDLL(os.path.join(OUT, "libabl_timeline.so"))
     lib.cocodr_gemm.argtypes = [C.POINTER(_native.GemmArgs), C.c_void_p]
     lib.cocodr_gemm_set_impl.argtypes = [C.c_int]
-    for name, M, N, K, ta, tb, nb, f32 in [SHAPES[i] for i in (2, 3, 1, 9)]:
+    for name, M, N, K, ta, tb, nb, f32 in [SHAPES[i] for i in ([int(x) for x in args.shapes.split(",")] if args.shapes else (2, 3, 1, 9))]:
         ashape = (nb, K, M) if ta else (nb, M, K)
         bshape = (nb, K, N) if tb else (nb, N, K)
         a = torch.randn(ashape, device="cuda").to(torch.bfloat16)
@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--ld64", action="store_true", help="NT shapes only: lda = ldb = 64, i.e. operands alias a ~1 MB L2-resident window")
     ap.add_argument("--variants", default="", help="comma separated subset of the built variants to time (default: the ablations)")
     ap.add_argument("--timeline", action="store_true", help="per-workgroup phase stamps instead of timings")
+    ap.add_argument("--shapes", default="", help="comma separated indices into tools/gemm_bench.py SHAPES")
     args = ap.parse_args()
     if args.build:
         return build()
@@ -110,7 +111,7 @@ def main():
     if args.timeline:
         return timeline(args, impls, stream)
     print(f"{'shape':32s} impl " + " ".join(f"{n:>12s}" for n in libs) + "   (us per launch)")
-    for name, M, N, K, ta, tb, nb, f32 in (SHAPES[:4] if args.ld64 else SHAPES[:11]):
+    for name, M, N, K, ta, tb, nb, f32 in ([SHAPES[int(x)] for x in args.shapes.split(",")] if args.shapes else (SHAPES[:4] if args.ld64 else SHAPES[:11])):
         ashape = (nb, K, M) if ta else (nb, M, K)
         bshape = (nb, K, N) if tb else (nb, N, K)
         a = torch.randn(ashape, device="cuda").to(torch.bfloat16)

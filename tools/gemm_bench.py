@@ -36,6 +36,18 @@ SHAPES = [  # (name, M, N, K, ta, tb, batch, out_f32)
     ("L wgrad qkv 24x 3072x1024x8192", 3072, 1024, 8192, 1, 1, 24, 1),
     ("L wgrad out 24x 1024x1024x8192", 1024, 1024, 8192, 1, 1, 24, 1),
     ("L wgrad ffn1 24x 4096x1024x8192", 4096, 1024, 8192, 1, 1, 24, 1),
+    # BERT-large at 25600 tokens (COCO/README.md:59-63: 100 documents = 200 spans per GPU)
+    ("XL fwd qkv  25600x3072x1024", 25600, 3072, 1024, 0, 0, 1, 0),
+    ("XL fwd out  25600x1024x1024", 25600, 1024, 1024, 0, 0, 1, 0),
+    ("XL fwd ffn1 25600x4096x1024", 25600, 4096, 1024, 0, 0, 1, 0),
+    ("XL fwd ffn2 25600x1024x4096", 25600, 1024, 4096, 0, 0, 1, 0),
+    ("XL dgrad ffn2 25600x4096x1024", 25600, 4096, 1024, 0, 1, 1, 0),
+    ("XL dgrad ffn1 25600x1024x4096", 25600, 1024, 4096, 0, 1, 1, 0),
+    ("XL dgrad qkv 25600x1024x3072", 25600, 1024, 3072, 0, 1, 1, 0),
+    ("XL wgrad qkv 24x 3072x1024x25600", 3072, 1024, 25600, 1, 1, 24, 1),
+    ("XL wgrad ffn1 24x 4096x1024x25600", 4096, 1024, 25600, 1, 1, 24, 1),
+    ("cube 4096", 4096, 4096, 4096, 0, 0, 1, 0),
+    ("cube 8192", 8192, 8192, 8192, 0, 0, 1, 0),
     # corpus-encode batch (512 x 128 tokens, forward only)
     ("enc qkv  65536x2304x768", 65536, 2304, 768, 0, 0, 1, 0),
     ("enc out  65536x768x768", 65536, 768, 768, 0, 0, 1, 0),
