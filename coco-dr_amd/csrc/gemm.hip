@@ -616,7 +616,16 @@ int select_impl(const cocodr_gemm_args& a) {
     const long long tiles96 = a.N % 96 == 0 ? (long long)((a.M + 255) / 256) * (a.N / 96) * batch : 0;
     static const bool no96 = getenv("COCODR_GEMM_NO96") != nullptr;  // A/B switch of this rule
     const bool fewer_rounds = !no96 && tiles96 > 0 && ((tiles96 + 255) / 256) * 3 < ((tiles256 + 255) / 256) * 4;
+    // ping-pong pipeline (gemm_pp.hip, 256x256 tiles): wins once its tiles fill the 256 CUs for nearly whole rounds -
+    // 2-12 % on the forward / dgrad forms from 400 tiles (BERT-large FFN1 at 8192 tokens, everything at 25600 tokens),
+    // 3-7 % on the grouped weight gradients from ~1500 tiles; with 1.5 rounds or less it loses to the 256x128 tiles
+    // (profiles/r02_gemm_pp_vs_glds.txt)
+    const long long tilespp = a.N % 256 == 0 ? (long long)((a.M + 255) / 256) * (a.N / 256) * batch : 0;
+    const long long roundspp = (tilespp + 255) / 256;
+    static const bool nopp = getenv("COCODR_GEMM_NOPP") != nullptr;  // A/B switch of this rule
+    const bool pp_fills = !nopp && tilespp >= (a.trans_a ? 1400 : 400) && tilespp * 100 >= roundspp * 256 * 78;
     if (!(k_ok && small)) impl = 1;
+    else if (pp_fills) impl = 13;
     else if (fewer_rounds && !a.trans_a && tiles256 >= 128 && !a.colsum && !a.colsum_partial) impl = 12;
     else if (tiles256 >= 384 && !(a.trans_a && tiles256 < 800) && !(!a.trans_a && a.K >= 2048)) impl = 5;
     else if (tiles256 >= 128) impl = 9;
