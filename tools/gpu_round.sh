@@ -1,0 +1,43 @@
+#!/bin/bash
+# One GPU visit: parity suite, the default bench line, kernel-trace stats and HBM-traffic PMC passes for the base and
+# large contrastive steps.  Usage (on the GPU box, from the repo root): tools/gpu_round.sh <tag> [commit] [stages]
+# stages: any of t (tests) b (bench) k (kernel stats) p (PMC traffic); default tbkp
+set -u
+tag=${1:-r02}; commit=${2:-unknown}; stages=${3:-tbkp}
+export TMPDIR=/tmp
+root=$PWD
+out=$root/gpurun_out/$tag
+mkdir -p $out
+if [[ $stages == *t* ]]; then
+  timeout 2400 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> $out/pytest_gpu.log
+  tail -3 $out/pytest_gpu.log
+fi
+if [[ $stages == *b* ]]; then
+  timeout 1500 python bench.py > $out/bench.json 2> $out/bench.err
+  echo "bench exit $?"; tail -c 600 $out/bench.json
+fi
+prof_args="--steps 10 --warmup 3 --no-cpu-baseline --no-full-step"
+for cfg in "base 64" "large 64" "large 200"; do
+  set -- $cfg; model=$1; nseq=$2
+  name=${model}_${nseq}x128
+  if [[ $stages == *k* ]]; then
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/kt_$name -o kt -- python $root/bench.py $prof_args --model $model --seq-per-gpu $nseq > $out/kt_$name.log 2>&1)
+    db=$(find $out/kt_$name -name "*.db" | head -1)
+    if [ -n "$db" ]; then python tools/rocpd_stats.py $db > $out/kernel_stats_$name.md; fi
+    grep '"metric"' $out/kt_$name.log > $out/kt_bench_$name.json
+  fi
+  if [[ $stages == *p* ]]; then
+    pmc_cmd="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-full-step --model $model --seq-per-gpu $nseq"
+    for c in FETCH_SIZE WRITE_SIZE; do
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${name}_$c -- python $root/$pmc_cmd > $out/pmc_${name}_$c.log 2>&1)
+    done
+    f=$(find $out/pmc_${name}_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+    w=$(find $out/pmc_${name}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ] && [ -n "$w" ]; then python tools/pmc_traffic.py $f $w $out/r02_gemm_pmc_$name.json "$pmc_cmd" $commit; fi
+  fi
+done
+# keep the merged-back payload small: drop raw traces
+find $out -name "*.db" -size +20M -delete
+find $out -name "*counter_collection.csv" -size +20M -delete
+ls -la $out | head -50

@@ -2,7 +2,7 @@
 """HBM-side bytes per GEMM launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE - separate runs, CSV output),
 corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE reports half of
 wide coalesced reads).  Writes the JSON bench.py reads for roofline.traffic.
-Usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
+Usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [command] [commit]"""
 import collections
 import csv
 import json
@@ -13,13 +13,13 @@ import sys
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and "gemm_glds_kernel" in r["Kernel_Name"]:
-            name = re.sub(r"^void |cocodr_gemm_v2::|\(.*$", "", r["Kernel_Name"])
+        if r["Counter_Name"] == counter and ("gemm_glds_kernel" in r["Kernel_Name"] or "gemm_pp_kernel" in r["Kernel_Name"]):
+            name = re.sub(r"^void |cocodr_gemm_v2::|cocodr_gemm_pp::|\(.*$", "", r["Kernel_Name"])
             acc[name].append(float(r["Counter_Value"]))
     return acc
 
 
-def main(fetch_csv, write_csv, out):
+def main(fetch_csv, write_csv, out, cmd="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-full-step", commit=None):
     f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     rows, tot_b, tot_n = [], 0.0, 0
     for k in sorted(f, key=lambda k: -sum(f[k])):
@@ -29,13 +29,13 @@ def main(fetch_csv, write_csv, out):
         rows.append({"kernel": k, "launches": n, "fetch_bytes_corrected": fb, "write_bytes": wb})
         tot_b += (fb + wb) * n
         tot_n += n
-    json.dump({"kernel": "gemm_glds_kernel (all instantiations)", "launches": tot_n, "hbm_bytes_per_launch": tot_b / max(1, tot_n),
-               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 "
-                         "--no-cpu-baseline --no-roofline --no-full-step`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+    json.dump({"kernel": "gemm_glds_kernel + gemm_pp_kernel (all instantiations)", "commit": commit, "launches": tot_n, "hbm_bytes_per_launch": tot_b / max(1, tot_n),
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `" + cmd + "`;"
+                         " bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                          "MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads on gfx950); Infinity-Cache hits are "
                          "included in FETCH_SIZE", "per_kernel": rows}, open(out, "w"), indent=1)
     print(f"{tot_n} GEMM launches, {tot_b / max(1, tot_n) / 1e6:.1f} MB per launch -> {out}")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])
