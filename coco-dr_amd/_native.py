@@ -12,6 +12,10 @@ LIB_PATH = os.path.join(HERE, "libcocodr_hip.so")
 c_void_p, c_int, c_float, c_size_t, c_longlong, c_double = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong, C.c_double
 
 
+class DropoutMask(C.Structure):  # mirrors cocodr_dropout_mask
+    _fields_ = [("k0", C.c_uint32), ("k1", C.c_uint32), ("threshold", C.c_uint32), ("scale", c_float)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p), ("R", c_void_p),
@@ -22,12 +26,14 @@ class GemmArgs(C.Structure):
         ("strideA", c_longlong), ("strideB", c_longlong), ("strideC", c_longlong), ("strideR", c_longlong),
         ("strideBias", c_longlong),
         ("colsum", c_void_p), ("colsum_partial", c_void_p),
+        ("drop", DropoutMask),
     ]
 
 
 class Config(C.Structure):
     _fields_ = [("hidden", c_int), ("heads", c_int), ("layers", c_int), ("inter", c_int), ("vocab", c_int),
-                ("max_pos", c_int), ("ln_eps", c_float)]
+                ("max_pos", c_int), ("ln_eps", c_float),
+                ("hidden_dropout", c_float), ("attn_dropout", c_float), ("drop_seed", C.c_ulonglong), ("drop_call", C.c_ulonglong)]
 
 
 class LayerParams(C.Structure):
@@ -71,6 +77,12 @@ SIGNATURES = {
     "cocodr_gemm_set_impl": (c_int, [c_int]),
     "cocodr_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cocodr_attn_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    "cocodr_dropout_mask_for": (c_int, [c_double, C.c_ulonglong, C.c_ulonglong, c_int, c_int, C.POINTER(DropoutMask)]),
+    "cocodr_attn_fwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
+    "cocodr_attn_bwd_drop": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
+    "cocodr_embed_ln_fwd_drop": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, C.POINTER(DropoutMask), c_void_p]),
+    "cocodr_embed_ln_bwd_drop": (c_int, [c_void_p] * 14 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
+    "cocodr_ln_bwd_drop": (c_int, [c_void_p] * 11 + [c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
     "cocodr_embed_ln_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "cocodr_embed_bwd_partial_floats": (c_size_t, [c_int, c_int]),
     "cocodr_embed_ln_bwd": (c_int, [c_void_p] * 14 + [c_int, c_int, c_int, c_int, c_void_p]),

@@ -56,6 +56,8 @@ class CondenserHead(nn.Module):
         self.flat_nodecay = nn.Parameter(torch.zeros(self.layout.nodecay_numel, dtype=torch.float32, device=dev))
         self._shadow = None
         self._shadow_version = -1
+        self.dropout_seed = None  # None: torch.initial_seed() at the first dropout forward
+        self._dropout_calls = 0
         self.vpad = (V + 127) // 128 * 128
         self.reset_parameters()
 
@@ -69,6 +71,18 @@ class CondenserHead(nn.Module):
 
     def hf_view(self, name):
         return self.layout.view((self.flat_decay.data, self.flat_nodecay.data), name)
+
+    def _next_dropout(self):
+        """(p_hidden, p_attention, seed, call) of the next forward of the c_head BertLayers, or None in eval mode / with both
+        probabilities 0.  The reference's c_head layers are the only part of the COCO step that drops
+        (COCO/modeling.py:198 puts the backbone in eval, trainer.py:146 the rest in train)."""
+        c = self.config
+        if not self.training or (c.hidden_dropout_prob <= 0 and c.attention_probs_dropout_prob <= 0):
+            return None
+        if self.dropout_seed is None:
+            self.dropout_seed = (int(torch.initial_seed()) ^ 0x5DEECE66D) & (2 ** 63 - 1)
+        self._dropout_calls += 1
+        return (float(c.hidden_dropout_prob), float(c.attention_probs_dropout_prob), int(self.dropout_seed), self._dropout_calls)
 
     def hf_named_grads(self):
         flats = (self.flat_decay.grad, self.flat_nodecay.grad)
@@ -136,7 +150,8 @@ class _CondenserStepFn(torch.autograd.Function):
         last = hidden[NL]
         # ---- Condenser head on cat(cls of the last layer, skip_from states without their first token)
         head._refresh_shadow()
-        hcfg = N.Config(H, cfg.num_attention_heads, nh, cfg.intermediate_size, V, cfg.max_position_embeddings, cfg.layer_norm_eps)
+        hdrop = head._next_dropout() or (0.0, 0.0, 0, 0)
+        hcfg = N.Config(H, cfg.num_attention_heads, nh, cfg.intermediate_size, V, cfg.max_position_embeddings, cfg.layer_norm_eps, *hdrop)
         hlay = N.EncoderLayout()
         check(lib().cocodr_encoder_layout(C.byref(hcfg), B, L, 1, C.byref(hlay)), "encoder_layout(head)")
         harena = torch.empty(hlay.total_bytes, dtype=torch.uint8, device=dev)
@@ -237,7 +252,7 @@ class _CondenserStepFn(torch.autograd.Function):
         bgn = torch.empty_like(bert.flat_nodecay.data)
         bgd[:lo.mat_begin].zero_()
         emb, arr, eg, garr = bert._param_structs((bgd, bgn))
-        bcfg = bert._c_config()
+        bcfg = bert._c_config(getattr(ctx.arena, "_cocodr_drop", None))
         d_last16 = d_last.to(torch.bfloat16)
         dx_view = ctx.arena[ctx.lay.bwd_dx: ctx.lay.bwd_dx + M * H * 2].view(torch.bfloat16).view(B, L, H)
 

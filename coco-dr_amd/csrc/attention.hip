@@ -104,10 +104,41 @@ __device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 
     }
 }
 
+// ---- dropout on the attention probabilities (include/cocodr.h "Dropout"): element (b, h, q, k) has flat index
+// ((b heads + h) L + q) L + k; pairs run along k.  Masks are regenerated wherever P is formed, never stored.
+__device__ __forceinline__ uint32_t prob_row_pair(int bh, int q, int L) { return (uint32_t)((((uint64_t)bh * L + q) * L) >> 1); }
+// lane = query layout (S^T accumulators): register rg*4 + e is key k0 + 8 rg + 4 half + e of this lane's row;
+// pairbase = pair of (row, k0 + 4 half).  f(r, keep) with r a compile-time register index.
+template <class F>
+__device__ __forceinline__ void for_keep_qlane(uint32_t pairbase, const cocodr_dropout_mask& dm, F&& f) {
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t w = drop_word(pairbase + rg * 4 + j, dm.k0, dm.k1);
+      f(rg * 4 + 2 * j, drop_keep_lo(w, dm.threshold));
+      f(rg * 4 + 2 * j + 1, drop_keep_hi(w, dm.threshold));
+    }
+}
+// lane = key layout (S accumulators): register rg*4 + e is query q0 + 8 rg + 4 half + e, this lane's key is fixed;
+// pairbase = pair of (q0 + 4 half, key), Lh = L / 2 pairs per row, shift = 16 for odd keys
+template <class F>
+__device__ __forceinline__ void for_keep_klane(uint32_t pairbase, uint32_t Lh, uint32_t shift, const cocodr_dropout_mask& dm, F&& f) {
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t w = drop_word(pairbase + (uint32_t)(8 * rg + e) * Lh, dm.k0, dm.k1);
+      f(rg * 4 + e, ((w >> shift) & 0xffffu) >= dm.threshold);
+    }
+}
+
 // three waves per SIMD (168 registers): at the default bound hipcc parks the O accumulators in AGPRs and pays an
 // accvgpr read + write per element for every online-softmax rescale
+template <bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
-                                                       uint16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H) {
+                                                       uint16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
+                                                       const cocodr_dropout_mask dm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
   char* Vt = smem + L * 128;
@@ -142,6 +173,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = kMaskNeg, lsum = 0.f;
   const float sl2 = kScale * kLog2e;
+  const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, q0 + (lane & 31), L) + 2 * half : 0u;
 
   for (int kb = 0; kb < L / 32; ++kb) {
     f32x16 sacc;
@@ -170,6 +202,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
       p[r] = fast_exp2(fmaf(sacc[r], sl2, -mnew));
       lsum += p[r];
     }
+    // the normaliser sums the un-dropped probabilities; the 1 / (1 - p) scale rides on the final 1 / l
+    if constexpr (DROP) for_keep_qlane(rowpair + kb * 16, dm, [&](int r, bool keep) { p[r] = keep ? p[r] : 0.f; });
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bf16x8 pf = pack_acc(p, j);
@@ -180,7 +214,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   if (lane < 32) lse[((size_t)b * heads + h) * L + q0 + lane] = (m + __log2f(ltot)) * kLn2;
-  store_acc_T(ctx + (size_t)(b * L + q0) * H + h * 64, H, o, 1.0f / ltot, lane);
+  store_acc_T(ctx + (size_t)(b * L + q0) * H + h * 64, H, o, (DROP ? dm.scale : 1.0f) / ltot, lane);
 }
 
 #if defined(COCODR_ABL_TIMELINE)  // tools/attn_timeline.py builds: per-workgroup phase stamps (100 MHz wall clock)
@@ -252,11 +286,15 @@ __device__ __forceinline__ void qk_bias_store(float* partial, float qacc, int b,
 }
 //  phase A: wave <-> 32 queries,  S^T/dP^T layout (lane = query):  dQ^T += K^T dS^T
 //  phase B: wave <-> 32 keys,     S / dP layout   (lane = key):    dV^T += dO^T P,  dK^T += Q^T dS
-template <bool QKSUM>
+// DROP (probabilities dropped in the forward, mask m, scale s): dV = (s m P)^T dO and dS = P (s m dP' - delta) with
+// dP' = dO V^T, delta = rowsum(dO O) as before (O already carries the mask).  The dP accumulators are seeded with
+// -delta / s, so dS / s = P (kept ? acc : seed): one select per element, and s rides on the final scales of dQ, dK, dV.
+template <bool QKSUM, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                           const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
                                                           const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L,
-                                                          int H, int stagger, float* __restrict__ qk_partial) {
+                                                          int H, int stagger, float* __restrict__ qk_partial,
+                                                          const cocodr_dropout_mask dm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qt = smem;
   char* Kt = smem + L * 128;
@@ -266,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   float* madd = reinterpret_cast<float*>(smem + 4 * L * 128);
   float* lse2 = madd + L;
   float* delta = lse2 + L;
+  const float inv_s = DROP ? 1.0f / dm.scale : 1.0f, out_s = DROP ? dm.scale : 1.0f;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
   const int ld = 3 * H;
@@ -311,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       part += dpp_partner<0xB1>(part);   // lane ^ 1
       part += dpp_partner<0x4E>(part);   // lane ^ 2
       part += dpp_partner<0x141>(part);  // the other quad of the 8 lanes that hold a row (DPP operands, no LDS round trip)
-      if (ch == 0) delta[row] = -part;  // negated: it seeds the dP accumulators below
+      if (ch == 0) delta[row] = DROP ? -part * inv_s : -part;  // negated: it seeds the dP accumulators below
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -330,7 +369,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       dof[s] = frag_rows(Dt, qb * 32, s, lane);
     }
     const float my_lse = lse2[qb * 32 + (lane & 31)];
-    const float my_ndelta = delta[qb * 32 + (lane & 31)];  // -delta of this lane's query
+    const float my_ndelta = delta[qb * 32 + (lane & 31)];  // -delta of this lane's query (DROP: / s)
+    const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, qb * 32 + (lane & 31), L) + 2 * half : 0u;
     f32x16 dq[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -346,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
         dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vt, kb * 32, s, lane), dof[s], dpacc, 0, 0, 0);
       }
       float ds[16];
+      [[maybe_unused]] float pa[DROP ? 16 : 1];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const float4 ma = *reinterpret_cast<const float4*>(madd + kb * 32 + 8 * rg + 4 * half);
@@ -355,8 +396,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
           const int r = rg * 4 + e;
           const float p = fast_exp2(sacc[r] * sl2 + mm[e] - my_lse);
           ds[r] = p * dpacc[r];  // dpacc was seeded with -delta
+          if constexpr (DROP) pa[r] = p;
         }
       }
+      if constexpr (DROP)  // dropped elements: dP = 0, i.e. dS / s = P * seed
+        for_keep_qlane(rowpair + kb * 16, dm, [&](int r, bool keep) { ds[r] = keep ? ds[r] : pa[r] * my_ndelta; });
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bf16x8 dsf = pack_acc(ds, j);
@@ -367,8 +411,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     }
     ATTN_STAMP(2);
     // (in front of the store: behind it hipcc interleaves the two and spills 72 SGPRs of lane masks instead of 9)
-    if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale, lane);
-    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
+    if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale * out_s, lane);
+    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane);
   }
   ATTN_STAMP(3);
   if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
@@ -382,6 +426,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       vf[s] = frag_rows(Vt, kb * 32, s, lane);
     }
     const float my_madd = madd[kb * 32 + (lane & 31)];
+    // pair of (query 4 half, this lane's key); a query step is L / 2 pairs
+    const uint32_t Lh = (uint32_t)L >> 1, kshift = (lane & 1) << 4;
+    const uint32_t keypair = DROP ? prob_row_pair(b * heads + h, 4 * half, L) + (uint32_t)((kb * 32 + (lane & 31)) >> 1) : 0u;
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -402,17 +449,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
         dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Dt, qb * 32, s, lane), vf[s], dpacc, 0, 0, 0);
       }
       float p[16], ds[16];
+      [[maybe_unused]] float sd[DROP ? 16 : 1];  // dS / s of a dropped element: P * seed
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const float4 l4 = *reinterpret_cast<const float4*>(lse2 + qb * 32 + 8 * rg + 4 * half);
         const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+        [[maybe_unused]] float dseed[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (DROP) {
+          const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
+          dseed[0] = d4.x; dseed[1] = d4.y; dseed[2] = d4.z; dseed[3] = d4.w;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = rg * 4 + e;
           p[r] = fast_exp2(sacc[r] * sl2 + my_madd - ll[e]);
           ds[r] = p[r] * dpacc[r];  // dpacc was seeded with -delta
+          if constexpr (DROP) sd[r] = p[r] * dseed[e];
         }
       }
+      if constexpr (DROP)
+        for_keep_klane(keypair + (uint32_t)(qb * 32) * Lh, Lh, kshift, dm, [&](int r, bool keep) {
+          ds[r] = keep ? ds[r] : sd[r];
+          p[r] = keep ? p[r] : 0.f;
+        });
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bf16x8 pf = pack_acc(p, j), dsf = pack_acc(ds, j);
@@ -425,8 +484,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     }
     ATTN_STAMP(4);
     uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
-    store_acc_T16(row0 + H, ld, dk, kScale, lane);
-    store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
+    store_acc_T16(row0 + H, ld, dk, kScale * out_s, lane);
+    store_acc_T16(row0 + 2 * H, ld, dv, out_s, lane);
   }
   ATTN_STAMP(5);
 }
@@ -441,12 +500,13 @@ __device__ __forceinline__ bf16x8 frag_rows_global(const uint16_t* base, int ld,
   return as_bf16x8(*reinterpret_cast<const uint4*>(base + (size_t)(r0 + (lane & 31)) * ld + (2 * s + (lane >> 5)) * 8));
 }
 
-template <bool QKSUM>
+template <bool QKSUM, bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                              const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H,
-                                                             float* __restrict__ qk_partial) {
+                                                             float* __restrict__ qk_partial, const cocodr_dropout_mask dm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const float inv_s = DROP ? 1.0f / dm.scale : 1.0f, out_s = DROP ? dm.scale : 1.0f;
   float qacc = 0.f;
   char* Kt = smem;
   char* Vt = smem + L * 128;
@@ -478,7 +538,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
       for (int e = 0; e < 8; ++e) dpart += df[e] * ofv[e];
     }
-    const float my_ndelta = -(dpart + __shfl_xor(dpart, 32, 64));  // lanes l and l^32 hold the two halves of row l & 31
+    const float my_ndelta = -(dpart + __shfl_xor(dpart, 32, 64)) * inv_s;  // lanes l and l^32 hold the two halves of row l & 31
+    const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, qb * 32 + (lane & 31), L) + 2 * half : 0u;
     const float my_lse = lse[((size_t)b * heads + h) * L + qb * 32 + (lane & 31)] * kLog2e;
     f32x16 dq[2];
 #pragma unroll
@@ -495,6 +556,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
         dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vt, kb * 32, s, lane), dof[s], dpacc, 0, 0, 0);
       }
       float ds[16];
+      [[maybe_unused]] float pa[DROP ? 16 : 1];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const float4 ma = *reinterpret_cast<const float4*>(madd + kb * 32 + 8 * rg + 4 * half);
@@ -504,8 +566,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
           const int r = rg * 4 + e;
           const float p = fast_exp2(sacc[r] * sl2 + mm[e] - my_lse);
           ds[r] = p * dpacc[r];  // dpacc was seeded with -delta
+          if constexpr (DROP) pa[r] = p;
         }
       }
+      if constexpr (DROP)  // dropped elements: dP = 0, i.e. dS / s = P * seed
+        for_keep_qlane(rowpair + kb * 16, dm, [&](int r, bool keep) { ds[r] = keep ? ds[r] : pa[r] * my_ndelta; });
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bf16x8 dsf = pack_acc(ds, j);
@@ -514,16 +579,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Kt, kb * 32 + j * 16, dt, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale, lane);
-    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale, lane);
+    if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale * out_s, lane);
+    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane);
   }
   if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                               const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
-                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H) {
+                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H,
+                                                              const cocodr_dropout_mask dm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const float inv_s = DROP ? 1.0f / dm.scale : 1.0f, out_s = DROP ? dm.scale : 1.0f;
   char* Qt = smem;
   char* Dt = smem + L * 128;
   float* lse2 = reinterpret_cast<float*>(smem + 2 * L * 128);
@@ -559,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
       part += dpp_partner<0xB1>(part);   // lane ^ 1
       part += dpp_partner<0x4E>(part);   // lane ^ 2
       part += dpp_partner<0x141>(part);  // the other quad of the 8 lanes that hold a row (DPP operands, no LDS round trip)
-      if (ch == 0) delta[row] = -part;  // negated: it seeds the dP accumulators below
+      if (ch == 0) delta[row] = DROP ? -part * inv_s : -part;  // negated: it seeds the dP accumulators below
     }
   }
   for (int i = tid; i < L; i += 256) lse2[i] = lse[((size_t)b * heads + h) * L + i] * kLog2e;
@@ -575,6 +643,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
       vf[s] = frag_rows_global(base + 2 * H, ld, kb * 32, s, lane);
     }
     const float my_madd = mask[b * L + kb * 32 + (lane & 31)] != 0 ? 0.f : kMaskNeg;
+    const uint32_t Lh = (uint32_t)L >> 1, kshift = (lane & 1) << 4;
+    const uint32_t keypair = DROP ? prob_row_pair(b * heads + h, 4 * half, L) + (uint32_t)((kb * 32 + (lane & 31)) >> 1) : 0u;
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -595,17 +665,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
         dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Dt, qb * 32, s, lane), vf[s], dpacc, 0, 0, 0);
       }
       float p[16], ds[16];
+      [[maybe_unused]] float sd[DROP ? 16 : 1];  // dS / s of a dropped element: P * seed
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const float4 l4 = *reinterpret_cast<const float4*>(lse2 + qb * 32 + 8 * rg + 4 * half);
         const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+        [[maybe_unused]] float dseed[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (DROP) {
+          const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
+          dseed[0] = d4.x; dseed[1] = d4.y; dseed[2] = d4.z; dseed[3] = d4.w;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = rg * 4 + e;
           p[r] = fast_exp2(sacc[r] * sl2 + my_madd - ll[e]);
           ds[r] = p[r] * dpacc[r];  // dpacc was seeded with -delta
+          if constexpr (DROP) sd[r] = p[r] * dseed[e];
         }
       }
+      if constexpr (DROP)
+        for_keep_klane(keypair + (uint32_t)(qb * 32) * Lh, Lh, kshift, dm, [&](int r, bool keep) {
+          ds[r] = keep ? ds[r] : sd[r];
+          p[r] = keep ? p[r] : 0.f;
+        });
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bf16x8 pf = pack_acc(p, j), dsf = pack_acc(ds, j);
@@ -617,8 +699,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
       }
     }
     uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
-    store_acc_T16(row0 + H, ld, dk, kScale, lane);
-    store_acc_T16(row0 + 2 * H, ld, dv, 1.0f, lane);
+    store_acc_T16(row0 + H, ld, dk, kScale * out_s, lane);
+    store_acc_T16(row0 + 2 * H, ld, dv, out_s, lane);
   }
 }
 
@@ -630,40 +712,59 @@ extern "C" int cocodr_debug_attn_timeline(unsigned long long* buf) {
 }
 #endif
 
-extern "C" int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
-                               cocodr_stream_t stream) {
+namespace {
+const cocodr_dropout_mask kNoDrop = {0, 0, 0, 1.0f};
+template <class K>
+void lds_attr(K kern) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+}  // namespace
+
+extern "C" int cocodr_attn_fwd_drop(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
+                                    const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
   CK_ARG(qkv && mask && ctx && lse, "attn_fwd: null pointer");
   CK_ARG(B > 0 && heads > 0, "attn_fwd: bad shape");
   CK_ARG(L % 32 == 0 && L >= 32 && L <= 512, "attn_fwd: L=%d must be a multiple of 32 in [32,512]", L);
+  const bool dropping = drop != nullptr && drop->threshold != 0;
+  CK_ARG(!dropping || ((unsigned long long)B * heads * L * L <= (1ull << 33) && drop->threshold < 65536),
+         "attn_fwd: dropout indexes at most 2^33 probabilities");
   const int H = heads * 64;
   const size_t lds = (size_t)2 * L * 128 + (size_t)L * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_attr(attn_fwd_kernel<false>);
+    lds_attr(attn_fwd_kernel<true>);
     attr_done = true;
   }
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_ATTN, st, 4.0 * B * heads * (double)L * L * 64);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads, B, (L + 127) / 128), dim3(256), lds, st, qkv, mask, ctx, lse, L, H);
+  hipLaunchKernelGGL(dropping ? attn_fwd_kernel<true> : attn_fwd_kernel<false>, dim3(heads, B, (L + 127) / 128), dim3(256), lds, st, qkv,
+                     mask, ctx, lse, L, H, dropping ? *drop : kNoDrop);
   CK_LAUNCH("attn_fwd");
   return COCODR_OK;
 }
-
-extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
-                               const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
+extern "C" int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
                                cocodr_stream_t stream) {
+  return cocodr_attn_fwd_drop(qkv, mask, ctx, lse, B, L, heads, nullptr, stream);
+}
+
+extern "C" int cocodr_attn_bwd_drop(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
+                                    const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
+                                    const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
   CK_ARG(qkv && mask && ctx && dctx && lse && dqkv, "attn_bwd: null pointer");
   CK_ARG(B > 0 && heads > 0, "attn_bwd: bad shape");
   CK_ARG(L % 32 == 0 && L >= 32 && L <= 512, "attn_bwd: L=%d must be a multiple of 32 in [32,512]", L);
+  const bool dropping = drop != nullptr && drop->threshold != 0;
+  CK_ARG(!dropping || ((unsigned long long)B * heads * L * L <= (1ull << 33) && drop->threshold < 65536),
+         "attn_bwd: dropout indexes at most 2^33 probabilities");
+  const cocodr_dropout_mask dm = dropping ? *drop : kNoDrop;
   const int H = heads * 64;
   const size_t lds = (size_t)4 * L * 128 + (size_t)3 * L * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_attr(attn_bwd_kernel<false, false>); lds_attr(attn_bwd_kernel<true, false>);
+    lds_attr(attn_bwd_kernel<false, true>); lds_attr(attn_bwd_kernel<true, true>);
+    lds_attr(attn_bwd_dq_kernel<false, false>); lds_attr(attn_bwd_dq_kernel<true, false>);
+    lds_attr(attn_bwd_dq_kernel<false, true>); lds_attr(attn_bwd_dq_kernel<true, true>);
+    lds_attr(attn_bwd_dkv_kernel<false>); lds_attr(attn_bwd_dkv_kernel<true>);
     attr_done = true;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -671,10 +772,12 @@ extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const u
   const bool qks = qk_bias_partial != nullptr;
   if (L > 256) {  // two kernels, each with the pair of [L,64] tiles it sweeps resident
     const size_t lds_q = (size_t)2 * L * 128 + (size_t)L * 4, lds_kv = (size_t)2 * L * 128 + (size_t)2 * L * 4;
-    hipLaunchKernelGGL(qks ? attn_bwd_dq_kernel<true> : attn_bwd_dq_kernel<false>, dim3(heads, B), dim3(256), lds_q, st, qkv, mask, ctx,
-                       dctx, lse, dqkv, L, H, qk_bias_partial);
+    auto kq = dropping ? (qks ? attn_bwd_dq_kernel<true, true> : attn_bwd_dq_kernel<false, true>)
+                       : (qks ? attn_bwd_dq_kernel<true, false> : attn_bwd_dq_kernel<false, false>);
+    hipLaunchKernelGGL(kq, dim3(heads, B), dim3(256), lds_q, st, qkv, mask, ctx, dctx, lse, dqkv, L, H, qk_bias_partial, dm);
     CK_LAUNCH("attn_bwd(dq)");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(heads, B), dim3(256), lds_kv, st, qkv, mask, ctx, dctx, lse, dqkv, L, H);
+    hipLaunchKernelGGL(dropping ? attn_bwd_dkv_kernel<true> : attn_bwd_dkv_kernel<false>, dim3(heads, B), dim3(256), lds_kv, st, qkv, mask,
+                       ctx, dctx, lse, dqkv, L, H, dm);
     CK_LAUNCH("attn_bwd(dkv)");
     return COCODR_OK;
   }
@@ -683,8 +786,15 @@ extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const u
     const char* e = getenv("COCODR_ATTN_STAGGER");
     stagger = e ? atoi(e) : 2;
   }
-  hipLaunchKernelGGL(qks ? attn_bwd_kernel<true> : attn_bwd_kernel<false>, dim3(heads, B), dim3(256), lds, st, qkv, mask, ctx, dctx, lse,
-                     dqkv, L, H, 2 * lds <= 160 * 1024 && heads * B > 512 ? stagger : 0, qk_bias_partial);
+  auto kf = dropping ? (qks ? attn_bwd_kernel<true, true> : attn_bwd_kernel<false, true>)
+                     : (qks ? attn_bwd_kernel<true, false> : attn_bwd_kernel<false, false>);
+  hipLaunchKernelGGL(kf, dim3(heads, B), dim3(256), lds, st, qkv, mask, ctx, dctx, lse, dqkv, L, H,
+                     2 * lds <= 160 * 1024 && heads * B > 512 ? stagger : 0, qk_bias_partial, dm);
   CK_LAUNCH("attn_bwd");
   return COCODR_OK;
+}
+extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
+                               const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
+                               cocodr_stream_t stream) {
+  return cocodr_attn_bwd_drop(qkv, mask, ctx, dctx, lse, dqkv, qk_bias_partial, B, L, heads, nullptr, stream);
 }

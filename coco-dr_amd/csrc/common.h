@@ -96,6 +96,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // q = (1 - erf(|x| / sqrt 2)) / 2 = the Gaussian tail probability, e = exp(-x^2 / 2); the constants of 7.1.26 carry the
 // 1/sqrt 2 of the argument and the 1/2 of the cdf, so the cdf is 1 - q (x >= 0) or q (x < 0) without further scaling
 __device__ __forceinline__ void gauss_tail_terms(float x, float& q, float& e) {
+#pragma clang fp contract(off)  // only the explicit fmaf below fuse: the value must not depend on what else the caller computes
   // v_rcp_f32 (1 ulp): __frcp_rn / 1.0f / x expand to the ten-instruction IEEE division sequence, per element, in a
   // VALU-bound epilogue; the approximation itself is good to 1.5e-7
   const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));   // 0.3275911 / sqrt 2
@@ -106,8 +107,14 @@ __device__ __forceinline__ void gauss_tail_terms(float x, float& q, float& e) {
   p = fmaf(p, t, 0.127414796f);
   q = p * t * e;
 }
-__device__ __forceinline__ float gauss_cdf(float x, float q) { return x >= 0.f ? 1.0f - q : q; }
+__device__ __forceinline__ float gauss_cdf(float x, float q) {
+#pragma clang fp contract(off)
+  return x >= 0.f ? 1.0f - q : q;
+}
+// (no implicit contraction: left to the compiler, x * (1 - q) becomes an fma in this function but not in gelu_erf_both, where
+// the cdf has a second use - the inference and the training forward then differ by a bf16 ulp here and there)
 __device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
   float q, e;
   gauss_tail_terms(x, q, e);
   return x * gauss_cdf(x, q);
@@ -119,11 +126,38 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 // value and derivative from one erf / exp evaluation (the forward saves the derivative for the backward)
 __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& gp) {
+#pragma clang fp contract(off)
   float q, e;
   gauss_tail_terms(x, q, e);
   const float cdf = gauss_cdf(x, q);
   g = x * cdf;
   gp = fmaf(x * 0.3989422804014327f, e, cdf);
+}
+
+// ------------------------------------------------------------------ dropout masks (cocodr_dropout_mask, include/cocodr.h)
+// One 32-bit word per PAIR of adjacent elements of the site's tensor: w = lowbias32(pair ^ k0) ^ k1, element 2 pair takes
+// the low 16 bits, element 2 pair + 1 the high 16 bits, keep iff the 16-bit value >= threshold (= round(p * 65536)).
+// lowbias32 is a bijection of the 32-bit pair index, so within a site no two pairs share a word by construction.
+__host__ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_word(uint32_t pair, uint32_t k0, uint32_t k1) { return lowbias32(pair ^ k0) ^ k1; }
+__host__ __device__ __forceinline__ bool drop_keep_lo(uint32_t w, uint32_t thr) { return (w & 0xffffu) >= thr; }
+__host__ __device__ __forceinline__ bool drop_keep_hi(uint32_t w, uint32_t thr) { return (w >> 16) >= thr; }
+// v[0..N) = consecutive elements starting at the EVEN flat index `first`: dropped ones -> 0, kept ones x scale
+template <int N>
+__device__ __forceinline__ void drop_apply(float (&v)[N], uint64_t first, const cocodr_dropout_mask& d) {
+  static_assert(N % 2 == 0, "pairs");
+  const uint32_t pair0 = (uint32_t)(first >> 1);
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j) {
+    const uint32_t w = drop_word(pair0 + j, d.k0, d.k1);
+    v[2 * j] = drop_keep_lo(w, d.threshold) ? v[2 * j] * d.scale : 0.f;
+    v[2 * j + 1] = drop_keep_hi(w, d.threshold) ? v[2 * j + 1] * d.scale : 0.f;
+  }
 }
 
 // ------------------------------------------------------------------ LDS tile addressing
@@ -178,5 +212,7 @@ int cocodr_reduce_partials(const float* partial, float* o0, float* o1, float* o2
                            long long stride_out, hipStream_t st);
 // LayerNorm backward without the final reduction: partial [ln_bwd_blocks(M)][nseg][H] (dgamma, dbeta[, dy column sums])
 int cocodr_ln_bwd_blocks(int M);
+// dy_drop / dm (optional): the dropout form of cocodr_ln_bwd_drop
 int cocodr_ln_bwd_partials(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
-                           uint16_t* dy, float* partial, int M, int H, int nseg, hipStream_t st);
+                           uint16_t* dy, float* partial, int M, int H, int nseg, hipStream_t st, uint16_t* dy_drop = nullptr,
+                           const cocodr_dropout_mask* dm = nullptr);

@@ -77,3 +77,26 @@ extern "C" int cocodr_prof_end(int* launches, double* total_ms, double* total_fl
   g_ps.used = 0;
   return COCODR_OK;
 }
+
+// ---- dropout keys (include/cocodr.h "Dropout"): host arithmetic only
+static inline unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+extern "C" int cocodr_dropout_mask_for(double p, unsigned long long seed, unsigned long long call, int layer, int kind,
+                                       cocodr_dropout_mask* out) {
+  CK_ARG(out != nullptr, "dropout_mask_for: null out");
+  CK_ARG(p >= 0.0 && p < 1.0, "dropout_mask_for: p=%g must be in [0, 1)", p);
+  CK_ARG(layer >= 0 && kind >= COCODR_DROP_ATTN_PROBS && kind <= COCODR_DROP_EMBED, "dropout_mask_for: bad site (layer %d, kind %d)", layer, kind);
+  const unsigned long long site = 4ull * (unsigned long long)layer + (unsigned long long)kind;
+  unsigned long long z = splitmix64(seed + 0x9E3779B97F4A7C15ull * (call + 1));
+  z = splitmix64(z ^ (0xD1B54A32D192ED03ull * (site + 1)));
+  out->k0 = (uint32_t)z;
+  out->k1 = (uint32_t)(z >> 32);
+  const long thr = (long)(p * 65536.0 + 0.5);
+  out->threshold = (uint32_t)(thr > 65535 ? 65535 : thr);
+  out->scale = 65536.0f / (float)(65536 - (long)out->threshold);
+  return COCODR_OK;
+}

@@ -28,6 +28,7 @@ struct Carver {
 struct BwdLayout {
   size_t dy2, du, dy1, dqkv;  // bf16 [layers][M,*]
   size_t dxa, dxb, dctx;      // bf16 [M,H]
+  size_t dres;                // bf16 [M,H]: with dropout, the un-masked LayerNorm-input gradient (the residual branch's)
   size_t ln_partial, colsum_partial, emb_partial;  // fp32
   size_t ln2_slots, ln1_slots, b1_slots, bv_slots, bqk_slots;  // fp32 per-layer partial rows of the deferred reductions
   size_t total;
@@ -44,6 +45,7 @@ BwdLayout bwd_layout(const cocodr_config* c, int B, int L) {
   b.dxa = cv.take(M * H * 2);
   b.dxb = cv.take(M * H * 2);
   b.dctx = cv.take(M * H * 2);
+  b.dres = cv.take(M * H * 2);
   b.ln_partial = cv.take(cocodr_ln_bwd_partial_floats((int)M, (int)H) * 4);
   b.colsum_partial = cv.take(std::max(cocodr_colsum_partial_floats((int)M, (int)std::max(I, 3 * H), (int)N),
                                       cocodr_gemm_colsum_partial_floats((int)M, (int)std::max(I, 3 * H))) * 4);
@@ -64,6 +66,7 @@ int check_cfg(const cocodr_config* c, int B, int L) {
   CK_ARG(c->inter % 128 == 0 && c->inter > 0, "encoder: intermediate=%d must be a multiple of 128", c->inter);
   CK_ARG(c->layers > 0 && c->vocab > 0, "encoder: bad layers/vocab");
   CK_ARG(B > 0 && L >= 32 && L % 32 == 0 && L <= 512 && L <= c->max_pos, "encoder: L=%d must be a multiple of 32 in [32, min(512,%d)]", L, c->max_pos);
+  CK_ARG(c->hidden_dropout >= 0.f && c->hidden_dropout < 1.f && c->attn_dropout >= 0.f && c->attn_dropout < 1.f, "encoder: dropout probabilities must be in [0, 1)");
   return COCODR_OK;
 }
 
@@ -72,6 +75,19 @@ int check_cfg(const cocodr_config* c, int B, int L) {
     const int rc_ = (expr);      \
     if (rc_ != COCODR_OK) return rc_; \
   } while (0)
+
+// dropout masks of one layer (threshold 0 everywhere when the call runs without dropout)
+struct LayerDrop {
+  cocodr_dropout_mask probs, attn_out, ffn_out;
+};
+bool drop_active(const cocodr_config* c) { return c->hidden_dropout > 0.f || c->attn_dropout > 0.f; }
+int layer_drop(const cocodr_config* c, bool active, int l, LayerDrop* d) {
+  const double ph = active ? c->hidden_dropout : 0.0, pa = active ? c->attn_dropout : 0.0;
+  TRY(cocodr_dropout_mask_for(pa, c->drop_seed, c->drop_call, l, COCODR_DROP_ATTN_PROBS, &d->probs));
+  TRY(cocodr_dropout_mask_for(ph, c->drop_seed, c->drop_call, l, COCODR_DROP_ATTN_OUT, &d->attn_out));
+  TRY(cocodr_dropout_mask_for(ph, c->drop_seed, c->drop_call, l, COCODR_DROP_FFN_OUT, &d->ffn_out));
+  return COCODR_OK;
+}
 
 cocodr_gemm_args gemm_base(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb) {
   cocodr_gemm_args g = {};
@@ -171,9 +187,14 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
 
   if (layer_hi < 0) layer_hi = NL;
   CK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= NL, "encoder_fwd: bad layer range [%d,%d)", layer_lo, layer_hi);
-  if (!from_hidden && layer_lo == 0)  // a bare layer stack (Condenser head) starts from hidden slot 0, filled by the caller
-    TRY(cocodr_embed_ln_fwd(ids, emb->word, emb->pos, emb->type0, emb->ln_g, emb->ln_b, hidden, (float*)(base + lay.emb_mean),
-                            (float*)(base + lay.emb_rstd), B, L, H, c->vocab, c->ln_eps, stream));
+  // dropout (hf nn.Dropout under model.train()): only a training forward drops; the site keys follow (seed, call, layer, kind)
+  const bool dropping = training && drop_active(c);
+  if (!from_hidden && layer_lo == 0) {  // a bare layer stack (Condenser head) starts from hidden slot 0, filled by the caller
+    cocodr_dropout_mask de;
+    TRY(cocodr_dropout_mask_for(dropping ? c->hidden_dropout : 0.0, c->drop_seed, c->drop_call, 0, COCODR_DROP_EMBED, &de));
+    TRY(cocodr_embed_ln_fwd_drop(ids, emb->word, emb->pos, emb->type0, emb->ln_g, emb->ln_b, hidden, (float*)(base + lay.emb_mean),
+                                 (float*)(base + lay.emb_rstd), B, L, H, c->vocab, c->ln_eps, &de, stream));
+  }
   for (int l = layer_lo; l < layer_hi; ++l) {
     const cocodr_layer_params& w = lp[l];
     const size_t lo = ls * l;
@@ -192,19 +213,21 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     float* mean2 = (float*)(base + lay.mean2) + lo * M;
     float* rstd2 = (float*)(base + lay.rstd2) + lo * M;
 
+    LayerDrop ld;
+    TRY(layer_drop(c, dropping, l, &ld));
     cocodr_gemm_args g = gemm_base(x_in, w.wqkv, qkv, M, 3 * H, H, H, H, 3 * H, 0, 0);
     g.bias = w.bqkv;
     TRY(cocodr_gemm(&g, stream));
-    TRY(cocodr_attn_fwd(qkv, mask, ctx, lse, B, L, c->heads, stream));
+    TRY(cocodr_attn_fwd_drop(qkv, mask, ctx, lse, B, L, c->heads, &ld.probs, stream));
     g = gemm_base(ctx, w.wo, y1, M, H, H, H, H, H, 0, 0);
-    g.bias = w.bo; g.epi = COCODR_EPI_ADD; g.R = x_in; g.ldr = H;
+    g.bias = w.bo; g.epi = COCODR_EPI_ADD; g.R = x_in; g.ldr = H; g.drop = ld.attn_out;
     TRY(cocodr_gemm(&g, stream));
     TRY(cocodr_ln_fwd(y1, w.ln1_g, w.ln1_b, x1, mean1, rstd1, nullptr, 0, M, H, c->ln_eps, stream));
     g = gemm_base(x1, w.w1, h, M, I, H, H, H, I, 0, 0);
     g.bias = w.b1; g.epi = COCODR_EPI_GELU; g.C2 = training ? u : nullptr;  // u: GELU'(pre-activation) for the backward
     TRY(cocodr_gemm(&g, stream));
     g = gemm_base(h, w.w2, y2, M, H, I, I, I, H, 0, 0);
-    g.bias = w.b2; g.epi = COCODR_EPI_ADD; g.R = x1; g.ldr = H;
+    g.bias = w.b2; g.epi = COCODR_EPI_ADD; g.R = x1; g.ldr = H; g.drop = ld.ffn_out;
     TRY(cocodr_gemm(&g, stream));
     TRY(cocodr_ln_fwd(y2, w.ln2_g, w.ln2_b, x_out, mean2, rstd2, (l == NL - 1) ? cls : nullptr, L, M, H, c->ln_eps, stream));
   }
@@ -249,6 +272,8 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
   uint16_t* dxa = (uint16_t*)(bb + bl.dxa);
   uint16_t* dxb = (uint16_t*)(bb + bl.dxb);
   uint16_t* dctx = (uint16_t*)(bb + bl.dctx);
+  uint16_t* dres = (uint16_t*)(bb + bl.dres);
+  const bool dropping = drop_active(c);  // the forward of this arena ran with the same config (header contract)
   float* ln_partial = (float*)(bb + bl.ln_partial);
   float* cs_partial = (float*)(bb + bl.colsum_partial);
   float* emb_partial = (float*)(bb + bl.emb_partial);
@@ -283,12 +308,15 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
               (lg[l].bo - lg[l - 1].bo == s_vec) && (lg[l].b2 - lg[l - 1].b2 == s_vec) && (lg[l].b1 - lg[l - 1].b1 == s_vec) &&
               (lg[l].bqkv - lg[l - 1].bqkv == s_vec);
   }
+  // the value-bias shortcut (sum_k dV[k] = sum_q dctx[q]) needs softmax rows that sum to 1: with dropout on the
+  // probabilities the bias gradient is the column sum of dV itself
+  const bool drop_probs = dropping && c->attn_dropout > 0.f;
   int rows_b1 = 0, rows_bv = 0;
   if (defer) {
     cocodr_gemm_args q = gemm_base(dy2_all, lp[layer_lo].w2, du_all, M, I, H, H, I, I, 0, 1);
     rows_b1 = cocodr_gemm_colsum_rows(&q);
     q = gemm_base(dy1_all, lp[layer_lo].wo, dctx, M, H, H, H, H, H, 0, 1);
-    rows_bv = cocodr_gemm_colsum_rows(&q);
+    rows_bv = drop_probs ? 0 : cocodr_gemm_colsum_rows(&q);
   }
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const cocodr_layer_params& w = lp[l];
@@ -312,35 +340,45 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
     // bias gradients ride on the kernels that produce the matrices they sum: b2 / bo on the LayerNorm backward, b1 on the
     // GELU' epilogue, and the value bias on the context-gradient GEMM (sum_k dV[k] = sum_q dctx[q]: softmax rows sum to 1)
     const size_t li = (size_t)(l - layer_lo);
-    if (defer) TRY(cocodr_ln_bwd_partials(dx, y2, w.ln2_g, mean2, rstd2, dy2, ln2_slots + li * ln_slot, M, H, 3, hst));
-    else TRY(cocodr_ln_bwd(dx, y2, w.ln2_g, mean2, rstd2, dy2, gr.ln2_g, gr.ln2_b, gr.b2, ln_partial, M, H, stream));
+    // With dropout the LayerNorm input was dropout(dense) + residual: dy2 / dy1 (what the dgrad / grouped wgrad GEMMs and the
+    // bias sums take) hold the masked gradient of the dense output, the un-masked one goes to dres for the residual add.
+    LayerDrop ld;
+    TRY(layer_drop(c, dropping, l, &ld));
+    const bool dh = ld.ffn_out.threshold != 0;  // hidden dropout on (both dense sites share the probability)
+    uint16_t* res2 = dh ? dres : dy2;
+    if (defer) TRY(cocodr_ln_bwd_partials(dx, y2, w.ln2_g, mean2, rstd2, res2, ln2_slots + li * ln_slot, M, H, 3, hst, dy2, &ld.ffn_out));
+    else TRY(cocodr_ln_bwd_drop(dx, y2, w.ln2_g, mean2, rstd2, res2, dy2, gr.ln2_g, gr.ln2_b, gr.b2, ln_partial, M, H, &ld.ffn_out, stream));
     cocodr_gemm_args g = gemm_base(dy2, w.w2, du, M, I, H, H, I, I, 0, 1);  // dh = dy2 W2, fused with GELU'(u)
     g.epi = COCODR_EPI_DGELU; g.R = u; g.ldr = I;
     if (rows_b1 > 0) g.colsum_partial = b1_slots + li * rows_b1 * I;
     else { g.colsum = gr.b1; g.colsum_partial = cs_partial; }
     TRY(cocodr_gemm(&g, stream));
     g = gemm_base(du, w.w1, dxa, M, H, I, I, H, H, 0, 1);  // dx1 = du W1 + dy2 (residual branch)
-    g.epi = COCODR_EPI_ADD; g.R = dy2; g.ldr = H;
+    g.epi = COCODR_EPI_ADD; g.R = res2; g.ldr = H;
     TRY(cocodr_gemm(&g, stream));
-    if (defer) TRY(cocodr_ln_bwd_partials(dxa, y1, w.ln1_g, mean1, rstd1, dy1, ln1_slots + li * ln_slot, M, H, 3, hst));
-    else TRY(cocodr_ln_bwd(dxa, y1, w.ln1_g, mean1, rstd1, dy1, gr.ln1_g, gr.ln1_b, gr.bo, ln_partial, M, H, stream));
+    uint16_t* res1 = dh ? dres : dy1;  // res2 has been consumed by the GEMM above (stream order)
+    if (defer) TRY(cocodr_ln_bwd_partials(dxa, y1, w.ln1_g, mean1, rstd1, res1, ln1_slots + li * ln_slot, M, H, 3, hst, dy1, &ld.attn_out));
+    else TRY(cocodr_ln_bwd_drop(dxa, y1, w.ln1_g, mean1, rstd1, res1, dy1, gr.ln1_g, gr.ln1_b, gr.bo, ln_partial, M, H, &ld.attn_out, stream));
     g = gemm_base(dy1, w.wo, dctx, M, H, H, H, H, H, 0, 1);  // dctx = dy1 Wo
     if (rows_bv > 0) g.colsum_partial = bv_slots + li * rows_bv * H;
-    else { g.colsum = gr.bqkv + 2 * H; g.colsum_partial = cs_partial; }
+    else if (!drop_probs) { g.colsum = gr.bqkv + 2 * H; g.colsum_partial = cs_partial; }
     TRY(cocodr_gemm(&g, stream));
     // the query / key bias gradients are column sums of dQ | dK: the attention backward leaves four partial rows per sequence
-    TRY(cocodr_attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, B, L, c->heads, stream));
+    TRY(cocodr_attn_bwd_drop(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, B, L, c->heads, &ld.probs, stream));
     if (!defer) TRY(cocodr_reduce_partials(bqk_slots + li * bqk_slot, gr.bqkv, nullptr, nullptr, 4 * B, 1, 2 * H, 1, 0, hst));
+    if (drop_probs) TRY(cocodr_colsum(dqkv + 2 * H, gr.bqkv + 2 * H, cs_partial, M, H, 3 * H, 1, 0, 0, stream));
     g = gemm_base(dqkv, w.wqkv, dxb, M, H, 3 * H, 3 * H, H, H, 0, 1);  // dx = dqkv Wqkv + dy1 (residual branch)
-    g.epi = COCODR_EPI_ADD; g.R = dy1; g.ldr = H;
+    g.epi = COCODR_EPI_ADD; g.R = res1; g.ldr = H;
     TRY(cocodr_gemm(&g, stream));
     dx = dxb;
   }
   if (do_embed) {
     CK_ARG(layer_lo == 0, "encoder_bwd: the embedding backward belongs to the range that ends at layer 0");
-    TRY(cocodr_embed_ln_bwd(dx, ids, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
-                            (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial, B,
-                            L, H, c->vocab, stream));
+    cocodr_dropout_mask de;
+    TRY(cocodr_dropout_mask_for(dropping ? c->hidden_dropout : 0.0, c->drop_seed, c->drop_call, 0, COCODR_DROP_EMBED, &de));
+    TRY(cocodr_embed_ln_bwd_drop(dx, ids, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
+                                 (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial,
+                                 B, L, H, c->vocab, &de, stream));
   }
   if (NG == 0) return COCODR_OK;
 

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const cocodr_gemm_args p) 
           for (int j = 0; j < 8; ++j) gelu_erf_both(v[j], v[j], gp[j]);
           *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(gp);
         } else if (p.epi == COCODR_EPI_ADD) {
+          if (p.drop.threshold) drop_apply<8>(v, (uint64_t)gm * p.N + gn, p.drop);
           float r[8];
           unpack8(*reinterpret_cast<const uint4*>(R + (size_t)gm * p.ldr + gn), r);
 #pragma unroll
@@ -251,7 +252,7 @@ struct Geom {
 
 template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, bool OUT_F32, int WC = 2, int NS = 3>
 __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC, NS>::NTHREADS), (Geom<BMv, BKv, WTM, WTN, LD, WC, NS>::MIN_WAVES_PER_SIMD)) void gemm_glds_kernel(
-    const cocodr_gemm_args p, const int stagger) {
+    const cocodr_gemm_args p, const int stagger, const int flat) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type only exists in the device pass; the host pass just needs the stub
   using G = Geom<BMv, BKv, WTM, WTN, LD, WC, NS>;
   constexpr int BNv = G::BNv;
@@ -260,12 +261,23 @@ __global__ __launch_bounds__((Geom<BMv, BKv, WTM, WTN, LD, WC, NS>::NTHREADS), (
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WC, wn = wid % WC;
   const int ntn = p.N / BNv, ntm = (p.M + BMv - 1) / BMv;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // flat (batched launches): one grid axis over (batch item, tile), item-major, XCD remap over all of it, so the tiles an
+  // XCD holds at a time belong to one or two items instead of a few tiles of each of many (see gemm_pp.hip)
+  int tile, z;
+  if (flat) {
+    const int per = ntm * ntn;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    z = id / per;
+    tile = id - z * per;
+  } else {
+    tile = xcd_remap(blockIdx.x, gridDim.x);
+    z = blockIdx.y;
+  }
   int tm_, tn_;
   if (TA == 0) grouped_tile(tile, ntm, ntn, 1024 / BMv, tm_, tn_);  // measured: helps fwd/dgrad, hurts the long-K wgrad
+  else if (flat) grouped_tile(tile, ntm, ntn, 8, tm_, tn_);
   else { tm_ = tile / ntn; tn_ = tile % ntn; }
   const int m0 = tm_ * BMv, n0 = tn_ * BNv;
-  const int z = blockIdx.y;
   const uint16_t* A = p.A + (size_t)z * p.strideA;
   const uint16_t* B = p.B + (size_t)z * p.strideB;
   const uint32_t a_bytes = (uint32_t)((size_t)(TA ? p.K : p.M) * p.lda * 2);
@@ -535,7 +547,13 @@ template <int BMv, int BKv, int WTM, int WTN, int LD, int TA, int TB, int WC = 2
 void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
   using G = Geom<BMv, BKv, WTM, WTN, LD, WC, NS>;
   const int ntm = (a.M + BMv - 1) / BMv, ntn = a.N / G::BNv;
-  dim3 grid(ntm * ntn, a.batch);
+  static int flat_env = -1;  // COCODR_PP_FLAT=0 keeps the per-item remap (A/B switch, shared with gemm_pp.hip)
+  if (flat_env < 0) {
+    const char* e = getenv("COCODR_PP_FLAT");
+    flat_env = e ? atoi(e) : 1;
+  }
+  const int flat = (a.batch > 1 && flat_env) ? 1 : 0;
+  dim3 grid(flat ? ntm * ntn * a.batch : ntm * ntn, flat ? 1 : a.batch);
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
   static bool attr_done = false;
   if (!attr_done) {
@@ -550,9 +568,9 @@ void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
   }
   const int sg = (int)(grid.x * grid.y) > 256 * G::WG_PER_CU / 2 ? stagger : 0;
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true, WC, NS>), grid, dim3(G::NTHREADS), lds, st, a, sg);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true, WC, NS>), grid, dim3(G::NTHREADS), lds, st, a, sg, flat);
   else
-    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false, WC, NS>), grid, dim3(G::NTHREADS), lds, st, a, sg);
+    hipLaunchKernelGGL((gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false, WC, NS>), grid, dim3(G::NTHREADS), lds, st, a, sg, flat);
 }
 
 template <int BMv, int BKv, int WTM, int WTN = 2, int LD = 0, int WC = 2, int NS = 3>
@@ -674,6 +692,8 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   CK_ARG((((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.C2 | (uintptr_t)a.R | (uintptr_t)a.bias) & 15) == 0,
          "gemm: pointers must be 16-byte aligned");
   if (a.epi != COCODR_EPI_ADD && a.epi != COCODR_EPI_DGELU) a.R = nullptr;
+  CK_ARG(a.drop.threshold == 0 || (a.epi == COCODR_EPI_ADD && a.batch == 1 && !a.colsum && !a.colsum_partial && a.drop.threshold < 65536),
+         "gemm: dropout belongs to an EPI_ADD call with batch == 1 and no column sums");
   CK_ARG(!(a.colsum || a.colsum_partial) || (a.colsum_partial && a.batch == 1 && !a.out_f32),
          "gemm: column sums need colsum_partial, batch == 1 and a bf16 output");
   float* const cs_out = a.colsum;

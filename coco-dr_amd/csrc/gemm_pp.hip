@@ -121,7 +121,7 @@ __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const Fra
 // segment behind the fragment reads; 2 = as 0 without s_setprio (-15 %); 3 = requested in front of the fragment reads (=).
 // Requesting them inside the MFMA segment instead cost 10-14 % (profiles/r02_gemm_pp_variants.txt).
 template <int NB, int TA, int TB, bool OUT_F32, int VAR = 0>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_args p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_args p, const int flat) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using S = Shape<NB>;
   constexpr int BN = S::BN;
@@ -130,12 +130,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;  // waves 0-3 (one per SIMD) form group 0, waves 4-7 group 1
   const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // flat (batched launches): ONE grid axis over (batch item, tile), item-major, and the XCD remap over all of it - every
+  // XCD walks a contiguous run of items' tiles, so the ~32 tiles its CUs hold at a time belong to one or two items and
+  // form an 8 x 4 block of one item's output: 12 operand panel streams through the XCD's L2 for 32 tiles.  With the
+  // remap per item (grid.y = item) an XCD held 4-6 tiles of each of 5-6 items at once, which share nothing: the grouped
+  // weight gradients fetched 3.5x their operands from the fabric (profiles/r02_gemm_pmc_large_200x128.json).
+  int tile, z;
+  if (flat) {
+    const int per = ntm * ntn;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    z = id / per;
+    tile = id - z * per;
+  } else {
+    tile = xcd_remap(blockIdx.x, gridDim.x);
+    z = blockIdx.y;
+  }
   int tm_, tn_;
   if (TA == 0) grouped_tile(tile, ntm, ntn, 4, tm_, tn_);
+  else if (flat) grouped_tile(tile, ntm, ntn, 8, tm_, tn_);
   else { tm_ = tile / ntn; tn_ = tile % ntn; }
   const int m0 = tm_ * BM, n0 = tn_ * BN;
-  const int z = blockIdx.y;
   const uint16_t* A = p.A + (size_t)z * p.strideA;
   const uint16_t* B = p.B + (size_t)z * p.strideB;
   const uint32_t a_bytes = (uint32_t)((size_t)(TA ? p.K : p.M) * p.lda * 2);
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_
 #endif
   uint32_t curA[4], curB[4];
 #if defined(COCODR_ABL_TIMELINE)  // per-workgroup stamps (100 MHz wall clock) into C2: [start, loop entry, loop exit, end]
-  unsigned long long* tl = reinterpret_cast<unsigned long long*>(p.C2) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+  unsigned long long* tl = reinterpret_cast<unsigned long long*>(p.C2) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;  // (flat: y = 0)
   if (tid == 0) { tl[0] = wall_clock64(); tl[1] = wall_clock64(); }
 #endif
 
@@ -362,7 +376,13 @@ template <int NB, int TA, int TB, int VAR = 0>
 void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
   using S = Shape<NB>;
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / S::BN;
-  dim3 grid(ntm * ntn, a.batch);
+  static int flat_env = -1;  // COCODR_PP_FLAT=0 keeps the per-item remap (A/B switch)
+  if (flat_env < 0) {
+    const char* e = getenv("COCODR_PP_FLAT");
+    flat_env = e ? atoi(e) : 1;
+  }
+  const int flat = (a.batch > 1 && flat_env) ? 1 : 0;
+  dim3 grid(flat ? ntm * ntn * a.batch : ntm * ntn, flat ? 1 : a.batch);
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, true, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -370,9 +390,9 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
     attr_done = true;
   }
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
   else
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
 }
 
 }  // namespace cocodr_gemm_pp

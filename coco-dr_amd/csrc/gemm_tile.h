@@ -185,6 +185,7 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
     for (int j = 0; j < 8; ++j) gelu_erf_both(v[j], v[j], gp[j]);
     *reinterpret_cast<uint4*>(p.C2 + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = pack8(gp);
   } else if (p.epi == COCODR_EPI_ADD) {
+    if (p.drop.threshold) drop_apply<8>(v, (uint64_t)gm * p.N + gn, p.drop);  // hf BertSelfOutput / BertOutput: dropout(dense(x)) + residual
     float r[8];
     unpack8(RPRE ? rpre : *reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn), r);
 #pragma unroll

@@ -82,6 +82,16 @@ __device__ __forceinline__ void ln_apply(RowVecT<NC>& r, const float* gamma, con
   }
 }
 
+// dropout mask of one token row held in registers (flat element index row * H + 4 c + e): dropped -> 0, kept -> x scale
+template <int NC>
+__device__ __forceinline__ void drop_row(RowVecT<NC>& r, int row, int H, int nch, int lane, const cocodr_dropout_mask& dm) {
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) drop_apply<4>(r.v[i], (uint64_t)row * H + c * 4, dm);
+  }
+}
+
 // gather word[id] + pos[l] + type0 into registers
 __device__ __forceinline__ void embed_gather(const float* word, const float* pos, const float* type0, int id, int l, int H,
                                              int nch, int lane, RowVec& r) {
@@ -103,7 +113,8 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int32_t* __rest
                                                            const float* __restrict__ pos, const float* __restrict__ type0,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            uint16_t* __restrict__ out, float* __restrict__ mean_o,
-                                                           float* __restrict__ rstd_o, int M, int L, int H, int vocab, float eps) {
+                                                           float* __restrict__ rstd_o, int M, int L, int H, int vocab, float eps,
+                                                           const cocodr_dropout_mask dm) {
   const int lane = threadIdx.x & 63, nch = H >> 2;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     int id = ids[row];
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int32_t* __rest
     float mean, rstd;
     row_stats(r, nch, lane, H, eps, mean, rstd);
     ln_apply(r, gamma, beta, nch, lane, mean, rstd);
+    if (dm.threshold) drop_row(r, row, H, nch, lane, dm);  // hf BertEmbeddings: dropout(LayerNorm(..))
     store_bf16_row(out + (size_t)row * H, nch, lane, r);
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
   }
@@ -262,11 +274,14 @@ __device__ __forceinline__ void unpack_raw_row(const RawRow<NC>& r, RowVecT<NC>&
 
 // NC = 16-B fp32 chunks per lane: 3 covers H <= 768 (a quarter fewer registers than the general 4: no spills at 4 waves / SIMD)
 // FULL: H == 256 NC (768 / 1024) - every lane owns all NC chunks, so the per-chunk guards fold away
-template <int NC, bool PREFETCH, bool FULL>
+// DROP: the LayerNorm input was dropout(dense) + residual - dy keeps the gradient of the sum (the residual branch's), dy_drop
+// gets it masked and scaled (the dense output's) and the column sums (that Linear's bias gradient) are taken of dy_drop
+template <int NC, bool PREFETCH, bool FULL, bool DROP = false>
 __global__ __launch_bounds__(RB_THREADS) void ln_bwd_kernel(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, uint16_t* __restrict__ dy,
-                                                     float* __restrict__ partial, int M, int H, int nseg, int per_pass) {
+                                                     float* __restrict__ partial, int M, int H, int nseg, int per_pass,
+                                                     uint16_t* __restrict__ dy_drop, const cocodr_dropout_mask dm) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = FULL ? 64 * NC : (H >> 2);
   const int rows_per = (M + gridDim.x - 1) / gridDim.x;
@@ -297,6 +312,10 @@ __global__ __launch_bounds__(RB_THREADS) void ln_bwd_kernel(const uint16_t* __re
     }
     ln_bwd_row(d, x, gamma, nch, lane, H, mean, rstd, dg, db);
     store_bf16_row(dy + (size_t)row * H, nch, lane, d);
+    if constexpr (DROP) {
+      drop_row(d, row, H, nch, lane, dm);
+      store_bf16_row(dy_drop + (size_t)row * H, nch, lane, d);
+    }
     if (nseg == 3) {
 #pragma unroll
       for (int i = 0; i < NC; ++i)
@@ -319,7 +338,8 @@ __global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_kernel(const uint16_t
                                                            const float* __restrict__ type0, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                            float* __restrict__ dword, float* __restrict__ dpos,
-                                                           float* __restrict__ partial, int B, int L, int H, int vocab) {
+                                                           float* __restrict__ partial, int B, int L, int H, int vocab,
+                                                           const cocodr_dropout_mask dm) {
   __shared__ __attribute__((aligned(16))) float red[NW * MAXC * 256];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
   const int l = blockIdx.x;
@@ -344,6 +364,7 @@ __global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_kernel(const uint16_t
 #pragma unroll
       for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(d.v[i][e]));
     if (wave_max(amax) == 0.f) continue;
+    if (dm.threshold) drop_row(d, row, H, nch, lane, dm);  // gradient of dropout(LayerNorm(..)) w.r.t. the LayerNorm output
     ln_bwd_row(d, x, gamma, nch, lane, H, mean_i[row], rstd_i[row], dg, db);
     float* wrow = dword + (size_t)id * H;
 #pragma unroll
@@ -501,9 +522,14 @@ int colsum_splits(int M) { return M >= 4096 ? 32 : (M >= 512 ? 8 : 1); }
 int ln_bwd_blocks(int M) { return M >= 256 * NW ? 256 : (M + NW - 1) / NW; }
 
 int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd, uint16_t* dy,
-                  float* partial, int M, int H, int nseg, hipStream_t st) {
+                  float* partial, int M, int H, int nseg, hipStream_t st, uint16_t* dy_drop = nullptr,
+                  const cocodr_dropout_mask* dm = nullptr) {
   static bool attr_done = false;
   if (!attr_done) {
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -512,9 +538,13 @@ int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, c
   }
   const size_t row_bytes = (size_t)NW * H * 4;  // one accumulator row of every wave
   const int per_pass = std::max(1, std::min(nseg, (int)((160 * 1024) / row_bytes)));
+  const bool drop = dm != nullptr && dm->threshold != 0;
+  const cocodr_dropout_mask dmv = drop ? *dm : cocodr_dropout_mask{0, 0, 0, 1.0f};
   auto kern = H == 768 ? ln_bwd_kernel<3, true, true> : (H < 768 ? ln_bwd_kernel<3, true, false> : (H == 1024 ? ln_bwd_kernel<MAXC, false, true> : ln_bwd_kernel<MAXC, false, false>));
+  if (drop)
+    kern = H == 768 ? ln_bwd_kernel<3, true, true, true> : (H < 768 ? ln_bwd_kernel<3, true, false, true> : (H == 1024 ? ln_bwd_kernel<MAXC, false, true, true> : ln_bwd_kernel<MAXC, false, false, true>));
   hipLaunchKernelGGL(kern, dim3(ln_bwd_blocks(M)), dim3(RB_THREADS), per_pass * row_bytes, st, dout, y, gamma, mean, rstd, dy, partial, M, H,
-                     nseg, per_pass);
+                     nseg, per_pass, dy_drop, dmv);
   CK_LAUNCH("ln_bwd");
   return COCODR_OK;
 }
@@ -561,8 +591,9 @@ int cocodr_reduce_partials_multi(const cocodr_reduce_job* jobs, int njobs, hipSt
 }
 int cocodr_ln_bwd_blocks(int M) { return ln_bwd_blocks(M); }
 int cocodr_ln_bwd_partials(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
-                           uint16_t* dy, float* partial, int M, int H, int nseg, hipStream_t st) {
-  return launch_ln_bwd(dout, y, gamma, mean, rstd, dy, partial, M, H, nseg, st);
+                           uint16_t* dy, float* partial, int M, int H, int nseg, hipStream_t st, uint16_t* dy_drop,
+                           const cocodr_dropout_mask* dm) {
+  return launch_ln_bwd(dout, y, gamma, mean, rstd, dy, partial, M, H, nseg, st, dy_drop, dm);
 }
 
 namespace {
@@ -570,16 +601,26 @@ int row_grid(int M) { return std::min((M + 3) / 4, 2048); }
 
 }  // namespace
 
-extern "C" int cocodr_embed_ln_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
-                                   const float* beta, uint16_t* out, float* mean, float* rstd, int B, int L, int H, int vocab,
-                                   float eps, cocodr_stream_t stream) {
+namespace {
+const cocodr_dropout_mask kNoDrop = {0, 0, 0, 1.0f};
+cocodr_dropout_mask drop_or_none(const cocodr_dropout_mask* d) { return d && d->threshold ? *d : kNoDrop; }
+}  // namespace
+
+extern "C" int cocodr_embed_ln_fwd_drop(const int32_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                                        const float* beta, uint16_t* out, float* mean, float* rstd, int B, int L, int H, int vocab,
+                                        float eps, const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
   CK_ARG(ids && word && pos && type0 && gamma && beta && out && mean && rstd, "embed_ln_fwd: null pointer");
   CK_ARG(B > 0 && L > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_fwd: bad shape B=%d L=%d H=%d", B, L, H);
   const int M = B * L;
   hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta,
-                     out, mean, rstd, M, L, H, vocab, eps);
+                     out, mean, rstd, M, L, H, vocab, eps, drop_or_none(drop));
   CK_LAUNCH("embed_ln_fwd");
   return COCODR_OK;
+}
+extern "C" int cocodr_embed_ln_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                                   const float* beta, uint16_t* out, float* mean, float* rstd, int B, int L, int H, int vocab,
+                                   float eps, cocodr_stream_t stream) {
+  return cocodr_embed_ln_fwd_drop(ids, word, pos, type0, gamma, beta, out, mean, rstd, B, L, H, vocab, eps, nullptr, stream);
 }
 
 int embed_bwd_splits(int B) { return B >= 64 ? 8 : (B >= 16 ? 2 : 1); }
@@ -589,13 +630,20 @@ extern "C" int cocodr_embed_ln_bwd(const uint16_t* dout, const int32_t* ids, con
                                    const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
                                    float* dtype0, float* dgamma, float* dbeta, float* partial, int B, int L, int H, int vocab,
                                    cocodr_stream_t stream) {
+  return cocodr_embed_ln_bwd_drop(dout, ids, word, pos, type0, gamma, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, partial, B, L, H,
+                                  vocab, nullptr, stream);
+}
+extern "C" int cocodr_embed_ln_bwd_drop(const uint16_t* dout, const int32_t* ids, const float* word, const float* pos, const float* type0,
+                                        const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
+                                        float* dtype0, float* dgamma, float* dbeta, float* partial, int B, int L, int H, int vocab,
+                                        const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
   CK_ARG(dout && ids && word && pos && type0 && gamma && mean && rstd && dword && dpos && dtype0 && dgamma && dbeta && partial,
          "embed_ln_bwd: null pointer");
   CK_ARG(B > 0 && L > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_bwd: bad shape B=%d L=%d H=%d", B, L, H);
   hipStream_t st = (hipStream_t)stream;
   const int S = embed_bwd_splits(B);
   hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(L, S), dim3(RB_THREADS), 0, st, dout, ids, word, pos, type0, gamma, mean, rstd, dword, dpos,
-                     partial, B, L, H, vocab);
+                     partial, B, L, H, vocab, drop_or_none(drop));
   CK_LAUNCH("embed_ln_bwd");
   hipLaunchKernelGGL(embed_dpos_kernel, dim3(L), dim3(256), 0, st, partial, dpos, L, H, S);
   CK_LAUNCH("embed_dpos");
@@ -616,16 +664,23 @@ extern "C" int cocodr_ln_fwd(const uint16_t* y, const float* gamma, const float*
 
 extern "C" size_t cocodr_ln_bwd_partial_floats(int M, int H) { return (size_t)ln_bwd_blocks(M) * 3 * H; }
 
-extern "C" int cocodr_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
-                             uint16_t* dy, float* dgamma, float* dbeta, float* dy_colsum, float* partial, int M, int H,
-                             cocodr_stream_t stream) {
+extern "C" int cocodr_ln_bwd_drop(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
+                                  uint16_t* dy, uint16_t* dy_drop, float* dgamma, float* dbeta, float* dy_colsum, float* partial, int M,
+                                  int H, const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
   CK_ARG(dout && y && gamma && mean && rstd && dy && dgamma && dbeta && partial, "ln_bwd: null pointer");
   CK_ARG(M > 0 && row_shape_ok(H), "ln_bwd: bad shape M=%d H=%d", M, H);
+  const bool dropping = drop != nullptr && drop->threshold != 0;
+  CK_ARG(!dropping || dy_drop, "ln_bwd: dropout needs the dy_drop output");
   hipStream_t st = (hipStream_t)stream;
   const int P = ln_bwd_blocks(M);
   const int nseg = dy_colsum ? 3 : 2;
-  if (int rc = launch_ln_bwd(dout, y, gamma, mean, rstd, dy, partial, M, H, nseg, st)) return rc;
+  if (int rc = launch_ln_bwd(dout, y, gamma, mean, rstd, dy, partial, M, H, nseg, st, dy_drop, drop)) return rc;
   return launch_reduce(partial, dgamma, dbeta, dy_colsum, P, nseg, H, 1, 0, st);
+}
+extern "C" int cocodr_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd,
+                             uint16_t* dy, float* dgamma, float* dbeta, float* dy_colsum, float* partial, int M, int H,
+                             cocodr_stream_t stream) {
+  return cocodr_ln_bwd_drop(dout, y, gamma, mean, rstd, dy, nullptr, dgamma, dbeta, dy_colsum, partial, M, H, nullptr, stream);
 }
 
 extern "C" size_t cocodr_colsum_partial_floats(int M, int N, int batch) { return (size_t)colsum_splits(M) * N * (batch > 0 ? batch : 1); }

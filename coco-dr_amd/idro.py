@@ -160,7 +160,7 @@ def _per_sequence_group_grads(bert, passes, arenas, unit, g, inv, all_grads, lay
     for ids, _mask in passes:
         Bp, L = ids.shape
         bl = N.EncoderBwdLayout()
-        check(lib().cocodr_encoder_bwd_layout(C.byref(ccfg), Bp, L, C.byref(bl)), "encoder_bwd_layout")
+        check(lib().cocodr_encoder_bwd_layout(C.byref(ccfg[0]), Bp, L, C.byref(bl)), "encoder_bwd_layout")
         if L % bl.ln_rows != 0 or bl.ln_rows * bl.ln_blocks != Bp * L:
             return False
         lays.append(bl)
@@ -170,7 +170,7 @@ def _per_sequence_group_grads(bert, passes, arenas, unit, g, inv, all_grads, lay
         M = Bp * L
         arena, bl, fl = arenas[p], lays[p], bert._layout_for(Bp, L, True)
         d16 = ops.scatter_cls_grad(unit[p].contiguous(), L)
-        check(lib().cocodr_encoder_bwd_range(C.byref(ccfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d16), Bp, L,
+        check(lib().cocodr_encoder_bwd_range(C.byref(ccfg[p]), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d16), Bp, L,
                                              ptr(arena), arena.numel(), l_hi, l_lo, 0, stream_ptr()), "encoder_bwd_range(idro)")
         seq_g = g if Bp == B else torch.cat([g, g])
 
@@ -246,7 +246,8 @@ class _IDROStepFn(torch.autograd.Function):
         all_grads = torch.zeros((G, (d1 - d0) + (n1 - n0)), dtype=torch.float32, device=dev)
         sd, sn = torch.empty_like(fd), torch.empty_like(fn)   # scratch gradient flats: only the selected slices are written
         emb, arr, eg, garr = bert._param_structs((sd, sn))
-        ccfg = bert._c_config()
+        # one config per pass: each training forward drew its own dropout call counter (it travels with the arena)
+        ccfg = [bert._c_config(getattr(a_, "_cocodr_drop", None)) for a_ in arenas]
         inv = 1.0 / counts.clamp(min=1.0)
         fast = (not dro.per_group_backward) and _per_sequence_group_grads(
             bert, passes, arenas, unit, g, inv, all_grads, (l_lo, l_hi), (d0, d1, n0, n1), (sd, sn), (emb, arr, eg, garr, ccfg))
@@ -262,7 +263,7 @@ class _IDROStepFn(torch.autograd.Function):
                 Bp, L = ids.shape
                 wp = w if Bp == B else torch.cat([w, w])
                 d16 = ops.scatter_cls_grad((unit[p] * wp[:, None]).contiguous(), L)
-                check(lib().cocodr_encoder_bwd_range(C.byref(ccfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d16),
+                check(lib().cocodr_encoder_bwd_range(C.byref(ccfg[p]), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d16),
                                                      Bp, L, ptr(arenas[p]), arenas[p].numel(), l_hi, l_lo, 0, stream_ptr()),
                       "encoder_bwd_range(idro)")
                 all_grads[gi, : d1 - d0] += sd[d0:d1]

@@ -19,15 +19,16 @@ Design (MI355X first, not a port of the torch module tree):
   * one autograd.Function wraps the whole encoder: forward = one C call, backward = one C call.
   * a bf16 shadow of the weight matrices is refreshed by one cast kernel whenever the fp32 master
     changes (tracked through the tensor version counter).
-Dropout is not implemented (treated as p = 0): COCO runs the backbone in eval mode
-(COCO/modeling.py:198); ANCE's training-time dropout cannot be matched bit-wise anyway (SURVEY 7 iv).
+Dropout (hf hidden_dropout_prob / attention_probs_dropout_prob) is active in train() mode as in the reference
+(ANCE/drivers/run_ann.py:293; COCO keeps the backbone in eval, COCO/modeling.py:198, so only its Condenser head drops):
+counter-based masks fused into the kernels that produce the dropped tensors, regenerated in the backward
+(include/cocodr.h "Dropout").  torch's Philox stream cannot be matched bit-wise (SURVEY 7 iv); the distribution is.
 """
 from __future__ import annotations
 
 import ctypes as C
 import json
 import os
-import warnings
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
@@ -231,8 +232,9 @@ class _EncoderFn(torch.autograd.Function):
     forward = cocodr_encoder_fwd, backward = cocodr_encoder_bwd."""
 
     @staticmethod
-    def forward(ctx, flat_decay, flat_nodecay, ids, mask, model):
-        training = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])  # False under torch.no_grad()
+    def forward(ctx, flat_decay, flat_nodecay, ids, mask, model, grad_mode=True):
+        # grad_mode: torch.is_grad_enabled() at the call site (always False in here); inference keeps no activations and never drops
+        training = bool(grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         arena, lay = model._run_forward(ids, mask, training)
         B, L = ids.shape
         H, NL = model.config.hidden_size, model.config.num_hidden_layers
@@ -256,7 +258,7 @@ class _EncoderFn(torch.autograd.Function):
         B, L = ctx.ids.shape
         H = model.config.hidden_size
         if d_last is None and d_cls is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if d_last is None:  # gradient enters at the [CLS] rows only (every reference wrapper)
             d16 = ops.scatter_cls_grad(d_cls.float().contiguous(), L)
         else:
@@ -267,7 +269,7 @@ class _EncoderFn(torch.autograd.Function):
                 d16.view(B, L, H)[:, 0] += d_cls.to(torch.bfloat16)
         gd, gn = model._run_backward(ctx.ids, ctx.mask, d16, ctx.arena)
         ctx.arena = None
-        return gd, gn, None, None, None
+        return gd, gn, None, None, None, None
 
 
 # =============================================================================== model
@@ -287,7 +289,8 @@ class CocoBertModel(nn.Module):
         self._shadow_version = -1
         self._extra_state: Dict[str, torch.Tensor] = {}  # checkpoint tensors outside the encoder (pooler, heads ...)
         self._last_hidden_states = None
-        self._warned_dropout = False
+        self.dropout_seed: Optional[int] = None  # None: torch.initial_seed() at the first dropout forward
+        self._dropout_calls = 0
         self.reset_parameters()
 
     # ---------------------------------------------------------------- init / HF naming
@@ -395,10 +398,31 @@ class CocoBertModel(nn.Module):
         return (1.0 - m) * torch.finfo(torch.float32).min
 
     # ---------------------------------------------------------------- native plumbing
-    def _c_config(self) -> N.Config:
+    def _c_config(self, drop=None) -> N.Config:
+        """``drop`` = (hidden p, attention p, seed, call) of a training forward with dropout, or None (no dropout)."""
         c = self.config
+        ph, pa, seed, call = drop if drop is not None else (0.0, 0.0, 0, 0)
         return N.Config(c.hidden_size, c.num_attention_heads, c.num_hidden_layers, c.intermediate_size, c.vocab_size,
-                        c.max_position_embeddings, c.layer_norm_eps)
+                        c.max_position_embeddings, c.layer_norm_eps, ph, pa, seed, call)
+
+    # ---------------------------------------------------------------- dropout (hf nn.Dropout under model.train())
+    def _next_dropout_peek(self) -> bool:
+        """True when a training forward of this module would drop (train() mode and a positive probability)."""
+        c = self.config
+        return bool(self.training and torch.is_grad_enabled() and (c.hidden_dropout_prob > 0 or c.attention_probs_dropout_prob > 0))
+
+    def _next_dropout(self, training: bool):
+        """The (p_hidden, p_attention, seed, call) tuple of the next training forward, or None when nothing drops: eval
+        mode, torch.no_grad() inference, or both probabilities 0.  Every call gets fresh masks (the counter), the
+        backward of a forward regenerates the same masks from the same tuple; the seed is torch's at first use unless
+        ``dropout_seed`` was set."""
+        c = self.config
+        if not (training and self.training) or (c.hidden_dropout_prob <= 0 and c.attention_probs_dropout_prob <= 0):
+            return None
+        if self.dropout_seed is None:
+            self.dropout_seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        self._dropout_calls += 1
+        return (float(c.hidden_dropout_prob), float(c.attention_probs_dropout_prob), int(self.dropout_seed), self._dropout_calls)
 
     def _ensure_shadow(self):
         lo = self.layout
@@ -451,7 +475,8 @@ class CocoBertModel(nn.Module):
         lay = self._layout_for(B, L, training)
         arena = torch.empty(lay.total_bytes, dtype=torch.uint8, device=ids.device)
         emb, arr, _, _ = self._param_structs()
-        cfg = self._c_config()
+        arena._cocodr_drop = self._next_dropout(training)  # travels with the arena to whoever runs its backward
+        cfg = self._c_config(arena._cocodr_drop)
         check(lib().cocodr_encoder_fwd(C.byref(cfg), C.byref(emb), arr, ptr(ids), ptr(mask), B, L, int(training), ptr(arena),
                                        arena.numel(), stream_ptr()), "encoder_fwd")
         return arena, lay
@@ -525,7 +550,7 @@ class CocoBertModel(nn.Module):
         gn = torch.empty_like(self.flat_nodecay.data)
         gd[:lo.mat_begin].zero_()  # embedding tables: sparse word rows are accumulated, unused position rows stay zero
         emb, arr, eg, garr = self._param_structs((gd, gn))
-        cfg = self._c_config()
+        cfg = self._c_config(getattr(arena, "_cocodr_drop", None))
         dp = getattr(self, "_dp_enabled", False)
         if not dp or self._dp_fwd_live != 1:  # several passes share the weights: reduced once, from the hook
             check(lib().cocodr_encoder_bwd(C.byref(cfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d_last16),
@@ -581,13 +606,10 @@ class CocoBertModel(nn.Module):
             raise NotImplementedError("token_type_ids != 0: the reference never passes segment ids (COCO/data.py:140)")
         if position_ids is not None:
             raise NotImplementedError("custom position_ids are not on the reference path")
-        if self.training and self.config.hidden_dropout_prob > 0 and not self._warned_dropout:
-            warnings.warn("cocodr_amd: dropout is not implemented on the native path (treated as p=0)")
-            self._warned_dropout = True
         ids, mask, L = self._prep(input_ids, attention_mask)
         if L > self.config.max_position_embeddings:
             raise ValueError(f"sequence length {L} exceeds max_position_embeddings={self.config.max_position_embeddings}")
-        last, cls = _EncoderFn.apply(self.flat_decay, self.flat_nodecay, ids, mask, self)
+        last, cls = _EncoderFn.apply(self.flat_decay, self.flat_nodecay, ids, mask, self, torch.is_grad_enabled())
         hs = None
         if output_hidden_states:
             hs = tuple(h[:, :L] for h in self._last_hidden_states[:-1].unbind(0)) + (last[:, :L],)
@@ -686,15 +708,23 @@ class BertDotNLL(nn.Module):
         # pass it would be written on the side stream while the passage pass (main stream) already believes it fresh
         self.bert._refresh_shadow()
         side.wait_stream(main)
+        # which batches went through the encoder together, with the dropout call number each pass drew (0 = no dropout):
+        # where the reference runs three passes (models.py:84-86), positives and negatives share one here when shapes allow
+        calls = lambda: self.bert._dropout_calls if self.bert._next_dropout_peek() else 0
+        self.last_passes = []
         with torch.cuda.stream(side):
             q = self.query_emb(query_ids, attention_mask_q)
+        self.last_passes.append(("q", calls()))
         B = q.shape[0]
         if input_ids_a.shape == input_ids_b.shape:  # one encoder pass for positives and negatives
             ab = self.body_emb(torch.cat([input_ids_a, input_ids_b]), torch.cat([attention_mask_a, attention_mask_b]))
             a, b = ab[:B], ab[B:]
+            self.last_passes.append(("ab", calls()))
         else:
             a = self.body_emb(input_ids_a, attention_mask_a)
+            self.last_passes.append(("a", calls()))
             b = self.body_emb(input_ids_b, attention_mask_b)
+            self.last_passes.append(("b", calls()))
         main.wait_stream(side)
         q.record_stream(main)
         w = None if weights is None else weights.to(torch.float32).contiguous()
@@ -806,6 +836,7 @@ class CoCondenserForPretraining(nn.Module):
     def forward(self, model_input, labels=None, **unused):
         ids, mask = model_input["input_ids"], model_input.get("attention_mask")
         mlm_loss = None
+        self.lm.eval()  # COCO/modeling.py:198: the backbone never drops; the Condenser head layers follow self.training
         if self.c_head is not None and labels is not None:
             from .condenser import condenser_step
             skip_from = int(getattr(self.model_args, "skip_from", 2))

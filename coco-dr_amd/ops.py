@@ -32,10 +32,27 @@ def build_info() -> str:
     return lib().cocodr_build_info().decode()
 
 
+# ----------------------------------------------------------------------------------------------- dropout masks
+KIND_ATTN_PROBS, KIND_ATTN_OUT, KIND_FFN_OUT, KIND_EMBED = 0, 1, 2, 3
+
+
+def dropout_mask(p: float, seed: int, call: int, layer: int, kind: int) -> N.DropoutMask:
+    """Keys / threshold / scale of one dropout site of one forward call (cocodr_dropout_mask_for; host arithmetic only)."""
+    dm = N.DropoutMask()
+    check(lib().cocodr_dropout_mask_for(float(p), int(seed) & (2 ** 64 - 1), int(call) & (2 ** 64 - 1), int(layer), int(kind), C.byref(dm)),
+          "dropout_mask_for")
+    return dm
+
+
+def _dm_ref(drop: Optional[N.DropoutMask]):
+    return C.byref(drop) if drop is not None else None
+
+
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          bias: Optional[torch.Tensor] = None, epi: int = N.EPI_NONE, r: Optional[torch.Tensor] = None,
-         out_f32: bool = False, out: Optional[torch.Tensor] = None, colsum: bool = False, split_k: int = 1):
+         out_f32: bool = False, out: Optional[torch.Tensor] = None, colsum: bool = False, split_k: int = 1,
+         drop: Optional[N.DropoutMask] = None):
     """C = epi(op(a) @ op(b)); a, b bf16 2-D (or 3-D batched with equal batch).  See cocodr_gemm.
     colsum=True (unbatched) also returns the fp32 column sums of C as the last element of the result tuple.
     split_k > 1 (plain 2-D product, trans_a=False): the contraction is cut into split_k slices that run as the batch items of
@@ -83,6 +100,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
     g.trans_a, g.trans_b, g.epi, g.out_f32 = int(trans_a), int(trans_b), int(epi), int(out_f32)
     g.batch = nb
     g.strideA, g.strideB, g.strideC = a2.numel(), b2.numel(), M * Nn
+    if drop is not None:  # EPI_ADD: out = dropout(a @ b + bias) + r
+        g.drop = drop
     cs = None
     if colsum:
         if batched:
@@ -123,7 +142,8 @@ def gemm_set_impl(impl: int) -> None:
 
 
 # ----------------------------------------------------------------------------------------------- attention
-def attn_fwd(qkv: torch.Tensor, mask: torch.Tensor, B: int, L: int, heads: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def attn_fwd(qkv: torch.Tensor, mask: torch.Tensor, B: int, L: int, heads: int,
+             drop: Optional[N.DropoutMask] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     _req(qkv, BF16, "qkv", 2)
     _req(mask, I32, "mask", 2)
     H = heads * 64
@@ -131,11 +151,11 @@ def attn_fwd(qkv: torch.Tensor, mask: torch.Tensor, B: int, L: int, heads: int) 
         raise ValueError(f"attn_fwd: qkv {tuple(qkv.shape)} / mask {tuple(mask.shape)} do not match B={B} L={L} heads={heads}")
     ctx = torch.empty((B * L, H), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, heads, L), dtype=F32, device=qkv.device)
-    check(lib().cocodr_attn_fwd(ptr(qkv), ptr(mask), ptr(ctx), ptr(lse), B, L, heads, stream_ptr()), "attn_fwd")
+    check(lib().cocodr_attn_fwd_drop(ptr(qkv), ptr(mask), ptr(ctx), ptr(lse), B, L, heads, _dm_ref(drop), stream_ptr()), "attn_fwd")
     return ctx, lse
 
 
-def attn_bwd(qkv, mask, ctx, dctx, lse, B: int, L: int, heads: int, qk_bias: bool = False):
+def attn_bwd(qkv, mask, ctx, dctx, lse, B: int, L: int, heads: int, qk_bias: bool = False, drop: Optional[N.DropoutMask] = None):
     """``qk_bias=True`` also returns the [4 B, 2H] fp32 partial column sums of dQ | dK (four rows per sequence; their sum over
     all rows is the query / key bias gradient)."""
     H = heads * 64
@@ -145,13 +165,13 @@ def attn_bwd(qkv, mask, ctx, dctx, lse, B: int, L: int, heads: int, qk_bias: boo
         raise ValueError("attn_bwd: shape mismatch")
     dqkv = torch.empty_like(qkv)
     part = torch.empty((4 * B, 2 * H), dtype=F32, device=qkv.device) if qk_bias else None
-    check(lib().cocodr_attn_bwd(ptr(qkv), ptr(mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(part) if qk_bias else None,
-                                B, L, heads, stream_ptr()), "attn_bwd")
+    check(lib().cocodr_attn_bwd_drop(ptr(qkv), ptr(mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(part) if qk_bias else None,
+                                     B, L, heads, _dm_ref(drop), stream_ptr()), "attn_bwd")
     return (dqkv, part) if qk_bias else dqkv
 
 
 # ----------------------------------------------------------------------------------------------- row kernels
-def embed_ln_fwd(ids, word, pos, type0, gamma, beta, eps: float = 1e-12):
+def embed_ln_fwd(ids, word, pos, type0, gamma, beta, eps: float = 1e-12, drop: Optional[N.DropoutMask] = None):
     _req(ids, I32, "ids", 2)
     for t, n in ((word, "word"), (pos, "pos"), (type0, "type0"), (gamma, "gamma"), (beta, "beta")):
         _req(t, F32, n)
@@ -162,12 +182,12 @@ def embed_ln_fwd(ids, word, pos, type0, gamma, beta, eps: float = 1e-12):
     out = torch.empty((B * L, H), dtype=BF16, device=ids.device)
     mean = torch.empty(B * L, dtype=F32, device=ids.device)
     rstd = torch.empty_like(mean)
-    check(lib().cocodr_embed_ln_fwd(ptr(ids), ptr(word), ptr(pos), ptr(type0), ptr(gamma), ptr(beta), ptr(out), ptr(mean),
-                                    ptr(rstd), B, L, H, V, eps, stream_ptr()), "embed_ln_fwd")
+    check(lib().cocodr_embed_ln_fwd_drop(ptr(ids), ptr(word), ptr(pos), ptr(type0), ptr(gamma), ptr(beta), ptr(out), ptr(mean),
+                                         ptr(rstd), B, L, H, V, eps, _dm_ref(drop), stream_ptr()), "embed_ln_fwd")
     return out, mean, rstd
 
 
-def embed_ln_bwd(dout, ids, word, pos, type0, gamma, mean, rstd):
+def embed_ln_bwd(dout, ids, word, pos, type0, gamma, mean, rstd, drop: Optional[N.DropoutMask] = None):
     _req(dout, BF16, "dout", 2); _req(ids, I32, "ids", 2)
     B, L = ids.shape
     V, H = word.shape
@@ -178,9 +198,9 @@ def embed_ln_bwd(dout, ids, word, pos, type0, gamma, mean, rstd):
     dgamma = torch.empty(H, dtype=F32, device=dev)
     dbeta = torch.empty(H, dtype=F32, device=dev)
     partial = torch.empty(lib().cocodr_embed_bwd_partial_floats(L, H), dtype=F32, device=dev)
-    check(lib().cocodr_embed_ln_bwd(ptr(dout), ptr(ids), ptr(word), ptr(pos), ptr(type0), ptr(gamma), ptr(mean), ptr(rstd),
-                                    ptr(dword), ptr(dpos), ptr(dtype0), ptr(dgamma), ptr(dbeta), ptr(partial), B, L, H, V,
-                                    stream_ptr()), "embed_ln_bwd")
+    check(lib().cocodr_embed_ln_bwd_drop(ptr(dout), ptr(ids), ptr(word), ptr(pos), ptr(type0), ptr(gamma), ptr(mean), ptr(rstd),
+                                         ptr(dword), ptr(dpos), ptr(dtype0), ptr(dgamma), ptr(dbeta), ptr(partial), B, L, H, V,
+                                         _dm_ref(drop), stream_ptr()), "embed_ln_bwd")
     return dword, dpos, dtype0, dgamma, dbeta
 
 
@@ -196,8 +216,9 @@ def ln_fwd(y, gamma, beta, eps: float = 1e-12, cls_stride: int = 0):
     return (out, mean, rstd, cls) if cls_stride > 0 else (out, mean, rstd)
 
 
-def ln_bwd(dout, y, gamma, mean, rstd, colsum: bool = False):
-    """(dy, dgamma, dbeta[, column sums of dy])"""
+def ln_bwd(dout, y, gamma, mean, rstd, colsum: bool = False, drop: Optional[N.DropoutMask] = None):
+    """(dy, dgamma, dbeta[, column sums of dy]); with ``drop`` (the LayerNorm input was dropout(dense) + residual):
+    (dy, dy_drop, dgamma, dbeta[, column sums of dy_drop])"""
     _req(dout, BF16, "dout", 2); _req(y, BF16, "y", 2)
     M, H = y.shape
     dy = torch.empty_like(y)
@@ -205,9 +226,11 @@ def ln_bwd(dout, y, gamma, mean, rstd, colsum: bool = False):
     dbeta = torch.empty(H, dtype=F32, device=y.device)
     dcs = torch.empty(H, dtype=F32, device=y.device) if colsum else None
     partial = torch.empty(lib().cocodr_ln_bwd_partial_floats(M, H), dtype=F32, device=y.device)
-    check(lib().cocodr_ln_bwd(ptr(dout), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(dy), ptr(dgamma), ptr(dbeta),
-                              ptr(dcs) if colsum else None, ptr(partial), M, H, stream_ptr()), "ln_bwd")
-    return (dy, dgamma, dbeta, dcs) if colsum else (dy, dgamma, dbeta)
+    dyd = torch.empty_like(y) if drop is not None else None
+    check(lib().cocodr_ln_bwd_drop(ptr(dout), ptr(y), ptr(gamma), ptr(mean), ptr(rstd), ptr(dy), ptr(dyd), ptr(dgamma), ptr(dbeta),
+                                   ptr(dcs) if colsum else None, ptr(partial), M, H, _dm_ref(drop), stream_ptr()), "ln_bwd")
+    head = (dy, dyd) if drop is not None else (dy,)
+    return head + ((dgamma, dbeta, dcs) if colsum else (dgamma, dbeta))
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:

@@ -41,6 +41,33 @@ const char* cocodr_last_error(void);
 const char* cocodr_build_info(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Dropout  (hf: the nn.Dropout of BertEmbeddings :68-108, BertSelfAttention / eager_attention_forward :111-203 on the
+ * attention probabilities, BertSelfOutput :282-293 and BertOutput :338-351 on the dense outputs in front of the residual
+ * add; active under model.train(): ANCE/drivers/run_ann.py:293, and in the Condenser head layers of
+ * COCO/modeling.py:212-220 - COCO keeps only the backbone in eval, :198).
+ * torch's Philox stream cannot be reproduced bit for bit, so the mask is a counter-based hash with the same
+ * distribution: for the element with row-major flat index i of the site's tensor
+ *     w = lowbias32((i >> 1) ^ k0) ^ k1,   u = (i & 1) ? w >> 16 : w & 0xffff,   keep iff u >= threshold,
+ * lowbias32(x): x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16   (32-bit wrap-around),
+ * kept elements are multiplied by scale.  threshold = round(p * 65536), scale = 65536 / (65536 - threshold): the keep
+ * probability is exact to 2^-16 and the scale matches it.  The mask is never stored: the backward regenerates it from
+ * the same keys.  Site tensors: attention probabilities [B, heads, L, L]; dense outputs and the embedding output [M, H].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  uint32_t k0, k1;
+  uint32_t threshold; /* 0 = no dropout */
+  float scale;
+} cocodr_dropout_mask;
+enum { COCODR_DROP_ATTN_PROBS = 0, COCODR_DROP_ATTN_OUT = 1, COCODR_DROP_FFN_OUT = 2, COCODR_DROP_EMBED = 3 };
+/* Keys of one site of one forward call (host function, no device work):  site = 4 * layer + kind (embedding: layer 0),
+ *   z = splitmix64(seed + 0x9E3779B97F4A7C15 * (call + 1));  z = splitmix64(z ^ (0xD1B54A32D192ED03 * (site + 1)));
+ *   k0 = low 32 bits of z, k1 = high 32 bits,
+ * splitmix64(x): x += 0x9E3779B97F4A7C15; x = (x ^ x >> 30) * 0xBF58476D1CE4E5B9; x = (x ^ x >> 27) * 0x94D049BB133111EB;
+ * x ^= x >> 31.  p must be in [0, 1); p == 0 gives threshold 0. */
+int cocodr_dropout_mask_for(double p, unsigned long long seed, unsigned long long call, int layer, int kind,
+                            cocodr_dropout_mask* out);
+
+/* ------------------------------------------------------------------------------------------
  * GEMM  (hf: nn.Linear in BertSelfAttention :111-203, BertSelfOutput :282-293,
  *        BertIntermediate/BertOutput :325-351, and their autograd backward)
  *
@@ -75,6 +102,8 @@ typedef struct {
    * whose output gradient this GEMM produces; colsum_partial is a workspace of cocodr_gemm_colsum_partial_floats(M,N) */
   float* colsum;
   float* colsum_partial;
+  /* EPI_ADD, batch == 1 only: C = dropout(acc + bias) + R with flat index m * N + n (threshold 0 = off) */
+  cocodr_dropout_mask drop;
 } cocodr_gemm_args;
 size_t cocodr_gemm_colsum_partial_floats(int M, int N);
 /* Deferred form: with colsum == NULL and colsum_partial != NULL the call only leaves its per-row-panel sums
@@ -108,6 +137,13 @@ int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, flo
 int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
                     const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
                     cocodr_stream_t stream);
+/* The same pair with dropout on the attention probabilities: ctx = (dropout(softmax(..)) V); lse stays the log-sum-exp of
+ * the un-dropped scores.  drop == NULL or threshold 0: identical to the calls above. */
+int cocodr_attn_fwd_drop(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
+                         const cocodr_dropout_mask* drop, cocodr_stream_t stream);
+int cocodr_attn_bwd_drop(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
+                         const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
+                         const cocodr_dropout_mask* drop, cocodr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row kernels (HBM bound)
@@ -126,6 +162,17 @@ int cocodr_embed_ln_bwd(const uint16_t* dout, const int32_t* ids, const float* w
                         const float* type0, const float* gamma, const float* mean, const float* rstd,
                         float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
                         float* partial, int B, int L, int H, int vocab, cocodr_stream_t stream);
+/* The embedding pair with dropout on the LayerNorm output (hf BertEmbeddings.forward: dropout(LayerNorm(..))); the
+ * backward masks and scales dout before the LayerNorm backward.  drop == NULL or threshold 0: the calls above. */
+int cocodr_embed_ln_fwd_drop(const int32_t* ids, const float* word, const float* pos, const float* type0,
+                             const float* gamma, const float* beta, uint16_t* out, float* mean, float* rstd,
+                             int B, int L, int H, int vocab, float eps, const cocodr_dropout_mask* drop,
+                             cocodr_stream_t stream);
+int cocodr_embed_ln_bwd_drop(const uint16_t* dout, const int32_t* ids, const float* word, const float* pos,
+                             const float* type0, const float* gamma, const float* mean, const float* rstd,
+                             float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                             float* partial, int B, int L, int H, int vocab, const cocodr_dropout_mask* drop,
+                             cocodr_stream_t stream);
 int cocodr_ln_fwd(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean,
                   float* rstd, float* cls_out /* fp32 [M/cls_stride, H] or NULL */, int cls_stride,
                   int M, int H, float eps, cocodr_stream_t stream);
@@ -135,6 +182,14 @@ size_t cocodr_ln_bwd_partial_floats(int M, int H);
 int cocodr_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean,
                   const float* rstd, uint16_t* dy, float* dgamma, float* dbeta, float* dy_colsum, float* partial,
                   int M, int H, cocodr_stream_t stream);
+/* LayerNorm(dropout(dense) + residual): dy stays the gradient w.r.t. the LayerNorm input (= the residual branch's),
+ * dy_drop [M,H] receives dy masked and scaled (= the gradient w.r.t. the dense output, what the dgrad / wgrad GEMMs of
+ * that Linear take), and dy_colsum sums dy_drop (its bias gradient).  drop == NULL or threshold 0: dy_drop is not
+ * written and the call is cocodr_ln_bwd. */
+int cocodr_ln_bwd_drop(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean,
+                       const float* rstd, uint16_t* dy, uint16_t* dy_drop, float* dgamma, float* dbeta,
+                       float* dy_colsum, float* partial, int M, int H, const cocodr_dropout_mask* drop,
+                       cocodr_stream_t stream);
 /* column sums of a bf16 [M,N] matrix (bias gradients), batched: out[z][n] = sum_m X[z][m][n] */
 size_t cocodr_colsum_partial_floats(int M, int N, int batch);
 int cocodr_colsum(const uint16_t* X, float* out, float* partial, int M, int N, int ldx, int batch,
@@ -222,6 +277,11 @@ int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int
 typedef struct {
   int hidden, heads, layers, inter, vocab, max_pos;
   float ln_eps;
+  /* dropout of a training forward (training != 0) and of its backward: hf hidden_dropout_prob /
+   * attention_probs_dropout_prob, and the (seed, call) pair the site keys derive from (cocodr_dropout_mask_for).  The
+   * backward of a forward must be given the same four values; 0 probabilities = no dropout (eval). */
+  float hidden_dropout, attn_dropout;
+  unsigned long long drop_seed, drop_call;
 } cocodr_config;
 
 typedef struct { /* one BertLayer; w* are bf16 shadows [out,in], vectors are the fp32 masters */

@@ -133,7 +133,21 @@ def layer_norm_bwd(dout: np.ndarray, xhat: np.ndarray, rstd: np.ndarray, g: np.n
 
 
 # --------------------------------------------------------------------------- encoder
-def embeddings_fwd(P, input_ids: np.ndarray, cache: Optional[dict] = None) -> np.ndarray:
+def _drop_mult(dropout, shape, layer: int, kind: int, dtype):
+    """Multiplier (0 or 1 / (1 - p)) of one dropout site, or None.  ``dropout`` = dict(p_hidden, p_attn, seed, call) - the
+    hf nn.Dropout sites under model.train() (see oracle/dropout_oracle.py) - or a callable (shape, layer, kind) -> array."""
+    if dropout is None:
+        return None
+    if callable(dropout):
+        return dropout(shape, layer, kind)
+    from . import dropout_oracle as D
+    p = dropout["p_attn"] if kind == D.KIND_ATTN_PROBS else dropout["p_hidden"]
+    if p <= 0:
+        return None
+    return D.multiplier(shape, p, dropout["seed"], dropout["call"], layer, kind, dtype)
+
+
+def embeddings_fwd(P, input_ids: np.ndarray, cache: Optional[dict] = None, dropout=None) -> np.ndarray:
     """hf: BertEmbeddings.forward - LN(word[ids] + type[0] + pos[0..L-1]).
 
     The reference never passes token_type_ids or position_ids
@@ -146,12 +160,16 @@ def embeddings_fwd(P, input_ids: np.ndarray, cache: Optional[dict] = None) -> np
     te = P["embeddings.token_type_embeddings.weight"]
     y = we[input_ids] + pe[None, :L] + te[0][None, None]
     out, xhat, rstd = layer_norm_fwd(y, P["embeddings.LayerNorm.weight"], P["embeddings.LayerNorm.bias"])
+    m = _drop_mult(dropout, out.shape, 0, 3, out.dtype.type)  # hf BertEmbeddings: dropout(LayerNorm(..))
+    if m is not None:
+        out = out * m
     if cache is not None:
-        cache["emb"] = dict(xhat=xhat, rstd=rstd, ids=input_ids)
+        cache["emb"] = dict(xhat=xhat, rstd=rstd, ids=input_ids, m=m)
     return out
 
 
-def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optional[dict], stack: str = "encoder.layer."):
+def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optional[dict], stack: str = "encoder.layer.",
+               dropout=None):
     """One BertLayer: hf BertSelfAttention (eager) + BertSelfOutput + BertIntermediate + BertOutput."""
     n = layer_names(i, stack)
     B, L, H = x.shape
@@ -171,28 +189,37 @@ def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optio
     s = s - s.max(-1, keepdims=True)
     e = np.exp(s)
     p = (e / e.sum(-1, keepdims=True)).astype(x.dtype)
-    ctx = (p @ vh).transpose(0, 2, 1, 3).reshape(B, L, H)
+    t = x.dtype.type
+    mp = _drop_mult(dropout, p.shape, i, 0, t)   # hf eager_attention_forward: dropout(softmax(..))
+    pd = p if mp is None else p * mp
+    ctx = (pd @ vh).transpose(0, 2, 1, 3).reshape(B, L, H)
     a = ctx @ P[n["wo"]].T + P[n["bo"]]
+    ma = _drop_mult(dropout, a.shape, i, 1, t)   # hf BertSelfOutput: LayerNorm(dropout(dense(..)) + input)
+    if ma is not None:
+        a = a * ma
     x1, xhat1, rstd1 = layer_norm_fwd(a + x, P[n["g1"]], P[n["b1"]])
     u = x1 @ P[n["w1"]].T + P[n["bi"]]
     h = gelu(u)
     f = h @ P[n["w2"]].T + P[n["b2"]]
+    mf = _drop_mult(dropout, f.shape, i, 2, t)   # hf BertOutput: LayerNorm(dropout(dense(..)) + input)
+    if mf is not None:
+        f = f * mf
     x2, xhat2, rstd2 = layer_norm_fwd(f + x1, P[n["g2"]], P[n["be2"]])
     if cache is not None:
         cache[i] = dict(x=x, qh=qh, kh=kh, vh=vh, p=p, ctx=ctx, xhat1=xhat1, rstd1=rstd1, x1=x1,
-                        u=u, h=h, xhat2=xhat2, rstd2=rstd2)
+                        u=u, h=h, xhat2=xhat2, rstd2=rstd2, mp=mp, ma=ma, mf=mf)
     return x2
 
 
 def encoder_fwd(P, cfg: OracleConfig, input_ids: np.ndarray, attention_mask: np.ndarray,
-                keep_cache: bool = False):
+                keep_cache: bool = False, dropout=None):
     """BertModel forward -> list of N+1 hidden states (``output_hidden_states=True``,
-    COCO/modeling.py:199-204) and the cache the backward needs."""
+    COCO/modeling.py:199-204) and the cache the backward needs.  ``dropout``: the train()-mode forward (see _drop_mult)."""
     cache = {} if keep_cache else None
-    x = embeddings_fwd(P, input_ids, cache)
+    x = embeddings_fwd(P, input_ids, cache, dropout)
     hs = [x]
     for i in range(cfg.num_hidden_layers):
-        x = _layer_fwd(P, i, x, attention_mask, cfg.num_attention_heads, cache)
+        x = _layer_fwd(P, i, x, attention_mask, cfg.num_attention_heads, cache, dropout=dropout)
         hs.append(x)
     if keep_cache:
         cache["mask"] = attention_mask
@@ -215,21 +242,26 @@ def layers_bwd(P, nh: int, cache: dict, layer_ids, dx: np.ndarray, G: Dict[str, 
         c = cache[i]
         B, L, H = c["x"].shape
         d = H // nh
-        dy2, G[n["g2"]], G[n["be2"]] = layer_norm_bwd(dx, c["xhat2"], c["rstd2"], P[n["g2"]])
+        dres2, G[n["g2"]], G[n["be2"]] = layer_norm_bwd(dx, c["xhat2"], c["rstd2"], P[n["g2"]])
+        dy2 = dres2 if c.get("mf") is None else dres2 * c["mf"]   # gradient of the dense output behind its dropout
         G[n["w2"]] = dy2.reshape(-1, H).T @ c["h"].reshape(-1, c["h"].shape[-1])
         G[n["b2"]] = dy2.reshape(-1, H).sum(0)
         dh = dy2 @ P[n["w2"]]
         du = dh * gelu_grad(c["u"])
         G[n["w1"]] = du.reshape(-1, du.shape[-1]).T @ c["x1"].reshape(-1, H)
         G[n["bi"]] = du.reshape(-1, du.shape[-1]).sum(0)
-        dx1 = du @ P[n["w1"]] + dy2
-        dy1, G[n["g1"]], G[n["b1"]] = layer_norm_bwd(dx1, c["xhat1"], c["rstd1"], P[n["g1"]])
+        dx1 = du @ P[n["w1"]] + dres2
+        dres1, G[n["g1"]], G[n["b1"]] = layer_norm_bwd(dx1, c["xhat1"], c["rstd1"], P[n["g1"]])
+        dy1 = dres1 if c.get("ma") is None else dres1 * c["ma"]
         G[n["wo"]] = dy1.reshape(-1, H).T @ c["ctx"].reshape(-1, H)
         G[n["bo"]] = dy1.reshape(-1, H).sum(0)
         dctx = (dy1 @ P[n["wo"]]).reshape(B, L, nh, d).transpose(0, 2, 1, 3)
         p = c["p"]
-        dv = p.transpose(0, 1, 3, 2) @ dctx
+        pd = p if c.get("mp") is None else p * c["mp"]
+        dv = pd.transpose(0, 1, 3, 2) @ dctx
         dp = dctx @ c["vh"].transpose(0, 1, 3, 2)
+        if c.get("mp") is not None:
+            dp = dp * c["mp"]
         ds = p * (dp - (dp * p).sum(-1, keepdims=True))
         scale = p.dtype.type(1.0 / np.sqrt(d))
         dq = (ds @ c["kh"]) * scale
@@ -246,7 +278,7 @@ def layers_bwd(P, nh: int, cache: dict, layer_ids, dx: np.ndarray, G: Dict[str, 
         G[n["bq"]] = dq.reshape(-1, H).sum(0)
         G[n["bk"]] = dk.reshape(-1, H).sum(0)
         G[n["bv"]] = dv.reshape(-1, H).sum(0)
-        dx = dq @ P[n["wq"]] + dk @ P[n["wk"]] + dv @ P[n["wv"]] + dy1
+        dx = dq @ P[n["wq"]] + dk @ P[n["wk"]] + dv @ P[n["wv"]] + dres1
         if extra is not None and i in extra:
             dx = dx + extra[i]
     return dx
@@ -259,6 +291,8 @@ def encoder_bwd(P, cfg: OracleConfig, cache: dict, d_last: np.ndarray,
     G: Dict[str, np.ndarray] = {}
     dx = layers_bwd(P, cfg.num_attention_heads, cache, range(cfg.num_hidden_layers), d_last, G, extra=extra)
     e = cache["emb"]
+    if e.get("m") is not None:
+        dx = dx * e["m"]
     dy, G["embeddings.LayerNorm.weight"], G["embeddings.LayerNorm.bias"] = layer_norm_bwd(
         dx, e["xhat"], e["rstd"], P["embeddings.LayerNorm.weight"])
     B, L, H = dy.shape

@@ -85,9 +85,11 @@ def _ce_mean(logits, labels):
 
 
 def condenser_step(P, Ph, cfg: "B.OracleConfig", input_ids, attention_mask, labels, n_head_layers: int, skip_from: int,
-                   late_mlm: bool, world_size: int = 1):
+                   late_mlm: bool, world_size: int = 1, head_dropout=None):
     """Loss and all gradients of CoCondenserForPretraining.forward (single process): returns
-    (total, parts dict(mlm_head, mlm_late, co), G encoder grads, Gh head+MLM grads)."""
+    (total, parts dict(mlm_head, mlm_late, co), G encoder grads, Gh head+MLM grads).
+    ``head_dropout`` (see bert_oracle._drop_mult): the c_head BertLayers in train() mode - the backbone never drops
+    (COCO/modeling.py:198 ``self.lm.eval()``), the head layers belong to the module the trainer puts in train()."""
     nh = cfg.num_attention_heads
     hs, cache = B.encoder_fwd(P, cfg, input_ids, attention_mask, keep_cache=True)
     last = hs[-1]
@@ -96,7 +98,7 @@ def condenser_step(P, Ph, cfg: "B.OracleConfig", input_ids, attention_mask, labe
     x = np.concatenate([last[:, :1], hs[skip_from][:, 1:]], axis=1)
     hcache = {}
     for i in range(n_head_layers):
-        x = B._layer_fwd(Ph, i, x, attention_mask, nh, hcache, stack="c_head.")
+        x = B._layer_fwd(Ph, i, x, attention_mask, nh, hcache, stack="c_head.", dropout=head_dropout)
     lab_mask = labels != -100
     rows = np.nonzero(lab_mask.reshape(-1))[0]
     lab = labels.reshape(-1)[rows]

@@ -211,6 +211,82 @@ def golden_ance():
     sys.path.pop(0)
 
 
+def golden_dropout():
+    """Where the reference drops: the reference's own BertDot_NLL_LN in train() mode (ANCE/drivers/run_ann.py:293) on top of
+    transformers' BertModel with hidden_dropout_prob = 0.1 / attention_probs_dropout_prob = 0.15, three encoder passes
+    (query, positive, negative).  torch.nn.functional.dropout - what nn.Dropout.forward and eager_attention_forward call -
+    is replaced by a multiplication with the oracle's counter-based mask of the site (oracle/dropout_oracle.py): the site is
+    identified by call order (embedding output, then per layer: attention probabilities, attention-output dense, FFN-output
+    dense), the pass number is the `call` of the keys.  Everything else - which tensors are dropped, on which side of the
+    residual add / LayerNorm, how the loss and the gradients follow - is the reference's and transformers' own code."""
+    sys.path.insert(0, os.path.join(REF, "ANCE"))
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    from model.models import BertDot_NLL_LN  # reference
+    from oracle import dropout_oracle as D
+
+    cfg = OracleConfig(vocab_size=800, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                       intermediate_size=256, max_position_embeddings=64)
+    seed, drop_seed, p_hidden, p_attn = 2468, 777, 0.1, 0.15
+    P = scale_final_ln(make_params(cfg, seed, std=STD), cfg)
+    hc = hf_config(cfg)
+    hc.hidden_dropout_prob, hc.attention_probs_dropout_prob = p_hidden, p_attn
+    torch.manual_seed(0)
+    model = BertDot_NLL_LN(hc)
+    load_into(model.bert, P)
+    model.train()
+    rng = np.random.Generator(np.random.PCG64(11))
+    B = 4
+    q_ids, q_mask = synth_batch(rng, B, 32, cfg.vocab_size)
+    a_ids, a_mask = synth_batch(rng, B, 32, cfg.vocab_size)
+    b_ids, b_mask = synth_batch(rng, B, 32, cfg.vocab_size)
+    weights = np.array([1.0, 0.5, 2.0, 1.0], np.float32)
+
+    state = dict(call=0, site=0)
+    sites_per_pass = 1 + 3 * cfg.num_hidden_layers
+    seen = []
+
+    def fake_dropout(x, p=0.5, training=True, inplace=False):
+        assert training and p > 0
+        k = state["site"] % sites_per_pass
+        if k == 0:
+            state["call"] += 1
+            layer, kind = 0, D.KIND_EMBED
+        else:
+            layer, kind = (k - 1) // 3, (k - 1) % 3
+        state["site"] += 1
+        assert abs(p - (p_attn if kind == D.KIND_ATTN_PROBS else p_hidden)) < 1e-9, (p, kind)
+        seen.append((state["call"], layer, kind, tuple(x.shape)))
+        m = D.multiplier(tuple(x.shape), p, drop_seed, state["call"], layer, kind)
+        return x * torch.from_numpy(m)
+
+    real = F.dropout
+    F.dropout = fake_dropout
+    torch.nn.functional.dropout = fake_dropout
+    try:
+        t = torch.from_numpy
+        model.zero_grad()
+        loss, acc, logits = model(t(q_ids), t(q_mask), t(a_ids), t(a_mask), t(b_ids), t(b_mask), weights=t(weights))
+        loss.backward()
+    finally:
+        F.dropout = real
+        torch.nn.functional.dropout = real
+    assert state["site"] == 3 * sites_per_pass and state["call"] == 3, state
+    assert [s[3] for s in seen[:4]] == [(B, 32, 128), (B, 2, 32, 32), (B, 32, 128), (B, 32, 128)], seen[:4]
+    out = dict(q_ids=q_ids, q_mask=q_mask, a_ids=a_ids, a_mask=a_mask, b_ids=b_ids, b_mask=b_mask, weights=weights,
+               seed=np.int64(seed), std=np.float64(STD), final_ln_scale=np.float64(FINAL_LN_SCALE), drop_seed=np.int64(drop_seed),
+               p_hidden=np.float64(p_hidden), p_attn=np.float64(p_attn), loss=np.float64(float(loss)),
+               logits=logits.detach().numpy(),
+               cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                             cfg.intermediate_size, cfg.max_position_embeddings, cfg.type_vocab_size]))
+    out.update(selected_grads(model.named_parameters(), "bert."))
+    np.savez_compressed(os.path.join(OUT, "dropout_sites.npz"), **out)
+    print("dropout golden: loss", float(loss), "logits", logits.detach().numpy())
+    sys.path.pop(0)
+
+
 def golden_mrr():
     """evaluate/evaluation/msmarco_eval.py:109-139 compute_metrics on a seeded synthetic run."""
     sys.path.insert(0, os.path.join(REF, "evaluate", "evaluation"))
@@ -674,7 +750,7 @@ def golden_negatives():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate", "evaldev", "negatives"]
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate", "evaldev", "negatives", "dropout"]
     if "evaldev" in which:
         golden_evaldev()
     if "negatives" in which:
@@ -697,3 +773,5 @@ if __name__ == "__main__":
         golden_ance()
     if "mrr" in which:
         golden_mrr()
+    if "dropout" in which:
+        golden_dropout()

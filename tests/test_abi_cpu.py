@@ -67,12 +67,12 @@ def test_ops_reject_cpu_tensors_and_model_refuses_cpu():
     from cocodr_amd.modeling import CocoBertConfig, CocoBertModel
     with pytest.raises(ValueError, match="GPU"):
         ops.gemm(torch.zeros(128, 64, dtype=torch.bfloat16), torch.zeros(128, 64, dtype=torch.bfloat16))
-    m = CocoBertModel(CocoBertConfig(vocab_size=100, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
+    m = CocoBertModel(CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=100, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
                                      intermediate_size=128, max_position_embeddings=32))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(2, 32, dtype=torch.long))
     with pytest.raises(ValueError):
-        CocoBertConfig(hidden_size=100, num_attention_heads=2)
+        CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, hidden_size=100, num_attention_heads=2)
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
@@ -97,7 +97,7 @@ def test_product_never_imports_the_oracle():
 
 def test_state_dict_uses_hf_bert_names_and_flat_layout_is_uniform():
     from cocodr_amd.modeling import CocoBertConfig, CocoBertModel
-    cfg = CocoBertConfig(vocab_size=200, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=200, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=64)
     m = CocoBertModel(cfg)
     from transformers import BertConfig, BertModel

@@ -26,7 +26,7 @@ def _worker(rank, world, port, ids, mask, q):
         torch.cuda.set_device(0)
         import cocodr_amd  # noqa: F401
         from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertConfig, CocoBertModel
-        cfg = CocoBertConfig(vocab_size=700, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
+        cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=700, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
                              max_position_embeddings=64)
         torch.manual_seed(0)
         bert = CocoBertModel(cfg).to("cuda")
@@ -69,7 +69,7 @@ def test_two_rank_coco_step_equals_single_process_on_the_full_batch():
     # single process, whole batch
     import cocodr_amd  # noqa: F401
     from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertConfig, CocoBertModel
-    cfg = CocoBertConfig(vocab_size=700, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=700, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=64)
     torch.manual_seed(0)
     bert = CocoBertModel(cfg).to("cuda")
@@ -128,7 +128,7 @@ _rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / (np.li
 
 def _small_cfg(layers=4):
     from cocodr_amd.modeling import CocoBertConfig
-    return CocoBertConfig(vocab_size=700, hidden_size=128, num_hidden_layers=layers, num_attention_heads=2, intermediate_size=256,
+    return CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=700, hidden_size=128, num_hidden_layers=layers, num_attention_heads=2, intermediate_size=256,
                           max_position_embeddings=64)
 
 

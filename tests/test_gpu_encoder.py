@@ -20,7 +20,7 @@ DEV = "cuda"
 
 
 def model_from_oracle(ocfg, P):
-    cfg = CocoBertConfig(vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
                          num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
                          max_position_embeddings=ocfg.max_position_embeddings, type_vocab_size=ocfg.type_vocab_size)
     m = CocoBertModel(cfg)
@@ -87,7 +87,7 @@ def test_ance_triplet_step_matches_reference_golden(golden_ance):
     parameter gradients at 8e-2 rel-L2."""
     g = golden_ance
     ocfg = cfg_from_golden(g)
-    cfg = CocoBertConfig(vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
                          num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
                          max_position_embeddings=ocfg.max_position_embeddings)
     model = BertDotNLL(cfg)
@@ -139,7 +139,7 @@ def test_encoder_vs_numpy_oracle_midsize(layers, H, heads, I, B, L):
 
 
 def test_padding_to_32_and_extra_masked_tokens_do_not_change_cls():
-    cfg = CocoBertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=500, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=128)
     torch.manual_seed(0)
     m = CocoBertModel(cfg).to(DEV).eval()
@@ -156,7 +156,7 @@ def test_padding_to_32_and_extra_masked_tokens_do_not_change_cls():
 
 
 def test_checkpoint_roundtrip_keeps_hf_names(tmp_path):
-    cfg = CocoBertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=64)
     m = CocoBertModel(cfg)
     sd = m.state_dict()
@@ -173,7 +173,7 @@ def test_full_size_config2_step_properties():
     non-zero, backward linear in the upstream gradient, and run-to-run determinism of everything but the
     atomically accumulated word-embedding rows."""
     torch.manual_seed(0)
-    m = CocoBertModel(CocoBertConfig.base()).to(DEV)
+    m = CocoBertModel(CocoBertConfig.base(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).to(DEV)
     model = CoCondenserForPretraining(m)
     B, L = 64, 128
     g = torch.Generator().manual_seed(1)
@@ -217,7 +217,7 @@ def test_chunked_backward_with_overlapped_allreduce_matches_single_call():
                                 device_id=torch.device("cuda", 0))
         created = True
     try:
-        cfg = CocoBertConfig(vocab_size=2000, hidden_size=256, num_hidden_layers=6, num_attention_heads=4,
+        cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=2000, hidden_size=256, num_hidden_layers=6, num_attention_heads=4,
                              intermediate_size=512, max_position_embeddings=128)
         torch.manual_seed(3)
         m = CocoBertModel(cfg).to(DEV)
@@ -280,7 +280,7 @@ def test_full_condenser_step_base_size_properties():
     all gradients finite and non-zero, MLM loss near log(V) at init."""
     import types
     torch.manual_seed(0)
-    m = CocoBertModel(CocoBertConfig.base()).to(DEV)
+    m = CocoBertModel(CocoBertConfig.base(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).to(DEV)
     model = CoCondenserForPretraining(m, types.SimpleNamespace(n_head_layers=2, skip_from=6, late_mlm=True)).to(DEV)
     B, L = 64, 128
     gen = torch.Generator().manual_seed(1)
@@ -306,7 +306,7 @@ def test_idro_reweighted_triplet_steps_match_reference_golden():
     import types
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "idro_steps.npz"))
     ocfg = cfg_from_golden(g)
-    cfg = CocoBertConfig(vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
                          num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
                          max_position_embeddings=ocfg.max_position_embeddings)
     model = BertDotNLL(cfg)
@@ -346,7 +346,7 @@ def test_dro_greedy_steps_match_reference_golden(weight_ema, tag):
     import types
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dro_greedy_steps.npz"))
     ocfg = cfg_from_golden(g)
-    cfg = CocoBertConfig(vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
                          num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
                          max_position_embeddings=ocfg.max_position_embeddings)
     model = BertDotNLL(cfg)
@@ -409,7 +409,7 @@ def test_forward_in_layer_ranges_equals_the_single_call():
     """cocodr_encoder_fwd_range over [0,2), [2,3), [3,5) leaves exactly the arena of one cocodr_encoder_fwd call."""
     import ctypes as C
     from cocodr_amd._native import check, lib, ptr, stream_ptr
-    cfg = CocoBertConfig(vocab_size=600, hidden_size=128, num_hidden_layers=5, num_attention_heads=2, intermediate_size=256,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=600, hidden_size=128, num_hidden_layers=5, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=64)
     torch.manual_seed(0)
     m = CocoBertModel(cfg).to(DEV)
@@ -460,7 +460,7 @@ def test_idro_single_pass_group_gradients_equal_the_per_group_backwards():
     """The per-sequence route (one un-weighted partial backward + per-sequence weight-gradient GEMMs) and the
     reference-shaped route (one partial backward per group) update the group weights identically."""
     import types
-    cfg = CocoBertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=12, num_attention_heads=2, intermediate_size=256,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=500, hidden_size=128, num_hidden_layers=12, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=64)
     rng = np.random.Generator(np.random.PCG64(31))
     B = 8
@@ -486,7 +486,7 @@ def test_contrastive_training_learns_span_pairs():
     backward, clip, FlatAdamW) on span pairs that share tokens drives the in-batch contrastive loss far below chance and
     stays finite."""
     from cocodr_amd.optim import FlatAdamW, clip_grad_norm_
-    cfg = CocoBertConfig(vocab_size=2000, hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=2000, hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512,
                          max_position_embeddings=64)
     torch.manual_seed(0)
     bert = CocoBertModel(cfg).to(DEV)

@@ -252,7 +252,7 @@ def test_colsum_and_cast():
 def test_flat_adamw_matches_torch_adamw_and_updates_shadow():
     from cocodr_amd.modeling import CocoBertConfig, CocoBertModel
     from cocodr_amd.optim import FlatAdamW
-    cfg = CocoBertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=64)
     torch.manual_seed(0)
     m = CocoBertModel(cfg).to(DEV)
@@ -317,7 +317,7 @@ def test_flat_lamb_on_the_model_matches_the_oracle_per_tensor():
     import oracle as O
     from cocodr_amd.modeling import CocoBertConfig, CocoBertModel
     from cocodr_amd.optim import FlatLamb, clip_grad_norm_
-    cfg = CocoBertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=64)
     torch.manual_seed(0)
     m = CocoBertModel(cfg).to(DEV)

@@ -82,7 +82,7 @@ def test_gemm_large_grouped_wgrad(nb, Mtok, No, Ni, gemm_impl):
 
 
 def _model_from_oracle(ocfg, P):
-    cfg = CocoBertConfig(vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_hidden_layers,
                          num_attention_heads=ocfg.num_attention_heads, intermediate_size=ocfg.intermediate_size,
                          max_position_embeddings=ocfg.max_position_embeddings, type_vocab_size=ocfg.type_vocab_size)
     m = CocoBertModel(cfg)

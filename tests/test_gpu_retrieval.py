@@ -58,7 +58,7 @@ def test_search_linearity_and_shard_merge_property_at_scale():
 
 def test_bert_large_triplet_step_config4_shapes():
     torch.manual_seed(0)
-    model = BertDotNLL(CocoBertConfig.large()).to(DEV)
+    model = BertDotNLL(CocoBertConfig.large(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).to(DEV)
     B = 32
     g = torch.Generator().manual_seed(1)
     q = torch.randint(1000, 30522, (B, 64), generator=g).to(DEV)
@@ -86,7 +86,7 @@ def test_encode_search_ndcg_pipeline_matches_fp32_oracle_pipeline():
     ocfg = O.OracleConfig(vocab_size=800, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                           max_position_embeddings=64)
     P = O.make_params(ocfg, 17, std=0.08)
-    cfg = CocoBertConfig(vocab_size=800, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=800, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                          max_position_embeddings=64)
     model = BertDotNLL(cfg)
     model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})

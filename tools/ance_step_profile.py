@@ -9,7 +9,7 @@ from cocodr_amd.optim import FlatLamb, clip_grad_norm_
 from bench import synth_batch
 
 dev = torch.device("cuda")
-cfg = CocoBertConfig.large()
+cfg = CocoBertConfig.large(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
 torch.manual_seed(0)
 model = BertDotNLL(cfg).to(dev)
 opt = FlatLamb.for_model(model.bert, lr=5e-6, eps=1e-8)

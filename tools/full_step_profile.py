@@ -9,7 +9,7 @@ from cocodr_amd.optim import FlatAdamW
 from bench import synth_batch
 
 dev = torch.device("cuda")
-cfg = CocoBertConfig.base()
+cfg = CocoBertConfig.base(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
 torch.manual_seed(0)
 bert = CocoBertModel(cfg).to(dev)
 model = CoCondenserForPretraining(bert, types.SimpleNamespace(n_head_layers=2, skip_from=6, late_mlm=True)).to(dev)

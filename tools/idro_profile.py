@@ -8,7 +8,7 @@ from cocodr_amd.modeling import BertDotNLL, CocoBertConfig
 from bench import synth_batch
 
 dev = torch.device("cuda")
-cfg = CocoBertConfig.large()
+cfg = CocoBertConfig.large(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
 torch.manual_seed(0)
 model = BertDotNLL(cfg).to(dev)
 model.add_group_loss(args=types.SimpleNamespace(model_size="large"), n_groups=50, dro_type="idro", alpha=0.25, eps=0.01, ema=0.1, rho=0.05)
