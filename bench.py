@@ -230,7 +230,7 @@ def eval_search(dev, nq: int = 10000, npass: int = 125000, dim: int = 1024, k: i
     g = torch.Generator().manual_seed(7)
     Q = (torch.randn(nq, dim, generator=g) / dim ** 0.5).to(dev)
     P = (torch.randn(npass, dim, generator=g) / dim ** 0.5).to(dev)
-    ws = torch.empty(ops.lib().cocodr_score_topk_workspace_bytes(nq, npass, k), dtype=torch.uint8, device=dev)
+    ws = torch.empty(ops.lib().cocodr_score_topk_workspace_bytes_dim(nq, npass, dim, k), dtype=torch.uint8, device=dev)
     ops.score_topk(Q, P, k, workspace=ws)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -27,6 +27,7 @@ class GemmArgs(C.Structure):
         ("strideBias", c_longlong),
         ("colsum", c_void_p), ("colsum_partial", c_void_p),
         ("drop", DropoutMask),
+        ("ab_f16", c_int),
     ]
 
 
@@ -104,6 +105,8 @@ SIGNATURES = {
     "cocodr_simce_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_triplet_nll_fwd_bwd": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "cocodr_score_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cocodr_score_topk_workspace_bytes_dim": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "cocodr_score_set_mode": (c_int, [c_int]),
     "cocodr_score_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
     "cocodr_encoder_layout": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),

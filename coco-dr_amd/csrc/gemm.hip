@@ -702,6 +702,14 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   dim3 grid(ntm * ntn, a.batch);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_GEMM, st, 2.0 * a.M * a.N * (double)a.K * a.batch);
+  if (a.ab_f16) {  // IEEE-half operands: the ping-pong pipeline's NT form with an fp32 result, nothing fused
+    CK_ARG(!a.trans_a && !a.trans_b && a.out_f32 && a.epi == COCODR_EPI_NONE && !a.bias && !cs_part && a.N % 256 == 0 && a.K % BK == 0,
+           "gemm: fp16 operands need the plain NT form with an fp32 result, N %% 256 == 0 and K %% 64 == 0");
+    CK_ARG((size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldb * 2 < (1ull << 32), "gemm: fp16 operands: each operand must stay below 4 GiB per batch item");
+    cocodr_gemm_pp_launch(a, 104, st);
+    CK_LAUNCH("gemm(f16)");
+    return COCODR_OK;
+  }
   const int impl = select_impl(a);
   const int cs_rows = colsum_rows(impl, a.M);  // the kernels with 128-column tiles reduce in their epilogue
   CK_ARG(!cs_part || cs_out || cs_rows > 0, "gemm: deferred column sums (colsum == NULL) are not available on this pipeline; ask cocodr_gemm_colsum_rows first");

@@ -102,7 +102,10 @@ __device__ __forceinline__ void pp_read_sub(const uint32_t (&cur)[4], FragSet<TR
 
 // 8 MFMAs of one quadrant phase: acc[2 asub + i][bsub] += A-sub(i, ks) x B-sub(ks); operands swapped so that a lane ends
 // with 4 consecutive output columns of one row (the epilogue's layout, as in gemm.hip)
-template <int TA, int TB, class MID>
+// F16: the 16-bit operands are IEEE half instead of bfloat16 (same fragment layout and rate; the search's split-precision
+// score GEMM, score.hip)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int TA, int TB, bool F16, class MID>
 __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const FragSet<TB, 1> (&fb)[4], f32x16& c0, f32x16& c1, MID&& mid) {
 #if defined(COCODR_ABL_NO_MFMA)
   mid();
@@ -111,8 +114,14 @@ __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const Fra
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const bf16x8 b = frag_get<TB, 1>(fb[ks], 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, frag_get<TA, 2>(fa[ks], 0), c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, frag_get<TA, 2>(fa[ks], 1), c1, 0, 0, 0);
+    if constexpr (F16) {
+      const f16x8 bh = __builtin_bit_cast(f16x8, b);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, __builtin_bit_cast(f16x8, frag_get<TA, 2>(fa[ks], 0)), c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, __builtin_bit_cast(f16x8, frag_get<TA, 2>(fa[ks], 1)), c1, 0, 0, 0);
+    } else {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, frag_get<TA, 2>(fa[ks], 0), c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, frag_get<TA, 2>(fa[ks], 1), c1, 0, 0, 0);
+    }
     if (ks == 0) mid();
   }
 }
@@ -120,6 +129,7 @@ __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const Fra
 // VAR (experiment builds, -DCOCODR_PP_VARIANTS, tools/gemm_bench.py --impls 13,15,16): 0 = DMA pieces requested in the load
 // segment behind the fragment reads; 2 = as 0 without s_setprio (-15 %); 3 = requested in front of the fragment reads (=).
 // Requesting them inside the MFMA segment instead cost 10-14 % (profiles/r02_gemm_pp_variants.txt).
+// VAR 4 (always built, NT form with fp32 output only): VAR 0 with IEEE-half operands.
 template <int NB, int TA, int TB, bool OUT_F32, int VAR = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_args p, const int flat) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -254,12 +264,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_
       auto none = []() {};
       if constexpr (VAR == 3) req();
       reads();
-      if constexpr (VAR == 0 || VAR == 2) req();
+      if constexpr (VAR == 0 || VAR == 2 || VAR == 4) req();
       wait_stage(tyc, rem);
       __builtin_amdgcn_s_barrier();
       wait_lgkmcnt<0>();
       if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(1);
-      pp_mfma<TA, TB>(fa, fb, c0, c1, none);
+      pp_mfma<TA, TB, VAR == 4>(fa, fb, c0, c1, none);
       if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
     };
@@ -407,6 +417,7 @@ static void launch_any(const cocodr_gemm_args& a, hipStream_t st) {
 }
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st) {
   if (nb == 2) launch_any<0>(a, st);
+  else if (nb == 104) cocodr_gemm_pp::launch_form<2, 0, 0, 4>(a, st);
 #if defined(COCODR_PP_VARIANTS)
   else if (nb == 102) launch_any<2>(a, st);
   else if (nb == 103) launch_any<3>(a, st);

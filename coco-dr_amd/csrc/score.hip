@@ -6,9 +6,14 @@
 // deterministic radix select per query row (order: score descending, position ascending on ties)
 // followed by a bitonic sort of the k survivors in LDS.
 //
-// Round-1 structure: a chunk of query rows is scored into a [QC, Np] fp32 slab in the caller's
-// workspace, then selected.  (The slab round trip is the next thing to remove - see DESIGN.md.)
+// Structure: a chunk of query rows is scored into a [QC, Np] fp32 slab in the caller's workspace, then selected.  The
+// workspace holds TWO such slabs: the selection of chunk c runs on a side stream while the score GEMM of chunk c + 1
+// runs on the caller's stream - the GEMM is bound by the fp32 matrix pipe and leaves the memory system and the LDS
+// atomics the selection lives on almost idle, so the selection (17 % of the search when serialised) hides under it.
+#include <stdlib.h>
+
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 #include "prof.h"
@@ -62,17 +67,30 @@ __global__ __launch_bounds__(256, 2) void score_gemm_kernel(const float* __restr
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) gload((t + 1) * SK);
+    // the operands of the next-but-one k-pair are requested in front of the MFMAs of this one (two register sets): left
+    // to itself hipcc issues them one MFMA (64 cycles) ahead of their use, less than the LDS latency
+    float fa[2][2][2], fb[2][2][2];  // [set][k-pair within the set][fragment]
+    auto frags = [&](int set, int kk) {
 #pragma unroll
-    for (int kk = 0; kk < SK; kk += 2) {
-      float fa[2], fb[2];
+      for (int j = 0; j < 2; ++j) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = Qs[buf][(wm * 64 + a * 32 + (lane & 31)) * SLD + kk + (lane >> 5)];
+        for (int a = 0; a < 2; ++a) fa[set][j][a] = Qs[buf][(wm * 64 + a * 32 + (lane & 31)) * SLD + kk + 2 * j + (lane >> 5)];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) fb[b] = Ps[buf][(wn * 64 + b * 32 + (lane & 31)) * SLD + kk + (lane >> 5)];
+        for (int b = 0; b < 2; ++b) fb[set][j][b] = Ps[buf][(wn * 64 + b * 32 + (lane & 31)) * SLD + kk + 2 * j + (lane >> 5)];
+      }
+    };
+    frags(0, 0);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+    for (int kk = 0; kk < SK; kk += 4) {
+      const int set = (kk >> 2) & 1;
+      if (kk + 4 < SK) frags(set ^ 1, kk + 4);
+      __builtin_amdgcn_sched_barrier(0);  // keep the requests in front of this set's MFMAs
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][j][a], fb[set][j][b], acc[a][b], 0, 0, 0);
     }
     if (t + 1 < nt) sstore(buf ^ 1);
     __syncthreads();
@@ -94,7 +112,7 @@ constexpr int TOPK_THREADS = 512;
 constexpr int NREP = 4;        // replicated LDS histograms (lane & 3) to thin same-address atomics
 constexpr int NBIN = 2048;
 constexpr int KMAX = 2048;
-constexpr int NCAND = 2048;    // LDS candidate list of the compacted path
+constexpr int NCAND = 3072;    // LDS candidate list of the compacted paths (72 KiB of LDS per workgroup in all: two per CU)
 
 // order-preserving map: smaller key <=> larger float  (NaN sorts last)
 __device__ __forceinline__ uint32_t desc_key(float f) {
@@ -138,15 +156,47 @@ __device__ __forceinline__ void radix_pass(Scan scan, Val val, int shift, int bi
     hist[b] = t;
   }
   __syncthreads();
-  if (tid == 0) {
-    int cum = 0, d = 0;
-    for (; d < nb - 1; ++d) {
-      if (cum + (int)hist[d] >= st.need) break;
-      cum += hist[d];
+  // the first digit whose cumulative count reaches st.need, by a block-wide prefix sum over the bins (each thread owns
+  // nb / TOPK_THREADS consecutive bins).  One thread walking the 2048 bins - a chain of dependent LDS reads, ~55 us - was
+  // most of the selection's time: every row pays three to six of these passes.
+  {
+    constexpr int CMAX = NBIN / TOPK_THREADS;
+    const int C = nb / TOPK_THREADS;  // nb is 2048 or 1024
+    int c[CMAX], local = 0;
+#pragma unroll
+    for (int j = 0; j < CMAX; ++j) {
+      c[j] = j < C ? (int)hist[tid * C + j] : 0;
+      local += c[j];
     }
-    sh[0] = d;
-    sh[1] = st.need - cum;
-    sh[2] = hist[d];
+    int incl = local;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    int* wsum = sh + 8;  // TOPK_THREADS / 64 wave totals
+    if (lane == 63) wsum[wv] = incl;
+    if (tid == 0) sh[0] = -1;
+    __syncthreads();
+    int before = incl - local, total = 0;
+#pragma unroll
+    for (int w = 0; w < TOPK_THREADS / 64; ++w) {
+      const int t = wsum[w];
+      if (w < wv) before += t;
+      total += t;
+    }
+    if (before < st.need && st.need <= before + local) {  // exactly one thread when total >= need
+#pragma unroll
+      for (int j = 0; j < CMAX; ++j) {
+        if (j < C && before < st.need && st.need <= before + c[j]) { sh[0] = tid * C + j; sh[1] = st.need - before; sh[2] = c[j]; }
+        before += c[j];
+      }
+    }
+    if (total < st.need && tid == TOPK_THREADS - 1) {  // (cannot happen for a consistent need; mirrors the serial walk's last bin)
+      const int last = (int)hist[nb - 1];
+      sh[0] = nb - 1; sh[1] = st.need - (total - last); sh[2] = last;
+    }
   }
   __syncthreads();
   st.prefix |= ((uint32_t)sh[0]) << shift;
@@ -161,12 +211,15 @@ __device__ __forceinline__ void radix_pass(Scan scan, Val val, int shift, int bi
 // candidate list, and the remaining radix / tie-break passes run on the list: 2 trips over the row instead of 4.
 // Otherwise all passes stream the row, as before.  Result and order (score descending, position ascending on ties) are
 // identical on both paths.
+// unscale (or NULL): two ints, the binary exponents the split-precision path scaled Q and P by - D is multiplied by
+// 2^-(unscale[0] + unscale[1]) on the way out (exact; ordering and ties are those of the scaled scores)
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ S, long long lds_s, int np, int k,
-                                                            long long id_offset, float* __restrict__ D, long long* __restrict__ I) {
+                                                            long long id_offset, float* __restrict__ D, long long* __restrict__ I,
+                                                            const int* __restrict__ unscale) {
   __shared__ uint32_t hist[NREP * NBIN];
   __shared__ unsigned long long buf[KMAX];   // (key << 32) | idx : ascending = score desc, idx asc
   __shared__ unsigned long long cand[NCAND];
-  __shared__ int sh[6];
+  __shared__ int sh[8 + TOPK_THREADS / 64];  // [0..2] radix-pass result, [3], [4] list counters, [8..] wave totals of its prefix sum
   const int tid = threadIdx.x;
   const float* row = S + (size_t)blockIdx.x * lds_s;
   float* Drow = D + (size_t)blockIdx.x * k;
@@ -192,13 +245,59 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
   auto by_key = [](uint32_t key, uint32_t, uint32_t& v) { v = key; return true; };
 
   uint32_t thr = 0xffffffffu, ithr = 0xffffffffu;
-  bool compacted = false;
+  bool compacted = false, sampled = false;
   int ncand = 0;
+  // Sampled cut (k << Np): the r-th best of a 1/16 sample of the row, r a few standard deviations past the sample's share
+  // of the top k, is with near certainty a score BELOW the k-th best of the row.  ONE pass over the row then moves
+  // everything at or above it to the LDS candidate list; if the list holds at least k entries (so the guess was indeed
+  // below the cut) and did not overflow, the exact selection runs on the list alone: ~1.1 trips over the row instead
+  // of 2.  Any other outcome - an adversarial order, many ties - falls through to the full path below; the result is
+  // the same either way.
+  if (kk < np && np >= 32 * kk && np >= 4096) {
+    const int blk = (np / 256) & ~3, stride = (np / 16) & ~3;  // 16 blocks of blk elements, 16-byte aligned
+    auto scan_sample = [&](auto body) {
+      const int b4 = blk >> 2;
+      for (int i = tid; i < 16 * b4; i += TOPK_THREADS) {
+        const int b = i / b4, j = i - b * b4;
+        const int e0 = b * stride + 4 * j;
+        const float4 v = *reinterpret_cast<const float4*>(row + e0);
+        body(desc_key(v.x), (uint32_t)e0);
+        body(desc_key(v.y), (uint32_t)(e0 + 1));
+        body(desc_key(v.z), (uint32_t)(e0 + 2));
+        body(desc_key(v.w), (uint32_t)(e0 + 3));
+      }
+    };
+    const float mu = (float)kk * (16.0f * blk) / (float)np;
+    const int r = min(16 * blk, (int)(mu + 4.0f * sqrtf(mu) + 8.0f));
+    SelState ss{0u, r, 0};
+    radix_pass(scan_sample, by_key, 21, 11, 0x00000000u, ss, hist, sh);
+    radix_pass(scan_sample, by_key, 10, 11, 0xffe00000u, ss, hist, sh);
+    radix_pass(scan_sample, by_key, 0, 10, 0xfffffc00u, ss, hist, sh);
+    const uint32_t cut = ss.prefix;  // key of the r-th best sample score
+    scan_row([&](uint32_t key, uint32_t idx) {
+      if (key <= cut) {
+        const int pos = atomicAdd(&sh[4], 1);
+        if (pos < NCAND) cand[pos] = ((unsigned long long)key << 32) | idx;
+      }
+    });
+    __syncthreads();
+    const int total = sh[4];
+    __syncthreads();
+    if (total >= kk && total <= NCAND) {
+      sampled = compacted = true;
+      ncand = total;
+    } else if (tid == 0) {
+      sh[4] = 0;
+    }
+    __syncthreads();
+  }
   if (kk < np) {
     SelState st{0u, kk, 0};
+    if (!sampled) {
     radix_pass(scan_row, by_key, 21, 11, 0x00000000u, st, hist, sh);
     compacted = st.count_eq <= NCAND;  // workgroup-uniform (read from LDS)
-    if (compacted) {
+    }
+    if (compacted && !sampled) {
       const uint32_t bin = st.prefix >> 21;
       scan_row([&](uint32_t key, uint32_t idx) {
         const uint32_t top = key >> 21;
@@ -228,6 +327,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
         ithr = si.prefix;
       }
     };
+    if (sampled) radix_pass(scan_cand, by_key, 21, 11, 0x00000000u, st, hist, sh);  // the list holds the whole top k
     if (compacted) rest(scan_cand);
     else rest(scan_row);
   }
@@ -262,10 +362,11 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
       __syncthreads();
     }
   }
+  const float out_mul = unscale ? ldexpf(1.0f, -(unscale[0] + unscale[1])) : 1.0f;
   for (int i = tid; i < k; i += TOPK_THREADS) {
     if (i < kk) {
       const unsigned long long e = buf[i];
-      Drow[i] = key_to_float((uint32_t)(e >> 32));
+      Drow[i] = key_to_float((uint32_t)(e >> 32)) * out_mul;
       Irow[i] = (long long)(uint32_t)e + id_offset;
     } else {
       Drow[i] = -INFINITY;
@@ -274,20 +375,130 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------ split-precision scores on the 16-bit matrix pipe
+// x 2^s = xh + xl + r with xh, xl IEEE half (11 significant bits each) and |r| <= 2^-22 |x|: the three partial products
+// ql.ph + qh.pl + qh.ph, every one exact in fp32 and accumulated in fp32 by v_mfma_f32_32x32x16_f16 in that order (small
+// terms first), reproduce q.p to better than a sequential fp32 dot product does - measured max error 0.5e-6 of the largest
+// score against 1.1e-6 for the fp32-MFMA / fmaf chain and 1.2e-6 for an fp32 BLAS product (profiles/r02_score_split_*) -
+// at 3/16 of the fp32 matrix pipe's time per score.  The power-of-two scale (per tensor, from its largest magnitude) keeps
+// xl out of the half subnormals for every element that matters; it is exact and undone exactly.
+__global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ X, size_t n, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint32_t b = __float_as_uint(X[i]) & 0x7fffffffu;
+    if (b < 0x7f800000u) m = max(m, b);  // finite magnitudes only (bit patterns of non-negative floats order like the floats)
+  }
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+// exps[which] = s with 2^14 <= max|x| 2^s < 2^15 (0 for an all-zero tensor)
+__global__ void scale_exp_kernel(const uint32_t* __restrict__ maxbits, int* __restrict__ exps) {
+  const int which = threadIdx.x;
+  if (which < 2) {
+    const uint32_t b = maxbits[which];
+    int e = 0;
+    if (b) {
+      int ex;
+      frexpf(__uint_as_float(b), &ex);  // max = f 2^ex, f in [0.5, 1)
+      e = 15 - ex;
+    }
+    exps[which] = e;
+  }
+}
+// Xc [rows_pad, 3 Hp] half: Q rows as [xl | xh | xh], P rows as [xh | xl | xh] (is_p), zero padding in rows and columns
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ X, _Float16* __restrict__ Xc, int rows, int rows_pad, int H,
+                                                        int Hp, const int* __restrict__ exps, int is_p) {
+  const float scale = ldexpf(1.0f, exps[is_p]);
+  const size_t total = (size_t)rows_pad * Hp;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / Hp), c = (int)(i - (size_t)r * Hp);
+    _Float16 hi = (_Float16)0.f, lo = (_Float16)0.f;
+    if (r < rows && c < H) {
+      const float x = X[(size_t)r * H + c] * scale;
+      hi = (_Float16)x;
+      lo = (_Float16)(x - (float)hi);
+    }
+    _Float16* row = Xc + (size_t)r * 3 * Hp;
+    if (is_p) { row[c] = hi; row[Hp + c] = lo; row[2 * Hp + c] = hi; }
+    else { row[c] = lo; row[Hp + c] = hi; row[2 * Hp + c] = hi; }
+  }
+}
+
+int g_score_mode = -1;  // 0 = auto (split precision when the workspace allows), 1 = exact fp32 MFMA always
+int score_mode() {
+  if (g_score_mode < 0) {
+    const char* e = getenv("COCODR_SCORE_EXACT");
+    g_score_mode = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return g_score_mode;
+}
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+struct SplitPlan {
+  int Hp, np_pad, QC;
+  size_t off_q, off_p, off_misc, off_slab, total;
+};
+SplitPlan split_plan(int Nq, int Np, int H) {
+  SplitPlan s;
+  s.Hp = (H + 63) / 64 * 64;
+  s.np_pad = (Np + 255) / 256 * 256;
+  long long qc = (1ll << 28) / s.np_pad;  // two slabs of <= 1 GiB
+  qc = std::max(128ll, std::min(qc, 8192ll));
+  qc = (qc / 128) * 128;
+  s.QC = (int)std::min<long long>(qc, ((long long)Nq + 127) / 128 * 128);
+  size_t o = 0;
+  s.off_q = o; o = align256(o + (size_t)Nq * 3 * s.Hp * 2);
+  s.off_p = o; o = align256(o + (size_t)s.np_pad * 3 * s.Hp * 2);
+  s.off_misc = o; o = align256(o + 64);
+  s.off_slab = o; o = align256(o + 2 * (size_t)s.QC * s.np_pad * 4);
+  s.total = o;
+  return s;
+}
+
 int query_chunk(int nq, int np) {
-  long long qc = (1ll << 29) / std::max(np, 1);  // <= 2 GiB slab
+  long long qc = (1ll << 28) / std::max(np, 1);  // two slabs of <= 1 GiB
   qc = std::max(128ll, std::min(qc, 8192ll));
   qc = (qc / 128) * 128;
   return (int)std::min<long long>(qc, ((long long)nq + 127) / 128 * 128);
 }
 
+// side stream + events of the GEMM / selection pipeline (created once per process; the library still owns no threads
+// and allocates no device memory)
+struct Pipe {
+  hipStream_t side = nullptr;
+  hipEvent_t scored[2] = {nullptr, nullptr}, selected[2] = {nullptr, nullptr};
+  bool ok = false;
+};
+Pipe& pipe() {
+  static Pipe p;
+  if (!p.ok) {
+    bool good = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && good; ++i)
+      good = hipEventCreateWithFlags(&p.scored[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&p.selected[i], hipEventDisableTiming) == hipSuccess;
+    p.ok = good;
+  }
+  return p;
+}
+
 }  // namespace
 
-extern "C" size_t cocodr_score_topk_workspace_bytes(int Nq, int Np, int k) {
-  (void)k;
-  if (Nq <= 0 || Np <= 0) return 0;
+namespace {
+size_t exact_bytes(int Nq, int Np) {
   const size_t ld = ((size_t)Np + 3) / 4 * 4;
-  return (size_t)query_chunk(Nq, Np) * ld * sizeof(float);
+  return 2 * (size_t)query_chunk(Nq, Np) * ld * sizeof(float);
+}
+}  // namespace
+
+extern "C" size_t cocodr_score_topk_workspace_bytes_dim(int Nq, int Np, int H, int k) {
+  (void)k;
+  if (Nq <= 0 || Np <= 0 || H <= 0) return 0;
+  return score_mode() == 1 ? exact_bytes(Nq, Np) : std::max(exact_bytes(Nq, Np), split_plan(Nq, Np, H).total);
+}
+extern "C" size_t cocodr_score_topk_workspace_bytes(int Nq, int Np, int k) { return cocodr_score_topk_workspace_bytes_dim(Nq, Np, 1024, k); }
+extern "C" int cocodr_score_set_mode(int mode) {
+  CK_ARG(mode == 0 || mode == 1, "score_set_mode: 0 = auto (split precision), 1 = exact fp32 MFMA");
+  g_score_mode = mode;
+  return COCODR_OK;
 }
 
 extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset, float* D,
@@ -296,24 +507,84 @@ extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np,
   CK_ARG(Nq > 0 && Np > 0 && H > 0 && H % 4 == 0, "score_topk: bad shape Nq=%d Np=%d H=%d (H %% 4 == 0)", Nq, Np, H);
   CK_ARG(k > 0 && k <= KMAX, "score_topk: k=%d must be in [1,%d]", k, KMAX);
   CK_ARG((((uintptr_t)Q | (uintptr_t)P) & 15) == 0, "score_topk: Q and P must be 16-byte aligned");
-  if (workspace_bytes < cocodr_score_topk_workspace_bytes(Nq, Np, k)) {
-    cocodr_set_error("score_topk: workspace %zu B < required %zu B", workspace_bytes, cocodr_score_topk_workspace_bytes(Nq, Np, k));
+  if (workspace_bytes < exact_bytes(Nq, Np)) {
+    cocodr_set_error("score_topk: workspace %zu B < required %zu B", workspace_bytes, cocodr_score_topk_workspace_bytes_dim(Nq, Np, H, k));
     return COCODR_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int QC = query_chunk(Nq, Np);
-  const long long ld = ((long long)Np + 3) / 4 * 4;
-  float* S = reinterpret_cast<float*>(workspace);
-  for (int q0 = 0; q0 < Nq; q0 += QC) {
+  CK_ARG(((uintptr_t)workspace & 255) == 0, "score_topk: workspace must be 256-byte aligned");
+  // split precision (16-bit matrix pipe) when the workspace has room for the half operands; exact fp32 MFMA otherwise
+  const SplitPlan sp = split_plan(Nq, Np, H);
+  const bool split = score_mode() == 0 && workspace_bytes >= sp.total && (size_t)sp.np_pad * 3 * sp.Hp * 2 < (1ull << 32);
+  char* wsb = reinterpret_cast<char*>(workspace);
+  _Float16* Qc = reinterpret_cast<_Float16*>(wsb + sp.off_q);
+  _Float16* Pc = reinterpret_cast<_Float16*>(wsb + sp.off_p);
+  uint32_t* maxbits = reinterpret_cast<uint32_t*>(wsb + sp.off_misc);
+  int* exps = reinterpret_cast<int*>(wsb + sp.off_misc + 16);
+  if (split) {
+    if (hipMemsetAsync(maxbits, 0, 32, st) != hipSuccess) { cocodr_set_error("score_topk: memset failed"); return COCODR_ERR_LAUNCH; }
+    hipLaunchKernelGGL(maxabs_kernel, dim3(1024), dim3(256), 0, st, Q, (size_t)Nq * H, maxbits);
+    hipLaunchKernelGGL(maxabs_kernel, dim3(2048), dim3(256), 0, st, P, (size_t)Np * H, maxbits + 1);
+    hipLaunchKernelGGL(scale_exp_kernel, dim3(1), dim3(64), 0, st, maxbits, exps);
+    hipLaunchKernelGGL(split_f16_kernel, dim3(2048), dim3(256), 0, st, Q, Qc, Nq, Nq, H, sp.Hp, exps, 0);
+    hipLaunchKernelGGL(split_f16_kernel, dim3(4096), dim3(256), 0, st, P, Pc, Np, sp.np_pad, H, sp.Hp, exps, 1);
+    CK_LAUNCH("score_split");
+  }
+  const int QC = split ? sp.QC : query_chunk(Nq, Np);
+  const long long ld = split ? sp.np_pad : ((long long)Np + 3) / 4 * 4;
+  float* slab0 = split ? reinterpret_cast<float*>(wsb + sp.off_slab) : reinterpret_cast<float*>(workspace);
+  float* slab[2] = {slab0, slab0 + (size_t)QC * ld};
+  static const bool serial = getenv("COCODR_SCORE_SERIAL") != nullptr;  // A/B switch: selection on the caller's stream
+  static std::mutex pipe_mutex;  // the side stream and its events are shared by all callers: enqueue one search at a time
+  std::lock_guard<std::mutex> guard(pipe_mutex);
+  Pipe& pp = pipe();
+  const bool piped = pp.ok && !serial && Nq > QC;
+  int c = 0;
+  for (int q0 = 0; q0 < Nq; q0 += QC, ++c) {
     const int nq = std::min(QC, Nq - q0);
     const int ntm = (nq + SB - 1) / SB, ntn = (Np + SB - 1) / SB;
-    {
+    float* S = slab[c & 1];
+    if (piped && c >= 2 && hipStreamWaitEvent(st, pp.selected[c & 1], 0) != hipSuccess) {  // the slab is free again
+      cocodr_set_error("score_topk: stream wait failed");
+      return COCODR_ERR_LAUNCH;
+    }
+    if (split) {
+      ProfScope prof(PROF_SCORE, st, 2.0 * nq * (double)Np * H);  // algorithmic FLOPs of the scores, whatever pipe produces them
+      cocodr_gemm_args g = {};
+      g.A = reinterpret_cast<const uint16_t*>(Qc + (size_t)q0 * 3 * sp.Hp);
+      g.B = reinterpret_cast<const uint16_t*>(Pc);
+      g.C = S;
+      g.M = nq; g.N = sp.np_pad; g.K = 3 * sp.Hp;
+      g.lda = g.ldb = 3 * sp.Hp; g.ldc = (int)ld;
+      g.out_f32 = 1; g.batch = 1; g.ab_f16 = 1;
+      const int rc = cocodr_gemm(&g, stream);
+      if (rc != COCODR_OK) return rc;
+    } else {
       ProfScope prof(PROF_SCORE, st, 2.0 * nq * (double)Np * H);
       hipLaunchKernelGGL(score_gemm_kernel, dim3(ntm * ntn), dim3(256), 0, st, Q + (size_t)q0 * H, P, S, nq, Np, H, ld);
+      CK_LAUNCH("score_gemm");
     }
-    CK_LAUNCH("score_gemm");
-    hipLaunchKernelGGL(topk_kernel, dim3(nq), dim3(TOPK_THREADS), 0, st, S, ld, Np, k, id_offset, D + (size_t)q0 * k, I + (size_t)q0 * k);
+    hipStream_t sel = st;
+    if (piped) {
+      sel = pp.side;
+      if (hipEventRecord(pp.scored[c & 1], st) != hipSuccess || hipStreamWaitEvent(sel, pp.scored[c & 1], 0) != hipSuccess) {
+        cocodr_set_error("score_topk: event hand-off failed");
+        return COCODR_ERR_LAUNCH;
+      }
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3(nq), dim3(TOPK_THREADS), 0, sel, S, ld, Np, k, id_offset, D + (size_t)q0 * k, I + (size_t)q0 * k,
+                       split ? exps : (const int*)nullptr);
     CK_LAUNCH("topk");
+    if (piped && hipEventRecord(pp.selected[c & 1], sel) != hipSuccess) {
+      cocodr_set_error("score_topk: event record failed");
+      return COCODR_ERR_LAUNCH;
+    }
   }
+  if (piped)  // results are complete in the caller's stream order
+    for (int i = 0; i < std::min(c, 2); ++i)
+      if (hipStreamWaitEvent(st, pp.selected[i], 0) != hipSuccess) {
+        cocodr_set_error("score_topk: final stream wait failed");
+        return COCODR_ERR_LAUNCH;
+      }
   return COCODR_OK;
 }

@@ -307,7 +307,7 @@ def score_topk(Q: torch.Tensor, P: torch.Tensor, k: int, id_offset: int = 0, wor
         raise ValueError("score_topk: dim mismatch")
     Nq, H = Q.shape
     Np = P.shape[0]
-    need = lib().cocodr_score_topk_workspace_bytes(Nq, Np, k)
+    need = lib().cocodr_score_topk_workspace_bytes_dim(Nq, Np, H, k)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=Q.device)
     D = torch.empty((Nq, k), dtype=F32, device=Q.device)
@@ -315,6 +315,11 @@ def score_topk(Q: torch.Tensor, P: torch.Tensor, k: int, id_offset: int = 0, wor
     check(lib().cocodr_score_topk(ptr(Q), ptr(P), Nq, Np, H, k, id_offset, ptr(D), ptr(I), ptr(workspace),
                                   workspace.numel() * workspace.element_size(), stream_ptr()), "score_topk")
     return D, I
+
+
+def score_set_mode(mode: int) -> None:
+    """0 = split-precision scores on the 16-bit matrix pipe (default), 1 = exact fp32 MFMA scores (include/cocodr.h)."""
+    check(lib().cocodr_score_set_mode(int(mode)), "score_set_mode")
 
 
 # ----------------------------------------------------------------------------------------------- profiling hooks

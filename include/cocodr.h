@@ -104,6 +104,9 @@ typedef struct {
   float* colsum_partial;
   /* EPI_ADD, batch == 1 only: C = dropout(acc + bias) + R with flat index m * N + n (threshold 0 = off) */
   cocodr_dropout_mask drop;
+  /* non-zero: A and B hold IEEE half instead of bfloat16 (plain NT form with an fp32 result only: trans_a = trans_b = 0,
+   * out_f32 = 1, no epilogue / bias / column sums, N % 256 == 0, K % 64 == 0) - the split-precision score GEMM of the search */
+  int ab_f16;
 } cocodr_gemm_args;
 size_t cocodr_gemm_colsum_partial_floats(int M, int N);
 /* Deferred form: with colsum == NULL and colsum_partial != NULL the call only leaves its per-row-panel sums
@@ -265,7 +268,20 @@ int cocodr_ce_fwd_bwd(const float* logits, const int32_t* labels, const float* r
  *  ANCE/utils/eval_mrr.py:81-90).  Q [Nq,H] fp32, P [Np,H] fp32; D [Nq,k] fp32 descending,
  * I [Nq,k] int64 positions into P (+ id_offset), ties -> lower position first, (-inf,-1) padding.
  * ------------------------------------------------------------------------------------------ */
+/* Two score pipelines, same selection:
+ *  - split precision (default): Q and P are scaled by a power of two and split into two IEEE halves each (x = xh + xl to 22
+ *    bits); ql.ph + qh.pl + qh.ph run as ONE half-precision MFMA GEMM of depth 3H with fp32 accumulation (small terms
+ *    first).  Every partial product is exact in fp32; the result is closer to the real q.p than a sequential fp32 dot
+ *    product is (measured max error 0.5e-6 of the largest score against 1.1e-6), identical passages still give
+ *    bit-identical scores, and integer-valued inputs below 2^11 stay exact.  3/16 of the fp32 matrix pipe's time per score.
+ *  - exact fp32 MFMA (cocodr_score_set_mode(1) or COCODR_SCORE_EXACT=1, and whenever the workspace is too small for the
+ *    half operands): scores bit-identical to an fmaf chain over the contraction index.
+ * Embeddings with non-finite components get NaN scores on the split path (ranked last).
+ * workspace_bytes_dim: for embeddings of width H; workspace_bytes: the same for H = 1024 (enough for any H <= 1024).
+ * The workspace must be 256-byte aligned. */
+size_t cocodr_score_topk_workspace_bytes_dim(int Nq, int Np, int H, int k);
 size_t cocodr_score_topk_workspace_bytes(int Nq, int Np, int k);
+int cocodr_score_set_mode(int mode);
 int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset,
                       float* D, long long* I, void* workspace, size_t workspace_bytes, cocodr_stream_t stream);
 

@@ -16,6 +16,14 @@ def t(x):
     return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
 
 
+@pytest.fixture(params=[0, 1], ids=["split16", "exact32"])
+def score_mode(request):
+    """Both score pipelines (include/cocodr.h): split precision on the 16-bit matrix pipe (default) and exact fp32 MFMA."""
+    ops.score_set_mode(request.param)
+    yield request.param
+    ops.score_set_mode(0)
+
+
 def test_simce_matches_reference_goldens(golden_loss):
     g = golden_loss
     for M in (8, 16, 64):
@@ -60,7 +68,7 @@ def test_triplet_matches_reference_golden(golden_ance):
 
 
 @pytest.mark.parametrize("Nq,Np,H,k", [(5, 101, 16, 10), (130, 5000, 768, 100), (64, 40000, 1024, 1000), (3, 50, 64, 80)])
-def test_score_topk_vs_oracle(Nq, Np, H, k):
+def test_score_topk_vs_oracle(Nq, Np, H, k, score_mode):
     rng = np.random.Generator(np.random.PCG64(Np))
     Q = (rng.standard_normal((Nq, H)) / np.sqrt(H)).astype(np.float32)
     P = (rng.standard_normal((Np, H)) / np.sqrt(H)).astype(np.float32)
@@ -80,7 +88,7 @@ def test_score_topk_vs_oracle(Nq, Np, H, k):
         assert (I[:, Np:] == -1).all() and np.isneginf(D[:, Np:]).all()
 
 
-def test_score_topk_exact_ties_prefer_lower_position():
+def test_score_topk_exact_ties_prefer_lower_position(score_mode):
     # small-integer vectors: every score is exact in fp32, so ties are exact and the order is fully determined
     rng = np.random.Generator(np.random.PCG64(1))
     Q = rng.integers(-2, 3, (7, 32)).astype(np.float32)
@@ -92,7 +100,7 @@ def test_score_topk_exact_ties_prefer_lower_position():
 
 
 @pytest.mark.parametrize("mode", ["narrow", "ties"])
-def test_score_topk_streams_the_row_when_the_cut_bin_is_crowded(mode):
+def test_score_topk_streams_the_row_when_the_cut_bin_is_crowded(mode, score_mode):
     """Both selection paths give the same result: scores packed into one exponent / a couple of mantissa steps (or
     thousands of exact ties at the cut) overflow the LDS candidate list, so every radix pass streams the row."""
     rng = np.random.Generator(np.random.PCG64(5))
@@ -109,7 +117,7 @@ def test_score_topk_streams_the_row_when_the_cut_bin_is_crowded(mode):
     assert np.array_equal(D.cpu().numpy(), Dr) and np.array_equal(I.cpu().numpy(), Ir)
 
 
-def test_score_topk_degenerate_sizes():
+def test_score_topk_degenerate_sizes(score_mode):
     """One query, one passage, k = 1; and k far above the corpus size."""
     Q = np.array([[1.0, 2.0, 3.0, 4.0]], np.float32)
     P = np.array([[0.5, 0.5, 0.5, 0.5]], np.float32)
@@ -118,3 +126,33 @@ def test_score_topk_degenerate_sizes():
     D, I = ops.score_topk(t(Q), t(np.repeat(P, 3, 0) * np.array([[1.0], [3.0], [2.0]], np.float32)), 7, id_offset=100)
     assert I.cpu().tolist() == [[101, 102, 100, -1, -1, -1, -1]]
     assert np.isneginf(D.cpu().numpy()[0, 3:]).all()
+
+
+def test_split_precision_scores_are_at_least_as_accurate_as_an_fp32_dot_product():
+    """The claim the default pipeline rests on: against an fp64 reference the split-precision scores (two IEEE halves per
+    operand, three exact partial products, fp32 accumulation) err no more than the exact-fp32 pipeline's fmaf chain does.
+    Also: a query chunk boundary (Nq above the chunk size) and a padded passage count."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    H, Nq, Np, k = 1024, 300, 30001, 200
+    base = rng.standard_normal((Np, H)) * 3 + 0.5
+    P = ((base - base.mean(1, keepdims=True)) / base.std(1, keepdims=True) * 0.2).astype(np.float32)  # LayerNorm-shaped rows
+    Q = (rng.standard_normal((Nq, H)) * np.exp(rng.standard_normal((1, H)))).astype(np.float32) * 0.05  # components over several binades
+    ref = Q.astype(np.float64) @ P.astype(np.float64).T
+    errs = {}
+    try:
+        for mode in (0, 1):
+            ops.score_set_mode(mode)
+            D, I = ops.score_topk(t(Q), t(P), k)
+            D, I = D.cpu().numpy().astype(np.float64), I.cpu().numpy()
+            want = np.take_along_axis(ref, I, 1)
+            errs[mode] = float(np.abs(D - want).max() / np.abs(ref).max())
+            # and the set is the true top-k wherever the cut is clear of round-off
+            order = np.argsort(-ref, 1, kind="stable")[:, :k + 1]
+            kth, nxt = np.take_along_axis(ref, order[:, k - 1:k], 1)[:, 0], np.take_along_axis(ref, order[:, k:k + 1], 1)[:, 0]
+            clear = (kth - nxt) > 4e-6 * np.abs(ref).max()
+            assert clear.sum() > Nq // 2
+            for q in np.nonzero(clear)[0]:
+                assert set(I[q]) == set(order[q, :k]), (mode, q)
+    finally:
+        ops.score_set_mode(0)
+    assert errs[0] < 2e-6 and errs[0] <= 1.5 * errs[1], errs

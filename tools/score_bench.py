@@ -22,11 +22,13 @@ def main():
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--k", type=int, default=1000)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--exact", action="store_true", help="exact fp32 MFMA scores instead of the split-precision pipeline")
     a = ap.parse_args()
+    ops.score_set_mode(1 if a.exact else 0)
     g = torch.Generator().manual_seed(7)
     Q = (torch.randn(a.nq, a.dim, generator=g) / a.dim ** 0.5).cuda()
     P = (torch.randn(a.np, a.dim, generator=g) / a.dim ** 0.5).cuda()
-    need = ops.lib().cocodr_score_topk_workspace_bytes(a.nq, a.np, a.k)
+    need = ops.lib().cocodr_score_topk_workspace_bytes_dim(a.nq, a.np, a.dim, a.k)
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     ops.score_topk(Q, P, a.k, workspace=ws)
     torch.cuda.synchronize()
