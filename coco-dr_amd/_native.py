@@ -59,6 +59,10 @@ class EncoderLayout(C.Structure):
         "rstd2", "emb_mean", "emb_rstd", "bwd_scratch", "bwd_bytes", "bwd_dx")]
 
 
+class PackedBatch(C.Structure):  # mirrors cocodr_packed_batch
+    _fields_ = [(n, c_void_p) for n in ("ids", "positions", "mask", "seq_off", "cls_slot")] + [(n, c_int) for n in ("B", "T", "max_len", "drop_L")]
+
+
 class LambPlan(C.Structure):  # mirrors cocodr_lamb_plan
     _fields_ = [("chunk_start", c_void_p), ("chunk_len", c_void_p), ("chunk_seg", c_void_p), ("seg_chunk_begin", c_void_p),
                 ("nchunk", c_int), ("nseg", c_int)]
@@ -84,6 +88,18 @@ SIGNATURES = {
     "cocodr_embed_ln_fwd_drop": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, C.POINTER(DropoutMask), c_void_p]),
     "cocodr_embed_ln_bwd_drop": (c_int, [c_void_p] * 14 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
     "cocodr_ln_bwd_drop": (c_int, [c_void_p] * 11 + [c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
+    "cocodr_attn_fwd_packed": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_int, c_void_p]),
+    "cocodr_attn_bwd_packed": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_int, c_void_p]),
+    "cocodr_embed_ln_fwd_packed": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_float, C.POINTER(DropoutMask), c_void_p]),
+    "cocodr_embed_bwd_packed_partial_floats": (c_size_t, [c_int, c_int]),
+    "cocodr_embed_ln_bwd_packed": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
+    "cocodr_ln_fwd_slots": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "cocodr_encoder_layout_packed": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),
+    "cocodr_encoder_fwd_packed": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), C.POINTER(PackedBatch), c_int,
+                                          c_void_p, c_size_t, c_void_p]),
+    "cocodr_encoder_bwd_packed": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), C.POINTER(EmbedGrads),
+                                          C.POINTER(LayerGrads), C.POINTER(PackedBatch), c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
+                                          c_void_p]),
     "cocodr_embed_ln_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "cocodr_embed_bwd_partial_floats": (c_size_t, [c_int, c_int]),
     "cocodr_embed_ln_bwd": (c_int, [c_void_p] * 14 + [c_int, c_int, c_int, c_int, c_void_p]),

@@ -133,27 +133,48 @@ __device__ __forceinline__ void for_keep_klane(uint32_t pairbase, uint32_t Lh, u
     }
 }
 
+// Packed (variable-length) batches: sequence b occupies rows [seq_off[b], seq_off[b + 1]) of the [T, .] activations, an
+// extent that is a multiple of 32 rows (its tail rows are padding with mask 0); lse is [heads, T].  seq_off == NULL: the
+// padded layout, B sequences of Lmax rows.  drop_L: the padded length the dropout indices are defined on, so a packed
+// and a padded run of the same batch draw the same masks.
+struct AttnPacked {
+  const int32_t* seq_off;
+  int T, drop_L;
+};
+#define ATTN_EXTENT(Lmax, pk)                                                                     \
+  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;                                    \
+  int L = (Lmax), dropL = (Lmax);                                                                 \
+  size_t row0 = (size_t)b * (Lmax), lse0 = ((size_t)b * heads + h) * (Lmax);                      \
+  if ((pk).seq_off) {                                                                             \
+    const int o_ = (pk).seq_off[b];                                                               \
+    L = (pk).seq_off[b + 1] - o_;                                                                 \
+    row0 = (size_t)o_;                                                                            \
+    lse0 = (size_t)h * (pk).T + o_;                                                               \
+    dropL = (pk).drop_L;                                                                          \
+  }
+
 // three waves per SIMD (168 registers): at the default bound hipcc parks the O accumulators in AGPRs and pays an
 // accvgpr read + write per element for every online-softmax rescale
 template <bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
-                                                       uint16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
-                                                       const cocodr_dropout_mask dm) {
+                                                       uint16_t* __restrict__ ctx, float* __restrict__ lse, int Lmax, int H,
+                                                       const cocodr_dropout_mask dm, const AttnPacked pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ATTN_EXTENT(Lmax, pk)
+  if ((int)blockIdx.z * 128 >= L) return;  // (packed batches: a sequence shorter than the longest has fewer query blocks)
   char* Kt = smem;
   char* Vt = smem + L * 128;
   float* madd = reinterpret_cast<float*>(smem + 2 * L * 128);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
   const int ld = 3 * H;
-  const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
+  const uint16_t* base = qkv + row0 * ld + h * 64;
   stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
   stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4);
   // additive key mask in units of the raw q.k scores; it seeds the S accumulators, so no add per element later.  -2e5 raw
   // = -3.6e4 in the exponent: exp2 underflows to an exact 0 against any real score, and a row whose keys are ALL masked
   // still gets a finite softmax over its raw scores (what adding finfo.min to every key gives the reference); a seed
   // of -1e30 would leave the fma below with a rounding residue of ~1e22 there.
-  for (int i = tid; i < L; i += 256) madd[i] = mask[b * L + i] != 0 ? 0.f : -2.0e5f;
+  for (int i = tid; i < L; i += 256) madd[i] = mask[row0 + i] != 0 ? 0.f : -2.0e5f;
   const int q0 = blockIdx.z * 128 + wid * 32;
   const int half = lane >> 5;
   bf16x8 qf[4];
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = kMaskNeg, lsum = 0.f;
   const float sl2 = kScale * kLog2e;
-  const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, q0 + (lane & 31), L) + 2 * half : 0u;
+  const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, q0 + (lane & 31), dropL) + 2 * half : 0u;
 
   for (int kb = 0; kb < L / 32; ++kb) {
     f32x16 sacc;
@@ -213,8 +234,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
     }
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-  if (lane < 32) lse[((size_t)b * heads + h) * L + q0 + lane] = (m + __log2f(ltot)) * kLn2;
-  store_acc_T(ctx + (size_t)(b * L + q0) * H + h * 64, H, o, (DROP ? dm.scale : 1.0f) / ltot, lane);
+  if (lane < 32) lse[lse0 + q0 + lane] = (m + __log2f(ltot)) * kLn2;
+  store_acc_T(ctx + (row0 + q0) * H + h * 64, H, o, (DROP ? dm.scale : 1.0f) / ltot, lane);
 }
 
 #if defined(COCODR_ABL_TIMELINE)  // tools/attn_timeline.py builds: per-workgroup phase stamps (100 MHz wall clock)
@@ -292,10 +313,11 @@ __device__ __forceinline__ void qk_bias_store(float* partial, float qacc, int b,
 template <bool QKSUM, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                           const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
-                                                          const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L,
+                                                          const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int Lmax,
                                                           int H, int stagger, float* __restrict__ qk_partial,
-                                                          const cocodr_dropout_mask dm) {
+                                                          const cocodr_dropout_mask dm, const AttnPacked pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ATTN_EXTENT(Lmax, pk)
   char* Qt = smem;
   char* Kt = smem + L * 128;
   char* Vt = smem + 2 * L * 128;
@@ -306,11 +328,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   float* delta = lse2 + L;
   const float inv_s = DROP ? 1.0f / dm.scale : 1.0f, out_s = DROP ? dm.scale : 1.0f;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
   const int ld = 3 * H;
-  const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
-  const uint16_t* obase = ctx + (size_t)b * L * H + h * 64;
-  const uint16_t* dobase = dctx + (size_t)b * L * H + h * 64;
+  const uint16_t* base = qkv + row0 * ld + h * 64;
+  const uint16_t* obase = ctx + row0 * H + h * 64;
+  const uint16_t* dobase = dctx + row0 * H + h * 64;
   // Two workgroups share a CU and all of them take the same time: un-staggered, both stage (an HBM burst of the whole
   // grid) and then both compute, round after round.  The first-round workgroup in the upper LDS slot starts
   // `stagger` x 4096 clocks late once, so from then on one workgroup's loads run under the other's MFMAs.
@@ -333,8 +354,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       oreg[i] = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
     }
   for (int i = tid; i < L; i += 256) {
-    madd[i] = mask[b * L + i] != 0 ? 0.f : kMaskNeg;
-    lse2[i] = lse[((size_t)b * heads + h) * L + i] * kLog2e;
+    madd[i] = mask[row0 + i] != 0 ? 0.f : kMaskNeg;
+    lse2[i] = lse[lse0 + i] * kLog2e;
   }
 #pragma unroll
   for (int i = 0; i < kMaxIt; ++i)
@@ -370,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     }
     const float my_lse = lse2[qb * 32 + (lane & 31)];
     const float my_ndelta = delta[qb * 32 + (lane & 31)];  // -delta of this lane's query (DROP: / s)
-    const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, qb * 32 + (lane & 31), L) + 2 * half : 0u;
+    const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, qb * 32 + (lane & 31), dropL) + 2 * half : 0u;
     f32x16 dq[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -412,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     ATTN_STAMP(2);
     // (in front of the store: behind it hipcc interleaves the two and spills 72 SGPRs of lane masks instead of 9)
     if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale * out_s, lane);
-    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane);
+    store_acc_T16(dqkv + (row0 + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane);
   }
   ATTN_STAMP(3);
   if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
@@ -427,8 +448,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     }
     const float my_madd = madd[kb * 32 + (lane & 31)];
     // pair of (query 4 half, this lane's key); a query step is L / 2 pairs
-    const uint32_t Lh = (uint32_t)L >> 1, kshift = (lane & 1) << 4;
-    const uint32_t keypair = DROP ? prob_row_pair(b * heads + h, 4 * half, L) + (uint32_t)((kb * 32 + (lane & 31)) >> 1) : 0u;
+    const uint32_t Lh = (uint32_t)dropL >> 1, kshift = (lane & 1) << 4;
+    const uint32_t keypair = DROP ? prob_row_pair(b * heads + h, 4 * half, dropL) + (uint32_t)((kb * 32 + (lane & 31)) >> 1) : 0u;
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -483,9 +504,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       }
     }
     ATTN_STAMP(4);
-    uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
-    store_acc_T16(row0 + H, ld, dk, kScale * out_s, lane);
-    store_acc_T16(row0 + 2 * H, ld, dv, out_s, lane);
+    uint16_t* out0 = dqkv + (row0 + kb * 32) * ld + h * 64;
+    store_acc_T16(out0 + H, ld, dk, kScale * out_s, lane);
+    store_acc_T16(out0 + 2 * H, ld, dv, out_s, lane);
   }
   ATTN_STAMP(5);
 }
@@ -503,23 +524,23 @@ __device__ __forceinline__ bf16x8 frag_rows_global(const uint16_t* base, int ld,
 template <bool QKSUM, bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                              const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
-                                                             const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H,
-                                                             float* __restrict__ qk_partial, const cocodr_dropout_mask dm) {
+                                                             const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int Lmax, int H,
+                                                             float* __restrict__ qk_partial, const cocodr_dropout_mask dm, const AttnPacked pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ATTN_EXTENT(Lmax, pk)
   const float inv_s = DROP ? 1.0f / dm.scale : 1.0f, out_s = DROP ? dm.scale : 1.0f;
   float qacc = 0.f;
   char* Kt = smem;
   char* Vt = smem + L * 128;
   float* madd = reinterpret_cast<float*>(smem + 2 * L * 128);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
-  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
   const int ld = 3 * H;
-  const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
-  const uint16_t* obase = ctx + (size_t)b * L * H + h * 64;
-  const uint16_t* dobase = dctx + (size_t)b * L * H + h * 64;
+  const uint16_t* base = qkv + row0 * ld + h * 64;
+  const uint16_t* obase = ctx + row0 * H + h * 64;
+  const uint16_t* dobase = dctx + row0 * H + h * 64;
   stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
   stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4);
-  for (int i = tid; i < L; i += 256) madd[i] = mask[b * L + i] != 0 ? 0.f : kMaskNeg;
+  for (int i = tid; i < L; i += 256) madd[i] = mask[row0 + i] != 0 ? 0.f : kMaskNeg;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float sl2 = kScale * kLog2e;
@@ -539,8 +560,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
       for (int e = 0; e < 8; ++e) dpart += df[e] * ofv[e];
     }
     const float my_ndelta = -(dpart + __shfl_xor(dpart, 32, 64)) * inv_s;  // lanes l and l^32 hold the two halves of row l & 31
-    const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, qb * 32 + (lane & 31), L) + 2 * half : 0u;
-    const float my_lse = lse[((size_t)b * heads + h) * L + qb * 32 + (lane & 31)] * kLog2e;
+    const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, qb * 32 + (lane & 31), dropL) + 2 * half : 0u;
+    const float my_lse = lse[lse0 + qb * 32 + (lane & 31)] * kLog2e;
     f32x16 dq[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -580,7 +601,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
       }
     }
     if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale * out_s, lane);
-    store_acc_T16(dqkv + (size_t)(b * L + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane);
+    store_acc_T16(dqkv + (row0 + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane);
   }
   if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
 }
@@ -588,20 +609,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 template <bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
                                                               const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
-                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int L, int H,
-                                                              const cocodr_dropout_mask dm) {
+                                                              const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int Lmax, int H,
+                                                              const cocodr_dropout_mask dm, const AttnPacked pk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ATTN_EXTENT(Lmax, pk)
   const float inv_s = DROP ? 1.0f / dm.scale : 1.0f, out_s = DROP ? dm.scale : 1.0f;
   char* Qt = smem;
   char* Dt = smem + L * 128;
   float* lse2 = reinterpret_cast<float*>(smem + 2 * L * 128);
   float* delta = lse2 + L;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
-  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
   const int ld = 3 * H;
-  const uint16_t* base = qkv + (size_t)b * L * ld + h * 64;
-  const uint16_t* obase = ctx + (size_t)b * L * H + h * 64;
-  const uint16_t* dobase = dctx + (size_t)b * L * H + h * 64;
+  const uint16_t* base = qkv + row0 * ld + h * 64;
+  const uint16_t* obase = ctx + row0 * H + h * 64;
+  const uint16_t* dobase = dctx + row0 * H + h * 64;
   stage_tile_dma(Qt, base, ld, L, lane, wid, 4);
   for (int q0 = 0; q0 < L * 8; q0 += 256 * 4) {  // dO through registers (delta = rowsum(dO * O)), four 16-B chunks per thread a round
     uint4 dreg[4], oreg[4];
@@ -630,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
       if (ch == 0) delta[row] = DROP ? -part * inv_s : -part;  // negated: it seeds the dP accumulators below
     }
   }
-  for (int i = tid; i < L; i += 256) lse2[i] = lse[((size_t)b * heads + h) * L + i] * kLog2e;
+  for (int i = tid; i < L; i += 256) lse2[i] = lse[lse0 + i] * kLog2e;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float sl2 = kScale * kLog2e;
@@ -642,9 +663,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
       kf[s] = frag_rows_global(base + H, ld, kb * 32, s, lane);
       vf[s] = frag_rows_global(base + 2 * H, ld, kb * 32, s, lane);
     }
-    const float my_madd = mask[b * L + kb * 32 + (lane & 31)] != 0 ? 0.f : kMaskNeg;
-    const uint32_t Lh = (uint32_t)L >> 1, kshift = (lane & 1) << 4;
-    const uint32_t keypair = DROP ? prob_row_pair(b * heads + h, 4 * half, L) + (uint32_t)((kb * 32 + (lane & 31)) >> 1) : 0u;
+    const float my_madd = mask[row0 + kb * 32 + (lane & 31)] != 0 ? 0.f : kMaskNeg;
+    const uint32_t Lh = (uint32_t)dropL >> 1, kshift = (lane & 1) << 4;
+    const uint32_t keypair = DROP ? prob_row_pair(b * heads + h, 4 * half, dropL) + (uint32_t)((kb * 32 + (lane & 31)) >> 1) : 0u;
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -698,9 +719,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
         }
       }
     }
-    uint16_t* row0 = dqkv + (size_t)(b * L + kb * 32) * ld + h * 64;
-    store_acc_T16(row0 + H, ld, dk, kScale * out_s, lane);
-    store_acc_T16(row0 + 2 * H, ld, dv, out_s, lane);
+    uint16_t* out0 = dqkv + (row0 + kb * 32) * ld + h * 64;
+    store_acc_T16(out0 + H, ld, dk, kScale * out_s, lane);
+    store_acc_T16(out0 + 2 * H, ld, dv, out_s, lane);
   }
 }
 
@@ -718,13 +739,15 @@ template <class K>
 void lds_attr(K kern) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
 }  // namespace
 
-extern "C" int cocodr_attn_fwd_drop(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
-                                    const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
+namespace {
+int attn_fwd_any(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads, const cocodr_dropout_mask* drop,
+                 const AttnPacked& pk, cocodr_stream_t stream) {
   CK_ARG(qkv && mask && ctx && lse, "attn_fwd: null pointer");
   CK_ARG(B > 0 && heads > 0, "attn_fwd: bad shape");
   CK_ARG(L % 32 == 0 && L >= 32 && L <= 512, "attn_fwd: L=%d must be a multiple of 32 in [32,512]", L);
   const bool dropping = drop != nullptr && drop->threshold != 0;
-  CK_ARG(!dropping || ((unsigned long long)B * heads * L * L <= (1ull << 33) && drop->threshold < 65536),
+  const int dl = pk.seq_off ? pk.drop_L : L;
+  CK_ARG(!dropping || ((unsigned long long)B * heads * dl * dl <= (1ull << 33) && drop->threshold < 65536),
          "attn_fwd: dropout indexes at most 2^33 probabilities");
   const int H = heads * 64;
   const size_t lds = (size_t)2 * L * 128 + (size_t)L * 4;
@@ -737,23 +760,42 @@ extern "C" int cocodr_attn_fwd_drop(const uint16_t* qkv, const int32_t* mask, ui
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_ATTN, st, 4.0 * B * heads * (double)L * L * 64);
   hipLaunchKernelGGL(dropping ? attn_fwd_kernel<true> : attn_fwd_kernel<false>, dim3(heads, B, (L + 127) / 128), dim3(256), lds, st, qkv,
-                     mask, ctx, lse, L, H, dropping ? *drop : kNoDrop);
+                     mask, ctx, lse, L, H, dropping ? *drop : kNoDrop, pk);
   CK_LAUNCH("attn_fwd");
   return COCODR_OK;
+}
+int check_packed(const int32_t* seq_off, int B, int T, int max_len, int drop_L) {
+  CK_ARG(seq_off != nullptr && B > 0 && T >= 32 * B && T % 32 == 0, "attn(packed): need seq_off, T %% 32 == 0 and T >= 32 B (T=%d, B=%d)", T, B);
+  CK_ARG(max_len % 32 == 0 && max_len >= 32 && max_len <= 512 && drop_L >= max_len, "attn(packed): max_len=%d must be a multiple of 32 in [32,512] and <= drop_L=%d", max_len, drop_L);
+  return COCODR_OK;
+}
+}  // namespace
+
+extern "C" int cocodr_attn_fwd_drop(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
+                                    const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
+  return attn_fwd_any(qkv, mask, ctx, lse, B, L, heads, drop, AttnPacked{nullptr, 0, 0}, stream);
+}
+extern "C" int cocodr_attn_fwd_packed(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, const int32_t* seq_off, int B,
+                                      int T, int max_len, int heads, const cocodr_dropout_mask* drop, int drop_L,
+                                      cocodr_stream_t stream) {
+  if (int rc = check_packed(seq_off, B, T, max_len, drop_L)) return rc;
+  return attn_fwd_any(qkv, mask, ctx, lse, B, max_len, heads, drop, AttnPacked{seq_off, T, drop_L}, stream);
 }
 extern "C" int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
                                cocodr_stream_t stream) {
   return cocodr_attn_fwd_drop(qkv, mask, ctx, lse, B, L, heads, nullptr, stream);
 }
 
-extern "C" int cocodr_attn_bwd_drop(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
-                                    const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
-                                    const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
+namespace {
+int attn_bwd_any(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx, const float* lse, uint16_t* dqkv,
+                 float* qk_bias_partial, int B, int L, int heads, const cocodr_dropout_mask* drop, const AttnPacked& pk,
+                 cocodr_stream_t stream) {
   CK_ARG(qkv && mask && ctx && dctx && lse && dqkv, "attn_bwd: null pointer");
   CK_ARG(B > 0 && heads > 0, "attn_bwd: bad shape");
   CK_ARG(L % 32 == 0 && L >= 32 && L <= 512, "attn_bwd: L=%d must be a multiple of 32 in [32,512]", L);
   const bool dropping = drop != nullptr && drop->threshold != 0;
-  CK_ARG(!dropping || ((unsigned long long)B * heads * L * L <= (1ull << 33) && drop->threshold < 65536),
+  const int dl = pk.seq_off ? pk.drop_L : L;
+  CK_ARG(!dropping || ((unsigned long long)B * heads * dl * dl <= (1ull << 33) && drop->threshold < 65536),
          "attn_bwd: dropout indexes at most 2^33 probabilities");
   const cocodr_dropout_mask dm = dropping ? *drop : kNoDrop;
   const int H = heads * 64;
@@ -774,10 +816,10 @@ extern "C" int cocodr_attn_bwd_drop(const uint16_t* qkv, const int32_t* mask, co
     const size_t lds_q = (size_t)2 * L * 128 + (size_t)L * 4, lds_kv = (size_t)2 * L * 128 + (size_t)2 * L * 4;
     auto kq = dropping ? (qks ? attn_bwd_dq_kernel<true, true> : attn_bwd_dq_kernel<false, true>)
                        : (qks ? attn_bwd_dq_kernel<true, false> : attn_bwd_dq_kernel<false, false>);
-    hipLaunchKernelGGL(kq, dim3(heads, B), dim3(256), lds_q, st, qkv, mask, ctx, dctx, lse, dqkv, L, H, qk_bias_partial, dm);
+    hipLaunchKernelGGL(kq, dim3(heads, B), dim3(256), lds_q, st, qkv, mask, ctx, dctx, lse, dqkv, L, H, qk_bias_partial, dm, pk);
     CK_LAUNCH("attn_bwd(dq)");
     hipLaunchKernelGGL(dropping ? attn_bwd_dkv_kernel<true> : attn_bwd_dkv_kernel<false>, dim3(heads, B), dim3(256), lds_kv, st, qkv, mask,
-                       ctx, dctx, lse, dqkv, L, H, dm);
+                       ctx, dctx, lse, dqkv, L, H, dm, pk);
     CK_LAUNCH("attn_bwd(dkv)");
     return COCODR_OK;
   }
@@ -789,9 +831,22 @@ extern "C" int cocodr_attn_bwd_drop(const uint16_t* qkv, const int32_t* mask, co
   auto kf = dropping ? (qks ? attn_bwd_kernel<true, true> : attn_bwd_kernel<false, true>)
                      : (qks ? attn_bwd_kernel<true, false> : attn_bwd_kernel<false, false>);
   hipLaunchKernelGGL(kf, dim3(heads, B), dim3(256), lds, st, qkv, mask, ctx, dctx, lse, dqkv, L, H,
-                     2 * lds <= 160 * 1024 && heads * B > 512 ? stagger : 0, qk_bias_partial, dm);
+                     2 * lds <= 160 * 1024 && heads * B > 512 && !pk.seq_off ? stagger : 0, qk_bias_partial, dm, pk);
   CK_LAUNCH("attn_bwd");
   return COCODR_OK;
+}
+}  // namespace
+
+extern "C" int cocodr_attn_bwd_drop(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
+                                    const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
+                                    const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
+  return attn_bwd_any(qkv, mask, ctx, dctx, lse, dqkv, qk_bias_partial, B, L, heads, drop, AttnPacked{nullptr, 0, 0}, stream);
+}
+extern "C" int cocodr_attn_bwd_packed(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
+                                      const float* lse, uint16_t* dqkv, float* qk_bias_partial, const int32_t* seq_off, int B, int T,
+                                      int max_len, int heads, const cocodr_dropout_mask* drop, int drop_L, cocodr_stream_t stream) {
+  if (int rc = check_packed(seq_off, B, T, max_len, drop_L)) return rc;
+  return attn_bwd_any(qkv, mask, ctx, dctx, lse, dqkv, qk_bias_partial, B, max_len, heads, drop, AttnPacked{seq_off, T, drop_L}, stream);
 }
 extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
                                const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,

@@ -34,8 +34,8 @@ struct BwdLayout {
   size_t total;
 };
 
-BwdLayout bwd_layout(const cocodr_config* c, int B, int L) {
-  const size_t M = (size_t)B * L, H = c->hidden, I = c->inter, N = c->layers;
+BwdLayout bwd_layout_m(const cocodr_config* c, size_t M, int B, int L) {
+  const size_t H = c->hidden, I = c->inter, N = c->layers;
   Carver cv;
   BwdLayout b;
   b.dy2 = cv.take(N * M * H * 2);
@@ -49,7 +49,7 @@ BwdLayout bwd_layout(const cocodr_config* c, int B, int L) {
   b.ln_partial = cv.take(cocodr_ln_bwd_partial_floats((int)M, (int)H) * 4);
   b.colsum_partial = cv.take(std::max(cocodr_colsum_partial_floats((int)M, (int)std::max(I, 3 * H), (int)N),
                                       cocodr_gemm_colsum_partial_floats((int)M, (int)std::max(I, 3 * H))) * 4);
-  b.emb_partial = cv.take(cocodr_embed_bwd_partial_floats(L, (int)H) * 4);
+  b.emb_partial = cv.take(std::max(cocodr_embed_bwd_partial_floats(L, (int)H), cocodr_embed_bwd_packed_partial_floats((int)M, (int)H)) * 4);
   b.ln2_slots = cv.take(N * cocodr_ln_bwd_partial_floats((int)M, (int)H) * 4);
   b.ln1_slots = cv.take(N * cocodr_ln_bwd_partial_floats((int)M, (int)H) * 4);
   b.b1_slots = cv.take(N * cocodr_gemm_colsum_partial_floats((int)M, (int)I) * 4);
@@ -58,6 +58,7 @@ BwdLayout bwd_layout(const cocodr_config* c, int B, int L) {
   b.total = cv.off;
   return b;
 }
+BwdLayout bwd_layout(const cocodr_config* c, int B, int L) { return bwd_layout_m(c, (size_t)B * L, B, L); }
 
 int check_cfg(const cocodr_config* c, int B, int L) {
   CK_ARG(c != nullptr, "encoder: null config");
@@ -99,10 +100,32 @@ cocodr_gemm_args gemm_base(const void* A, const void* B, void* C, int M, int N, 
 
 }  // namespace
 
+namespace {
+int check_packed_batch(const cocodr_config* c, const cocodr_packed_batch* pk) {
+  CK_ARG(pk != nullptr && pk->mask && pk->seq_off, "encoder(packed): null batch");
+  TRY(check_cfg(c, 1, 32));
+  CK_ARG(pk->B > 0 && pk->T >= 32 * pk->B && pk->T % 32 == 0, "encoder(packed): T=%d must be a multiple of 32 and >= 32 B (B=%d)", pk->T, pk->B);
+  CK_ARG(pk->max_len >= 32 && pk->max_len % 32 == 0 && pk->max_len <= 512 && pk->max_len <= c->max_pos && pk->drop_L >= pk->max_len,
+         "encoder(packed): max_len=%d must be a multiple of 32 in [32, min(512,%d)] and <= drop_L=%d", pk->max_len, c->max_pos, pk->drop_L);
+  return COCODR_OK;
+}
+int layout_m(const cocodr_config* c, size_t M, int B, int L, int training, cocodr_encoder_layout_t* out);
+}  // namespace
+
 extern "C" int cocodr_encoder_layout(const cocodr_config* c, int B, int L, int training, cocodr_encoder_layout_t* out) {
   TRY(check_cfg(c, B, L));
   CK_ARG(out != nullptr, "encoder_layout: null out");
-  const size_t M = (size_t)B * L, H = c->hidden, I = c->inter;
+  return layout_m(c, (size_t)B * L, B, L, training, out);
+}
+extern "C" int cocodr_encoder_layout_packed(const cocodr_config* c, int T, int B, int training, cocodr_encoder_layout_t* out) {
+  TRY(check_cfg(c, 1, 32));
+  CK_ARG(out != nullptr && B > 0 && T >= 32 * B && T % 32 == 0, "encoder_layout_packed: T=%d must be a multiple of 32 and >= 32 B (B=%d)", T, B);
+  return layout_m(c, (size_t)T, B, 32, training, out);
+}
+
+namespace {
+int layout_m(const cocodr_config* c, size_t M, int B, int L, int training, cocodr_encoder_layout_t* out) {
+  const size_t H = c->hidden, I = c->inter;
   const size_t NL = training ? c->layers : 1;
   Carver cv;
   out->hidden = cv.take((size_t)(c->layers + 1) * M * H * 2);
@@ -122,16 +145,17 @@ extern "C" int cocodr_encoder_layout(const cocodr_config* c, int B, int L, int t
   out->emb_mean = cv.take(M * 4);
   out->emb_rstd = cv.take(M * 4);
   out->bwd_scratch = cv.off;
-  out->bwd_bytes = training ? bwd_layout(c, B, L).total : 0;
-  out->bwd_dx = training ? cv.off + bwd_layout(c, B, L).dxb : 0;
+  out->bwd_bytes = training ? bwd_layout_m(c, M, B, L).total : 0;
+  out->bwd_dx = training ? cv.off + bwd_layout_m(c, M, B, L).dxb : 0;
   out->total_bytes = cv.off + out->bwd_bytes;
   return COCODR_OK;
 }
+}  // namespace
 
 namespace {
 int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp, const int32_t* ids,
                      const int32_t* mask, int B, int L, int training, void* arena, size_t arena_bytes, bool from_hidden,
-                     cocodr_stream_t stream, int layer_lo = 0, int layer_hi = -1);
+                     cocodr_stream_t stream, int layer_lo = 0, int layer_hi = -1, const cocodr_packed_batch* pk = nullptr);
 }
 
 extern "C" int cocodr_encoder_bwd_layout(const cocodr_config* c, int B, int L, cocodr_encoder_bwd_layout_t* out) {
@@ -162,6 +186,13 @@ extern "C" int cocodr_encoder_fwd_range(const cocodr_config* c, const cocodr_emb
   return encoder_fwd_impl(c, emb, lp, ids, mask, B, L, training, arena, arena_bytes, false, stream, layer_lo, layer_hi);
 }
 
+extern "C" int cocodr_encoder_fwd_packed(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
+                                         const cocodr_packed_batch* batch, int training, void* arena, size_t arena_bytes,
+                                         cocodr_stream_t stream) {
+  CK_ARG(emb && batch && batch->ids && batch->positions && batch->cls_slot, "encoder_fwd_packed: null pointer");
+  return encoder_fwd_impl(c, emb, lp, nullptr, nullptr, 0, 0, training, arena, arena_bytes, false, stream, 0, -1, batch);
+}
+
 extern "C" int cocodr_stack_fwd(const cocodr_config* c, const cocodr_layer_params* lp, const int32_t* mask, int B, int L,
                                 int training, void* arena, size_t arena_bytes, cocodr_stream_t stream) {
   return encoder_fwd_impl(c, nullptr, lp, nullptr, mask, B, L, training, arena, arena_bytes, true, stream);
@@ -170,9 +201,15 @@ extern "C" int cocodr_stack_fwd(const cocodr_config* c, const cocodr_layer_param
 namespace {
 int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp, const int32_t* ids,
                      const int32_t* mask, int B, int L, int training, void* arena, size_t arena_bytes, bool from_hidden,
-                     cocodr_stream_t stream, int layer_lo, int layer_hi) {
+                     cocodr_stream_t stream, int layer_lo, int layer_hi, const cocodr_packed_batch* pk) {
   cocodr_encoder_layout_t lay;
-  TRY(cocodr_encoder_layout(c, B, L, training, &lay));
+  if (pk) {  // packed batch: T rows, per-sequence extents (ids / mask / B come from the batch)
+    TRY(check_packed_batch(c, pk));
+    TRY(cocodr_encoder_layout_packed(c, pk->T, pk->B, training, &lay));
+    ids = pk->ids; mask = pk->mask; B = pk->B; L = pk->max_len;
+  } else {
+    TRY(cocodr_encoder_layout(c, B, L, training, &lay));
+  }
   CK_ARG(lp && mask && arena, "encoder_fwd: null pointer");
   if (arena_bytes < lay.total_bytes) {
     cocodr_set_error("encoder_fwd: arena %zu B < required %zu B", arena_bytes, lay.total_bytes);
@@ -180,7 +217,7 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   }
   CK_ARG(((uintptr_t)arena & 255) == 0, "encoder_fwd: arena must be 256-byte aligned");
   char* base = (char*)arena;
-  const int M = B * L, H = c->hidden, I = c->inter, NL = c->layers;
+  const int M = pk ? pk->T : B * L, H = c->hidden, I = c->inter, NL = c->layers;
   const size_t ls = training ? 1 : 0;  // per-layer stride multiplier
   uint16_t* hidden = (uint16_t*)(base + lay.hidden);
   float* cls = (float*)(base + lay.cls_f32);
@@ -192,8 +229,14 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   if (!from_hidden && layer_lo == 0) {  // a bare layer stack (Condenser head) starts from hidden slot 0, filled by the caller
     cocodr_dropout_mask de;
     TRY(cocodr_dropout_mask_for(dropping ? c->hidden_dropout : 0.0, c->drop_seed, c->drop_call, 0, COCODR_DROP_EMBED, &de));
-    TRY(cocodr_embed_ln_fwd_drop(ids, emb->word, emb->pos, emb->type0, emb->ln_g, emb->ln_b, hidden, (float*)(base + lay.emb_mean),
-                                 (float*)(base + lay.emb_rstd), B, L, H, c->vocab, c->ln_eps, &de, stream));
+    if (pk) {
+      CK_ARG(pk->ids && pk->positions, "encoder_fwd(packed): the embedding needs ids and positions");
+      TRY(cocodr_embed_ln_fwd_packed(pk->ids, pk->positions, emb->word, emb->pos, emb->type0, emb->ln_g, emb->ln_b, hidden,
+                                     (float*)(base + lay.emb_mean), (float*)(base + lay.emb_rstd), M, H, c->vocab, c->ln_eps, &de, stream));
+    } else {
+      TRY(cocodr_embed_ln_fwd_drop(ids, emb->word, emb->pos, emb->type0, emb->ln_g, emb->ln_b, hidden, (float*)(base + lay.emb_mean),
+                                   (float*)(base + lay.emb_rstd), B, L, H, c->vocab, c->ln_eps, &de, stream));
+    }
   }
   for (int l = layer_lo; l < layer_hi; ++l) {
     const cocodr_layer_params& w = lp[l];
@@ -218,7 +261,8 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     cocodr_gemm_args g = gemm_base(x_in, w.wqkv, qkv, M, 3 * H, H, H, H, 3 * H, 0, 0);
     g.bias = w.bqkv;
     TRY(cocodr_gemm(&g, stream));
-    TRY(cocodr_attn_fwd_drop(qkv, mask, ctx, lse, B, L, c->heads, &ld.probs, stream));
+    if (pk) TRY(cocodr_attn_fwd_packed(qkv, mask, ctx, lse, pk->seq_off, B, M, pk->max_len, c->heads, &ld.probs, pk->drop_L, stream));
+    else TRY(cocodr_attn_fwd_drop(qkv, mask, ctx, lse, B, L, c->heads, &ld.probs, stream));
     g = gemm_base(ctx, w.wo, y1, M, H, H, H, H, H, 0, 0);
     g.bias = w.bo; g.epi = COCODR_EPI_ADD; g.R = x_in; g.ldr = H; g.drop = ld.attn_out;
     TRY(cocodr_gemm(&g, stream));
@@ -229,18 +273,45 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     g = gemm_base(h, w.w2, y2, M, H, I, I, I, H, 0, 0);
     g.bias = w.b2; g.epi = COCODR_EPI_ADD; g.R = x1; g.ldr = H; g.drop = ld.ffn_out;
     TRY(cocodr_gemm(&g, stream));
-    TRY(cocodr_ln_fwd(y2, w.ln2_g, w.ln2_b, x_out, mean2, rstd2, (l == NL - 1) ? cls : nullptr, L, M, H, c->ln_eps, stream));
+    TRY(cocodr_ln_fwd_slots(y2, w.ln2_g, w.ln2_b, x_out, mean2, rstd2, (l == NL - 1) ? cls : nullptr, L, pk ? pk->cls_slot : nullptr, M, H,
+                            c->ln_eps, stream));
   }
   return COCODR_OK;
 }
 }  // namespace
 
+namespace {
+int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
+                     const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const int32_t* ids, const int32_t* mask,
+                     const uint16_t* d_in, int B, int L, void* arena, size_t arena_bytes, int layer_hi, int layer_lo, int do_embed,
+                     cocodr_stream_t stream, const cocodr_packed_batch* pk);
+}
 extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
                                         const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const int32_t* ids,
                                         const int32_t* mask, const uint16_t* d_in, int B, int L, void* arena,
                                         size_t arena_bytes, int layer_hi, int layer_lo, int do_embed, cocodr_stream_t stream) {
+  return encoder_bwd_impl(c, emb, lp, eg, lg, ids, mask, d_in, B, L, arena, arena_bytes, layer_hi, layer_lo, do_embed, stream, nullptr);
+}
+extern "C" int cocodr_encoder_bwd_packed(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
+                                         const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const cocodr_packed_batch* batch,
+                                         const uint16_t* d_in, void* arena, size_t arena_bytes, int layer_hi, int layer_lo,
+                                         int do_embed, cocodr_stream_t stream) {
+  CK_ARG(batch != nullptr, "encoder_bwd_packed: null batch");
+  return encoder_bwd_impl(c, emb, lp, eg, lg, nullptr, nullptr, d_in, 0, 0, arena, arena_bytes, layer_hi, layer_lo, do_embed, stream, batch);
+}
+namespace {
+int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
+                     const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const int32_t* ids, const int32_t* mask,
+                     const uint16_t* d_in, int B, int L, void* arena, size_t arena_bytes, int layer_hi, int layer_lo, int do_embed,
+                     cocodr_stream_t stream, const cocodr_packed_batch* pk) {
   cocodr_encoder_layout_t lay;
-  TRY(cocodr_encoder_layout(c, B, L, 1, &lay));
+  if (pk) {
+    TRY(check_packed_batch(c, pk));
+    TRY(cocodr_encoder_layout_packed(c, pk->T, pk->B, 1, &lay));
+    ids = pk->ids; mask = pk->mask; B = pk->B; L = pk->max_len;
+  } else {
+    TRY(cocodr_encoder_layout(c, B, L, 1, &lay));
+  }
   CK_ARG(lp && lg && mask && arena && (!do_embed || (emb && eg && ids)), "encoder_bwd: null pointer");
   CK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= c->layers, "encoder_bwd: bad layer range [%d,%d)", layer_lo, layer_hi);
   CK_ARG(d_in != nullptr || layer_hi < c->layers, "encoder_bwd: the first (top) range needs the upstream gradient d_in");
@@ -248,7 +319,7 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
     cocodr_set_error("encoder_bwd: arena %zu B < required %zu B (was the forward run with training=1?)", arena_bytes, lay.total_bytes);
     return COCODR_ERR_WORKSPACE;
   }
-  const int M = B * L, H = c->hidden, I = c->inter, NL = c->layers;
+  const int M = pk ? pk->T : B * L, H = c->hidden, I = c->inter, NL = c->layers;
   // uniform layer stride of the gradient blocks (see header)
   long long s_wqkv = 0, s_wo = 0, s_w1 = 0, s_w2 = 0, s_bqkv = 0, s_bo = 0, s_b1 = 0, s_b2 = 0;
   if (NL > 1) {
@@ -262,7 +333,7 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
     }
   }
   char* base = (char*)arena;
-  const BwdLayout bl = bwd_layout(c, B, L);
+  const BwdLayout bl = pk ? bwd_layout_m(c, (size_t)M, B, 32) : bwd_layout(c, B, L);
   char* bb = base + lay.bwd_scratch;
   uint16_t* hidden = (uint16_t*)(base + lay.hidden);
   uint16_t* dy2_all = (uint16_t*)(bb + bl.dy2);
@@ -364,7 +435,9 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
     else if (!drop_probs) { g.colsum = gr.bqkv + 2 * H; g.colsum_partial = cs_partial; }
     TRY(cocodr_gemm(&g, stream));
     // the query / key bias gradients are column sums of dQ | dK: the attention backward leaves four partial rows per sequence
-    TRY(cocodr_attn_bwd_drop(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, B, L, c->heads, &ld.probs, stream));
+    if (pk) TRY(cocodr_attn_bwd_packed(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, pk->seq_off, B, M, pk->max_len, c->heads,
+                                       &ld.probs, pk->drop_L, stream));
+    else TRY(cocodr_attn_bwd_drop(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, B, L, c->heads, &ld.probs, stream));
     if (!defer) TRY(cocodr_reduce_partials(bqk_slots + li * bqk_slot, gr.bqkv, nullptr, nullptr, 4 * B, 1, 2 * H, 1, 0, hst));
     if (drop_probs) TRY(cocodr_colsum(dqkv + 2 * H, gr.bqkv + 2 * H, cs_partial, M, H, 3 * H, 1, 0, 0, stream));
     g = gemm_base(dqkv, w.wqkv, dxb, M, H, 3 * H, 3 * H, H, H, 0, 1);  // dx = dqkv Wqkv + dy1 (residual branch)
@@ -376,9 +449,16 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
     CK_ARG(layer_lo == 0, "encoder_bwd: the embedding backward belongs to the range that ends at layer 0");
     cocodr_dropout_mask de;
     TRY(cocodr_dropout_mask_for(dropping ? c->hidden_dropout : 0.0, c->drop_seed, c->drop_call, 0, COCODR_DROP_EMBED, &de));
-    TRY(cocodr_embed_ln_bwd_drop(dx, ids, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
-                                 (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial,
-                                 B, L, H, c->vocab, &de, stream));
+    if (pk) {
+      CK_ARG(pk->ids && pk->positions, "encoder_bwd(packed): the embedding needs ids and positions");
+      TRY(cocodr_embed_ln_bwd_packed(dx, pk->ids, pk->positions, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
+                                     (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial, M,
+                                     pk->max_len, H, c->vocab, &de, stream));
+    } else {
+      TRY(cocodr_embed_ln_bwd_drop(dx, ids, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
+                                   (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial,
+                                   B, L, H, c->vocab, &de, stream));
+    }
   }
   if (NG == 0) return COCODR_OK;
 
@@ -411,6 +491,7 @@ extern "C" int cocodr_encoder_bwd_range(const cocodr_config* c, const cocodr_emb
   }
   return COCODR_OK;
 }
+}  // namespace
 
 extern "C" int cocodr_encoder_bwd(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp,
                                   const cocodr_embed_grads* eg, const cocodr_layer_grads* lg, const int32_t* ids,

@@ -114,13 +114,13 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int32_t* __rest
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            uint16_t* __restrict__ out, float* __restrict__ mean_o,
                                                            float* __restrict__ rstd_o, int M, int L, int H, int vocab, float eps,
-                                                           const cocodr_dropout_mask dm) {
+                                                           const cocodr_dropout_mask dm, const int32_t* __restrict__ positions) {
   const int lane = threadIdx.x & 63, nch = H >> 2;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     int id = ids[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     RowVec r;
-    embed_gather(word, pos, type0, id, row % L, H, nch, lane, r);
+    embed_gather(word, pos, type0, id, positions ? positions[row] : row % L, H, nch, lane, r);  // packed batches carry their position ids
     float mean, rstd;
     row_stats(r, nch, lane, H, eps, mean, rstd);
     ln_apply(r, gamma, beta, nch, lane, mean, rstd);
@@ -135,7 +135,8 @@ template <int NC, bool FULL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const uint16_t* __restrict__ y, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, uint16_t* __restrict__ out,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                     float* __restrict__ cls_out, int cls_stride, int M, int H, float eps) {
+                                                     float* __restrict__ cls_out, int cls_stride, int M, int H, float eps,
+                                                     const int32_t* __restrict__ cls_slot) {
   const int lane = threadIdx.x & 63, nch = FULL ? 64 * NC : (H >> 2);
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     RowVecT<NC> r;
@@ -145,8 +146,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const uint16_t* __restrict_
     ln_apply(r, gamma, beta, nch, lane, mean, rstd);
     store_bf16_row(out + (size_t)row * H, nch, lane, r);
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
-    if (cls_out && row % cls_stride == 0) {
-      float* dst = cls_out + (size_t)(row / cls_stride) * H;
+    const int slot = !cls_out ? -1 : (cls_slot ? cls_slot[row] : (row % cls_stride == 0 ? row / cls_stride : -1));
+    if (slot >= 0) {  // fp32 copy of a sequence's first row (packed batches name the rows: cls_slot[row] = sequence or -1)
+      float* dst = cls_out + (size_t)slot * H;
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
@@ -386,6 +388,58 @@ __global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_kernel(const uint16_t
   block_reduce_store(dp, red, prow + 2 * H, nch, tid);
 }
 
+// Packed batches: rows are tokens in arbitrary (sequence, position) order, so the position-embedding gradient goes by fp32
+// atomics like the word rows (dpos zeroed by the caller side of the entry point); partial rows [block][3][H] = dgamma,
+// dbeta, sum of dx (the segment-0 type embedding's gradient).
+__global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_packed_kernel(const uint16_t* __restrict__ dout, const int32_t* __restrict__ ids,
+                                                                  const int32_t* __restrict__ positions, const float* __restrict__ word,
+                                                                  const float* __restrict__ pos, const float* __restrict__ type0,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                                  const float* __restrict__ rstd_i, float* __restrict__ dword,
+                                                                  float* __restrict__ dpos, float* __restrict__ partial, int T, int H,
+                                                                  int vocab, const cocodr_dropout_mask dm) {
+  __shared__ __attribute__((aligned(16))) float red[NW * MAXC * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
+  RowVec dg, db, dp;
+  zero_row(dg);
+  zero_row(db);
+  zero_row(dp);
+  for (int row = blockIdx.x * NW + wid; row < T; row += gridDim.x * NW) {
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int l = positions[row];
+    RowVec d, x;
+    load_bf16_row(dout + (size_t)row * H, nch, lane, d);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(d.v[i][e]));
+    if (wave_max(amax) == 0.f) continue;  // alignment padding rows carry an exactly-zero gradient
+    embed_gather(word, pos, type0, id, l, H, nch, lane, x);
+    if (dm.threshold) drop_row(d, row, H, nch, lane, dm);
+    ln_bwd_row(d, x, gamma, nch, lane, H, mean_i[row], rstd_i[row], dg, db);
+    float* wrow = dword + (size_t)id * H;
+    float* prow = dpos + (size_t)l * H;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dp.v[i][e] += d.v[i][e];
+          atomicAdd(wrow + c * 4 + e, d.v[i][e]);
+          atomicAdd(prow + c * 4 + e, d.v[i][e]);
+        }
+      }
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * 3 * H;
+  block_reduce_store(dg, red, out, nch, tid);
+  block_reduce_store(db, red, out + H, nch, tid);
+  block_reduce_store(dp, red, out + 2 * H, nch, tid);
+}
+
 // dpos[l][:] = sum over batch splits of the position partial rows
 __global__ __launch_bounds__(256) void embed_dpos_kernel(const float* __restrict__ partial, float* __restrict__ dpos, int L, int H, int S) {
   const int l = blockIdx.x;
@@ -613,8 +667,19 @@ extern "C" int cocodr_embed_ln_fwd_drop(const int32_t* ids, const float* word, c
   CK_ARG(B > 0 && L > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_fwd: bad shape B=%d L=%d H=%d", B, L, H);
   const int M = B * L;
   hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta,
-                     out, mean, rstd, M, L, H, vocab, eps, drop_or_none(drop));
+                     out, mean, rstd, M, L, H, vocab, eps, drop_or_none(drop), (const int32_t*)nullptr);
   CK_LAUNCH("embed_ln_fwd");
+  return COCODR_OK;
+}
+extern "C" int cocodr_embed_ln_fwd_packed(const int32_t* ids, const int32_t* positions, const float* word, const float* pos,
+                                          const float* type0, const float* gamma, const float* beta, uint16_t* out, float* mean,
+                                          float* rstd, int T, int H, int vocab, float eps, const cocodr_dropout_mask* drop,
+                                          cocodr_stream_t stream) {
+  CK_ARG(ids && positions && word && pos && type0 && gamma && beta && out && mean && rstd, "embed_ln_fwd(packed): null pointer");
+  CK_ARG(T > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_fwd(packed): bad shape T=%d H=%d", T, H);
+  hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(row_grid(T)), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta,
+                     out, mean, rstd, T, 1, H, vocab, eps, drop_or_none(drop), positions);
+  CK_LAUNCH("embed_ln_fwd(packed)");
   return COCODR_OK;
 }
 extern "C" int cocodr_embed_ln_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
@@ -652,14 +717,40 @@ extern "C" int cocodr_embed_ln_bwd_drop(const uint16_t* dout, const int32_t* ids
 
 extern "C" int cocodr_ln_fwd(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean, float* rstd,
                              float* cls_out, int cls_stride, int M, int H, float eps, cocodr_stream_t stream) {
+  return cocodr_ln_fwd_slots(y, gamma, beta, out, mean, rstd, cls_out, cls_stride, nullptr, M, H, eps, stream);
+}
+extern "C" int cocodr_ln_fwd_slots(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean, float* rstd,
+                                   float* cls_out, int cls_stride, const int32_t* cls_slot, int M, int H, float eps,
+                                   cocodr_stream_t stream) {
   CK_ARG(y && gamma && beta && out && mean && rstd, "ln_fwd: null pointer");
   CK_ARG(M > 0 && row_shape_ok(H), "ln_fwd: bad shape M=%d H=%d", M, H);
-  CK_ARG(!cls_out || cls_stride > 0, "ln_fwd: cls_stride must be positive");
+  CK_ARG(!cls_out || cls_slot || cls_stride > 0, "ln_fwd: cls_stride must be positive");
   auto kern = H == 768 ? ln_fwd_kernel<3, true> : (H < 768 ? ln_fwd_kernel<3, false> : (H == 1024 ? ln_fwd_kernel<MAXC, true> : ln_fwd_kernel<MAXC, false>));
   hipLaunchKernelGGL(kern, dim3(row_grid(M)), dim3(256), 0, (hipStream_t)stream, y, gamma, beta, out, mean, rstd, cls_out,
-                     cls_stride > 0 ? cls_stride : 1, M, H, eps);
+                     cls_stride > 0 ? cls_stride : 1, M, H, eps, cls_slot);
   CK_LAUNCH("ln_fwd");
   return COCODR_OK;
+}
+
+extern "C" size_t cocodr_embed_bwd_packed_partial_floats(int T, int H) { return (size_t)std::min(256, (T + NW - 1) / NW) * 3 * H; }
+extern "C" int cocodr_embed_ln_bwd_packed(const uint16_t* dout, const int32_t* ids, const int32_t* positions, const float* word,
+                                          const float* pos, const float* type0, const float* gamma, const float* mean,
+                                          const float* rstd, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                                          float* partial, int T, int max_len, int H, int vocab, const cocodr_dropout_mask* drop,
+                                          cocodr_stream_t stream) {
+  CK_ARG(dout && ids && positions && word && pos && type0 && gamma && mean && rstd && dword && dpos && dtype0 && dgamma && dbeta && partial,
+         "embed_ln_bwd(packed): null pointer");
+  CK_ARG(T > 0 && max_len > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_bwd(packed): bad shape T=%d H=%d", T, H);
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = std::min(256, (T + NW - 1) / NW);
+  if (hipMemsetAsync(dpos, 0, (size_t)max_len * H * sizeof(float), st) != hipSuccess) {  // rows [0, max_len) are rewritten, as on the padded path
+    cocodr_set_error("embed_ln_bwd(packed): memset failed");
+    return COCODR_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(embed_ln_bwd_packed_kernel, dim3(nblk), dim3(RB_THREADS), 0, st, dout, ids, positions, word, pos, type0, gamma, mean,
+                     rstd, dword, dpos, partial, T, H, vocab, drop_or_none(drop));
+  CK_LAUNCH("embed_ln_bwd(packed)");
+  return launch_reduce(partial, dgamma, dbeta, dtype0, nblk, 3, H, 1, 0, st);
 }
 
 extern "C" size_t cocodr_ln_bwd_partial_floats(int M, int H) { return (size_t)ln_bwd_blocks(M) * 3 * H; }

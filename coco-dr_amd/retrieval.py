@@ -38,15 +38,25 @@ def merged_order(n: int, world: int) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------- encode
 @torch.no_grad()
 def encode_corpus(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, batch_size: int = 512,
-                  record_ids: Optional[torch.Tensor] = None, is_query: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Eval-mode ``query_emb`` / ``body_emb`` over a token cache, fp32 [n,H] kept ON DEVICE plus the record ids -
-    the reference copies every batch to the host (``.cpu().numpy()``, run_ann_data_gen.py:191-199); here the shard
-    stays in HBM for the search that follows."""
+                  record_ids: Optional[torch.Tensor] = None, is_query: bool = False, pack: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval-mode ``query_emb`` / ``body_emb`` over a token cache (under ``torch.no_grad()``, as run_ann_data_gen.py:183 does), fp32
+    [n,H] kept ON DEVICE plus the record ids - the reference copies every batch to the host (``.cpu().numpy()``,
+    run_ann_data_gen.py:191-199); here the shard stays in HBM for the search that follows.  ``pack``: store each batch's
+    sequences back to back instead of padded (same embeddings, no work on the padding rows; include/cocodr.h)."""
     n = input_ids.shape[0]
     fn = model.query_emb if is_query else model.body_emb
     outs = []
-    for s in range(0, n, batch_size):
-        outs.append(fn(input_ids[s:s + batch_size], attention_mask[s:s + batch_size]).float())
+    bert = getattr(model, "bert", None)
+    was = getattr(bert, "pack_sequences", False)
+    if bert is not None:
+        bert.pack_sequences = bool(pack) or was
+    try:
+        with torch.no_grad():
+            for s in range(0, n, batch_size):
+                outs.append(fn(input_ids[s:s + batch_size], attention_mask[s:s + batch_size]).float())
+    finally:
+        if bert is not None:
+            bert.pack_sequences = was
     emb = torch.cat(outs) if outs else torch.empty((0, model.config.hidden_size), device=input_ids.device)
     ids = torch.arange(n, dtype=torch.int64) if record_ids is None else record_ids
     return emb, ids

@@ -389,6 +389,58 @@ int cocodr_encoder_bwd_range(const cocodr_config* cfg, const cocodr_embed_params
                              int layer_lo, int do_embed, cocodr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Packed (variable-length) batches - SURVEY 7 (iii).  The reference pads every sequence of a batch to one length and
+ * lets the attention mask hide the padding (COCO/data.py:135-144, ANCE/utils/util.py); on MS MARCO-shaped batches 40 % of
+ * the token rows are padding.  Here the B sequences may be stored back to back instead: sequence b owns rows
+ * [seq_off[b], seq_off[b+1]) of every [T, .] activation, an extent that is a multiple of 32 rows >= its length (mask [T]
+ * is 0 on the at most 31 alignment rows at the end of an extent), seq_off is int32 [B+1] in device memory, T % 32 == 0,
+ * max_len = the longest extent.  Every row kernel and GEMM simply sees T rows; the kernels below are the ones that need
+ * the sequence structure.  lse is [heads, T] on this layout.  drop_L: the padded length the dropout indices of the
+ * attention probabilities are defined on ((b, h, q, k) -> ((b heads + h) drop_L + q) drop_L + k), so a packed and a padded
+ * run of one batch draw the same masks; hidden-state dropout indexes rows, which differ between the layouts.
+ * Results at the real tokens equal the padded path's (same arithmetic per token); padding rows hold other values.
+ * ------------------------------------------------------------------------------------------ */
+int cocodr_attn_fwd_packed(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, const int32_t* seq_off, int B,
+                           int T, int max_len, int heads, const cocodr_dropout_mask* drop, int drop_L, cocodr_stream_t stream);
+int cocodr_attn_bwd_packed(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx, const float* lse,
+                           uint16_t* dqkv, float* qk_bias_partial, const int32_t* seq_off, int B, int T, int max_len, int heads,
+                           const cocodr_dropout_mask* drop, int drop_L, cocodr_stream_t stream);
+/* positions: int32 [T], the position id of every row (0.. within its sequence) */
+int cocodr_embed_ln_fwd_packed(const int32_t* ids, const int32_t* positions, const float* word, const float* pos,
+                               const float* type0, const float* gamma, const float* beta, uint16_t* out, float* mean,
+                               float* rstd, int T, int H, int vocab, float eps, const cocodr_dropout_mask* drop,
+                               cocodr_stream_t stream);
+size_t cocodr_embed_bwd_packed_partial_floats(int T, int H);
+int cocodr_embed_ln_bwd_packed(const uint16_t* dout, const int32_t* ids, const int32_t* positions, const float* word,
+                               const float* pos, const float* type0, const float* gamma, const float* mean, const float* rstd,
+                               float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta, float* partial, int T,
+                               int max_len, int H, int vocab, const cocodr_dropout_mask* drop, cocodr_stream_t stream);
+/* cocodr_ln_fwd whose fp32 [CLS] copies are named row by row: cls_slot int32 [M], -1 or the row of cls_out a row goes to */
+int cocodr_ln_fwd_slots(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean, float* rstd,
+                        float* cls_out, int cls_stride, const int32_t* cls_slot, int M, int H, float eps,
+                        cocodr_stream_t stream);
+
+/* Whole-encoder calls on a packed batch.  ids / positions / mask / cls_slot are int32 [T] (cls_slot: b on the first row of
+ * sequence b, -1 elsewhere); the arena layout is cocodr_encoder_layout_packed's (every [M, .] block has T rows, cls_f32 B
+ * rows, lse [heads, T]).  The backward mirrors cocodr_encoder_bwd_range (same ranges, same gradient contract). */
+typedef struct {
+  const int32_t* ids;
+  const int32_t* positions;
+  const int32_t* mask;
+  const int32_t* seq_off;
+  const int32_t* cls_slot;
+  int B, T, max_len, drop_L;
+} cocodr_packed_batch;
+int cocodr_encoder_layout_packed(const cocodr_config* cfg, int T, int B, int training, cocodr_encoder_layout_t* out);
+int cocodr_encoder_fwd_packed(const cocodr_config* cfg, const cocodr_embed_params* emb, const cocodr_layer_params* layers_host,
+                              const cocodr_packed_batch* batch, int training, void* arena, size_t arena_bytes,
+                              cocodr_stream_t stream);
+int cocodr_encoder_bwd_packed(const cocodr_config* cfg, const cocodr_embed_params* emb, const cocodr_layer_params* layers_host,
+                              const cocodr_embed_grads* emb_grads, const cocodr_layer_grads* grads_host,
+                              const cocodr_packed_batch* batch, const uint16_t* d_in, void* arena, size_t arena_bytes,
+                              int layer_hi, int layer_lo, int do_embed, cocodr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * On-device Condenser / coCondenser collator (COCO/data.py:24-156): per span a random truncation window of
  * max_seq_length - 2 tokens (:101-117), the whole-word-mask proxy (:44-55, 68-99: words = a token plus its "##"
  * continuations, shuffled, taken greedily up to round(len * mlm_probability) tokens), [CLS] .. [SEP] + padding

@@ -1,0 +1,175 @@
+"""Packed (variable-length) batches: sequences stored back to back with 32-row alignment instead of padded to one length
+(include/cocodr.h "Packed batches", SURVEY 7 iii).  The arithmetic per real token is the padded path's, so the packed path is
+checked against the padded one (tight tolerance) and against the numpy oracle (the usual bf16 tolerances)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cocodr_amd  # noqa: E402
+from cocodr_amd import ops  # noqa: E402
+from cocodr_amd import _native as N  # noqa: E402
+from cocodr_amd._native import check, lib, ptr, stream_ptr  # noqa: E402
+from cocodr_amd.modeling import BertDotNLL, CoCondenserForPretraining, CocoBertConfig, CocoBertModel, PackedIndex  # noqa: E402
+import oracle as O  # noqa: E402  (checker only)
+
+DEV = "cuda"
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def ragged_batch(B, L, V, seed, lens=None):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if lens is None:
+        lens = np.clip(np.rint(rng.normal(0.6 * L, 0.25 * L, B)), 3, L).astype(np.int64)
+        lens[0] = L
+    ids = rng.integers(5, V, (B, L))
+    mask = (np.arange(L)[None] < np.asarray(lens)[:, None]).astype(np.int64)
+    return ids * mask, mask, np.asarray(lens)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def cfg_small(**kw):
+    d = dict(vocab_size=700, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256, max_position_embeddings=512,
+             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    d.update(kw)
+    return d
+
+
+def build(cfgd, P):
+    m = CocoBertModel(CocoBertConfig(**cfgd))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    return m.to(DEV)
+
+
+def test_packed_index_layout():
+    ids, mask, lens = ragged_batch(5, 64, 700, 1, lens=[64, 1, 33, 32, 7])
+    pk = PackedIndex.build(t(ids).int(), t(mask).int())
+    assert pk.seq_off.cpu().tolist() == [0, 64, 96, 160, 192, 224] and pk.T == 224 and pk.max_len == 64
+    pos = pk.positions.cpu().numpy()
+    assert pos[:64].tolist() == list(range(64)) and pos[64:96].tolist() == list(range(32))
+    m = pk.mask.cpu().numpy()
+    assert m[:64].all() and m[64] == 1 and not m[65:96].any() and m[96:129].all() and not m[129:160].any()
+    assert pk.cls_slot.cpu().numpy()[[0, 64, 96, 160, 192]].tolist() == [0, 1, 2, 3, 4] and (pk.cls_slot.cpu().numpy() >= 0).sum() == 5
+    got = pk.ids.cpu().numpy()
+    assert np.array_equal(got[96:129], ids[2, :33]) and not got[129:160].any()
+    # a mask with a hole is not a prefix mask: such a batch runs padded
+    bad = mask.copy()
+    bad[0, 5] = 0
+    assert PackedIndex.build(t(ids).int(), t(bad).int()) is None
+
+
+@pytest.mark.parametrize("L,heads", [(64, 2), (128, 4), (256, 2), (384, 2)])
+def test_packed_attention_matches_per_sequence_padded_attention(L, heads):
+    B, H = 5, heads * 64
+    _, mask, lens = ragged_batch(B, L, 100, L)
+    pk = PackedIndex.build(t(mask).int(), t(mask).int())
+    g = torch.Generator().manual_seed(L)
+    qkv_pad = (torch.randn(B * L, 3 * H, generator=g)).to(torch.bfloat16).to(DEV)
+    dctx_pad = (torch.randn(B * L, H, generator=g)).to(torch.bfloat16).to(DEV)
+    qkv = qkv_pad[pk.src].contiguous()
+    dctx = dctx_pad[pk.src].contiguous()
+    ctx = torch.empty((pk.T, H), dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty((heads, pk.T), dtype=torch.float32, device=DEV)
+    check(lib().cocodr_attn_fwd_packed(ptr(qkv), ptr(pk.mask), ptr(ctx), ptr(lse), ptr(pk.seq_off), B, pk.T, pk.max_len, heads, None, L,
+                                       stream_ptr()), "attn_fwd_packed")
+    rctx, rlse = ops.attn_fwd(qkv_pad, t(mask).int(), B, L, heads)
+    real = pk.mask.bool()
+    assert torch.equal(ctx[real], rctx[pk.src][real])  # same arithmetic per real token: masked key blocks contribute exact zeros
+    rl = rlse.permute(1, 0, 2).reshape(heads, B * L)[:, pk.src]
+    assert torch.allclose(lse[:, real], rl[:, real], atol=1e-6, rtol=1e-6)
+    dqkv = torch.empty_like(qkv)
+    part = torch.empty((4 * B, 2 * H), dtype=torch.float32, device=DEV)
+    check(lib().cocodr_attn_bwd_packed(ptr(qkv), ptr(pk.mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(part), ptr(pk.seq_off), B, pk.T,
+                                       pk.max_len, heads, None, L, stream_ptr()), "attn_bwd_packed")
+    # the padded reference needs zero upstream gradient on its padding rows (the packed layout does not have them)
+    dpad = torch.zeros_like(dctx_pad)
+    dpad[pk.src] = dctx
+    rd, rpart = ops.attn_bwd(qkv_pad, t(mask).int(), rctx, dpad, rlse, B, L, heads, qk_bias=True)
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert rel_l2(dqkv[real][:, sl], rd[pk.src][real][:, sl]) < 2e-3, name
+    assert rel_l2(part.view(B, 4, 2 * H).sum(1), rpart.view(B, 4, 2 * H).sum(1)) < 2e-3
+
+
+@pytest.mark.parametrize("L", [64, 128])
+def test_packed_forward_equals_padded_forward(L):
+    cfgd = cfg_small()
+    P = O.make_params(O.OracleConfig(**{k: v for k, v in cfgd.items() if "dropout" not in k}), 5, std=0.08)
+    m = build(cfgd, P).eval()
+    ids, mask, lens = ragged_batch(9, L, cfgd["vocab_size"], 3)
+    with torch.no_grad():
+        ref = m(input_ids=t(ids), attention_mask=t(mask), output_hidden_states=True)
+        m.pack_sequences = True
+        got = m(input_ids=t(ids), attention_mask=t(mask), output_hidden_states=True)
+    assert torch.equal(got.cls_fp32, ref.cls_fp32)
+    valid = t(mask).bool()
+    for a, b in zip(got.hidden_states, ref.hidden_states):
+        assert torch.equal(a[valid], b[valid])
+    # odd lengths / L not a multiple of 32 (the wrapper pads to 32 first) and a batch that cannot be packed
+    ids2, mask2, _ = ragged_batch(4, 50, cfgd["vocab_size"], 4)
+    with torch.no_grad():
+        got2 = m(input_ids=t(ids2), attention_mask=t(mask2))
+        m.pack_sequences = False
+        ref2 = m(input_ids=t(ids2), attention_mask=t(mask2))
+    assert got2.last_hidden_state.shape == ref2.last_hidden_state.shape == (4, 50, cfgd["hidden_size"])
+    assert torch.equal(got2.cls_fp32, ref2.cls_fp32)
+
+
+def test_packed_training_step_matches_padded_step_and_oracle():
+    cfgd = cfg_small()
+    ocfg = O.OracleConfig(**{k: v for k, v in cfgd.items() if "dropout" not in k})
+    P = O.make_params(ocfg, 6, std=0.08)
+    ids, mask, lens = ragged_batch(8, 64, cfgd["vocab_size"], 7)
+    res = {}
+    for packed in (False, True):
+        m = build(cfgd, P)
+        m.pack_sequences = packed
+        model = CoCondenserForPretraining(m)
+        loss = model({"input_ids": t(ids), "attention_mask": t(mask)}, None)
+        loss.backward()
+        res[packed] = (float(loss), {k: v.detach().float().cpu().numpy() for k, v in m.hf_named_grads()})
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0])
+    for name, ref in res[False][1].items():
+        if name.endswith("key.bias"):
+            continue
+        assert rel_l2(res[True][1][name], ref) < 5e-3, (name, rel_l2(res[True][1][name], ref))
+    hs, cache = O.encoder_fwd(P, ocfg, ids, mask, keep_cache=True)
+    ref_loss, dE = O.contrastive_loss_grad(O.cls_embedding(hs[-1]).copy(), 1)
+    assert abs(res[True][0] - ref_loss) < 2e-2 * abs(ref_loss)  # raw [CLS] logits O(100) at H = 128: the padded path sits at the same 1 % here
+    d_last = np.zeros_like(hs[-1])
+    d_last[:, 0] = dE
+    G = O.encoder_bwd(P, ocfg, cache, d_last)
+    for name in ("encoder.layer.0.attention.self.query.weight", "encoder.layer.2.output.dense.weight", "embeddings.position_embeddings.weight",
+                 "embeddings.LayerNorm.weight", "encoder.layer.1.intermediate.dense.bias", "embeddings.token_type_embeddings.weight"):
+        assert rel_l2(res[True][1][name], G[name]) < 8e-2, (name, rel_l2(res[True][1][name], G[name]))
+    rows = np.unique(ids[mask.astype(bool)])
+    assert rel_l2(res[True][1]["embeddings.word_embeddings.weight"][rows], G["embeddings.word_embeddings.weight"][rows]) < 8e-2
+
+
+def test_packed_ance_step_and_attention_dropout_draw_the_padded_masks():
+    """BertDotNLL on packed batches; with dropout on the attention probabilities only, the packed run reproduces the padded
+    run (the probability masks are indexed on the padded length in both layouts)."""
+    cfgd = cfg_small(num_hidden_layers=2, attention_probs_dropout_prob=0.2)
+    B = 4
+    q = ragged_batch(B, 32, cfgd["vocab_size"], 1)
+    a = ragged_batch(B, 64, cfgd["vocab_size"], 2)
+    b = ragged_batch(B, 64, cfgd["vocab_size"], 3)
+    res = {}
+    for packed in (False, True):
+        torch.manual_seed(0)
+        model = BertDotNLL(CocoBertConfig(**cfgd)).to(DEV).train()
+        model.bert.dropout_seed = 11
+        model.bert.pack_sequences = packed
+        loss, _acc, logits = model(t(q[0]), t(q[1]), t(a[0]), t(a[1]), t(b[0]), t(b[1]))
+        loss.backward()
+        res[packed] = (float(loss), logits.detach().clone(), model.bert.flat_decay.grad.detach().clone())
+    assert abs(res[True][0] - res[False][0]) < 1e-4 * max(1.0, abs(res[False][0]))
+    assert torch.allclose(res[True][1], res[False][1], rtol=1e-4, atol=1e-4)
+    assert rel_l2(res[True][2], res[False][2]) < 5e-3
