@@ -214,10 +214,18 @@ class EncoderOutput:
     tuple-unpacking (ANCE/model/models.py:228 indexes ``outputs1[0]``)."""
 
     def __init__(self, last_hidden_state, hidden_states=None, cls_fp32=None):
-        self.last_hidden_state = last_hidden_state
+        # ``last_hidden_state`` may be a zero-argument callable (packed batches: the padded [B, L, H] view of the last layer is
+        # only materialised for callers that read it - every reference wrapper consumes the [CLS] rows alone)
+        self._last = last_hidden_state
         self.pooler_output = None
         self.hidden_states = hidden_states
         self.cls_fp32 = cls_fp32
+
+    @property
+    def last_hidden_state(self):
+        if callable(self._last):
+            self._last = self._last()
+        return self._last
 
     def __getitem__(self, i):
         return (self.last_hidden_state, self.pooler_output, self.hidden_states)[i]
@@ -329,7 +337,7 @@ class _PackedEncoderFn(torch.autograd.Function):
         ctx.arena = arena if training else None
         model._last_hidden_states = hidden
         ctx.set_materialize_grads(False)
-        return pk.unpack(hidden[NL]), cls.clone()
+        return hidden[NL], cls.clone()  # the last layer stays packed [T, H]; PackedIndex.unpack (differentiable) pads it on demand
 
     @staticmethod
     def backward(ctx, d_last, d_cls):
@@ -342,7 +350,9 @@ class _PackedEncoderFn(torch.autograd.Function):
         if d_last is None:
             d16 = torch.zeros((pk.T, H), dtype=torch.bfloat16, device=d_cls.device)
         else:
-            d16 = d_last.reshape(pk.B * pk.L, H)[pk.src].to(torch.bfloat16).contiguous()
+            d16 = d_last.to(torch.bfloat16).contiguous()
+            if d_cls is not None and d16.data_ptr() == d_last.data_ptr():
+                d16 = d16.clone()
         if d_cls is not None:
             d16[pk.cls_rows] += d_cls.to(torch.bfloat16)
         gd, gn = model._run_backward_packed(pk, d16, ctx.arena)
@@ -755,9 +765,16 @@ class CocoBertModel(nn.Module):
         else:
             last, cls = _EncoderFn.apply(self.flat_decay, self.flat_nodecay, ids, mask, self, torch.is_grad_enabled())
         hs = None
-        if output_hidden_states and pk is not None:
-            hs = tuple(pk.unpack(h)[:, :L] for h in self._last_hidden_states[:-1].unbind(0)) + (last[:, :L],)
-        elif output_hidden_states:
+        if pk is not None:
+            last_packed = last
+            last = (lambda: pk.unpack(last_packed)[:, :L])
+            if output_hidden_states:
+                last = last()
+                hs = tuple(pk.unpack(h)[:, :L] for h in self._last_hidden_states[:-1].unbind(0)) + (last,)
+            out = EncoderOutput(last, hs, cls)
+            self._last_hidden_states = None
+            return out if return_dict else (out.last_hidden_state, None)
+        if output_hidden_states:
             hs = tuple(h[:, :L] for h in self._last_hidden_states[:-1].unbind(0)) + (last[:, :L],)
         out = EncoderOutput(last[:, :L], hs, cls)
         self._last_hidden_states = None
