@@ -606,7 +606,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG(impl >= 0 && impl <= 16, "gemm_set_impl: impl must be in [0,13] (14-16: ping-pong schedule variants of experiment builds)");
+  CK_ARG(impl >= 0 && impl <= 18 && impl != 17, "gemm_set_impl: impl must be in [0,13] or 18 (ping-pong with two fat phases per K-tile); 14-16: schedule variants of experiment builds");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -641,7 +641,8 @@ int select_impl(const cocodr_gemm_args& a) {
     const long long tilespp = a.N % 256 == 0 ? (long long)((a.M + 255) / 256) * (a.N / 256) * batch : 0;
     const long long roundspp = (tilespp + 255) / 256;
     static const bool nopp = getenv("COCODR_GEMM_NOPP") != nullptr;  // A/B switch of this rule
-    const bool pp_fills = !nopp && tilespp >= (a.trans_a ? 1400 : 400) && tilespp * 100 >= roundspp * 256 * 78;
+    // (with two fat phases per K-tile the grouped weight gradients gain from ~400 tiles as well: profiles/r02_gemm_pp_fat.txt)
+    const bool pp_fills = !nopp && tilespp >= 400 && tilespp * 100 >= roundspp * 256 * 78;
     if (!(k_ok && small)) impl = 1;
     else if (pp_fills) impl = 13;
     else if (fewer_rounds && !a.trans_a && tiles256 >= 128 && !a.colsum && !a.colsum_partial) impl = 12;

@@ -129,8 +129,14 @@ __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const Fra
 // VAR (experiment builds, -DCOCODR_PP_VARIANTS, tools/gemm_bench.py --impls 13,15,16): 0 = DMA pieces requested in the load
 // segment behind the fragment reads; 2 = as 0 without s_setprio (-15 %); 3 = requested in front of the fragment reads (=).
 // Requesting them inside the MFMA segment instead cost 10-14 % (profiles/r02_gemm_pp_variants.txt).
-// VAR 4 (always built, NT form with fp32 output only): VAR 0 with IEEE-half operands.
-template <int NB, int TA, int TB, bool OUT_F32, int VAR = 0>
+// VAR 5 (impl 18; the search's score GEMM): "fat" phases - two per K-tile of 16 MFMAs each, (A0: B0, B1) and (A1: B1, B0), i.e.
+// half the barriers per MFMA.  The fragment reads of a phase are retired (lgkmcnt) in FRONT of its first barrier, so that a
+// half-tile may be requested one phase after its last read even by the group that runs a barrier ahead.  Back to back in
+// tools/gemm_bench.py it is 3-9 % faster than VAR 0 on every shape (profiles/r02_gemm_pp_fat.txt), inside the BERT-large
+// training step 0.8 % SLOWER (same box, two alternating runs each: 3 741 vs 3 771 sequences/s) - under the package power limit
+// a denser loop buys a lower clock, not time - so the encoder keeps VAR 0 and the long back-to-back launches of the search
+// (+2 %) take VAR 5.  F16: IEEE-half operands.
+template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_args p, const int flat) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using S = Shape<NB>;
@@ -215,9 +221,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_
   if (nt > 1) {
     stage(std::integral_constant<int, 0>{}, 1);
     stage(std::integral_constant<int, 1>{}, 1);
-    wait_vmcnt<8>();
+    if constexpr (VAR == 5) wait_vmcnt<6>();  // the first fat phase reads A0, B0 and B1
+    else wait_vmcnt<8>();
   } else {
-    wait_vmcnt<4>();
+    if constexpr (VAR == 5) wait_vmcnt<2>();
+    else wait_vmcnt<4>();
   }
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0 from here on
@@ -264,16 +272,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_
       auto none = []() {};
       if constexpr (VAR == 3) req();
       reads();
-      if constexpr (VAR == 0 || VAR == 2 || VAR == 4) req();
+      if constexpr (VAR == 0 || VAR == 2) req();
       wait_stage(tyc, rem);
       __builtin_amdgcn_s_barrier();
       wait_lgkmcnt<0>();
       if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(1);
-      pp_mfma<TA, TB, VAR == 4>(fa, fb, c0, c1, none);
+      pp_mfma<TA, TB, F16>(fa, fb, c0, c1, none);
       if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
     };
-    if constexpr (NB == 2) {
+    if constexpr (NB == 2 && VAR == 5) {
+      auto none = []() {};
+      // X: (A0, B0), (A0, B1).  Requests B1(t+1); afterwards A1(t) - read by Y - must have landed: behind it in the queue are
+      // A0, B0 and B1 of K-tile t + 1 (when that tile exists)
+      pp_read_sub<TA, 2, 0 * HALF_BYTES>(curA, fa);
+      pp_read_sub<TB, 1, 1 * HALF_BYTES>(curB, fb0);
+      pp_read_sub<TB, 1, 2 * HALF_BYTES>(curB, fb1);
+      if (rem >= 2) { stage(std::integral_constant<int, 2>{}, t + 1); wait_vmcnt<6>(); }
+      else wait_vmcnt<0>();
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      pp_mfma<TA, TB, F16>(fa, fb0, acc[0][0], acc[1][0], none);
+      pp_mfma<TA, TB, F16>(fa, fb1, acc[0][1], acc[1][1], none);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      // Y: (A1, B1), (A1, B0).  Requests A1(t+1), A0(t+2), B0(t+2); afterwards A0, B0, B1 of K-tile t + 1 - read by the next X -
+      // must have landed: behind B1(t+1) in the queue are exactly this phase's own requests
+      pp_read_sub<TA, 2, 3 * HALF_BYTES>(curA, fa);
+      if (rem >= 2) stage(std::integral_constant<int, 3>{}, t + 1);
+      if (rem >= 3) {
+        stage(std::integral_constant<int, 0>{}, t + 2);
+        stage(std::integral_constant<int, 1>{}, t + 2);
+        wait_vmcnt<6>();
+      } else if (rem == 2) {
+        wait_vmcnt<2>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      pp_mfma<TA, TB, F16>(fa, fb1, acc[2][1], acc[3][1], none);
+      pp_mfma<TA, TB, F16>(fa, fb0, acc[2][0], acc[3][0], none);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    } else if constexpr (NB == 2) {
       phase(std::integral_constant<int, 0>{}, [&]() { pp_read_sub<TA, 2, 0 * HALF_BYTES>(curA, fa); pp_read_sub<TB, 1, 1 * HALF_BYTES>(curB, fb0); },
             fb0, acc[0][0], acc[1][0]);                                                                  // (A0, B0)
       phase(std::integral_constant<int, 1>{}, [&]() { pp_read_sub<TB, 1, 2 * HALF_BYTES>(curB, fb1); }, fb1, acc[0][1], acc[1][1]);  // (A0, B1)
@@ -382,7 +426,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_
 #endif
 }
 
-template <int NB, int TA, int TB, int VAR = 0>
+template <int NB, int TA, int TB, int VAR = 5, bool F16 = false>
 void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
   using S = Shape<NB>;
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / S::BN;
@@ -395,14 +439,14 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
   dim3 grid(flat ? ntm * ntn * a.batch : ntm * ntn, flat ? 1 : a.batch);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, true, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, true, VAR, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
   else
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
 }
 
 }  // namespace cocodr_gemm_pp
@@ -416,8 +460,11 @@ static void launch_any(const cocodr_gemm_args& a, hipStream_t st) {
   else launch_form<2, 1, 1, VAR>(a, st);
 }
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st) {
-  if (nb == 2) launch_any<0>(a, st);
-  else if (nb == 104) cocodr_gemm_pp::launch_form<2, 0, 0, 4>(a, st);
+  static const bool fat = getenv("COCODR_PP_FAT") != nullptr;                    // A/B switch: two fat phases per K-tile everywhere
+  if (nb == 2 && fat) launch_any<5>(a, st);
+  else if (nb == 2) launch_any<0>(a, st);                                        // four thin phases per K-tile (the default)
+  else if (nb == 104) cocodr_gemm_pp::launch_form<2, 0, 0, 5, true>(a, st);      // IEEE-half operands (the search): fat phases
+  else if (nb == 105) launch_any<5>(a, st);                                      // impl 18: two fat phases per K-tile
 #if defined(COCODR_PP_VARIANTS)
   else if (nb == 102) launch_any<2>(a, st);
   else if (nb == 103) launch_any<3>(a, st);

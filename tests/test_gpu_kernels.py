@@ -49,7 +49,7 @@ def test_probe_ds_read_tr16_layout():
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13], ids=["regstage", "glds128x64", "glds256x64", "glds128x32", "glds256x32", "glds256x32w4", "glds256x64w4", "glds128x192", "glds256x64ld4", "glds256x64w4ld4", "glds256x256", "glds256x96ld4", "pingpong256x256"], autouse=False)
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18], ids=["regstage", "glds128x64", "glds256x64", "glds128x32", "glds256x32", "glds256x32w4", "glds256x64w4", "glds128x192", "glds256x64ld4", "glds256x64w4ld4", "glds256x256", "glds256x96ld4", "pingpong256x256", "pingpong256x256fat"], autouse=False)
 def gemm_impl(request):
     ops.gemm_set_impl(request.param)
     yield request.param
