@@ -515,7 +515,7 @@ extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np,
   CK_ARG(((uintptr_t)workspace & 255) == 0, "score_topk: workspace must be 256-byte aligned");
   // split precision (16-bit matrix pipe) when the workspace has room for the half operands; exact fp32 MFMA otherwise
   const SplitPlan sp = split_plan(Nq, Np, H);
-  const bool split = score_mode() == 0 && workspace_bytes >= sp.total && (size_t)sp.np_pad * 3 * sp.Hp * 2 < (1ull << 32);
+  const bool split = score_mode() == 0 && workspace_bytes >= sp.total;
   char* wsb = reinterpret_cast<char*>(workspace);
   _Float16* Qc = reinterpret_cast<_Float16*>(wsb + sp.off_q);
   _Float16* Pc = reinterpret_cast<_Float16*>(wsb + sp.off_p);
@@ -550,15 +550,20 @@ extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np,
     }
     if (split) {
       ProfScope prof(PROF_SCORE, st, 2.0 * nq * (double)Np * H);  // algorithmic FLOPs of the scores, whatever pipe produces them
-      cocodr_gemm_args g = {};
-      g.A = reinterpret_cast<const uint16_t*>(Qc + (size_t)q0 * 3 * sp.Hp);
-      g.B = reinterpret_cast<const uint16_t*>(Pc);
-      g.C = S;
-      g.M = nq; g.N = sp.np_pad; g.K = 3 * sp.Hp;
-      g.lda = g.ldb = 3 * sp.Hp; g.ldc = (int)ld;
-      g.out_f32 = 1; g.batch = 1; g.ab_f16 = 1;
-      const int rc = cocodr_gemm(&g, stream);
-      if (rc != COCODR_OK) return rc;
+      // the GEMM addresses an operand with 32-bit byte offsets: passages go in column blocks of < 4 GiB of half operands
+      int pblk = (int)std::min<long long>(sp.np_pad, ((1ll << 32) / ((long long)3 * sp.Hp * 2) - 1) / 256 * 256);
+      if (const char* e = getenv("COCODR_SCORE_PBLK")) pblk = std::max(256, std::min(pblk, atoi(e) / 256 * 256));  // test hook: small column blocks
+      for (int p0 = 0; p0 < sp.np_pad; p0 += pblk) {
+        cocodr_gemm_args g = {};
+        g.A = reinterpret_cast<const uint16_t*>(Qc + (size_t)q0 * 3 * sp.Hp);
+        g.B = reinterpret_cast<const uint16_t*>(Pc + (size_t)p0 * 3 * sp.Hp);
+        g.C = S + p0;
+        g.M = nq; g.N = std::min(pblk, sp.np_pad - p0); g.K = 3 * sp.Hp;
+        g.lda = g.ldb = 3 * sp.Hp; g.ldc = (int)ld;
+        g.out_f32 = 1; g.batch = 1; g.ab_f16 = 1;
+        const int rc = cocodr_gemm(&g, stream);
+        if (rc != COCODR_OK) return rc;
+      }
     } else {
       ProfScope prof(PROF_SCORE, st, 2.0 * nq * (double)Np * H);
       hipLaunchKernelGGL(score_gemm_kernel, dim3(ntm * ntn), dim3(256), 0, st, Q + (size_t)q0 * H, P, S, nq, Np, H, ld);

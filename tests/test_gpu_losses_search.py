@@ -156,3 +156,15 @@ def test_split_precision_scores_are_at_least_as_accurate_as_an_fp32_dot_product(
     finally:
         ops.score_set_mode(0)
     assert errs[0] < 2e-6 and errs[0] <= 1.5 * errs[1], errs
+
+
+def test_split_precision_search_in_passage_column_blocks(monkeypatch):
+    """Shards whose half operands exceed the GEMM's 32-bit operand offsets are scored in column blocks; forced small here."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    Q = (rng.standard_normal((70, 256)) / 16).astype(np.float32)
+    P = (rng.standard_normal((3000, 256)) / 16).astype(np.float32)
+    ops.score_set_mode(0)
+    D0, I0 = ops.score_topk(t(Q), t(P), 40)
+    monkeypatch.setenv("COCODR_SCORE_PBLK", "512")
+    D1, I1 = ops.score_topk(t(Q), t(P), 40)
+    assert torch.equal(D0, D1) and torch.equal(I0, I1)
