@@ -310,3 +310,34 @@ def test_one_rank_rccl_step_equals_the_plain_step():
     loss.backward()
     assert abs(out[0] - float(loss.detach())) < 1e-6
     assert _rel(out[1], bert.flat_decay.grad.cpu().numpy()) < 1e-5 and _rel(out[2], bert.flat_nodecay.grad.cpu().numpy()) < 1e-5
+
+
+def _coco_rank_packed(rank, world, ids, mask, packed):
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
+    torch.manual_seed(0)
+    bert = CocoBertModel(_small_cfg()).to("cuda")
+    bert.pack_sequences = packed
+    model = CoCondenserForPretraining(bert)
+    bert.enable_grad_allreduce(chunks=2)
+    n = ids.shape[0] // world
+    sl = slice(rank * n, (rank + 1) * n)
+    loss = model({"input_ids": torch.from_numpy(ids[sl]).cuda(), "attention_mask": torch.from_numpy(mask[sl]).cuda()}, None)
+    loss.backward()
+    return float(loss.detach()), bert.flat_decay.grad.cpu().numpy(), bert.flat_nodecay.grad.cpu().numpy()
+
+
+def test_two_rank_packed_step_equals_two_rank_padded_step():
+    """The overlapped (ranged) data-parallel backward on packed batches: every rank packs its own rows (different row counts per
+    rank), the averaged gradients equal those of the padded two-rank step."""
+    rng = np.random.Generator(np.random.PCG64(21))
+    ids = rng.integers(5, 700, (8, 64))
+    lens = np.array([64, 9, 33, 40, 5, 64, 17, 50])
+    mask = (np.arange(64)[None] < lens[:, None]).astype(np.int64)
+    ids = ids * mask
+    ref = _spawn(_coco_rank_packed, 2, "gloo", ids, mask, False)
+    got = _spawn(_coco_rank_packed, 2, "gloo", ids, mask, True)
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])  # both ranks hold the same average
+    for r in (0, 1):
+        assert abs(got[r][0] - ref[r][0]) < 1e-5 * abs(ref[r][0])
+    assert _rel(got[0][1], ref[0][1]) < 5e-3 and _rel(got[0][2], ref[0][2]) < 5e-3
