@@ -633,7 +633,9 @@ int select_impl(const cocodr_gemm_args& a) {
     // smaller tiles instead of 2.25 (measured 2-8 % on those shapes; the long-K wgrads lose 10-60 % and stay out)
     const long long tiles96 = a.N % 96 == 0 ? (long long)((a.M + 255) / 256) * (a.N / 96) * batch : 0;
     static const bool no96 = getenv("COCODR_GEMM_NO96") != nullptr;  // A/B switch of this rule
-    const bool fewer_rounds = !no96 && tiles96 > 0 && ((tiles96 + 255) / 256) * 3 < ((tiles256 + 255) / 256) * 4;
+    // (only while there are few rounds to quantise: from ~3 rounds of 256-row tiles on, the larger tiles win again - packed
+    // batches of 512 sequences, 45 312 x 768 x 3072: 814 vs 946-970 TFLOP/s)
+    const bool fewer_rounds = !no96 && tiles96 > 0 && tiles256 <= 768 && ((tiles96 + 255) / 256) * 3 < ((tiles256 + 255) / 256) * 4;
     // ping-pong pipeline (gemm_pp.hip, 256x256 tiles): wins once its tiles fill the 256 CUs for nearly whole rounds -
     // 2-12 % on the forward / dgrad forms from 400 tiles (BERT-large FFN1 at 8192 tokens, everything at 25600 tokens),
     // 3-7 % on the grouped weight gradients from ~1500 tiles; with 1.5 rounds or less it loses to the 256x128 tiles

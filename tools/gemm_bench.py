@@ -46,6 +46,17 @@ SHAPES = [  # (name, M, N, K, ta, tb, batch, out_f32)
     ("XL dgrad qkv 25600x1024x3072", 25600, 1024, 3072, 0, 1, 1, 0),
     ("XL wgrad qkv 24x 3072x1024x25600", 3072, 1024, 25600, 1, 1, 24, 1),
     ("XL wgrad ffn1 24x 4096x1024x25600", 4096, 1024, 25600, 1, 1, 24, 1),
+    # packed batches (SURVEY 7 iii): row counts that are no multiple of the tile height (64 / 512 MS MARCO-shaped sequences)
+    ("pk fwd qkv   5664x2304x768", 5664, 2304, 768, 0, 0, 1, 0),
+    ("pk fwd out   5664x768x768", 5664, 768, 768, 0, 0, 1, 0),
+    ("pk fwd ffn1  5664x3072x768", 5664, 3072, 768, 0, 0, 1, 0),
+    ("pk fwd ffn2  5664x768x3072", 5664, 768, 3072, 0, 0, 1, 0),
+    ("pk dgrad ffn1 5664x768x3072", 5664, 768, 3072, 0, 1, 1, 0),
+    ("pk wgrad ffn1 12x 3072x768x5664", 3072, 768, 5664, 1, 1, 12, 1),
+    ("pk enc qkv  45312x2304x768", 45312, 2304, 768, 0, 0, 1, 0),
+    ("pk enc out  45312x768x768", 45312, 768, 768, 0, 0, 1, 0),
+    ("pk enc ffn1 45312x3072x768", 45312, 3072, 768, 0, 0, 1, 0),
+    ("pk enc ffn2 45312x768x3072", 45312, 768, 3072, 0, 0, 1, 0),
     ("cube 4096", 4096, 4096, 4096, 0, 0, 1, 0),
     ("cube 8192", 8192, 8192, 8192, 0, 0, 1, 0),
     # corpus-encode batch (512 x 128 tokens, forward only)
