@@ -460,8 +460,8 @@ static void launch_any(const cocodr_gemm_args& a, hipStream_t st) {
   else launch_form<2, 1, 1, VAR>(a, st);
 }
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st) {
-  static const bool fat = getenv("COCODR_PP_FAT") != nullptr;                    // A/B switch: two fat phases per K-tile everywhere
-  if (nb == 2 && fat) launch_any<5>(a, st);
+  static const int fat = getenv("COCODR_PP_FAT") ? atoi(getenv("COCODR_PP_FAT")) : 0;  // A/B switch: 1 = fat phases everywhere,
+  if (nb == 2 && (fat == 1 || (fat == 2 && !a.trans_a) || (fat == 3 && a.trans_a))) launch_any<5>(a, st);  // 2 = forward / dgrad only, 3 = wgrads only
   else if (nb == 2) launch_any<0>(a, st);                                        // four thin phases per K-tile (the default)
   else if (nb == 104) cocodr_gemm_pp::launch_form<2, 0, 0, 5, true>(a, st);      // IEEE-half operands (the search): fat phases
   else if (nb == 105) launch_any<5>(a, st);                                      // impl 18: two fat phases per K-tile
