@@ -119,6 +119,7 @@ SIGNATURES = {
     "cocodr_scatter_cls_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cocodr_simce_workspace_floats": (c_size_t, [c_int]),
     "cocodr_simce_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cocodr_allgather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "cocodr_triplet_nll_fwd_bwd": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "cocodr_score_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "cocodr_score_topk_workspace_bytes_dim": (c_size_t, [c_int, c_int, c_int, c_int]),

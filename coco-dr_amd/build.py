@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcocodr_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "loss.hip", "score.hip", "encoder.hip", "collate.hip", "probe.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "loss.hip", "score.hip", "encoder.hip", "collate.hip", "probe.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 FLAGS += os.environ.get("COCODR_EXTRA_FLAGS", "").split()  # experiment builds only (e.g. -DCOCODR_PP_VARIANTS)
 
@@ -58,7 +58,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(BUILD, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])

@@ -255,6 +255,14 @@ int cocodr_triplet_nll_fwd_bwd(const float* q, const float* a, const float* b, c
                                int B, int H, float* loss_rows, float* logits /* [B,2] */, float* loss,
                                float* dq, float* da, float* db, cocodr_stream_t stream);
 
+/* COCO's negative gather (COCO/modeling.py:182-190: all_gather of the [2b, H] [CLS] block; the reference builds a list of W
+ * tensors, overwrites its own slot and concatenates): ONE RCCL all-gather of `rows` x H fp32 rows per rank into the contiguous
+ * [W rows, H] matrix cocodr_simce_fwd_bwd takes, enqueued on `stream`.  nccl_comm is the caller's ncclComm_t (rank r's rows land
+ * at gathered + r rows H; no gradient exchange is needed afterwards: simce_fwd_bwd returns the gradient of the local rows).
+ * RCCL is resolved at run time from the copy the process has loaded (e.g. torch's) - the library itself does not link it.  The
+ * Python host reaches the same collective through torch.distributed.all_gather_into_tensor on its process group. */
+int cocodr_allgather_rows(const float* local_rows, float* gathered, int rows, int H, void* nccl_comm, cocodr_stream_t stream);
+
 /* Masked-LM cross entropy over the vocabulary (hf BertForMaskedLM loss / COCO/modeling.py:87-93 mlm_loss):
  * logits fp32 [n, ld] (columns >= V are padding), labels int32 [n] in [0,V); row_scale fp32 [n] carries the
  * 1/(number of labelled rows of the row's group) factor of the mean.  loss_rows[i] = lse_i - logit_i[label_i];

@@ -341,3 +341,37 @@ def test_two_rank_packed_step_equals_two_rank_padded_step():
     for r in (0, 1):
         assert abs(got[r][0] - ref[r][0]) < 1e-5 * abs(ref[r][0])
     assert _rel(got[0][1], ref[0][1]) < 5e-3 and _rel(got[0][2], ref[0][2]) < 5e-3
+
+
+def test_native_rccl_allgather_rows_entry_point():
+    """cocodr_allgather_rows on a real ncclComm_t: a 1-rank RCCL communicator created through the same librccl
+    the process has loaded (torch's), the collective enqueued on the current stream by the native entry point."""
+    import ctypes as C
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd import _native as N
+    torch.cuda.init()
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rccl = C.CDLL(os.path.join(libdir, "librccl.so"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        rows, H = 16, 256
+        x = torch.randn(rows, H, device="cuda")
+        out = torch.full((rows, H), float("nan"), device="cuda")
+        N.check(N.lib().cocodr_allgather_rows(N.ptr(x), N.ptr(out), rows, H, comm, N.stream_ptr()), "allgather_rows")
+        torch.cuda.synchronize()
+        assert torch.equal(out, x)
+        with pytest.raises(ValueError):
+            N.check(N.lib().cocodr_allgather_rows(N.ptr(x), N.ptr(out), rows, H, None, N.stream_ptr()), "allgather_rows")
+    finally:
+        rccl.ncclCommDestroy(comm)
