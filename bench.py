@@ -542,6 +542,13 @@ def main():
             large[f"{n_seq}_sequences"] = {"sequences_per_sec": round(v, 1), "ms_per_step": round(ldt / k_steps * 1e3, 3), "steps": k_steps,
                                            "loss": round(lloss, 4), "algorithmic_tflops_whole_step": round(tf, 1),
                                            "whole_step_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "roofline": lroof}
+        # and the 200-sequence step on packed batches (same loss and gradients, no work on padding rows; side number)
+        pdt, ploss, proof, _, _ = contrastive_leg("large", 200, SEQ_LEN, 6, 3, dev, 0, 1, False, args.dp_chunks, not args.no_roofline, args.dense,
+                                                  packed=True)
+        large["200_sequences_packed"] = {"sequences_per_sec": round(200 * 6 / pdt, 1), "ms_per_step": round(pdt / 6 * 1e3, 3), "steps": 6,
+                                         "loss": round(ploss, 4), "rows_per_step": proof.get("rows_per_step") if proof else None,
+                                         "rows_per_step_padded": 200 * SEQ_LEN, "gemm_tflops_on_stored_rows": proof.get("achieved") if proof else None,
+                                         "note": "sequences stored back to back (32-row alignment); FLOP fractions are not comparable with the padded legs"}
         large["workload"] = "cocodr-large (BERT-large, 24 x 1024) contrastive step, seq_len 128, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW, 1 GPU"
         extras["north_star_large_step"] = large
         # the same headline step on PACKED batches (SURVEY 7 iii): identical loss and gradients (tests/test_gpu_packed.py), the
