@@ -25,30 +25,6 @@ struct Carver {
   }
 };
 
-// Optional overlap of the grouped weight gradients with the dgrad chain (COCODR_WGRAD_SIDE=G: every G finished layers, their
-// weight-gradient launches go to a low-priority side stream and fill the compute units the dgrad launches' ragged last
-// rounds leave idle).  Created once per process; the caller's stream waits for the side stream before the call returns.
-struct WgradSide {
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
-};
-WgradSide& wgrad_side() {
-  static WgradSide w;
-  if (!w.ok) {
-    int least = 0, greatest = 0;
-    hipDeviceGetStreamPriorityRange(&least, &greatest);
-    w.ok = hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, least) == hipSuccess &&
-           hipEventCreateWithFlags(&w.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&w.join, hipEventDisableTiming) == hipSuccess;
-  }
-  return w;
-}
-int wgrad_side_group() {
-  static const int g = getenv("COCODR_WGRAD_SIDE") ? atoi(getenv("COCODR_WGRAD_SIDE")) : 0;
-  return g;
-}
-
 struct BwdLayout {
   size_t dy2, du, dy1, dqkv;  // bf16 [layers][M,*]
   size_t dxa, dxb, dctx;      // bf16 [M,H]
@@ -99,15 +75,6 @@ int check_cfg(const cocodr_config* c, int B, int L) {
   do {                           \
     const int rc_ = (expr);      \
     if (rc_ != COCODR_OK) return rc_; \
-  } while (0)
-
-#define HIP_TRY(expr)                                                         \
-  do {                                                                        \
-    const hipError_t e_ = (expr);                                             \
-    if (e_ != hipSuccess) {                                                   \
-      cocodr_set_error("encoder: %s: %s", #expr, hipGetErrorString(e_));      \
-      return COCODR_ERR_LAUNCH;                                               \
-    }                                                                         \
   } while (0)
 
 // dropout masks of one layer (threshold 0 everywhere when the call runs without dropout)
@@ -422,28 +389,6 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     q = gemm_base(dy1_all, lp[layer_lo].wo, dctx, M, H, H, H, H, H, 0, 1);
     rows_bv = drop_probs ? 0 : cocodr_gemm_colsum_rows(&q);
   }
-  // ---- grouped weight gradients of layers [l0, l0 + n): one batched TN launch per matrix, batch = layer
-  const long long sMH = (long long)M * H, sMI = (long long)M * I, sM3H = (long long)M * 3 * H;
-  auto wgrads = [&](int first, int n, cocodr_stream_t st) -> int {
-    const size_t l0 = (size_t)first;
-    const cocodr_layer_grads& g0 = lg[first];
-    cocodr_gemm_args g = gemm_base(dqkv_all + l0 * sM3H, hidden + l0 * sMH, g0.wqkv, 3 * H, H, M, 3 * H, H, H, 1, 1);
-    g.out_f32 = 1; g.batch = n; g.strideA = sM3H; g.strideB = sMH; g.strideC = s_wqkv;
-    TRY(cocodr_gemm(&g, st));
-    g = gemm_base(dy1_all + l0 * sMH, (const uint16_t*)(base + lay.ctx) + l0 * sMH, g0.wo, H, H, M, H, H, H, 1, 1);
-    g.out_f32 = 1; g.batch = n; g.strideA = sMH; g.strideB = sMH; g.strideC = s_wo;
-    TRY(cocodr_gemm(&g, st));
-    g = gemm_base(du_all + l0 * sMI, (const uint16_t*)(base + lay.x1) + l0 * sMH, g0.w1, I, H, M, I, H, H, 1, 1);
-    g.out_f32 = 1; g.batch = n; g.strideA = sMI; g.strideB = sMH; g.strideC = s_w1;
-    TRY(cocodr_gemm(&g, st));
-    g = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
-    g.out_f32 = 1; g.batch = n; g.strideA = sMH; g.strideB = sMI; g.strideC = s_w2;
-    TRY(cocodr_gemm(&g, st));
-    return COCODR_OK;
-  };
-  const int side_g = wgrad_side_group();
-  int side_hi = layer_hi;  // layers [side_hi, layer_hi) already have their weight gradients enqueued on the side stream
-  bool side_used = false;
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const cocodr_layer_params& w = lp[l];
     const cocodr_layer_grads& gr = lg[l];
@@ -499,15 +444,6 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     g.epi = COCODR_EPI_ADD; g.R = res1; g.ldr = H;
     TRY(cocodr_gemm(&g, stream));
     dx = dxb;
-    if (side_g > 0 && (l == layer_lo || (side_hi - l) >= side_g)) {  // layers [l, side_hi) are complete: their weight gradients overlap what follows
-      WgradSide& ws = wgrad_side();
-      CK_ARG(ws.ok, "encoder_bwd: could not create the weight-gradient side stream");
-      HIP_TRY(hipEventRecord(ws.fork, hst));
-      HIP_TRY(hipStreamWaitEvent(ws.side, ws.fork, 0));
-      TRY(wgrads(l, side_hi - l, (cocodr_stream_t)ws.side));
-      side_hi = l;
-      side_used = true;
-    }
   }
   if (do_embed) {
     CK_ARG(layer_lo == 0, "encoder_bwd: the embedding backward belongs to the range that ends at layer 0");
@@ -526,15 +462,24 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   }
   if (NG == 0) return COCODR_OK;
 
-  if (side_used) {  // the caller's stream continues only after the side stream's weight gradients
-    WgradSide& ws = wgrad_side();
-    HIP_TRY(hipEventRecord(ws.join, ws.side));
-    HIP_TRY(hipStreamWaitEvent(hst, ws.join, 0));
-  }
-  if (side_hi > layer_lo) TRY(wgrads(layer_lo, side_hi - layer_lo, stream));
+  // ---- grouped weight gradients of this range: one batched TN launch per matrix, batch = layer
+  const long long sMH = (long long)M * H, sMI = (long long)M * I, sM3H = (long long)M * 3 * H;
+  const size_t l0 = (size_t)layer_lo;
+  const cocodr_layer_grads& g0 = lg[layer_lo];
+  cocodr_gemm_args g = gemm_base(dqkv_all + l0 * sM3H, hidden + l0 * sMH, g0.wqkv, 3 * H, H, M, 3 * H, H, H, 1, 1);
+  g.out_f32 = 1; g.batch = NG; g.strideA = sM3H; g.strideB = sMH; g.strideC = s_wqkv;
+  TRY(cocodr_gemm(&g, stream));
+  g = gemm_base(dy1_all + l0 * sMH, (const uint16_t*)(base + lay.ctx) + l0 * sMH, g0.wo, H, H, M, H, H, H, 1, 1);
+  g.out_f32 = 1; g.batch = NG; g.strideA = sMH; g.strideB = sMH; g.strideC = s_wo;
+  TRY(cocodr_gemm(&g, stream));
+  g = gemm_base(du_all + l0 * sMI, (const uint16_t*)(base + lay.x1) + l0 * sMH, g0.w1, I, H, M, I, H, H, 1, 1);
+  g.out_f32 = 1; g.batch = NG; g.strideA = sMI; g.strideB = sMH; g.strideC = s_w1;
+  TRY(cocodr_gemm(&g, stream));
+  g = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
+  g.out_f32 = 1; g.batch = NG; g.strideA = sMH; g.strideB = sMI; g.strideC = s_w2;
+  TRY(cocodr_gemm(&g, stream));
   // ---- deferred reductions of the range (LayerNorm weight / bias + the Linear bias in front of it; b1; value bias)
   if (defer) {
-    const cocodr_layer_grads& g0 = lg[layer_lo];
     cocodr_reduce_job jobs[5];  // one launch for all of them
     int nj = 0;
     jobs[nj++] = {ln2_slots, g0.ln2_g, g0.ln2_b, g0.b2, P_ln, 3, H, NG, s_vec};
