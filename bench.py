@@ -587,7 +587,7 @@ def main():
             "config": {"workload": f"cocodr-{args.model} contrastive step (COCO in-batch negatives), seq_len={args.seq_len}, "
                                    f"{args.seq_per_gpu} sequences/GPU, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW; "
                                    + ("BASELINE configs[1]" if args.model == "base" and world == 1 else
-                                      "BASELINE configs[2] shape per GPU" if args.model == "base" else "north_star BERT-large target shape"),
+                                      "BASELINE configs[1]'s batch on every GPU, negatives all-gathered as in configs[2] (whose 2048 global batch at 8 GPUs is --seq-per-gpu 256)" if args.model == "base" else "north_star BERT-large target shape"),
                        "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len,
                        "batches": "8 pre-generated synthetic batches per rank, resident in HBM, visited round-robin",
                        "parallelism": par},
