@@ -82,6 +82,20 @@ EPI_SHAPES = [  # the encoder's fused epilogues: (name, M, N, K, tb, epi, bias, 
     ("dgrad ffn2 *gelu'     8192x3072x768", 8192, 3072, 768, 1, "dgelu", False, True),
     ("dgrad ffn1 +res       8192x768x3072", 8192, 768, 3072, 1, "add", False, True),
     ("dgrad qkv +res        8192x768x2304", 8192, 768, 2304, 1, "add", False, True),
+    ("L fwd qkv  +bias      8192x3072x1024", 8192, 3072, 1024, 0, "none", True, False),
+    ("L fwd out  +bias+res  8192x1024x1024", 8192, 1024, 1024, 0, "add", True, True),
+    ("L fwd ffn1 +bias+gelu 8192x4096x1024", 8192, 4096, 1024, 0, "gelu", True, False),
+    ("L fwd ffn2 +bias+res  8192x1024x4096", 8192, 1024, 4096, 0, "add", True, True),
+    ("L dgrad ffn2 *gelu'   8192x4096x1024", 8192, 4096, 1024, 1, "dgelu", False, True),
+    ("L dgrad ffn1 +res     8192x1024x4096", 8192, 1024, 4096, 1, "add", False, True),
+    ("L dgrad qkv +res      8192x1024x3072", 8192, 1024, 3072, 1, "add", False, True),
+    ("XL fwd qkv  +bias     25600x3072x1024", 25600, 3072, 1024, 0, "none", True, False),
+    ("XL fwd out  +bias+res 25600x1024x1024", 25600, 1024, 1024, 0, "add", True, True),
+    ("XL fwd ffn1 +bias+gelu 25600x4096x1024", 25600, 4096, 1024, 0, "gelu", True, False),
+    ("XL fwd ffn2 +bias+res 25600x1024x4096", 25600, 1024, 4096, 0, "add", True, True),
+    ("XL dgrad ffn2 *gelu'  25600x4096x1024", 25600, 4096, 1024, 1, "dgelu", False, True),
+    ("XL dgrad ffn1 +res    25600x1024x4096", 25600, 1024, 4096, 1, "add", False, True),
+    ("XL dgrad qkv +res     25600x1024x3072", 25600, 1024, 3072, 1, "add", False, True),
 ]
 
 
