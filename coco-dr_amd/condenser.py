@@ -46,11 +46,7 @@ class CondenserHead(nn.Module):
         H, V = config.hidden_size, config.vocab_size
         self.config = config
         self.n_head_layers = int(n_head_layers)
-        self.layout = _Layout(
-            config, self.n_head_layers, "c_head.",
-            decay_pre=[("cls.predictions.transform.dense.weight", (H, H))],
-            nodecay_pre=[("cls.predictions.transform.dense.bias", (H,)), ("cls.predictions.transform.LayerNorm.weight", (H,)),
-                         ("cls.predictions.transform.LayerNorm.bias", (H,)), ("cls.predictions.bias", (V,))])
+        self.layout = self._build_layout()
         dev = torch.device(device) if device is not None else torch.device("cpu")
         self.flat_decay = nn.Parameter(torch.zeros(self.layout.decay_numel, dtype=torch.float32, device=dev))
         self.flat_nodecay = nn.Parameter(torch.zeros(self.layout.nodecay_numel, dtype=torch.float32, device=dev))
@@ -58,8 +54,32 @@ class CondenserHead(nn.Module):
         self._shadow_version = -1
         self.dropout_seed = None  # None: torch.initial_seed() at the first dropout forward
         self._dropout_calls = 0
-        self.vpad = (V + 127) // 128 * 128
         self.reset_parameters()
+
+    def _build_layout(self):
+        H, V = self.config.hidden_size, self.config.vocab_size
+        self.vpad = (V + 127) // 128 * 128
+        return _Layout(
+            self.config, self.n_head_layers, "c_head.",
+            decay_pre=[("cls.predictions.transform.dense.weight", (H, H))],
+            nodecay_pre=[("cls.predictions.transform.dense.bias", (H,)), ("cls.predictions.transform.LayerNorm.weight", (H,)),
+                         ("cls.predictions.transform.LayerNorm.bias", (H,)), ("cls.predictions.bias", (V,))])
+
+    def resize_vocab(self, old: int, new: int) -> None:
+        """follow ``lm.resize_token_embeddings`` (the config object is the backbone's and already carries the new size): the
+        decoder bias is cut or zero-padded like hf's ``_get_resized_lm_head`` does, everything else is copied"""
+        keep = {name: self.hf_view(name).detach().clone() for name in self.layout.names}
+        self.layout = self._build_layout()
+        self.flat_nodecay = nn.Parameter(torch.zeros(self.layout.nodecay_numel, dtype=torch.float32, device=self.flat_nodecay.device))
+        with torch.no_grad():
+            for name in self.layout.names:
+                dst = self.hf_view(name)
+                if name == "cls.predictions.bias":
+                    n = min(old, new)
+                    dst[:n].copy_(keep[name][:n])
+                else:
+                    dst.copy_(keep[name])
+        self._shadow_version = -1
 
     def reset_parameters(self):
         with torch.no_grad():

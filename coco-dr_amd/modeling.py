@@ -361,6 +361,14 @@ class _PackedEncoderFn(torch.autograd.Function):
 
 
 # =============================================================================== model
+def _resize_rows(t: torch.Tensor, n: int) -> torch.Tensor:
+    """first dimension cut or zero-padded to n (hf pads a resized decoder bias with zeros)"""
+    out = torch.zeros((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    keep = min(n, t.shape[0])
+    out[:keep] = t[:keep]
+    return out
+
+
 class CocoBertModel(nn.Module):
     """BertModel (no pooler) on the native gfx950 kernels.  HF-compatible: ``from_pretrained``,
     ``save_pretrained``, ``state_dict`` key names, ``forward(input_ids=, attention_mask=)`` ->
@@ -477,10 +485,43 @@ class CocoBertModel(nn.Module):
         sd = {(prefix + k if k in own else k): v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
         save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
 
-    def resize_token_embeddings(self, n: int):
-        """COCO/run_coco_pre_training.py:158 calls this with len(tokenizer) == vocab_size."""
-        if n != self.config.vocab_size:
-            raise NotImplementedError("changing the vocabulary size of the flat parameter layout is not supported")
+    def resize_token_embeddings(self, n: Optional[int] = None):
+        """hf ``PreTrainedModel.resize_token_embeddings`` (COCO/run_coco_pre_training.py:158 calls it with ``len(tokenizer)``,
+        before the optimizer exists): the word table grows or shrinks to ``n`` rows - kept rows are copied, new rows drawn
+        like ``_init_weights`` draws an embedding (normal(0, initializer_range)) - and whoever shares the vocabulary (the
+        tied MLM decoder bias of a Condenser head, ``_vocab_listeners``) follows.  The flat parameters are re-created, so
+        optimizers and ``enable_grad_allreduce`` must be set up afterwards, as in the reference."""
+        old = self.config.vocab_size
+        if n is None or int(n) == old:
+            return self
+        n = int(n)
+        if n <= 0:
+            raise ValueError(f"resize_token_embeddings: vocabulary size must be positive, got {n}")
+        if getattr(self, "_dp_hooks", None):
+            raise RuntimeError("resize_token_embeddings after enable_grad_allreduce: resize first (the flat parameters are re-created)")
+        old_views = {name: v.detach().clone() for name, v in self.hf_named_parameters()}
+        dev = self.flat_decay.device
+        self.config.vocab_size = n
+        self.layout = _Layout(self.config)
+        self.flat_decay = nn.Parameter(torch.zeros(self.layout.decay_numel, dtype=torch.float32, device=dev))
+        word = "embeddings.word_embeddings.weight"
+        with torch.no_grad():
+            for name, dst in self.hf_named_parameters():
+                if name == word:
+                    keep = min(old, n)
+                    dst[:keep].copy_(old_views[name][:keep])
+                    if n > keep:
+                        dst[keep:].normal_(0.0, self.config.initializer_range)
+                else:
+                    dst.copy_(old_views[name])
+        for k in ("cls.predictions.decoder.weight", "cls.predictions.decoder.bias"):  # tied tensors a checkpoint carried along:
+            self._extra_state.pop(k, None)                                              # transformers re-ties them on load
+        bias = self._extra_state.get("cls.predictions.bias")
+        if bias is not None and bias.shape[0] == old:
+            self._extra_state["cls.predictions.bias"] = _resize_rows(bias, n)
+        self._shadow, self._shadow_version = None, -1
+        for fn in getattr(self, "_vocab_listeners", []):
+            fn(old, n)
         return self
 
     def get_extended_attention_mask(self, attention_mask, input_shape=None, device=None):
@@ -953,6 +994,9 @@ class CoCondenserForPretraining(nn.Module):
         if n_head > 0:
             from .condenser import CondenserHead
             self.c_head = CondenserHead(bert.config, n_head, device=bert.flat_decay.device)
+            if not hasattr(bert, "_vocab_listeners"):
+                bert._vocab_listeners = []
+            bert._vocab_listeners.append(self.c_head.resize_vocab)  # lm.resize_token_embeddings also resizes lm.cls's decoder bias
 
     @staticmethod
     def _world_size():

@@ -275,6 +275,56 @@ def test_full_condenser_step_matches_reference_golden():
             assert rel_l2(Gh[key[6:]], g[key]) < 8e-2, key
 
 
+def test_condenser_step_after_resize_token_embeddings_matches_oracle():
+    """COCO/run_coco_pre_training.py:158: `model.lm.resize_token_embeddings(len(tokenizer))` in front of training.  After growing
+    the vocabulary (to a size that is not a multiple of the decoder's 128-row padding) the full step - new token ids in the
+    inputs AND in the MLM labels - still agrees with the oracle evaluated on the resized parameters."""
+    import types
+    ocfg = O.OracleConfig(vocab_size=500, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=64)
+    P = O.make_params(ocfg, 21, std=0.06)
+    Ph = O.make_head_params(ocfg, 2, 22, std=0.06)
+    m = model_from_oracle(ocfg, P)
+    model = CoCondenserForPretraining(m, types.SimpleNamespace(n_head_layers=2, skip_from=1, late_mlm=True))
+    model.c_head.load_state_dict({k: torch.from_numpy(v) for k, v in Ph.items()})
+    model.to(DEV)
+    model.lm.resize_token_embeddings(517)
+    assert model.lm.flat_decay.device.type == "cuda" and model.c_head.flat_nodecay.device.type == "cuda"
+    with torch.no_grad():  # give the new rows / bias entries distinctive values, then export everything for the oracle
+        model.lm.hf_view("embeddings.word_embeddings.weight")[500:].mul_(3.0)
+        model.c_head.hf_view("cls.predictions.bias")[500:].copy_(torch.linspace(-0.5, 0.5, 17))
+    P2 = {k: v.detach().float().cpu().numpy() for k, v in model.lm.state_dict().items()}
+    Ph2 = {k: v.detach().float().cpu().numpy() for k, v in model.c_head.state_dict().items()}
+    ocfg2 = O.OracleConfig(vocab_size=517, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+                           max_position_embeddings=64)
+    rng = np.random.Generator(np.random.PCG64(5))
+    B, L = 8, 32
+    ids = rng.integers(5, 517, (B, L))
+    ids[:, 3] = rng.integers(500, 517, B)       # new tokens as inputs ...
+    mask = np.ones((B, L), np.int64)
+    mask[2, 20:] = 0
+    ids = ids * mask
+    labels = np.full((B, L), -100, np.int64)
+    pick = (rng.random((B, L)) < 0.2) & (mask > 0)
+    pick[:, 0] = False
+    labels[pick] = ids[pick]
+    labels[:, 5] = rng.integers(500, 517, B)    # ... and as MLM targets
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    loss = model({"input_ids": t(ids), "attention_mask": t(mask)}, t(labels))
+    loss.backward()
+    total, parts, Gref, Ghref = O.condenser_step(P2, Ph2, ocfg2, ids, mask, labels, 2, 1, late_mlm=True)
+    assert abs(float(loss.detach()) - total) < 1e-2 * abs(total)
+    G = grads_by_name(m)
+    Gh = {k: v.detach().float().cpu().numpy() for k, v in model.c_head.hf_named_grads()}
+    assert G["embeddings.word_embeddings.weight"].shape == (517, 128) and Gh["cls.predictions.bias"].shape == (517,)
+    assert np.abs(G["embeddings.word_embeddings.weight"][500:]).sum() > 0 and np.abs(Gh["cls.predictions.bias"][500:]).sum() > 0
+    for name in ("embeddings.word_embeddings.weight", "encoder.layer.0.attention.self.query.weight", "encoder.layer.2.output.dense.weight",
+                 "embeddings.position_embeddings.weight"):
+        assert rel_l2(G[name], Gref[name]) < 8e-2, (name, rel_l2(G[name], Gref[name]))
+    for name in ("cls.predictions.bias", "cls.predictions.transform.dense.weight", "c_head.1.intermediate.dense.weight"):
+        assert rel_l2(Gh[name], Ghref[name]) < 8e-2, (name, rel_l2(Gh[name], Ghref[name]))
+
+
 def test_full_condenser_step_base_size_properties():
     """BERT-base, 64 x 128 tokens, 2 head layers, skip_from 6, late MLM (COCO/README.md:49 settings): finite loss,
     all gradients finite and non-zero, MLM loss near log(V) at init."""
