@@ -10,6 +10,6 @@ __all__ = ["ops", "NativeLibraryError"]
 
 def __getattr__(name):  # lazy: torch is only imported when the tensor-level API is used
     import importlib
-    if name in ("ops", "modeling", "retrieval", "optim", "condenser", "data"):
+    if name in ("ops", "modeling", "retrieval", "optim", "condenser", "masked_lm", "data"):
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

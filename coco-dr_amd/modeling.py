@@ -236,11 +236,14 @@ class EncoderOutput:
 
 # =============================================================================== the encoder Function
 class _EncoderFn(torch.autograd.Function):
-    """(flat_decay, flat_nodecay, ids, mask) -> (last_hidden bf16 [B,L,H], cls fp32 [B,H]).
-    forward = cocodr_encoder_fwd, backward = cocodr_encoder_bwd."""
+    """(flat_decay, flat_nodecay, ids, mask) -> (last_hidden bf16 [B,L,H], cls fp32 [B,H][, hidden_states[0 .. N-1]]).
+    forward = cocodr_encoder_fwd, backward = cocodr_encoder_bwd.  With ``taps`` the intermediate hidden states are outputs
+    of the Function too, so a head that reads ``hidden_states[i]`` (the reference's Condenser head reads
+    ``hidden_states[skip_from]``, COCO/modeling.py:212-216) back-propagates into the backbone: the backward then walks the
+    layer stack in ranges and adds each such gradient where its layer range ends."""
 
     @staticmethod
-    def forward(ctx, flat_decay, flat_nodecay, ids, mask, model, grad_mode=True):
+    def forward(ctx, flat_decay, flat_nodecay, ids, mask, model, grad_mode=True, taps=False):
         # grad_mode: torch.is_grad_enabled() at the call site (always False in here); inference keeps no activations and never drops
         training = bool(grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         arena, lay = model._run_forward(ids, mask, training)
@@ -252,22 +255,29 @@ class _EncoderFn(torch.autograd.Function):
         ctx.model = model
         ctx.training = training
         ctx.arena = arena if training else None
+        ctx.lay = lay
         ctx.ids, ctx.mask = ids, mask
         model._last_hidden_states = hidden
         last = hidden[NL]
         ctx.set_materialize_grads(False)
+        if taps and training:  # views of the saved activations (read-only for the caller, like any saved tensor)
+            return (last, cls.clone()) + tuple(hidden[l] for l in range(NL))
         return last, cls.clone()
 
     @staticmethod
-    def backward(ctx, d_last, d_cls):
+    def backward(ctx, d_last, d_cls, *d_taps):
         model = ctx.model
         if not ctx.training or ctx.arena is None:
             raise RuntimeError("encoder backward called but the forward ran without saved activations")
         B, L = ctx.ids.shape
         H = model.config.hidden_size
+        taps = {l: d for l, d in enumerate(d_taps) if d is not None}
+        none = (None,) * 7
+        if d_last is None and d_cls is None and not taps:
+            return none
         if d_last is None and d_cls is None:
-            return None, None, None, None, None, None
-        if d_last is None:  # gradient enters at the [CLS] rows only (every reference wrapper)
+            d16 = torch.zeros((B * L, H), dtype=torch.bfloat16, device=ctx.ids.device)
+        elif d_last is None:  # gradient enters at the [CLS] rows only (every reference wrapper)
             d16 = ops.scatter_cls_grad(d_cls.float().contiguous(), L)
         else:
             d16 = d_last.reshape(B * L, H).to(torch.bfloat16).contiguous()
@@ -275,9 +285,12 @@ class _EncoderFn(torch.autograd.Function):
                 if d16.data_ptr() == d_last.data_ptr():
                     d16 = d16.clone()
                 d16.view(B, L, H)[:, 0] += d_cls.to(torch.bfloat16)
-        gd, gn = model._run_backward(ctx.ids, ctx.mask, d16, ctx.arena)
+        if taps:
+            gd, gn = model._run_backward_taps(ctx.ids, ctx.mask, d16, ctx.arena, ctx.lay, taps)
+        else:
+            gd, gn = model._run_backward(ctx.ids, ctx.mask, d16, ctx.arena)
         ctx.arena = None
-        return gd, gn, None, None, None, None
+        return (gd, gn) + none[2:]
 
 
 # =============================================================================== packed (variable-length) batches
@@ -755,6 +768,36 @@ class CocoBertModel(nn.Module):
         self._dp_skip_hooks = 2
         return gd, gn
 
+    def _run_backward_taps(self, ids, mask, d_last16, arena, lay, taps: Dict[int, torch.Tensor]):
+        """backward with gradients arriving at intermediate hidden states too: ``taps[l]`` = dL/d hidden_states[l] (the input
+        of layer l; l = 0 is the embedding output).  Top-down in ranges that end at every tapped layer; the range leaves its
+        input gradient in the arena, the tap is added there, the next range continues from it.  (Data-parallel runs reduce
+        such a backward from the post-accumulate hook - no overlapped ranges here.)"""
+        B, L = ids.shape
+        lo, NL, H = self.layout, self.config.num_hidden_layers, self.config.hidden_size
+        M = B * L
+        gd = torch.empty_like(self.flat_decay.data)
+        gn = torch.empty_like(self.flat_nodecay.data)
+        gd[:lo.mat_begin].zero_()
+        emb, arr, eg, garr = self._param_structs((gd, gn))
+        cfg = self._c_config(getattr(arena, "_cocodr_drop", None))
+        dx_view = arena[lay.bwd_dx: lay.bwd_dx + M * H * 2].view(torch.bfloat16).view(B, L, H)
+
+        def bwd_range(hi, lo_, d_in, do_embed):
+            check(lib().cocodr_encoder_bwd_range(C.byref(cfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask),
+                                                 ptr(d_in) if d_in is not None else None, B, L, ptr(arena), arena.numel(), hi, lo_,
+                                                 int(do_embed), stream_ptr()), "encoder_bwd_range")
+
+        hi, d_in = NL, d_last16
+        for l in sorted(taps, reverse=True):
+            if not (0 <= l < NL) or tuple(taps[l].shape) != (B, L, H):
+                raise ValueError(f"gradient of hidden_states[{l}] has shape {tuple(taps[l].shape)}, expected {(B, L, H)}")
+            bwd_range(hi, l, d_in, False)  # leaves dL/d hidden_states[l] (through the layers above) in the arena
+            dx_view += taps[l].to(torch.bfloat16)
+            hi, d_in = l, None
+        bwd_range(hi, 0, d_in, True)
+        return gd, gn
+
     def _grad_range(self, gd, gn, l_lo: int, l_hi: int):
         """the slices of the two flat gradients that layers [l_lo, l_hi) own (+ the embedding blocks when l_lo == 0)"""
         lo = self.layout
@@ -804,7 +847,9 @@ class CocoBertModel(nn.Module):
         if pk is not None:
             last, cls = _PackedEncoderFn.apply(self.flat_decay, self.flat_nodecay, self, pk, torch.is_grad_enabled())
         else:
-            last, cls = _EncoderFn.apply(self.flat_decay, self.flat_nodecay, ids, mask, self, torch.is_grad_enabled())
+            want_taps = bool(output_hidden_states and torch.is_grad_enabled() and self.flat_decay.requires_grad)
+            outs = _EncoderFn.apply(self.flat_decay, self.flat_nodecay, ids, mask, self, torch.is_grad_enabled(), want_taps)
+            last, cls, taps = outs[0], outs[1], outs[2:]
         hs = None
         if pk is not None:
             last_packed = last
@@ -815,8 +860,9 @@ class CocoBertModel(nn.Module):
             out = EncoderOutput(last, hs, cls)
             self._last_hidden_states = None
             return out if return_dict else (out.last_hidden_state, None)
-        if output_hidden_states:
-            hs = tuple(h[:, :L] for h in self._last_hidden_states[:-1].unbind(0)) + (last[:, :L],)
+        if output_hidden_states:  # in a training forward every entry is differentiable (a head may read any layer)
+            below = taps if taps else self._last_hidden_states[:-1].unbind(0)
+            hs = tuple(h[:, :L] for h in below) + (last[:, :L],)
         out = EncoderOutput(last[:, :L], hs, cls)
         self._last_hidden_states = None
         return out if return_dict else (out.last_hidden_state, None)

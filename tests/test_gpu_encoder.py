@@ -275,6 +275,55 @@ def test_full_condenser_step_matches_reference_golden():
             assert rel_l2(Gh[key[6:]], g[key]) < 8e-2, key
 
 
+def test_intermediate_hidden_states_are_differentiable():
+    """A head that reads hidden_states[i] (the reference's own Condenser head reads hidden_states[skip_from],
+    COCO/modeling.py:212-216, through `lm(..., output_hidden_states=True)`) back-propagates into the backbone: gradients arriving
+    at the embedding output, a middle layer and the last layer at once, against the oracle's backward with the same taps."""
+    ocfg = O.OracleConfig(vocab_size=400, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=64)
+    P = O.make_params(ocfg, 31, std=0.08)
+    m = model_from_oracle(ocfg, P)
+    rng = np.random.Generator(np.random.PCG64(6))
+    B, L = 6, 40  # L is not a multiple of 32: the hidden states come back cut to L, their gradients are zero-padded
+    ids = rng.integers(5, 400, (B, L))
+    mask = np.ones((B, L), np.int64)
+    mask[1, 17:] = 0
+    mask[4, 33:] = 0
+    ids = ids * mask
+    w = {l: (rng.standard_normal((B, L, 128)) * mask[..., None]).astype(np.float32) for l in (0, 2, 4)}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    out = m(input_ids=t(ids), attention_mask=t(mask), output_hidden_states=True)
+    assert len(out.hidden_states) == 5 and all(h.shape == (B, L, 128) and h.requires_grad for h in out.hidden_states)
+    loss = sum((out.hidden_states[l].float() * t(w[l])).sum() for l in (0, 2, 4))
+    loss.backward()
+    G = grads_by_name(m)
+    hs, cache = O.encoder_fwd(P, ocfg, ids, mask, keep_cache=True)
+    ref_loss = sum(float((hs[l] * w[l]).sum()) for l in (0, 2, 4))
+    assert abs(float(loss.detach()) - ref_loss) < 2e-2 * abs(ref_loss) + 0.5
+    Gref = O.encoder_bwd(P, ocfg, cache, w[4].copy(), extra={0: w[0], 2: w[2]})
+    bad = {n: rel_l2(G[n], Gref[n]) for n in Gref if not n.endswith("key.bias") and n != "embeddings.word_embeddings.weight"
+           and rel_l2(G[n], Gref[n]) > 8e-2}
+    assert not bad, bad
+    rows = np.unique(ids[mask.astype(bool)])
+    assert rel_l2(G["embeddings.word_embeddings.weight"][rows], Gref["embeddings.word_embeddings.weight"][rows]) < 8e-2
+    # a tap alone (nothing arrives at the last layer), and the tapped forward without any tap used = the plain backward
+    m.zero_grad(set_to_none=True)
+    out = m(input_ids=t(ids), attention_mask=t(mask), output_hidden_states=True)
+    (out.hidden_states[1].float() * t(w[2])).sum().backward()
+    G1 = grads_by_name(m)
+    Gref1 = O.encoder_bwd(P, ocfg, cache, np.zeros_like(w[4]), extra={1: w[2]})
+    assert rel_l2(G1["encoder.layer.0.output.dense.weight"], Gref1["encoder.layer.0.output.dense.weight"]) < 8e-2
+    assert float(np.abs(G1["encoder.layer.1.output.dense.weight"]).max()) == 0.0  # layers above the tap see no gradient
+    res = []
+    for flag in (True, False):
+        m.zero_grad(set_to_none=True)
+        out = m(input_ids=t(ids), attention_mask=t(mask), output_hidden_states=flag)
+        (out.last_hidden_state.float() * t(w[4])).sum().backward()
+        res.append(m.flat_decay.grad.clone())
+    mb = m.layout.mat_begin  # (the embedding tables accumulate sparse rows with atomics: equal up to summation order)
+    assert torch.equal(res[0][mb:], res[1][mb:]) and torch.allclose(res[0][:mb], res[1][:mb], rtol=1e-4, atol=1e-5)
+
+
 def test_condenser_step_after_resize_token_embeddings_matches_oracle():
     """COCO/run_coco_pre_training.py:158: `model.lm.resize_token_embeddings(len(tokenizer))` in front of training.  After growing
     the vocabulary (to a size that is not a multiple of the decoder's 128-row padding) the full step - new token ids in the
