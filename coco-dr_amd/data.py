@@ -9,6 +9,9 @@ interchange with this implementation.
   * embedding shards - ``barrier_array_merge`` ANCE/utils/util.py:117-123 / evaluate_beir.py:200-209: pickle protocol 4
         ndarrays ``{prefix}__emb_p__data_obj_{rank}.pb`` and ``{prefix}__embid_p__data_obj_{rank}.pb``
   * hard-negative file - ANCE/drivers/run_ann_data_gen.py:403-429: ``qid\\tpos\\tneg,neg,...`` written in 5 splits
+  * training batches - ``GetTripletTrainingDataProcessingFn`` / ``GetTrainingDataProcessingFn`` (ANCE/data/msmarco_data.py:328-384)
+        over ``StreamingDataset`` (ANCE/utils/util.py:372-399, line i -> rank i % W) and a DataLoader of ``train_batch_size``:
+        ``triplet_records`` / ``pair_records`` / ``TripletStream`` build the same rows in the same order, a batch per gather
 The whole cache is memory-mapped and batches are gathered with one fancy-index (no per-record seeks).
 """
 from __future__ import annotations
@@ -22,7 +25,7 @@ import numpy as np
 import torch
 
 __all__ = ["TokenCache", "write_token_cache", "save_embedding_shard", "load_embedding_shards", "write_triplets",
-           "read_triplets"]
+           "read_triplets", "triplet_records", "pair_records", "TripletStream"]
 
 
 class TokenCache:
@@ -129,3 +132,58 @@ def read_triplets(path: str) -> List[Tuple[int, int, List[int]]]:
             a = line.rstrip("\n").split("\t")
             out.append((int(a[0]), int(a[1]), [int(x) for x in a[2].split(",")] if len(a) > 2 and a[2] else []))
     return out
+
+
+# ----------------------------------------------------------------------------------------------- training batches
+def _parse_line(line: str) -> Tuple[int, int, List[int]]:
+    a = line.rstrip("\n").split("\t")  # ANCE/data/msmarco_data.py:330-334 (a line without negatives yields nothing)
+    return int(a[0]), int(a[1]), [int(x) for x in a[2].split(",")] if len(a) > 2 and a[2].strip() else []
+
+
+def triplet_records(lines: Sequence[str], rank: int = 0, world_size: int = 1) -> np.ndarray:
+    """[n, 3] int64 rows (qid, positive pid, negative pid) in the order ``StreamingDataset`` over
+    ``GetTripletTrainingDataProcessingFn`` yields them on ``rank``: line i belongs to rank i % world_size
+    (ANCE/utils/util.py:390-392), one row per negative of the line (ANCE/data/msmarco_data.py:377-382)."""
+    rows = []
+    for i, line in enumerate(lines):
+        if world_size > 1 and i % world_size != rank:
+            continue
+        qid, pos, negs = _parse_line(line)
+        rows.extend((qid, pos, n) for n in negs)
+    return np.asarray(rows, dtype=np.int64).reshape(-1, 3)
+
+
+def pair_records(lines: Sequence[str], rank: int = 0, world_size: int = 1) -> np.ndarray:
+    """[n, 3] int64 rows (qid, pid, label) of ``GetTrainingDataProcessingFn`` (ANCE/data/msmarco_data.py:328-356): for every
+    negative of a line the positive pair (label 1) then the negative pair (label 0)."""
+    t = triplet_records(lines, rank, world_size)
+    out = np.empty((2 * len(t), 3), dtype=np.int64)
+    out[0::2, 0], out[0::2, 1], out[0::2, 2] = t[:, 0], t[:, 1], 1
+    out[1::2, 0], out[1::2, 1], out[1::2, 2] = t[:, 0], t[:, 2], 0
+    return out
+
+
+class TripletStream:
+    """The ANCE training stream of one rank (ANCE/drivers/run_ann.py:247-256, 297-308): batches of ``batch_size`` consecutive
+    triplet rows as the keyword arguments of ``BertDot_NLL_LN.forward`` - ``query_ids / attention_mask_q`` [b, Lq],
+    ``input_ids_a / attention_mask_a`` (positive) and ``input_ids_b / attention_mask_b`` (negative) [b, Lp] - gathered from the two
+    token caches with one fancy-index each.  Like the reference's DataLoader the last batch may be short."""
+
+    def __init__(self, lines: Sequence[str], query_cache: "TokenCache", passage_cache: "TokenCache", batch_size: int,
+                 rank: int = 0, world_size: int = 1, device=None):
+        if batch_size <= 0:
+            raise ValueError("batch_size must be positive")
+        self.rows = triplet_records(lines, rank, world_size)
+        self.q, self.p, self.bs, self.device = query_cache, passage_cache, int(batch_size), device
+
+    def __len__(self) -> int:
+        return (len(self.rows) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        for o in range(0, len(self.rows), self.bs):
+            r = self.rows[o:o + self.bs]
+            q_ids, q_mask, _ = self.q.batch(r[:, 0], self.device)
+            a_ids, a_mask, _ = self.p.batch(r[:, 1], self.device)
+            b_ids, b_mask, _ = self.p.batch(r[:, 2], self.device)
+            yield {"query_ids": q_ids, "attention_mask_q": q_mask, "input_ids_a": a_ids, "attention_mask_a": a_mask,
+                   "input_ids_b": b_ids, "attention_mask_b": b_mask}

@@ -425,6 +425,82 @@ def golden_token_cache():
     sys.path.pop(0)
 
 
+def golden_training_rows():
+    """The ANCE training stream: the reference's own ``GetTripletTrainingDataProcessingFn`` / ``GetTrainingDataProcessingFn``
+    (ANCE/data/msmarco_data.py:328-384) over its ``StreamingDataset`` (ANCE/utils/util.py:372-399) and a DataLoader, on a small
+    query / passage cache read with its ``EmbeddingCache``.  World sizes 1 and 2 (``dist`` is stubbed on the dataset module: the
+    sharding rule only asks it for rank and world size).  Same ``pytrec_eval`` stand-in as the token-cache golden."""
+    sys.modules.setdefault("pytrec_eval", types.ModuleType("pytrec_eval"))
+    sys.path.insert(0, os.path.join(REF, "ANCE"))
+    sys.path.insert(0, os.path.join(REF, "ANCE", "data"))
+    import json
+    import tempfile
+    import utils.util as U  # reference
+    import msmarco_data as MD  # reference
+    from torch.utils.data import DataLoader
+    rng = np.random.Generator(np.random.PCG64(31))
+    d = tempfile.mkdtemp()
+
+    def make_cache(name, n, L):
+        blob = b""
+        for i in range(n):
+            toks = [int(x) for x in rng.integers(1, 30000, int(rng.integers(1, L + 6)))]
+            blob += min(len(toks), L).to_bytes(4, "big") + np.array(U.pad_input_ids(toks, L), np.int32).tobytes()
+        path = os.path.join(d, name)
+        with open(path, "wb") as f:
+            f.write(blob)
+        with open(path + "_meta", "w") as f:
+            json.dump({"type": "int32", "total_number": n, "embedding_size": L}, f)
+        return path, np.frombuffer(blob, np.uint8)
+
+    Lq, Lp = 8, 12
+    qpath, qblob = make_cache("queries", 7, Lq)
+    ppath, pblob = make_cache("passages", 20, Lp)
+    lines = []
+    for qid in (3, 0, 5, 6, 1):
+        negs = [int(x) for x in rng.choice(20, int(rng.integers(1, 4)), replace=False)]
+        lines.append("{}\t{}\t{}\n".format(qid, int(rng.integers(0, 20)), ",".join(map(str, negs))))
+    args = types.SimpleNamespace(max_query_length=Lq, max_seq_length=Lp)
+    out = dict(q_blob=qblob, p_blob=pblob, Lq=np.int64(Lq), Lp=np.int64(Lp), lines=np.array(lines), batch_size=np.int64(3))
+
+    class FakeDist:
+        def __init__(self, rank, world):
+            self.rank, self.world = rank, world
+
+        def is_initialized(self):
+            return self.world > 1
+
+        def get_world_size(self):
+            return self.world
+
+        def get_rank(self):
+            return self.rank
+
+    real_dist = U.dist
+    with U.EmbeddingCache(qpath) as qc, U.EmbeddingCache(ppath) as pc:
+        for world in (1, 2):
+            for rank in range(world):
+                U.dist = FakeDist(rank, world)
+                ds = U.StreamingDataset(lines, MD.GetTripletTrainingDataProcessingFn(args, qc, pc), size=-1)
+                batches = list(DataLoader(ds, batch_size=3))
+                for bi, b in enumerate(batches):
+                    for name, j in (("q_ids", 0), ("q_mask", 1), ("a_ids", 3), ("a_mask", 4), ("b_ids", 6), ("b_mask", 7)):
+                        out[f"trip_w{world}_r{rank}_b{bi}_{name}"] = b[j].long().numpy()
+                out[f"trip_w{world}_r{rank}_nb"] = np.int64(len(batches))
+        U.dist = FakeDist(0, 1)
+        ds = U.StreamingDataset(lines, MD.GetTrainingDataProcessingFn(args, qc, pc), size=-1)
+        recs = list(ds)
+        out["pair_q_ids"] = np.stack([r[0].long().numpy() for r in recs])
+        out["pair_p_ids"] = np.stack([r[3].long().numpy() for r in recs])
+        out["pair_p_mask"] = np.stack([r[4].long().numpy() for r in recs])
+        out["pair_label"] = np.array([int(r[6]) for r in recs])
+    U.dist = real_dist
+    np.savez_compressed(os.path.join(OUT, "training_rows.npz"), **out)
+    print("training rows golden:", {k: v for k, v in out.items() if k.endswith("_nb")}, len(recs), "pair records")
+    sys.path.pop(0)
+    sys.path.pop(0)
+
+
 def golden_idro():
     """f2: two training steps of the reference's iDRO re-weighting (ANCE/model/dro_loss.py:160-254) driven through
     BertDot_NLL_LN.forward(group_ids=...) (ANCE/model/models.py:234-273) on a 12-layer toy BERT (iDROLoss selects
@@ -750,7 +826,7 @@ def golden_negatives():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate", "evaldev", "negatives", "dropout"]
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate", "evaldev", "negatives", "dropout", "training_rows"]
     if "evaldev" in which:
         golden_evaldev()
     if "negatives" in which:
@@ -765,6 +841,8 @@ if __name__ == "__main__":
         golden_lamb()
     if "cache" in which:
         golden_token_cache()
+    if "training_rows" in which:
+        golden_training_rows()
     if "coco" in which:
         golden_coco()
     if "condenser" in which:

@@ -66,3 +66,63 @@ def test_triplet_file_format(tmp_path):
     assert n == len(rows) == 10 and rows[0] == (9, 90, [200, 201]) and rows[1] == (7, 70, [100, 101])
     assert rows[-1] == (7, 70, [108, 109])
     assert open(path).readline() == "9\t90\t200,201\n"
+
+
+def _caches_from_golden(g, tmp_path):
+    out = []
+    for name, blob, L in (("queries", g["q_blob"], int(g["Lq"])), ("passages", g["p_blob"], int(g["Lp"]))):
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(blob.tobytes())
+        with open(path + "_meta", "w") as f:
+            json.dump({"type": "int32", "total_number": len(blob) // (4 * L + 4), "embedding_size": L}, f)
+        out.append(D.TokenCache(path))
+    return out
+
+
+def test_training_stream_matches_reference_processing_fns(tmp_path):
+    """ANCE/data/msmarco_data.py:328-384 over ANCE/utils/util.py:372-399 + DataLoader(batch_size): the reference's own
+    functions produced tests/golden/training_rows.npz; the stream here must give the same batches on every rank."""
+    g = load_golden("training_rows.npz")
+    qc, pc = _caches_from_golden(g, tmp_path)
+    lines = [str(x) for x in g["lines"]]
+    bs = int(g["batch_size"])
+    keys = (("query_ids", "q_ids"), ("attention_mask_q", "q_mask"), ("input_ids_a", "a_ids"), ("attention_mask_a", "a_mask"),
+            ("input_ids_b", "b_ids"), ("attention_mask_b", "b_mask"))
+    for world in (1, 2):
+        seen = 0
+        for rank in range(world):
+            stream = D.TripletStream(lines, qc, pc, bs, rank=rank, world_size=world)
+            batches = list(stream)
+            assert len(batches) == len(stream) == int(g[f"trip_w{world}_r{rank}_nb"])
+            for bi, b in enumerate(batches):
+                for ours, theirs in keys:
+                    ref = g[f"trip_w{world}_r{rank}_b{bi}_{theirs}"]
+                    assert b[ours].dtype == torch.int64 and np.array_equal(b[ours].numpy(), ref), (world, rank, bi, ours)
+                seen += b["query_ids"].shape[0]
+        assert seen == sum(len(l.rstrip("\n").split("\t")[2].split(",")) for l in lines)  # every negative exactly once
+    # the pairwise form: positive pair (label 1), then negative pair (label 0), per negative
+    rows = D.pair_records(lines)
+    assert rows[:, 2].tolist() == g["pair_label"].tolist()
+    q_ids, _, _ = qc.batch(rows[:, 0])
+    p_ids, p_mask, _ = pc.batch(rows[:, 1])
+    assert np.array_equal(q_ids.numpy(), g["pair_q_ids"]) and np.array_equal(p_ids.numpy(), g["pair_p_ids"])
+    assert np.array_equal(p_mask.numpy(), g["pair_p_mask"])
+
+
+def test_training_stream_edge_cases(tmp_path):
+    g = load_golden("training_rows.npz")
+    qc, pc = _caches_from_golden(g, tmp_path)
+    assert D.triplet_records([]).shape == (0, 3) and list(D.TripletStream([], qc, pc, 4)) == []
+    assert D.triplet_records(["3\t5\t\n", "1\t2\t7\n"]).tolist() == [[1, 2, 7]]  # a line without negatives yields nothing
+    assert D.triplet_records(["1\t2\t7,8\n", "3\t4\t9\n"], rank=1, world_size=2).tolist() == [[3, 4, 9]]
+    try:
+        D.TripletStream([], qc, pc, 0)
+        raise AssertionError("batch_size 0 accepted")
+    except ValueError:
+        pass
+    try:
+        list(D.TripletStream(["1\t2\t999\n"], qc, pc, 2))  # a pid outside the cache
+        raise AssertionError("out-of-range pid accepted")
+    except IndexError:
+        pass
