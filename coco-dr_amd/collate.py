@@ -10,7 +10,7 @@ import torch
 
 from ._native import check, lib, ptr, stream_ptr
 
-__all__ = ["CondenserCollator", "CoCondenserCollator", "subword_flags_from_vocab"]
+__all__ = ["CondenserCollator", "CoCondenserCollator", "CoCondenserDataset", "subword_flags_from_vocab"]
 
 
 BERT_SPECIALS = ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]")  # BertTokenizer.all_special_tokens
@@ -77,3 +77,23 @@ class CoCondenserCollator(CondenserCollator):
     def __call__(self, examples):
         spans = [s for e in examples for s in e["span"]]
         return self.collate_spans(spans)
+
+
+class CoCondenserDataset(torch.utils.data.Dataset):
+    """``CoCondenserDataset`` (COCO/data.py:169-183): item i = two spans of document i - the single span twice when the
+    document has only one, otherwise ``random.sample(spans, 2)`` (Python's global ``random``, as the reference: seed it with
+    ``random.seed`` / the trainer's ``set_seed`` for reproducible pairs).  ``dataset[i]["spans"]`` is a list of token-id lists."""
+
+    def __init__(self, dataset, data_args=None):
+        self.dataset = dataset
+        self.data_args = data_args
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, item):
+        import random
+        spans = self.dataset[item]["spans"]
+        if len(spans) == 1:
+            return {"span": spans + spans}
+        return {"span": random.sample(spans, 2)}

@@ -501,6 +501,33 @@ def golden_training_rows():
     sys.path.pop(0)
 
 
+def golden_coco_dataset():
+    """``CoCondenserDataset.__getitem__`` (COCO/data.py:169-183) under a seeded Python ``random``: which two spans of each
+    document become the positive pair."""
+    import random
+    sys.path.insert(0, os.path.join(REF, "COCO"))
+    from data import CoCondenserDataset  # reference
+    rng = np.random.Generator(np.random.PCG64(41))
+    docs = []
+    for n_spans in (1, 2, 5, 3, 1, 8):
+        docs.append({"spans": [[int(x) for x in rng.integers(1000, 30000, int(rng.integers(2, 9)))] for _ in range(n_spans)]})
+    ds = CoCondenserDataset(docs, None)
+    random.seed(1234)
+    picks = []
+    for epoch in range(2):
+        for i in range(len(ds)):
+            picks.append(ds[i]["span"])
+    flat = [s for d in docs for s in d["spans"]]
+    np.savez_compressed(os.path.join(OUT, "coco_dataset.npz"),
+                        span_tokens=np.concatenate([np.asarray(s, np.int64) for s in flat]),
+                        span_lens=np.asarray([len(s) for s in flat]), doc_spans=np.asarray([len(d["spans"]) for d in docs]),
+                        seed=np.int64(1234),
+                        pick_tokens=np.concatenate([np.asarray(s, np.int64) for p in picks for s in p]),
+                        pick_lens=np.asarray([len(s) for p in picks for s in p]))
+    print("coco dataset golden:", len(picks), "items")
+    sys.path.pop(0)
+
+
 def golden_idro():
     """f2: two training steps of the reference's iDRO re-weighting (ANCE/model/dro_loss.py:160-254) driven through
     BertDot_NLL_LN.forward(group_ids=...) (ANCE/model/models.py:234-273) on a 12-layer toy BERT (iDROLoss selects
@@ -826,7 +853,7 @@ def golden_negatives():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate", "evaldev", "negatives", "dropout", "training_rows"]
+    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate", "evaldev", "negatives", "dropout", "training_rows", "coco_dataset"]
     if "evaldev" in which:
         golden_evaldev()
     if "negatives" in which:
@@ -843,6 +870,8 @@ if __name__ == "__main__":
         golden_token_cache()
     if "training_rows" in which:
         golden_training_rows()
+    if "coco_dataset" in which:
+        golden_coco_dataset()
     if "coco" in which:
         golden_coco()
     if "condenser" in which:

@@ -126,3 +126,26 @@ def test_training_stream_edge_cases(tmp_path):
         raise AssertionError("out-of-range pid accepted")
     except IndexError:
         pass
+
+
+def test_cocondenser_dataset_pairs_match_reference_sampling():
+    """COCO/data.py:169-183: the reference's own CoCondenserDataset under random.seed(1234) chose these span pairs
+    (tests/golden/coco_dataset.npz); one-span documents give the span twice."""
+    import random
+    from cocodr_amd.collate import CoCondenserDataset
+    g = load_golden("coco_dataset.npz")
+    spans = np.split(g["span_tokens"], np.cumsum(g["span_lens"])[:-1])
+    docs, o = [], 0
+    for n in g["doc_spans"]:
+        docs.append({"spans": [s.tolist() for s in spans[o:o + int(n)]]})
+        o += int(n)
+    ds = CoCondenserDataset(docs)
+    assert len(ds) == len(docs)
+    random.seed(int(g["seed"]))
+    got = [s for _epoch in range(2) for i in range(len(ds)) for s in ds[i]["span"]]
+    want = np.split(g["pick_tokens"], np.cumsum(g["pick_lens"])[:-1])
+    assert len(got) == len(want) == 4 * len(docs)
+    for a, b in zip(got, want):
+        assert list(a) == b.tolist()
+    one = ds[0]["span"]
+    assert one[0] == one[1] == docs[0]["spans"][0]
