@@ -156,6 +156,7 @@ class CocoBertForMaskedLM(nn.Module):
 
     def __init__(self, config: CocoBertConfig, device=None):
         super().__init__()
+        config = CocoBertConfig.coerce(config)
         self.config = config
         self.bert = CocoBertModel(config, device=device)
         self.cls = CocoMLMHead(self.bert)

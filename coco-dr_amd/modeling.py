@@ -105,6 +105,16 @@ class CocoBertConfig:
         with open(os.path.join(path, "config.json"), "w") as f:
             json.dump(self.to_dict(), f, indent=2, sort_keys=True)
 
+    @classmethod
+    def coerce(cls, config) -> "CocoBertConfig":
+        """A transformers ``BertConfig`` (what the reference passes as ``config=`` to ``from_pretrained``:
+        COCO/modeling.py:100-101, ANCE/drivers/run_ann.py:889-901) or a plain dict -> this class, with its validation."""
+        if isinstance(config, cls):
+            return config
+        d = dict(config) if isinstance(config, dict) else dict(config.to_dict())
+        d.pop("model_type", None)
+        return cls(**d)
+
 
 # =============================================================================== flat parameter layout
 class _Layout:
@@ -389,6 +399,7 @@ class CocoBertModel(nn.Module):
 
     def __init__(self, config: CocoBertConfig, device: Optional[torch.device] = None):
         super().__init__()
+        config = CocoBertConfig.coerce(config)
         self.config = config
         self.layout = _Layout(config)
         dev = torch.device(device) if device is not None else torch.device("cpu")
@@ -895,6 +906,7 @@ class BertDotNLL(nn.Module):
 
     def __init__(self, config: CocoBertConfig, model_argobj=None, device=None):
         super().__init__()
+        config = CocoBertConfig.coerce(config)
         self.config = config
         self.bert = CocoBertModel(config, device=device)
         self.total = 0

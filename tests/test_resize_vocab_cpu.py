@@ -90,3 +90,21 @@ def test_resize_rejects_bad_sizes_and_late_calls():
     m._dp_hooks = [object()]  # as after enable_grad_allreduce
     with pytest.raises(RuntimeError):
         m.resize_token_embeddings(400)
+
+
+def test_transformers_config_objects_are_accepted():
+    """The reference passes `config=AutoConfig.from_pretrained(...)` into `from_pretrained` (COCO/modeling.py:100-101,
+    ANCE/drivers/run_ann.py:889-901): a transformers BertConfig (or a dict) becomes a validated CocoBertConfig."""
+    transformers = pytest.importorskip("transformers")
+    from cocodr_amd.modeling import BertDotNLL
+    hf = transformers.BertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                 max_position_embeddings=48, hidden_dropout_prob=0.05)
+    for m in (CocoBertModel(hf), BertDotNLL(hf).bert, CocoBertModel(hf.to_dict())):
+        assert isinstance(m.config, CocoBertConfig)
+        assert (m.config.vocab_size, m.config.hidden_size, m.config.num_hidden_layers, m.config.hidden_dropout_prob) == (300, 128, 2, 0.05)
+    bad = transformers.BertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256)
+    with pytest.raises(ValueError):
+        CocoBertModel(bad)  # head_dim 32: the validation still applies
+    with pytest.raises(ValueError):
+        CocoBertModel(transformers.BertConfig(vocab_size=300, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                                              hidden_act="relu"))
