@@ -71,6 +71,13 @@ SHAPES = [  # (name, M, N, K, ta, tb, batch, out_f32)
     ("ksweep 8192x3072x1536", 8192, 3072, 1536, 0, 0, 1, 0),
     ("ksweep 8192x3072x3072", 8192, 3072, 3072, 0, 0, 1, 0),
     ("ksweep 8192x3072x6144", 8192, 3072, 6144, 0, 0, 1, 0),
+    ("pkXL fwd qkv  17896x3072x1024", 17896, 3072, 1024, 0, 0, 1, 0),   # 54-60: the 200-sequence BERT-large batch, packed
+    ("pkXL fwd out  17896x1024x1024", 17896, 1024, 1024, 0, 0, 1, 0),
+    ("pkXL fwd ffn1 17896x4096x1024", 17896, 4096, 1024, 0, 0, 1, 0),
+    ("pkXL fwd ffn2 17896x1024x4096", 17896, 1024, 4096, 0, 0, 1, 0),
+    ("pkXL dgrad ffn2 17896x4096x1024", 17896, 4096, 1024, 0, 1, 1, 0),
+    ("pkXL dgrad ffn1 17896x1024x4096", 17896, 1024, 4096, 0, 1, 1, 0),
+    ("pkXL dgrad qkv 17896x1024x3072", 17896, 1024, 3072, 0, 1, 1, 0),
 ]
 
 
