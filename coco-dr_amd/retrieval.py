@@ -21,7 +21,7 @@ import torch
 from . import ops
 
 __all__ = ["shard_indices", "merged_order", "encode_corpus", "search", "sharded_search", "merge_topk", "eval_dev_query",
-           "EvalDevQuery", "generate_negatives", "ndcg_at_10", "map_at_10", "recall_at", "mrr_at_10"]
+           "EvalDevQuery", "generate_negatives", "ndcg_at_10", "map_at_10", "recall_at", "mrr_at_10", "build_ann_training_data"]
 
 
 # ----------------------------------------------------------------------------------------------- sharding
@@ -279,3 +279,36 @@ def generate_negatives(query_embedding2id, passage_embedding2id, training_query_
         _, first = np.unique(window, return_index=True)
         negatives[qid] = window[np.sort(first)][:negative_sample].tolist()
     return negatives, np.array(rr)
+
+
+def build_ann_training_data(query_embedding: torch.Tensor, query_embedding2id, passage_embedding: torch.Tensor, passage_embedding2id,
+                            training_query_positive_id: Dict[int, int], output_num: int, out_path: str, topk_training: int = 200,
+                            negative_sample: int = 20, ann_chunk_factor: int = 1, ann_measure_topk_mrr: bool = False,
+                            shuffle: Optional[Callable[[list], None]] = None, n_splits: int = 5):
+    """The training-set half of ``generate_new_ann`` (ANCE/drivers/run_ann_data_gen.py:332-429, the non-clustered branch) on
+    resident embeddings: pick this round's chunk of the training queries (``output_num % ann_chunk_factor``, the last chunk takes
+    the remainder), search the top ``topk_training`` passages (exact inner product, ``search``), draw the hard negatives
+    (``generate_negatives``), shuffle the query order and write ``qid\\tpos\\tneg,neg,...`` in ``n_splits`` passes, each with its
+    slice of every query's negatives.  ``shuffle`` permutes a list in place (default ``random.shuffle`` as in the driver) and is
+    used for the negatives' walk order and for the query order.  Returns (lines written, reciprocal ranks of the positives)."""
+    import random
+    from .data import write_triplets
+    shuffle = shuffle or random.shuffle
+    q2id = np.asarray(query_embedding2id).reshape(-1)
+    chunk_factor = int(ann_chunk_factor)
+    effective_idx = int(output_num) % chunk_factor if chunk_factor > 0 else 0  # (the driver takes the modulus before its <= 0 guard)
+    if chunk_factor <= 0:
+        chunk_factor = 1
+    n = len(q2id)
+    per = n // chunk_factor
+    lo = per * effective_idx
+    hi = n if effective_idx == chunk_factor - 1 else lo + per
+    Q, q2id = query_embedding[lo:hi], q2id[lo:hi]
+    _, I = search(Q, passage_embedding, int(topk_training))
+    effective = {int(x) for x in q2id}
+    negatives, rr = generate_negatives(q2id, passage_embedding2id, training_query_positive_id, I, negative_sample, effective,
+                                       ann_measure_topk_mrr, shuffle)
+    order = list(range(len(q2id)))
+    shuffle(order)
+    lines = write_triplets(out_path, [int(q2id[i]) for i in order], training_query_positive_id, negatives, n_splits)
+    return lines, rr

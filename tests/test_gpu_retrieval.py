@@ -118,3 +118,66 @@ def test_encode_search_ndcg_pipeline_matches_fp32_oracle_pipeline():
     # the bf16 encoder against the fp32 oracle: at most two near-tie swaps among the 60 noisy queries (which ones flip moves
     # with the last bits of the LayerNorm statistics, i.e. with the summation order of the wave reductions)
     assert abs(ndcg - ndcg_r) <= 1e-3 + 2.0 / nq * 0.4, (ndcg, ndcg_r)
+
+
+def test_ance_refresh_cycle_in_miniature(tmp_path):
+    """BASELINE configs[3] end to end at toy size: encode passages and training queries with the current model, rebuild the
+    hard-negative training file (generate_new_ann's training-set half, ANCE/drivers/run_ann_data_gen.py:332-429), stream it back
+    as triplet batches (ANCE/drivers/run_ann.py:247-256) and take a training step on them.  The file is checked line by line
+    against the oracle's search + GenerateNegativePassaageID restatement under the same permutations."""
+    from cocodr_amd import data as DT
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=800, hidden_size=128, num_hidden_layers=2,
+                         num_attention_heads=2, intermediate_size=256, max_position_embeddings=64)
+    torch.manual_seed(5)
+    model = BertDotNLL(cfg).to(DEV)
+    with torch.no_grad():
+        model.bert.flat_decay.mul_(3.0)
+    rng = np.random.Generator(np.random.PCG64(8))
+    npass, nq, Lp, Lq = 300, 41, 32, 16
+    qpath, ppath = str(tmp_path / "train-query"), str(tmp_path / "passages")
+    DT.write_token_cache(ppath, [[1] + rng.integers(5, 800, int(rng.integers(6, Lp + 5))).tolist() for _ in range(npass)], Lp)
+    DT.write_token_cache(qpath, [[1] + rng.integers(5, 800, int(rng.integers(3, Lq + 3))).tolist() for _ in range(nq)], Lq)
+    qc, pc = DT.TokenCache(qpath), DT.TokenCache(ppath)
+    model.eval()
+    p_ids, p_mask, p2id = pc.batch(np.arange(npass), DEV)
+    q_ids, q_mask, q2id = qc.batch(np.arange(nq), DEV)
+    Pe, _ = R.encode_corpus(model, p_ids, p_mask, batch_size=128)
+    Qe, _ = R.encode_corpus(model, q_ids, q_mask, batch_size=32, is_query=True)
+    positives = {int(q): int(rng.integers(0, npass)) for q in range(nq)}
+    topk, nneg, chunk_factor, output_num = 40, 10, 2, 3   # round 3 of 2 chunks -> the second half of the queries (+ the remainder)
+    perms = []
+
+    def shuffle(lst):  # a recorded stand-in for random.shuffle: the oracle replays the same permutations
+        p = rng.permutation(len(lst)).tolist()
+        lst[:] = [lst[i] for i in p]
+        perms.append(list(lst))
+
+    out = str(tmp_path / "ann_training_data_3")
+    n_lines, rr = R.build_ann_training_data(Qe, q2id.cpu().numpy(), Pe, p2id.cpu().numpy(), positives, output_num, out, topk_training=topk,
+                                            negative_sample=nneg, ann_chunk_factor=chunk_factor, shuffle=shuffle)
+    lo = (nq // 2) * 1
+    qsel = np.arange(lo, nq)
+    assert len(perms) == len(qsel) + 1 and len(rr) == len(qsel)
+    Dr, Ir = O.score_topk(Qe.cpu().numpy()[qsel], Pe.cpu().numpy(), topk)
+    neg_ref, rr_ref = O.generate_negatives(qsel, np.arange(npass), positives, Ir, nneg, set(qsel.tolist()), select_topk=False,
+                                           permutations=perms[:-1])
+    np.testing.assert_allclose(rr, rr_ref)
+    want = []
+    for split in range(5):
+        for qi in perms[-1]:
+            qid = int(qsel[qi])
+            k = len(neg_ref[qid]) // 5
+            want.append("{}\t{}\t{}\n".format(qid, positives[qid], ",".join(str(x) for x in neg_ref[qid][split * k:(split + 1) * k])))
+    with open(out) as f:
+        got = f.readlines()
+    assert n_lines == len(got) == 5 * len(qsel) and got == want
+    # ... and train on it: two ranks' streams partition the rows; one step on rank 0's first batch
+    s0 = DT.TripletStream(got, qc, pc, 16, rank=0, world_size=2, device=DEV)
+    s1 = DT.TripletStream(got, qc, pc, 16, rank=1, world_size=2, device=DEV)
+    assert len(s0.rows) + len(s1.rows) == sum(len(neg_ref[int(q)]) // 5 * 5 for q in qsel)
+    model.train()
+    kw = next(iter(s0))
+    assert kw["query_ids"].shape == (16, Lq) and kw["input_ids_b"].shape == (16, Lp)
+    loss, acc, _ = model(**kw)
+    loss.backward()
+    assert torch.isfinite(loss) and float(model.bert.flat_decay.grad.abs().sum()) > 0
