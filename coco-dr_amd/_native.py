@@ -109,6 +109,8 @@ SIGNATURES = {
     "cocodr_gemm_colsum_partial_floats": (c_size_t, [c_int, c_int]),
     "cocodr_gemm_colsum_rows": (c_int, [C.POINTER(GemmArgs)]),
     "cocodr_colsum_partial_floats": (c_size_t, [c_int, c_int, c_int]),
+    "cocodr_gram_f32_workspace_floats": (c_size_t, [c_int, c_longlong]),
+    "cocodr_gram_f32": (c_int, [c_void_p, c_longlong, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
     "cocodr_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
     "cocodr_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "cocodr_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_float, c_float,

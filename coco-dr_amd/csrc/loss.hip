@@ -9,6 +9,8 @@
 //                 Gs[i][j] = exp(S_ij - lse_i) + exp(S_ij - lse_j) - 2 [j == t(i)],  Gs[i][i] = 0
 //             so a rank only needs its own row block of S - never G^T - and no backward collective.
 //  * triplet: ANCE/model/models.py:97-106 (logits, -log_softmax[:,0]) and :260-261 ((loss*w).mean()).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -279,5 +281,186 @@ extern "C" int cocodr_triplet_nll_fwd_bwd(const float* q, const float* a, const 
   CK_LAUNCH("triplet");
   hipLaunchKernelGGL(weighted_mean_kernel, dim3(1), dim3(256), 0, st, loss_rows, weights, loss, B, 1.0f / (float)B);
   CK_LAUNCH("triplet_mean");
+  return COCODR_OK;
+}
+
+// ------------------------------------------------------------------ gram of a short, very wide fp32 matrix
+// out = A A^T for A [G, D], G <= 64 rows, D ~ 1e7 columns: the per-group gradient matrix of iDRO
+// (ANCE/model/dro_loss.py:236-238 `all_grads @ all_grads.T`).  One pass over HBM: 8 x 8 blocks of the output, the
+// workgroups of a block pair split the columns, every thread keeps the 64 products of its columns in registers; per-workgroup
+// partials are summed by a second kernel in a fixed order (deterministic, no atomics).  A block pair (i, j) streams rows 8i..
+// and 8j.. once: G <= 8 reads A once, G = 16 twice - byte stream work, nowhere near a GEMM.
+namespace {
+constexpr int GRAM_B = 8, GRAM_WGS = 512;
+__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ A, long long lda, int G, long long D,
+                                                           float* __restrict__ partial, int nblk) {
+  // blockIdx.y = block pair p -> (bi, bj), bi <= bj, enumerated row-major over the upper triangle
+  int bi = 0, p = blockIdx.y;
+  while (p >= nblk - bi) { p -= nblk - bi; ++bi; }
+  const int bj = bi + p;
+  float acc[GRAM_B][GRAM_B];
+#pragma unroll
+  for (int i = 0; i < GRAM_B; ++i)
+#pragma unroll
+    for (int j = 0; j < GRAM_B; ++j) acc[i][j] = 0.f;
+  const float* Ai = A + (long long)bi * GRAM_B * lda;
+  const float* Aj = A + (long long)bj * GRAM_B * lda;
+  const int ri = min(GRAM_B, G - bi * GRAM_B), rj = min(GRAM_B, G - bj * GRAM_B);
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < D; c += (long long)gridDim.x * 256) {
+    float x[GRAM_B], y[GRAM_B];
+#pragma unroll
+    for (int i = 0; i < GRAM_B; ++i) x[i] = i < ri ? Ai[i * lda + c] : 0.f;
+    if (bi == bj) {
+#pragma unroll
+      for (int j = 0; j < GRAM_B; ++j) y[j] = x[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < GRAM_B; ++j) y[j] = j < rj ? Aj[j * lda + c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < GRAM_B; ++i)
+#pragma unroll
+      for (int j = 0; j < GRAM_B; ++j) acc[i][j] = fmaf(x[i], y[j], acc[i][j]);
+  }
+  __shared__ float red[4][GRAM_B * GRAM_B];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < GRAM_B; ++i)
+#pragma unroll
+    for (int j = 0; j < GRAM_B; ++j) {
+      const float s = wave_sum(acc[i][j]);
+      if (lane == 0) red[wid][i * GRAM_B + j] = s;
+    }
+  __syncthreads();
+  if (threadIdx.x < GRAM_B * GRAM_B)
+    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (GRAM_B * GRAM_B) + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(64) void gram_finish_kernel(const float* __restrict__ partial, int nwg, int G, int nblk,
+                                                         float* __restrict__ out) {
+  int bi = 0, p = blockIdx.x;
+  while (p >= nblk - bi) { p -= nblk - bi; ++bi; }
+  const int bj = bi + p;
+  const int e = threadIdx.x, i = bi * GRAM_B + e / GRAM_B, j = bj * GRAM_B + e % GRAM_B;
+  float s = 0.f;
+  for (int w = 0; w < nwg; ++w) s += partial[((size_t)blockIdx.x * nwg + w) * (GRAM_B * GRAM_B) + e];
+  if (i < G && j < G) {
+    out[(size_t)i * G + j] = s;
+    if (bi != bj) out[(size_t)j * G + i] = s;
+  }
+}
+// G in (16, 64]: one workgroup owns the WHOLE G x G partial of its column slabs.  A slab = 64 rows x 128 columns in LDS (rows
+// >= G zero, row stride 132 floats: the 16 consecutive rows one 16-B read instruction touches fall into distinct bank groups);
+// thread (ty, tx) of the 16 x 16 grid accumulates the 4 x 4 outputs of rows ty + 16 i x tx + 16 j over the slab's columns from 8
+// float4 reads per 4 columns.  A is read exactly once.
+constexpr int GS_COLS = 128, GS_LD = 132;
+__global__ __launch_bounds__(256) void gram_slab_kernel(const float* __restrict__ A, long long lda, int G, long long D,
+                                                        float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float slab[64 * GS_LD];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int tx = lane & 7, ty = lane >> 3;
+  // every wave keeps its own 64 x 64 partial (8 x 8 outputs per lane: rows ty + 8 i x tx + 8 j) over a quarter of the slab's
+  // column groups: 16 LDS reads per 128 packed FMAs.  Two partial sums per output (even / odd columns) so that the products run as
+  // v_pk_fma_f32 (two FMAs per lane and instruction); with 4 x 4 outputs per lane the loop was bound by the LDS reads
+  cocodr_f32x2 acc2[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc2[i][j] = cocodr_f32x2{0.f, 0.f};
+  const long long nslab = (D + GS_COLS - 1) / GS_COLS;
+  const bool vec = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);  // 16-B loads when every row starts aligned
+  constexpr int NV = 64 * GS_COLS / 4 / 256;  // float4 chunks per thread and slab
+  // (fetching the next slab into registers under this slab's products needs 32 more VGPRs and drops the kernel to one wave per
+  // SIMD: 5.0 -> 8.2 ms at 50 x 37.8 M; two resident workgroups per CU overlap each other's loads instead)
+  for (long long sl = blockIdx.x; sl < nslab; sl += gridDim.x) {
+    const long long c0 = sl * GS_COLS;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int e = threadIdx.x + k * 256, r = e / (GS_COLS / 4), c = (e % (GS_COLS / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < G) {
+        const float* src = A + (long long)r * lda + c0 + c;
+        if (vec && c0 + c + 3 < D) v = *reinterpret_cast<const float4*>(src);
+        else {
+          if (c0 + c < D) v.x = src[0];
+          if (c0 + c + 1 < D) v.y = src[1];
+          if (c0 + c + 2 < D) v.z = src[2];
+          if (c0 + c + 3 < D) v.w = src[3];
+        }
+      }
+      *reinterpret_cast<float4*>(&slab[r * GS_LD + c]) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int c = wid * 4; c < GS_COLS; c += 16) {
+      float4 x[8], y[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float4*>(&slab[(ty + 8 * i) * GS_LD + c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = *reinterpret_cast<const float4*>(&slab[(tx + 8 * j) * GS_LD + c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc2[i][j] = __builtin_elementwise_fma(cocodr_f32x2{x[i].x, x[i].y}, cocodr_f32x2{y[j].x, y[j].y}, acc2[i][j]);
+          acc2[i][j] = __builtin_elementwise_fma(cocodr_f32x2{x[i].z, x[i].w}, cocodr_f32x2{y[j].z, y[j].w}, acc2[i][j]);
+        }
+    }
+  }
+  // the four waves' partials, summed through LDS in wave order (deterministic)
+  float* tile = slab;  // [64][64]
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wid == w) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int o = (ty + 8 * i) * 64 + tx + 8 * j;
+          const float v = acc2[i][j][0] + acc2[i][j][1];
+          tile[o] = w == 0 ? v : tile[o] + v;
+        }
+    }
+  }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * 64 * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) out[e] = tile[e];
+}
+__global__ __launch_bounds__(256) void gram_slab_finish_kernel(const float* __restrict__ partial, int nwg, int G, float* __restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;  // element of the 64 x 64 partial
+  const int i = e >> 6, j = e & 63;
+  if (i >= G || j >= G) return;
+  float s = 0.f;
+  for (int w = 0; w < nwg; ++w) s += partial[(size_t)w * 4096 + e];
+  out[(size_t)i * G + j] = s;
+}
+int gram_slab_wgs(long long D) { return (int)std::max<long long>(1, std::min<long long>(1024, (D + GS_COLS * 4 - 1) / (GS_COLS * 4))); }
+int gram_wgs(long long D) { return (int)std::max<long long>(1, std::min<long long>(GRAM_WGS, (D + 256 * 8 - 1) / (256 * 8))); }
+}  // namespace
+
+extern "C" size_t cocodr_gram_f32_workspace_floats(int G, long long D) {
+  if (G <= 0 || D <= 0) return 0;
+  if (G > 16) return (size_t)gram_slab_wgs(D) * 64 * 64;
+  const int nblk = (G + GRAM_B - 1) / GRAM_B;
+  return (size_t)(nblk * (nblk + 1) / 2) * gram_wgs(D) * GRAM_B * GRAM_B;
+}
+extern "C" int cocodr_gram_f32(const float* A, long long lda, int G, long long D, float* out, float* workspace, cocodr_stream_t stream) {
+  CK_ARG(A && out && workspace, "gram: null pointer");
+  CK_ARG(G > 0 && G <= 64 && D > 0 && lda >= D, "gram: bad shape G=%d D=%lld lda=%lld (G <= 64)", G, D, lda);
+  hipStream_t st = (hipStream_t)stream;
+  if (G > 16) {  // the slab form reads A once whatever G is; the register form below would re-read it per 8-row block pair
+    const int nwg = gram_slab_wgs(D);
+    hipLaunchKernelGGL(gram_slab_kernel, dim3(nwg), dim3(256), 0, st, A, lda, G, D, workspace);
+    CK_LAUNCH("gram_slab");
+    hipLaunchKernelGGL(gram_slab_finish_kernel, dim3(16), dim3(256), 0, st, workspace, nwg, G, out);
+    CK_LAUNCH("gram_slab_finish");
+    return COCODR_OK;
+  }
+  const int nblk = (G + GRAM_B - 1) / GRAM_B, pairs = nblk * (nblk + 1) / 2, nwg = gram_wgs(D);
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(nwg, pairs), dim3(256), 0, st, A, lda, G, D, workspace, nblk);
+  CK_LAUNCH("gram_partial");
+  hipLaunchKernelGGL(gram_finish_kernel, dim3(pairs), dim3(64), 0, st, workspace, nwg, G, nblk, out);
+  CK_LAUNCH("gram_finish");
   return COCODR_OK;
 }

@@ -61,18 +61,21 @@ class IDROLoss(torch.nn.Module):
         self.h_fun = torch.clamp(h, min=self.eps)                                           # :252
 
 
-def _gram(a: torch.Tensor, chunk: int = 1 << 16) -> torch.Tensor:
-    """a @ a.T for a short, very wide fp32 matrix: batched over column chunks (the BLAS kernel picked for one
-    [G, D] x [D, G] product with D ~ 2.5e7 runs at a fraction of the HBM rate)."""
-    G, D = a.shape
-    n = D // chunk
-    out = torch.zeros((G, G), dtype=torch.float32, device=a.device)
-    if n > 0:
-        body = a[:, : n * chunk].view(G, n, chunk).transpose(0, 1)        # [n, G, chunk], strided view
-        out += torch.bmm(body, body.transpose(1, 2)).sum(0)
-    if n * chunk < D:
-        tail = a[:, n * chunk:]
-        out += tail @ tail.T
+def _gram(a: torch.Tensor) -> torch.Tensor:
+    """a @ a.T for the [groups, D] gradient matrix (ANCE/model/dro_loss.py:236): the native streaming gram (ops.gram), in
+    blocks of 64 groups should there ever be more"""
+    G = a.shape[0]
+    if G <= 64:
+        return ops.gram(a.contiguous())
+    out = torch.empty((G, G), dtype=torch.float32, device=a.device)
+    for i in range(0, G, 32):
+        for j in range(i, G, 32):
+            ni, nj = min(32, G - i), min(32, G - j)
+            if j == i:
+                out[i:i + ni, i:i + ni] = ops.gram(a[i:i + ni].contiguous())
+            else:  # ni == 32 here: the cross block of the stacked [32 + nj] rows
+                out[i:i + ni, j:j + nj] = ops.gram(torch.cat([a[i:i + ni], a[j:j + nj]]).contiguous())[:ni, ni:ni + nj]
+                out[j:j + nj, i:i + ni] = out[i:i + ni, j:j + nj].T
     return out
 
 

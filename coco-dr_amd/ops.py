@@ -244,6 +244,18 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gram(a: torch.Tensor) -> torch.Tensor:
+    """a @ a.T for a short, very wide fp32 matrix [G <= 64, D] (iDRO's per-group gradient gram): one streaming pass, deterministic"""
+    _req(a, F32, "a", 2)
+    if a.stride(1) != 1:
+        raise ValueError("gram: rows must be contiguous")
+    G, D = a.shape
+    out = torch.empty((G, G), dtype=F32, device=a.device)
+    ws = torch.empty(lib().cocodr_gram_f32_workspace_floats(G, D), dtype=F32, device=a.device)
+    check(lib().cocodr_gram_f32(ptr(a), a.stride(0), G, D, ptr(out), ptr(ws), stream_ptr()), "gram_f32")
+    return out
+
+
 def cast_f32_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(src, F32, "src")
     if dst is None:

@@ -270,6 +270,12 @@ int cocodr_allgather_rows(const float* local_rows, float* gathered, int rows, in
 int cocodr_ce_fwd_bwd(const float* logits, const int32_t* labels, const float* row_scale, int n, int V, int ld,
                       float* loss_rows, uint16_t* dlogits, cocodr_stream_t stream);
 
+/* out [G,G] = A A^T for a short, very wide fp32 matrix A [G, D] (row stride lda), G <= 64: iDRO's gram of the per-group
+ * gradients (ANCE/model/dro_loss.py:236-238 `all_grads @ all_grads.T`, D = the parameters of BertLayers 9-11).  One pass
+ * over A per 8-row block pair, deterministic; workspace: cocodr_gram_f32_workspace_floats(G, D) floats. */
+size_t cocodr_gram_f32_workspace_floats(int G, long long D);
+int cocodr_gram_f32(const float* A, long long lda, int G, long long D, float* out, float* workspace, cocodr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Brute-force inner-product search: faiss.IndexFlatIP(dim).add(P); .search(Q,k)
  * (evaluate/evaluation/evaluate_beir.py:220-224, ANCE/drivers/run_ann_data_gen.py:310-317,390,

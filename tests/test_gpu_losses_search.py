@@ -168,3 +168,20 @@ def test_split_precision_search_in_passage_column_blocks(monkeypatch):
     monkeypatch.setenv("COCODR_SCORE_PBLK", "512")
     D1, I1 = ops.score_topk(t(Q), t(P), 40)
     assert torch.equal(D0, D1) and torch.equal(I0, I1)
+
+
+@pytest.mark.parametrize("G,D", [(1, 1000), (4, 21_257_216), (8, 4096), (12, 300_001), (16, 1 << 20), (33, 70_000), (64, 10_000)])
+def test_gram_of_a_wide_matrix_matches_fp64(G, D):
+    """iDRO's `all_grads @ all_grads.T` (ANCE/model/dro_loss.py:236-238) as one streaming pass: against a float64 product,
+    symmetric, deterministic (two runs bit-identical); (4, 21 M) is the BERT-base size (layers 9-11, four groups)."""
+    g = torch.Generator(device="cpu").manual_seed(G * 7 + D % 1000)
+    a = torch.randn(G, D, generator=g, dtype=torch.float32)
+    a[:, D // 3] *= 50.0
+    dev = a.to("cuda")
+    out = ops.gram(dev)
+    ref = (a.double() @ a.double().T)
+    err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    assert torch.equal(out, out.T) and torch.equal(out, ops.gram(dev))
+    with pytest.raises(ValueError):
+        ops.gram(dev.t())  # rows must be contiguous
