@@ -53,7 +53,7 @@ class IDROLoss(torch.nn.Module):
         nrm = 1e-12 + torch.sqrt(torch.clamp(torch.diagonal(raw), min=0.0))
         RTG = raw / (nrm[:, None] * nrm[None, :])
         gl = torch.pow(group_losses.unsqueeze(-1), self.alpha)                              # :240
-        RTG = (gl @ gl.T) * RTG                                                             # :241
+        RTG = (gl * gl.T) * RTG              # :241 gl [G,1]: the outer product, as a broadcast                  
         ex = self.rho * RTG.mean(dim=0) * mask                                              # :242-244
         ex = ex - ex.max()                                                                  # :246
         h = torch.pow(self.h_fun, self.ema) * torch.exp(ex) * (counts != 0).to(torch.float32)  # :248-250
