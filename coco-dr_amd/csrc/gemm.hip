@@ -742,5 +742,6 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
 
 extern "C" size_t cocodr_gemm_colsum_partial_floats(int M, int N) {
   const size_t panels = (size_t)(M + 127) / 128;
-  return (panels > 32 ? panels : 32) * (size_t)(N > 0 ? N : 0);  // >= cocodr_colsum_partial_floats(M, N, 1) for the fallback
+  const size_t fused = panels * (size_t)(N > 0 ? N : 0);
+  return std::max(fused, cocodr_colsum_partial_floats(M, N, 1));  // the pipelines without fused sums run cocodr_colsum on the result
 }

@@ -531,7 +531,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
   const uint16_t* Xz = X + (size_t)z * strideX;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (col < N) {
-    for (int row = r_begin + wid; row < r_end; row += 4) {
+    int row = r_begin + wid;
+    for (; row + 12 < r_end; row += 16) {  // four independent 8-B loads per lane in flight
+      uint2 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint2*>(Xz + (size_t)(row + 4 * k) * ldx + col);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t[4];
+        unpack4(v[k], t);
+        acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3];
+      }
+    }
+    for (; row < r_end; row += 4) {
       float t[4];
       unpack4(*reinterpret_cast<const uint2*>(Xz + (size_t)row * ldx + col), t);
       acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3];
@@ -572,7 +584,8 @@ __global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restric
   }
 }
 
-int colsum_splits(int M) { return M >= 4096 ? 32 : (M >= 512 ? 8 : 1); }
+// row ranges per column strip: a [8192, 1024] matrix has only four 256-column strips, so the row axis has to fill the 256 CUs
+int colsum_splits(int M) { return M >= 4096 ? 128 : (M >= 512 ? 16 : 1); }
 int ln_bwd_blocks(int M) { return M >= 256 * NW ? 256 : (M + NW - 1) / NW; }
 
 int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd, uint16_t* dy,
@@ -595,8 +608,13 @@ int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, c
   const bool drop = dm != nullptr && dm->threshold != 0;
   const cocodr_dropout_mask dmv = drop ? *dm : cocodr_dropout_mask{0, 0, 0, 1.0f};
   auto kern = H == 768 ? ln_bwd_kernel<3, true, true> : (H < 768 ? ln_bwd_kernel<3, true, false> : (H == 1024 ? ln_bwd_kernel<MAXC, false, true> : ln_bwd_kernel<MAXC, false, false>));
-  if (drop)
+  // with the mask hash in the loop the guard-free (FULL) instantiations spill 52 / 73 VGPRs at 4 waves per SIMD, the guarded ones
+  // 0 / 2: the dropout form takes the guarded kernels at every width (COCODR_LN_DROP_FULL=1: A/B switch back)
+  static const bool drop_full = getenv("COCODR_LN_DROP_FULL") != nullptr;
+  if (drop && drop_full)
     kern = H == 768 ? ln_bwd_kernel<3, true, true, true> : (H < 768 ? ln_bwd_kernel<3, true, false, true> : (H == 1024 ? ln_bwd_kernel<MAXC, false, true, true> : ln_bwd_kernel<MAXC, false, false, true>));
+  else if (drop)
+    kern = H <= 768 ? ln_bwd_kernel<3, true, false, true> : ln_bwd_kernel<MAXC, false, false, true>;
   hipLaunchKernelGGL(kern, dim3(ln_bwd_blocks(M)), dim3(RB_THREADS), per_pass * row_bytes, st, dout, y, gamma, mean, rstd, dy, partial, M, H,
                      nseg, per_pass, dy_drop, dmv);
   CK_LAUNCH("ln_bwd");
