@@ -607,14 +607,14 @@ int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, c
   const int per_pass = std::max(1, std::min(nseg, (int)((160 * 1024) / row_bytes)));
   const bool drop = dm != nullptr && dm->threshold != 0;
   const cocodr_dropout_mask dmv = drop ? *dm : cocodr_dropout_mask{0, 0, 0, 1.0f};
-  auto kern = H == 768 ? ln_bwd_kernel<3, true, true> : (H < 768 ? ln_bwd_kernel<3, true, false> : (H == 1024 ? ln_bwd_kernel<MAXC, false, true> : ln_bwd_kernel<MAXC, false, false>));
-  // with the mask hash in the loop the guard-free (FULL) instantiations spill 52 / 73 VGPRs at 4 waves per SIMD, the guarded ones
-  // 0 / 2: the dropout form takes the guarded kernels at every width (COCODR_LN_DROP_FULL=1: A/B switch back)
-  static const bool drop_full = getenv("COCODR_LN_DROP_FULL") != nullptr;
-  if (drop && drop_full)
-    kern = H == 768 ? ln_bwd_kernel<3, true, true, true> : (H < 768 ? ln_bwd_kernel<3, true, false, true> : (H == 1024 ? ln_bwd_kernel<MAXC, false, true, true> : ln_bwd_kernel<MAXC, false, false, true>));
-  else if (drop)
-    kern = H <= 768 ? ln_bwd_kernel<3, true, false, true> : ln_bwd_kernel<MAXC, false, false, true>;
+  // The guard-free (FULL) instantiations looked good in isolation but spill at four waves per SIMD (23 VGPRs at H = 1024, 73 with
+  // the dropout hash in the loop; the guarded ones 0 / 2): inside the training steps the guarded kernels are 0.1-1 % faster
+  // without dropout (profiles/r02x) and 1.5-2.3x per call with it.  COCODR_LN_FULL=1: A/B switch back to the guard-free ones.
+  static const bool full = getenv("COCODR_LN_FULL") != nullptr;
+  auto kern = H <= 768 ? ln_bwd_kernel<3, true, false> : ln_bwd_kernel<MAXC, false, false>;
+  if (drop) kern = H <= 768 ? ln_bwd_kernel<3, true, false, true> : ln_bwd_kernel<MAXC, false, false, true>;
+  if (full && H == 768) kern = drop ? ln_bwd_kernel<3, true, true, true> : ln_bwd_kernel<3, true, true>;
+  if (full && H == 1024) kern = drop ? ln_bwd_kernel<MAXC, false, true, true> : ln_bwd_kernel<MAXC, false, true>;
   hipLaunchKernelGGL(kern, dim3(ln_bwd_blocks(M)), dim3(RB_THREADS), per_pass * row_bytes, st, dout, y, gamma, mean, rstd, dy, partial, M, H,
                      nseg, per_pass, dy_drop, dmv);
   CK_LAUNCH("ln_bwd");
