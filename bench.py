@@ -316,6 +316,20 @@ def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3):
     out = {"sequences_per_sec": round(3 * rows / dt, 1), "rows_per_sec": round(rows / dt, 1), "ms_per_step": round(dt * 1e3, 3),
            "loss": round(float(loss.detach()), 4),
            "scope": f"cocodr-large triplet step, {rows} rows (q L64 + pos/neg L128), bf16, clip_grad_norm_(1.0) + LAMB; BASELINE configs[3]"}
+    # the same step with queries, positives and negatives stored back to back as ONE packed encoder pass (side number: same
+    # loss and gradients as the two padded passes without dropout; fewer rows, one backward, no second gradient to add)
+    model.bert.pack_sequences = model.merge_passes = True
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    mdt = (time.perf_counter() - t0) / steps
+    out["packed_single_pass"] = {"rows_per_sec": round(rows / mdt, 1), "ms_per_step": round(mdt * 1e3, 3),
+                                 "note": "BertDotNLL.merge_passes + pack_sequences: one packed encoder pass for q + pos + neg"}
+    model.bert.pack_sequences = model.merge_passes = False
     # the same step with iDRO re-weighting: 50 query clusters, per-group gradients of the last 2 layers
     import types
     n_groups = 50

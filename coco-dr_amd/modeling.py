@@ -910,6 +910,7 @@ class BertDotNLL(nn.Module):
         self.config = config
         self.bert = CocoBertModel(config, device=device)
         self.total = 0
+        self.merge_passes = False  # with bert.pack_sequences: queries + positives + negatives as one packed encoder pass
         self.dro_type, self.loss = "erm", None
 
     def add_group_loss(self, args=None, n_groups: int = 0, dro_type: str = "idro", alpha: float = 0.0, eps: float = 0.1,
@@ -946,6 +947,24 @@ class BertDotNLL(nn.Module):
     def query_emb(self, input_ids, attention_mask):
         return self.bert(input_ids=input_ids, attention_mask=attention_mask).cls_fp32
 
+    def _forward_merged(self, query_ids, attention_mask_q, input_ids_a, attention_mask_a, input_ids_b, attention_mask_b):
+        """Queries, positives and negatives as ONE packed batch (``merge_passes`` with ``bert.pack_sequences``): the packed layout
+        stores every sequence at its own length, so the [B, 64] queries and the [2B, 128] passages need not be separate encoder
+        passes - one forward, one backward (one weight-gradient pass over all rows, no second full-size gradient to add), GEMMs at
+        the row count of the whole step.  Returns None when the masks are not prefix masks (the caller runs the two passes)."""
+        Lq, Lp = query_ids.shape[1], input_ids_a.shape[1]
+        pad = lambda t: torch.nn.functional.pad(t, (0, Lp - Lq)) if Lp > Lq else t
+        ids = torch.cat([pad(query_ids), input_ids_a, input_ids_b])
+        mask = torch.cat([pad(attention_mask_q), attention_mask_a, attention_mask_b])
+        pk = self.bert.pack(ids, mask)
+        if pk is None:
+            return None
+        calls = lambda: self.bert._dropout_calls if self.bert._next_dropout_peek() else 0
+        e = self.bert(input_ids=ids, attention_mask=mask, packed_index=pk).cls_fp32
+        self.last_passes = [("qab", calls())]
+        B = query_ids.shape[0]
+        return e[:B], e[B:2 * B], e[2 * B:]
+
     def body_emb(self, input_ids, attention_mask):
         return self.query_emb(input_ids, attention_mask)
 
@@ -962,6 +981,21 @@ class BertDotNLL(nn.Module):
                 group_ids)
             self.total += rows.shape[0] * (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
             return robust, torch.argmax(logits, dim=1), group_losses, group_counts
+        if self.merge_passes and self.bert.pack_sequences and input_ids_a.shape == input_ids_b.shape \
+                and query_ids.shape[1] <= input_ids_a.shape[1] and query_ids.shape[0] == input_ids_a.shape[0]:
+            merged = self._forward_merged(query_ids, attention_mask_q, input_ids_a, attention_mask_a, input_ids_b, attention_mask_b)
+            if merged is not None:
+                q, a, b = merged
+                B = q.shape[0]
+                w = None if weights is None else weights.to(torch.float32).contiguous()
+                if group_ids is not None:
+                    loss, rows, logits = _TripletFn.apply(q, a, b, self.loss.row_weights(group_ids, w).contiguous())
+                    group_losses, group_counts = self.loss.update(rows, group_ids, w)
+                    self.total += B * (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
+                    return loss, torch.argmax(logits, dim=1), group_losses, group_counts
+                loss, rows, logits = _TripletFn.apply(q, a, b, w)
+                self.total += B * (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
+                return loss, torch.argmax(logits, dim=1), logits
         # The short query pass (B x 64 tokens) fills a fraction of the CUs; it runs on a side stream next to the passage
         # pass.  Autograd replays each pass's backward on its forward stream, so the two backward passes overlap as well.
         main = torch.cuda.current_stream()

@@ -173,3 +173,44 @@ def test_packed_ance_step_and_attention_dropout_draw_the_padded_masks():
     assert abs(res[True][0] - res[False][0]) < 1e-4 * max(1.0, abs(res[False][0]))
     assert torch.allclose(res[True][1], res[False][1], rtol=1e-4, atol=1e-4)
     assert rel_l2(res[True][2], res[False][2]) < 5e-3
+
+
+def test_merged_single_pass_triplet_step_equals_the_separate_passes():
+    """`merge_passes`: queries [B, 32], positives and negatives [B, 64] as ONE packed encoder pass - same embeddings (each
+    sequence attends to itself only), same loss, same gradients as the query pass + passage pass; with dropout it still trains
+    (one call number for the whole step)."""
+    cfgd = cfg_small(num_hidden_layers=2)
+    B = 5
+    q = ragged_batch(B, 32, cfgd["vocab_size"], 11)
+    a = ragged_batch(B, 64, cfgd["vocab_size"], 12)
+    b = ragged_batch(B, 64, cfgd["vocab_size"], 13)
+    res = {}
+    for mode in ("padded", "packed", "merged"):
+        torch.manual_seed(0)
+        model = BertDotNLL(CocoBertConfig(**cfgd)).to(DEV).train()
+        with torch.no_grad():
+            model.bert.flat_decay.mul_(2.0)
+        model.bert.pack_sequences = mode != "padded"
+        model.merge_passes = mode == "merged"
+        loss, _acc, logits = model(t(q[0]), t(q[1]), t(a[0]), t(a[1]), t(b[0]), t(b[1]))
+        loss.backward()
+        res[mode] = (float(loss), logits.detach().clone(), model.bert.flat_decay.grad.detach().clone(), list(model.last_passes))
+    assert [p[0] for p in res["merged"][3]] == ["qab"] and [p[0] for p in res["packed"][3]] == ["q", "ab"]
+    for ref in ("padded", "packed"):
+        assert abs(res["merged"][0] - res[ref][0]) < 1e-4 * max(1.0, abs(res[ref][0]))
+        assert torch.allclose(res["merged"][1], res[ref][1], rtol=1e-4, atol=1e-4)
+        assert rel_l2(res["merged"][2], res[ref][2]) < 5e-3
+    # masks with a hole cannot be packed: the step falls back to the two passes
+    model = BertDotNLL(CocoBertConfig(**cfgd)).to(DEV).train()
+    model.bert.pack_sequences = model.merge_passes = True
+    bad = q[1].copy()
+    bad[0, 2] = 0
+    loss, _acc, _l = model(t(q[0]), t(bad), t(a[0]), t(a[1]), t(b[0]), t(b[1]))
+    assert torch.isfinite(loss) and [p[0] for p in model.last_passes] == ["q", "ab"]
+    # dropout on: one pass, one call number, finite loss and gradients
+    model = BertDotNLL(CocoBertConfig(**cfg_small(num_hidden_layers=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1))).to(DEV).train()
+    model.bert.pack_sequences = model.merge_passes = True
+    model.bert.dropout_seed = 3
+    loss, _acc, _l = model(t(q[0]), t(q[1]), t(a[0]), t(a[1]), t(b[0]), t(b[1]))
+    loss.backward()
+    assert model.last_passes == [("qab", 1)] and torch.isfinite(loss) and torch.isfinite(model.bert.flat_decay.grad).all()
