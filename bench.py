@@ -364,11 +364,11 @@ def corpus_encode(cfg, dev, n: int = 8192, seq_len: int = 128, batch: int = 512,
     from cocodr_amd.modeling import BertDotNLL
     model = BertDotNLL(cfg).to(dev).eval()
     ids, mask = synth_batch(0, n, seq_len, cfg.vocab_size, dev)
-    retrieval.encode_corpus(model, ids[:batch], mask[:batch], batch_size=batch)
+    retrieval.encode_corpus(model, ids[:batch], mask[:batch], batch_size=batch, pack=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        emb, _ = retrieval.encode_corpus(model, ids, mask, batch_size=batch)
+        emb, _ = retrieval.encode_corpus(model, ids, mask, batch_size=batch, pack=False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     retrieval.encode_corpus(model, ids[:batch], mask[:batch], batch_size=batch, pack=True)

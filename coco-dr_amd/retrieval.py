@@ -38,11 +38,12 @@ def merged_order(n: int, world: int) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------- encode
 @torch.no_grad()
 def encode_corpus(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, batch_size: int = 512,
-                  record_ids: Optional[torch.Tensor] = None, is_query: bool = False, pack: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                  record_ids: Optional[torch.Tensor] = None, is_query: bool = False, pack: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Eval-mode ``query_emb`` / ``body_emb`` over a token cache (under ``torch.no_grad()``, as run_ann_data_gen.py:183 does), fp32
     [n,H] kept ON DEVICE plus the record ids - the reference copies every batch to the host (``.cpu().numpy()``,
     run_ann_data_gen.py:191-199); here the shard stays in HBM for the search that follows.  ``pack``: store each batch's
-    sequences back to back instead of padded (same embeddings, no work on the padding rows; include/cocodr.h)."""
+    sequences back to back instead of padded (bit-identical embeddings, no work on the padding rows, +18-21 % passages/s;
+    include/cocodr.h "Packed batches"; a batch whose masks are not prefix masks runs padded).  ``pack=False``: always padded."""
     n = input_ids.shape[0]
     fn = model.query_emb if is_query else model.body_emb
     outs = []
