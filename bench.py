@@ -548,7 +548,8 @@ def main():
         # at 1 GPU"): cocodr-large at this line's 64 sequences and at COCO/README.md:59-63's per-GPU batch for the large
         # model (100 documents = 200 spans), each with its own HIP-event roofline block
         large = {}
-        for n_seq, k_steps in ((64, 10), (200, 6)):
+        # (256 sequences: every GEMM of the step fills whole rounds of the 256 CUs - what the kernels reach without tile-count tails)
+        for n_seq, k_steps in ((64, 10), (200, 6), (256, 5)):
             ldt, lloss, lroof, lcfg, _ = contrastive_leg("large", n_seq, SEQ_LEN, k_steps, 3, dev, 0, 1, False, args.dp_chunks,
                                                          not args.no_roofline, args.dense)
             v = n_seq * k_steps / ldt
