@@ -466,18 +466,18 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   const long long sMH = (long long)M * H, sMI = (long long)M * I, sM3H = (long long)M * 3 * H;
   const size_t l0 = (size_t)layer_lo;
   const cocodr_layer_grads& g0 = lg[layer_lo];
-  cocodr_gemm_args g = gemm_base(dqkv_all + l0 * sM3H, hidden + l0 * sMH, g0.wqkv, 3 * H, H, M, 3 * H, H, H, 1, 1);
-  g.out_f32 = 1; g.batch = NG; g.strideA = sM3H; g.strideB = sMH; g.strideC = s_wqkv;
-  TRY(cocodr_gemm(&g, stream));
-  g = gemm_base(dy1_all + l0 * sMH, (const uint16_t*)(base + lay.ctx) + l0 * sMH, g0.wo, H, H, M, H, H, H, 1, 1);
-  g.out_f32 = 1; g.batch = NG; g.strideA = sMH; g.strideB = sMH; g.strideC = s_wo;
-  TRY(cocodr_gemm(&g, stream));
-  g = gemm_base(du_all + l0 * sMI, (const uint16_t*)(base + lay.x1) + l0 * sMH, g0.w1, I, H, M, I, H, H, 1, 1);
-  g.out_f32 = 1; g.batch = NG; g.strideA = sMI; g.strideB = sMH; g.strideC = s_w1;
-  TRY(cocodr_gemm(&g, stream));
-  g = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
-  g.out_f32 = 1; g.batch = NG; g.strideA = sMH; g.strideB = sMI; g.strideC = s_w2;
-  TRY(cocodr_gemm(&g, stream));
+  // (the four matrices of the range in ONE launch where the pipeline allows - cocodr_gemm_multi: launched one after the other,
+  // each of the four pays its own partial last round of the 256 CUs)
+  cocodr_gemm_args wg[4];
+  wg[0] = gemm_base(dqkv_all + l0 * sM3H, hidden + l0 * sMH, g0.wqkv, 3 * H, H, M, 3 * H, H, H, 1, 1);
+  wg[0].out_f32 = 1; wg[0].batch = NG; wg[0].strideA = sM3H; wg[0].strideB = sMH; wg[0].strideC = s_wqkv;
+  wg[1] = gemm_base(dy1_all + l0 * sMH, (const uint16_t*)(base + lay.ctx) + l0 * sMH, g0.wo, H, H, M, H, H, H, 1, 1);
+  wg[1].out_f32 = 1; wg[1].batch = NG; wg[1].strideA = sMH; wg[1].strideB = sMH; wg[1].strideC = s_wo;
+  wg[2] = gemm_base(du_all + l0 * sMI, (const uint16_t*)(base + lay.x1) + l0 * sMH, g0.w1, I, H, M, I, H, H, 1, 1);
+  wg[2].out_f32 = 1; wg[2].batch = NG; wg[2].strideA = sMI; wg[2].strideB = sMH; wg[2].strideC = s_w1;
+  wg[3] = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
+  wg[3].out_f32 = 1; wg[3].batch = NG; wg[3].strideA = sMH; wg[3].strideB = sMI; wg[3].strideC = s_w2;
+  TRY(cocodr_gemm_multi(wg, 4, stream));
   // ---- deferred reductions of the range (LayerNorm weight / bias + the Linear bias in front of it; b1; value bias)
   if (defer) {
     cocodr_reduce_job jobs[5];  // one launch for all of them

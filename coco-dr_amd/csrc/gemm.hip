@@ -583,6 +583,7 @@ void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
 }  // namespace cocodr_gemm_v2
 using cocodr_gemm_v2::launch_glds_any;
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st);  // gemm_pp.hip: the ping-pong pipeline
+void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, hipStream_t st);
 
 namespace {
 
@@ -744,4 +745,36 @@ extern "C" size_t cocodr_gemm_colsum_partial_floats(int M, int N) {
   const size_t panels = (size_t)(M + 127) / 128;
   const size_t fused = panels * (size_t)(N > 0 ? N : 0);
   return std::max(fused, cocodr_colsum_partial_floats(M, N, 1));  // the pipelines without fused sums run cocodr_colsum on the result
+}
+
+// n independent (batched) weight-gradient problems - form TN, fp32 result, no epilogue - as ONE launch on the ping-pong pipeline
+// when together they fill it (>= 400 tiles of 256 x 256); otherwise, or when a problem does not fit that form, n plain calls.
+extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, cocodr_stream_t stream) {
+  CK_ARG(problems != nullptr && n >= 1 && n <= 4, "gemm_multi: 1..4 problems");
+  static const bool off = getenv("COCODR_GEMM_NOMULTI") != nullptr;  // A/B switch
+  bool ok = !off && n > 1 && gemm_impl_override() == 0;
+  long long tiles = 0;
+  for (int q = 0; q < n && ok; ++q) {
+    const cocodr_gemm_args& a = problems[q];
+    ok = a.A && a.B && a.C && a.trans_a && a.trans_b && a.out_f32 && a.epi == COCODR_EPI_NONE && !a.bias && !a.colsum &&
+         !a.colsum_partial && !a.drop.threshold && !a.ab_f16 && a.M > 0 && a.N > 0 && a.K == problems[0].K && a.K > 0 &&
+         a.N % 256 == 0 && a.M % 8 == 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && a.lda >= a.M &&
+         a.ldb >= a.N && a.ldc >= a.N && (size_t)a.K * a.lda * 2 < (1ull << 32) && (size_t)a.K * a.ldb * 2 < (1ull << 32);
+    tiles += (long long)((a.M + 255) / 256) * (a.N / 256) * (a.batch > 0 ? a.batch : 1);
+  }
+  if (ok && tiles >= 400 && tiles < (1ll << 30)) {
+    cocodr_gemm_args copy[4];
+    for (int q = 0; q < n; ++q) {
+      copy[q] = problems[q];
+      if (copy[q].batch <= 0) copy[q].batch = 1;
+    }
+    cocodr_gemm_pp_launch_multi(copy, n, (hipStream_t)stream);
+    CK_LAUNCH("gemm_multi");
+    return COCODR_OK;
+  }
+  for (int q = 0; q < n; ++q) {
+    const int rc = cocodr_gemm(&problems[q], stream);
+    if (rc != COCODR_OK) return rc;
+  }
+  return COCODR_OK;
 }

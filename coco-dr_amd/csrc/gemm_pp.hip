@@ -136,8 +136,16 @@ __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const Fra
 // training step 0.8 % SLOWER (same box, two alternating runs each: 3 741 vs 3 771 sequences/s) - under the package power limit
 // a denser loop buys a lower clock, not time - so the encoder keeps VAR 0 and the long back-to-back launches of the search
 // (+2 %) take VAR 5.  F16: IEEE-half operands.
-template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_args p, const int flat) {
+// MULTI: up to four independent batched problems of one form in ONE launch (the weight gradients of a layer range: Wqkv, Wo, W1,
+// W2 differ in shape, so they cannot be batch items of one problem) - the grid is the concatenation of the problems' flat
+// (item, tile) ranges, a workgroup picks its problem from the kernel argument table
+struct MultiArgs {
+  cocodr_gemm_args p[4];
+  int tile_end[4];  // running totals of the problems' workgroup counts
+};
+template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std::conditional<MULTI, MultiArgs, cocodr_gemm_args>::type pa,
+                                                              const int flat) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using S = Shape<NB>;
   constexpr int BN = S::BN;
@@ -145,6 +153,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;  // waves 0-3 (one per SIMD) form group 0, waves 4-7 group 1
+  int mq = 0, mid = 0;  // MULTI: problem index and the workgroup's id inside that problem's range
+  if constexpr (MULTI) {
+    mid = xcd_remap(blockIdx.x, gridDim.x);
+    while (mq < 3 && mid >= pa.tile_end[mq]) ++mq;
+    if (mq > 0) mid -= pa.tile_end[mq - 1];
+  }
+  const cocodr_gemm_args& p = [&]() -> const cocodr_gemm_args& {
+    if constexpr (MULTI) return pa.p[mq];
+    else return pa;
+  }();
   const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
   // flat (batched launches): ONE grid axis over (batch item, tile), item-major, and the XCD remap over all of it - every
   // XCD walks a contiguous run of items' tiles, so the ~32 tiles its CUs hold at a time belong to one or two items and
@@ -152,7 +170,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const cocodr_gemm_
   // remap per item (grid.y = item) an XCD held 4-6 tiles of each of 5-6 items at once, which share nothing: the grouped
   // weight gradients fetched 3.5x their operands from the fabric (profiles/r02_gemm_pmc_large_200x128.json).
   int tile, z;
-  if (flat) {
+  if constexpr (MULTI) {
+    const int per = ntm * ntn;
+    z = mid / per;
+    tile = mid - z * per;
+  } else if (flat) {
     const int per = ntm * ntn;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     z = id / per;
@@ -450,6 +472,25 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
 }
 
 }  // namespace cocodr_gemm_pp
+
+// n <= 4 batched TN problems with fp32 results (validated by cocodr_gemm_multi) as one launch
+void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, hipStream_t st) {
+  using namespace cocodr_gemm_pp;
+  MultiArgs ma;
+  int total = 0;
+  for (int q = 0; q < 4; ++q) {
+    ma.p[q] = a[q < n ? q : n - 1];
+    if (q < n) total += ((a[q].M + BM - 1) / BM) * (a[q].N / Shape<2>::BN) * (a[q].batch > 0 ? a[q].batch : 1);
+    ma.tile_end[q] = total;
+  }
+  auto kern = gemm_pp_kernel<2, 1, 1, true, 0, false, true>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
+}
 
 // nb = 2: 256 x 256 tile (N % 256 == 0), nb = 1: 256 x 128 tile; the caller has validated the arguments (cocodr_gemm)
 template <int VAR>

@@ -115,6 +115,11 @@ size_t cocodr_gemm_colsum_partial_floats(int M, int N);
  * all layers of a backward range in one launch. */
 int cocodr_gemm_colsum_rows(const cocodr_gemm_args* args);
 int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream);
+/* n (1..4) independent problems, same result as n cocodr_gemm calls.  Weight-gradient problems (trans_a = trans_b = 1, fp32
+ * result, no epilogue, one contraction length) run as ONE launch when together they fill the chip: the four weight matrices of a
+ * layer range (dW = dY^T X per nn.Linear, hf BertLayer's backward) have different shapes, so they cannot be batch items of one
+ * problem, and launched one after the other each pays its own partial last round of the 256 CUs. */
+int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, cocodr_stream_t stream);
 /* tuning / test hook: 0 = auto, 1 = register-staged pipeline,
  * direct-to-LDS <BM,BK,wave rows/32>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile,
  * 9 / 10 = 3 / 7 with four dedicated loader waves per workgroup, 11 = 256x256 tile, 12 = 256x96 tile (4x3 MFMA waves of

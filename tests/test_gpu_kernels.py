@@ -346,3 +346,50 @@ def test_flat_lamb_on_the_model_matches_the_oracle_per_tensor():
         np.testing.assert_allclose(m.hf_view(n).detach().cpu().numpy(), ref[n], rtol=3e-4, atol=1e-6, err_msg=n)
     lo = m.layout
     assert torch.equal(m._shadow, m.flat_decay.data[lo.mat_begin:].to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("layers,M,H,I", [(6, 2048, 768, 3072), (2, 1024, 256, 512), (3, 4096, 1024, 4096)])
+def test_gemm_multi_weight_gradients_in_one_launch(layers, M, H, I):
+    """cocodr_gemm_multi: the four weight-gradient problems of a layer range (different shapes, one contraction length) as one
+    launch - the same numbers as four cocodr_gemm calls (bit for bit: same pipeline, same K order) and as fp32 torch.  The
+    smallest case stays below the merged pipeline's tile threshold and takes the four plain calls."""
+    import ctypes as C
+    from cocodr_amd import _native as N
+    from cocodr_amd._native import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(layers * M)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    shapes = [(3 * H, H), (H, H), (I, H), (H, I)]  # (out features, in features) of Wqkv, Wo, W1, W2
+    dys = [mk(layers, M, o) for o, _ in shapes]
+    xs = [mk(layers, M, i) for _, i in shapes]
+    outs = [torch.empty(layers, o, i, dtype=torch.float32, device=DEV) for o, i in shapes]
+    outs1 = [torch.empty_like(t) for t in outs]
+
+    def problem(dy, x, out):
+        o, i = out.shape[1], out.shape[2]
+        a = N.GemmArgs()
+        a.A, a.B, a.C = ptr(dy), ptr(x), ptr(out)
+        a.M, a.N, a.K, a.lda, a.ldb, a.ldc = o, i, M, o, i, i
+        a.trans_a = a.trans_b = a.out_f32 = 1
+        a.epi, a.batch = N.EPI_NONE, layers
+        a.strideA, a.strideB, a.strideC = M * o, M * i, o * i
+        return a
+
+    arr = (N.GemmArgs * 4)(*[problem(d, x, o) for d, x, o in zip(dys, xs, outs)])
+    check(lib().cocodr_gemm_multi(arr, 4, stream_ptr()), "gemm_multi")
+    for d, x, o in zip(dys, xs, outs1):
+        a = problem(d, x, o)
+        check(lib().cocodr_gemm(C.byref(a), stream_ptr()), "gemm")
+    for d, x, o, o1 in zip(dys, xs, outs, outs1):
+        ref = torch.bmm(d.float().transpose(1, 2), x.float())
+        assert float((o - ref).norm() / ref.norm()) < 2e-3
+        assert float((o - o1).norm() / ref.norm()) < 1e-6  # (equal up to the pipelines' tile shapes; both accumulate K in order)
+    # a problem outside the merged form (bf16 result) makes the call fall back to plain launches - same results
+    out16 = torch.empty(layers, shapes[1][0], shapes[1][1], dtype=torch.bfloat16, device=DEV)
+    a0, a1 = problem(dys[0], xs[0], outs[0]), problem(dys[1], xs[1], out16)
+    a1.out_f32 = 0
+    outs[0].zero_()
+    arr2 = (N.GemmArgs * 2)(a0, a1)
+    check(lib().cocodr_gemm_multi(arr2, 2, stream_ptr()), "gemm_multi(fallback)")
+    assert float((outs[0] - outs1[0]).abs().max()) == 0.0
+    assert float((out16.float() - outs1[1]).norm() / outs1[1].norm()) < 5e-3
+    assert lib().cocodr_gemm_multi(arr2, 5, stream_ptr()) != 0  # more than four problems
