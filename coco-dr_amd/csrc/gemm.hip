@@ -764,10 +764,13 @@ extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, cocodr
   }
   if (ok && tiles >= 400 && tiles < (1ll << 30)) {
     cocodr_gemm_args copy[4];
+    double flops = 0.0;
     for (int q = 0; q < n; ++q) {
       copy[q] = problems[q];
       if (copy[q].batch <= 0) copy[q].batch = 1;
+      flops += 2.0 * copy[q].M * copy[q].N * (double)copy[q].K * copy[q].batch;
     }
+    ProfScope prof(PROF_GEMM, (hipStream_t)stream, flops);  // bench.py's roofline sample: one launch, the FLOPs of all problems
     cocodr_gemm_pp_launch_multi(copy, n, (hipStream_t)stream);
     CK_LAUNCH("gemm_multi");
     return COCODR_OK;
