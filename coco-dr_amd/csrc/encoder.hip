@@ -31,6 +31,7 @@ struct BwdLayout {
   size_t dres;                // bf16 [M,H]: with dropout, the un-masked LayerNorm-input gradient (the residual branch's)
   size_t ln_partial, colsum_partial, emb_partial;  // fp32
   size_t ln2_slots, ln1_slots, b1_slots, bv_slots, bqk_slots;  // fp32 per-layer partial rows of the deferred reductions
+  size_t multi_ws;  // fp32 partial tiles of the merged weight-gradient launch's cut last round (cocodr_gemm_multi)
   size_t total;
 };
 
@@ -55,6 +56,7 @@ BwdLayout bwd_layout_m(const cocodr_config* c, size_t M, int B, int L) {
   b.b1_slots = cv.take(N * cocodr_gemm_colsum_partial_floats((int)M, (int)I) * 4);
   b.bv_slots = cv.take(N * cocodr_gemm_colsum_partial_floats((int)M, (int)H) * 4);
   b.bqk_slots = cv.take(N * (size_t)4 * B * 2 * H * 4);  // attention backward: 4 B partial rows of dQ | dK column sums
+  b.multi_ws = cv.take(cocodr_gemm_multi_workspace_floats() * 4);
   b.total = cv.off;
   return b;
 }
@@ -477,7 +479,7 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   wg[2].out_f32 = 1; wg[2].batch = NG; wg[2].strideA = sMI; wg[2].strideB = sMH; wg[2].strideC = s_w1;
   wg[3] = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
   wg[3].out_f32 = 1; wg[3].batch = NG; wg[3].strideA = sMH; wg[3].strideB = sMI; wg[3].strideC = s_w2;
-  TRY(cocodr_gemm_multi(wg, 4, stream));
+  TRY(cocodr_gemm_multi(wg, 4, (float*)(bb + bl.multi_ws), cocodr_gemm_multi_workspace_floats(), stream));
   // ---- deferred reductions of the range (LayerNorm weight / bias + the Linear bias in front of it; b1; value bias)
   if (defer) {
     cocodr_reduce_job jobs[5];  // one launch for all of them

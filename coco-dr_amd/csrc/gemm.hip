@@ -583,7 +583,8 @@ void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
 }  // namespace cocodr_gemm_v2
 using cocodr_gemm_v2::launch_glds_any;
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st);  // gemm_pp.hip: the ping-pong pipeline
-void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, hipStream_t st);
+void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, hipStream_t st);
+size_t cocodr_gemm_pp_multi_ws_floats();
 
 namespace {
 
@@ -749,8 +750,13 @@ extern "C" size_t cocodr_gemm_colsum_partial_floats(int M, int N) {
 
 // n independent (batched) weight-gradient problems - form TN, fp32 result, no epilogue - as ONE launch on the ping-pong pipeline
 // when together they fill it (>= 400 tiles of 256 x 256); otherwise, or when a problem does not fit that form, n plain calls.
-extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, cocodr_stream_t stream) {
+extern "C" size_t cocodr_gemm_multi_workspace_floats(void) { return cocodr_gemm_pp_multi_ws_floats(); }
+
+extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, float* workspace, size_t workspace_floats,
+                                 cocodr_stream_t stream) {
   CK_ARG(problems != nullptr && n >= 1 && n <= 4, "gemm_multi: 1..4 problems");
+  CK_ARG(workspace == nullptr || (((uintptr_t)workspace & 15) == 0), "gemm_multi: workspace must be 16-byte aligned");
+  if (workspace_floats < cocodr_gemm_pp_multi_ws_floats()) workspace = nullptr;  // too small: whole tiles only
   static const bool off = getenv("COCODR_GEMM_NOMULTI") != nullptr;  // A/B switch
   bool ok = !off && n > 1 && gemm_impl_override() == 0;
   long long tiles = 0;
@@ -771,7 +777,7 @@ extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, cocodr
       flops += 2.0 * copy[q].M * copy[q].N * (double)copy[q].K * copy[q].batch;
     }
     ProfScope prof(PROF_GEMM, (hipStream_t)stream, flops);  // bench.py's roofline sample: one launch, the FLOPs of all problems
-    cocodr_gemm_pp_launch_multi(copy, n, (hipStream_t)stream);
+    cocodr_gemm_pp_launch_multi(copy, n, workspace, (hipStream_t)stream);
     CK_LAUNCH("gemm_multi");
     return COCODR_OK;
   }

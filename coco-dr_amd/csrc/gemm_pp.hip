@@ -139,10 +139,17 @@ __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const Fra
 // MULTI: up to four independent batched problems of one form in ONE launch (the weight gradients of a layer range: Wqkv, Wo, W1,
 // W2 differ in shape, so they cannot be batch items of one problem) - the grid is the concatenation of the problems' flat
 // (item, tile) ranges, a workgroup picks its problem from the kernel argument table
+// The last partial round: when the tiles of all problems leave r <= 64 over whole rounds of the 256 CUs, those r tiles are
+// not launched as one more (nearly empty) round of whole tiles but cut into s = 256 / r slices of the contraction each: r s
+// workgroups write fp32 partial tiles to a workspace and a small second kernel adds the s slices in a fixed order
+// (deterministic, no atomics).  split_first = first workgroup id of that region (= the grid size when nothing is cut).
 struct MultiArgs {
   cocodr_gemm_args p[4];
   int tile_end[4];  // running totals of the problems' workgroup counts
+  int split_first, split_s;
+  float* split_ws;
 };
+constexpr int SPLIT_TILE = BM * 256;  // floats of one partial tile
 template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std::conditional<MULTI, MultiArgs, cocodr_gemm_args>::type pa,
                                                               const int flat) {
@@ -154,8 +161,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;  // waves 0-3 (one per SIMD) form group 0, waves 4-7 group 1
   int mq = 0, mid = 0;  // MULTI: problem index and the workgroup's id inside that problem's range
+  int split_chunk = -1;  // >= 0: this workgroup computes one contraction slice of a tile of the last partial round
+  float* split_out = nullptr;
   if constexpr (MULTI) {
-    mid = xcd_remap(blockIdx.x, gridDim.x);
+    if ((int)blockIdx.x < pa.split_first) {
+      mid = xcd_remap(blockIdx.x, pa.split_first);
+    } else {
+      const int w = (int)blockIdx.x - pa.split_first;
+      mid = pa.split_first + w / pa.split_s;
+      split_chunk = w % pa.split_s;
+      split_out = pa.split_ws + (size_t)w * SPLIT_TILE;
+    }
     while (mq < 3 && mid >= pa.tile_end[mq]) ++mq;
     if (mq > 0) mid -= pa.tile_end[mq - 1];
   }
@@ -207,7 +223,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     }
   const uint32_t stepa = TA ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2);
   const uint32_t stepb = TB ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
-  const int nt = (p.K + BK - 1) / BK;
+  int nt = (p.K + BK - 1) / BK, t0 = 0;  // K-tiles of this workgroup: all of them, or one slice [t0, t0 + nt)
+  if constexpr (MULTI) {
+    if (split_chunk >= 0) {
+      t0 = (int)((long long)split_chunk * nt / pa.split_s);
+      nt = (int)((long long)(split_chunk + 1) * nt / pa.split_s) - t0;
+    }
+  }
 
   auto stage = [&](auto tyc, int t) {  // request half-tile `ty` of K-tile t
     constexpr int ty = decltype(tyc)::value;
@@ -216,11 +238,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
 #endif
     char* dst = smem + (t & 1) * S::KT_BYTES + ty * HALF_BYTES + wid * 2048;
     if constexpr (type_is_a<NB>(ty)) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))dst, 16, off[ty][0] + t * stepa, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + t * stepa, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))dst, 16, off[ty][0] + (t + t0) * stepa, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + (t + t0) * stepa, 0, 0, 0);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))dst, 16, off[ty][0] + t * stepb, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + t * stepb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))dst, 16, off[ty][0] + (t + t0) * stepb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + (t + t0) * stepb, 0, 0, 0);
     }
   };
 
@@ -351,6 +373,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   if (tid == 0) tl[2] = wall_clock64();
 #endif
   if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 catches up with group 1's last barrier
+  if constexpr (MULTI) {
+    if (split_chunk >= 0) {  // a contraction slice: the raw fp32 tile goes to the workspace, gemm_pp_split_finish adds the slices
+#pragma unroll
+      for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int row = wr * 128 + ai * 32 + (lane & 31);
+            const int col = wc * 32 * NB + b * 32 + 8 * rg + 4 * (lane >> 5);
+            *reinterpret_cast<float4*>(split_out + row * BN + col) =
+                make_float4(acc[ai][b][rg * 4 + 0], acc[ai][b][rg * 4 + 1], acc[ai][b][rg * 4 + 2], acc[ai][b][rg * 4 + 3]);
+          }
+      return;
+    }
+  }
 
   // ---- epilogue (gemm.hip's, for this geometry): two 128-row passes of the fp32 tile through LDS, row-major 16-B stores
   const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
@@ -473,8 +511,36 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
 
 }  // namespace cocodr_gemm_pp
 
-// n <= 4 batched TN problems with fp32 results (validated by cocodr_gemm_multi) as one launch
-void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, hipStream_t st) {
+namespace cocodr_gemm_pp {
+// C tile = sum of the s contraction slices (fixed order), for the r tiles of the cut last round; grid = (r, 64), 256 threads
+__global__ __launch_bounds__(256) void gemm_pp_split_finish(const MultiArgs ma, int r) {
+  const int lt = blockIdx.x;
+  int q = 0, id = ma.split_first + lt;
+  while (q < 3 && id >= ma.tile_end[q]) ++q;
+  if (q > 0) id -= ma.tile_end[q - 1];
+  const cocodr_gemm_args& p = ma.p[q];
+  const int ntn = p.N / 256, ntm = (p.M + BM - 1) / BM, per = ntm * ntn;
+  const int z = id / per, tile = id - z * per;
+  int tm_, tn_;
+  cocodr_gemm_v2::grouped_tile(tile, ntm, ntn, 8, tm_, tn_);  // the mapping of the flat TN form in gemm_pp_kernel
+  const int e = (blockIdx.y * 256 + threadIdx.x) * 4, row = e / 256, col = e % 256;
+  const float* src = ma.split_ws + (size_t)lt * ma.split_s * SPLIT_TILE + e;
+  float4 acc = *reinterpret_cast<const float4*>(src);
+  for (int c = 1; c < ma.split_s; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * SPLIT_TILE);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const int gm = tm_ * BM + row, gn = tn_ * 256 + col;
+  if (gm < p.M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = acc;
+}
+}  // namespace cocodr_gemm_pp
+
+// floats of workspace the cut last round of a merged launch may need (see MultiArgs)
+size_t cocodr_gemm_pp_multi_ws_floats() { return (size_t)256 * cocodr_gemm_pp::SPLIT_TILE; }
+
+// n <= 4 batched TN problems with fp32 results (validated by cocodr_gemm_multi) as one launch; ws: optional workspace of
+// cocodr_gemm_pp_multi_ws_floats() floats for the cut last round (NULL: whole tiles only)
+void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, hipStream_t st) {
   using namespace cocodr_gemm_pp;
   MultiArgs ma;
   int total = 0;
@@ -483,13 +549,30 @@ void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, hipStream_t s
     if (q < n) total += ((a[q].M + BM - 1) / BM) * (a[q].N / Shape<2>::BN) * (a[q].batch > 0 ? a[q].batch : 1);
     ma.tile_end[q] = total;
   }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0 || n_cu % 8 != 0) n_cu = -1;
+  }
+  static const bool nosplit = getenv("COCODR_GEMM_NOSPLIT") != nullptr;  // A/B switch
+  const int r = n_cu > 0 ? total % n_cu : 0;
+  const int nt_min = (a[0].K + BK - 1) / BK;
+  int s = r > 0 ? n_cu / r : 0;
+  if (s > nt_min) s = nt_min;
+  const bool split = ws != nullptr && !nosplit && r > 0 && total > n_cu && s >= 4 && (size_t)r * s <= 256;
+  ma.split_first = split ? total - r : total;
+  ma.split_s = split ? s : 1;
+  ma.split_ws = ws;
   auto kern = gemm_pp_kernel<2, 1, 1, true, 0, false, true>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
+  hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
+  if (split) hipLaunchKernelGGL(gemm_pp_split_finish, dim3(r, SPLIT_TILE / 4 / 256), dim3(256), 0, st, ma, r);
 }
 
 // nb = 2: 256 x 256 tile (N % 256 == 0), nb = 1: 256 x 128 tile; the caller has validated the arguments (cocodr_gemm)

@@ -118,8 +118,12 @@ int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream);
 /* n (1..4) independent problems, same result as n cocodr_gemm calls.  Weight-gradient problems (trans_a = trans_b = 1, fp32
  * result, no epilogue, one contraction length) run as ONE launch when together they fill the chip: the four weight matrices of a
  * layer range (dW = dY^T X per nn.Linear, hf BertLayer's backward) have different shapes, so they cannot be batch items of one
- * problem, and launched one after the other each pays its own partial last round of the 256 CUs. */
-int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, cocodr_stream_t stream);
+ * problem, and launched one after the other each pays its own partial last round of the 256 CUs.
+ * workspace (optional, cocodr_gemm_multi_workspace_floats() floats, 16-byte aligned): lets the merged launch cut the tiles of its
+ * last partial round of the 256 CUs into contraction slices (fp32 partial tiles, added in a fixed order by a second small
+ * kernel) instead of running one more nearly empty round of whole tiles; NULL / too small: whole tiles only. */
+size_t cocodr_gemm_multi_workspace_floats(void);
+int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, float* workspace, size_t workspace_floats, cocodr_stream_t stream);
 /* tuning / test hook: 0 = auto, 1 = register-staged pipeline,
  * direct-to-LDS <BM,BK,wave rows/32>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile,
  * 9 / 10 = 3 / 7 with four dedicated loader waves per workgroup, 11 = 256x256 tile, 12 = 256x96 tile (4x3 MFMA waves of

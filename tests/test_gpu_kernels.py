@@ -375,7 +375,9 @@ def test_gemm_multi_weight_gradients_in_one_launch(layers, M, H, I):
         return a
 
     arr = (N.GemmArgs * 4)(*[problem(d, x, o) for d, x, o in zip(dys, xs, outs)])
-    check(lib().cocodr_gemm_multi(arr, 4, stream_ptr()), "gemm_multi")
+    nws = lib().cocodr_gemm_multi_workspace_floats()
+    ws = torch.empty(nws, dtype=torch.float32, device=DEV)
+    check(lib().cocodr_gemm_multi(arr, 4, ptr(ws), nws, stream_ptr()), "gemm_multi")
     for d, x, o in zip(dys, xs, outs1):
         a = problem(d, x, o)
         check(lib().cocodr_gemm(C.byref(a), stream_ptr()), "gemm")
@@ -389,7 +391,14 @@ def test_gemm_multi_weight_gradients_in_one_launch(layers, M, H, I):
     a1.out_f32 = 0
     outs[0].zero_()
     arr2 = (N.GemmArgs * 2)(a0, a1)
-    check(lib().cocodr_gemm_multi(arr2, 2, stream_ptr()), "gemm_multi(fallback)")
+    check(lib().cocodr_gemm_multi(arr2, 2, None, 0, stream_ptr()), "gemm_multi(fallback)")
     assert float((outs[0] - outs1[0]).abs().max()) == 0.0
     assert float((out16.float() - outs1[1]).norm() / outs1[1].norm()) < 5e-3
-    assert lib().cocodr_gemm_multi(arr2, 5, stream_ptr()) != 0  # more than four problems
+    assert lib().cocodr_gemm_multi(arr2, 5, None, 0, stream_ptr()) != 0  # more than four problems
+    # without a workspace the merged launch runs whole tiles only - the same numbers up to the summation order of the cut tiles
+    outs2 = [torch.empty_like(t) for t in outs]
+    arr3 = (N.GemmArgs * 4)(*[problem(d, x, o) for d, x, o in zip(dys, xs, outs2)])
+    check(lib().cocodr_gemm_multi(arr3, 4, None, 0, stream_ptr()), "gemm_multi(no workspace)")
+    check(lib().cocodr_gemm_multi(arr, 4, ptr(ws), nws, stream_ptr()), "gemm_multi")
+    for o, o2 in zip(outs, outs2):
+        assert float((o - o2).norm() / o2.norm()) < 1e-6
