@@ -768,7 +768,8 @@ extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, float*
          a.ldb >= a.N && a.ldc >= a.N && (size_t)a.K * a.lda * 2 < (1ull << 32) && (size_t)a.K * a.ldb * 2 < (1ull << 32);
     tiles += (long long)((a.M + 255) / 256) * (a.N / 256) * (a.batch > 0 ? a.batch : 1);
   }
-  if (ok && tiles >= 400 && tiles < (1ll << 30)) {
+  static const long long min_tiles = getenv("COCODR_GEMM_MULTI_MIN") ? atoll(getenv("COCODR_GEMM_MULTI_MIN")) : 400;  // tuning hook
+  if (ok && tiles >= min_tiles && tiles < (1ll << 30)) {
     cocodr_gemm_args copy[4];
     double flops = 0.0;
     for (int q = 0; q < n; ++q) {
