@@ -348,7 +348,7 @@ def test_flat_lamb_on_the_model_matches_the_oracle_per_tensor():
     assert torch.equal(m._shadow, m.flat_decay.data[lo.mat_begin:].to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("layers,M,H,I", [(6, 2048, 768, 3072), (2, 1024, 256, 512), (3, 4096, 1024, 4096)])
+@pytest.mark.parametrize("layers,M,H,I", [(6, 2048, 768, 3072), (2, 1024, 256, 512), (3, 4096, 1024, 4096), (12, 1024, 768, 3072)])
 def test_gemm_multi_weight_gradients_in_one_launch(layers, M, H, I):
     """cocodr_gemm_multi: the four weight-gradient problems of a layer range (different shapes, one contraction length) as one
     launch - the same numbers as four cocodr_gemm calls (bit for bit: same pipeline, same K order) and as fp32 torch.  The
