@@ -1,0 +1,46 @@
+"""The driver's contract with bench.py: one JSON line on stdout with the agreed keys, the roofline block measured in the run, and
+the multi-rank code path (two ranks sharing the GPU fall back to gloo and say so)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "COCODR_FORCE_DIST"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # exactly one JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contract_keys_and_a_measured_roofline():
+    d = _run("--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-full-step")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"] == "contrastive-step sequences/sec" and d["unit"] == "sequences/sec" and d["n_gpus"] == 1
+    assert (d["steps"], d["warmup"]) == (4, 2) and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 64 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]  # whole-job sequences per second
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert 0.05 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert 5000 < d["value"] < 50000  # an MI355X, not a fallback
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    d = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline")
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
+    assert "gloo" in d["config"]["parallelism"] or "RCCL" in d["config"]["parallelism"]
+    assert d["value"] > 0
