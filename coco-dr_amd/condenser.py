@@ -259,7 +259,9 @@ class _CondenserStepFn(torch.autograd.Function):
         harr, hgarr = hlo.layer_structs(head._shadow.data_ptr(), 0, head.flat_nodecay.data_ptr(), (ghd.data_ptr(), ghn.data_ptr()))
         check(lib().cocodr_encoder_bwd_range(C.byref(ctx.hcfg), None, harr, None, hgarr, None, ptr(ctx.mask), ptr(d_head_out), B, L,
                                              ptr(ctx.harena), ctx.harena.numel(), nh, 0, 0, stream_ptr()), "encoder_bwd_range(head)")
-        dp = getattr(bert, "_dp_enabled", False) and bert._dp_fwd_live == 1
+        # in flight only when this is the step's single pass and nothing un-reduced waits in .grad; otherwise the hooks on the
+        # backbone AND head flats (adopted in condenser_step) reduce the accumulated gradients
+        dp = bert._dp_overlap_ok()
         works = bert._dp_reduce_async([ghd, ghn]) if dp else []  # the head's gradients travel under the whole backbone backward
         d_hin = ctx.harena[ctx.hlay.bwd_dx: ctx.hlay.bwd_dx + M * H * 2].view(torch.bfloat16).view(B, L, H)
         d_last.view(B, L, H)[:, 0] += d_hin[:, 0].float()
@@ -301,7 +303,7 @@ class _CondenserStepFn(torch.autograd.Function):
         if dp:
             works += bert._dp_reduce_async(bert._grad_range(bgd, bgn, *lower))
             bert._dp_finish(works)
-            bert._dp_skip_hooks = 2
+            bert._dp_mark_reduced(bert.flat_decay, bert.flat_nodecay, head.flat_decay, head.flat_nodecay)
         ctx.arena = ctx.harena = None
         ctx.saved = None
         return bgd, bgn, ghd, ghn, None, None, None, None, None, None, None
@@ -315,5 +317,7 @@ def condenser_step(bert: CocoBertModel, head: CondenserHead, input_ids, attentio
         labels = torch.nn.functional.pad(labels, (0, ids.shape[1] - L), value=-100)
     if not (0 <= skip_from <= bert.config.num_hidden_layers):
         raise ValueError(f"skip_from={skip_from} outside [0, {bert.config.num_hidden_layers}]")
+    if getattr(bert, "_dp_hooks", None) is not None and hasattr(bert, "_dp_unsynced"):
+        bert._dp_adopt(head.flat_decay, head.flat_nodecay)  # the head's gradients are averaged with the backbone's, in flight or by hook
     return _CondenserStepFn.apply(bert.flat_decay, bert.flat_nodecay, head.flat_decay, head.flat_nodecay, ids, mask,
                                   labels.contiguous(), bert, head, int(skip_from), bool(late_mlm))

@@ -126,6 +126,108 @@ __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const Fra
   }
 }
 
+// ---- register-direct epilogue (bf16 results): the accumulators never pass through LDS.
+// With the operands swapped a lane holds, per 32 x 32 block, ONE output row (lane & 31) and the 4-column groups
+// 8 rg + 4 (lane >> 5) .. + 3, rg = 0..3.  Bias / GELU / residual / dropout are applied there in fp32; after the bf16 pack one
+// v_permlane32_swap per dword hands the upper half-wave's group rg to the lower lane and the lower half-wave's group rg + 1 to
+// the upper lane, so every lane ends with 8 consecutive columns = one 16-B store (lanes 0-31: columns 16 k .. + 7,
+// lanes 32-63: 16 k + 8 .. + 15 of the same row).  No barrier, no LDS pass, no second wave-row pass.
+// The residual / GELU' operand is read in the same layout (8 B per lane and group), one 32-row block ahead.
+// MEASURED AND NOT ADOPTED (round 3, profiles/r03_gemm_pp_reg_epilogue.md; opt-in with COCODR_PP_REGEPI=1): in the BERT-large
+// training step it is 4 % SLOWER at 200 sequences and 1-2 % slower at 64 (the residual / GELU' reads in this layout expose their
+// latency; 32-B row segments per store instruction); with the stores compiled out the kernels lose only 4-7 % with EITHER
+// epilogue - the "5.3 us per tile" of the LDS-staged form is the memory system taking the tile's 128 KB, not the LDS passes.
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+template <int NB>
+__device__ __forceinline__ void pp_reg_epilogue(const cocodr_gemm_args& p, const int z, const f32x16 (&acc)[4][NB], const int m0,
+                                                const int n0, const int wr, const int wc, const int lane) {
+  const int rl = lane & 31, hh = lane >> 5;
+  const int colw = n0 + wc * 32 * NB + 4 * hh;  // this lane's first column (block 0, group 0)
+  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
+  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
+  uint16_t* __restrict__ C = reinterpret_cast<uint16_t*>(p.C) + (size_t)z * p.strideC;
+  uint16_t* __restrict__ C2 = p.C2 ? p.C2 + (size_t)z * p.strideC : nullptr;
+  const int epi = p.epi;
+  const bool need_r = R_ != nullptr && (epi == COCODR_EPI_ADD || epi == COCODR_EPI_DGELU);
+  float4 bv[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+      bv[b][rg] = bias ? *reinterpret_cast<const float4*>(bias + colw + b * 32 + 8 * rg) : make_float4(0.f, 0.f, 0.f, 0.f);
+  uint2 rr[2][NB][4];
+  auto fetch_r = [&](int ai, uint2 (&dst)[NB][4]) {
+    const int gm = m0 + wr * 128 + ai * 32 + rl;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        dst[b][rg] = make_uint2(0, 0);
+        if (need_r && gm < p.M) dst[b][rg] = *reinterpret_cast<const uint2*>(R_ + (size_t)gm * p.ldr + colw + b * 32 + 8 * rg);
+      }
+  };
+  fetch_r(0, rr[0]);
+#pragma unroll
+  for (int ai = 0; ai < 4; ++ai) {
+    if (ai + 1 < 4) fetch_r(ai + 1, rr[(ai + 1) & 1]);
+    const int gm = m0 + wr * 128 + ai * 32 + rl;
+    const bool ok = gm < p.M;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        uint32_t w[2][2], w2[2][2];  // [group 2k / 2k + 1][dword] packed bf16 pairs of the result (and of GELU')
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int rg = 2 * k + g;
+          float v[4] = {acc[ai][b][rg * 4 + 0] + bv[b][rg].x, acc[ai][b][rg * 4 + 1] + bv[b][rg].y,
+                        acc[ai][b][rg * 4 + 2] + bv[b][rg].z, acc[ai][b][rg * 4 + 3] + bv[b][rg].w};
+          if (epi == COCODR_EPI_GELU && C2 == nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+          } else if (epi == COCODR_EPI_GELU) {
+            float gp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gelu_erf_both(v[j], v[j], gp[j]);
+            w2[g][0] = pack2bf(gp[0], gp[1]);
+            w2[g][1] = pack2bf(gp[2], gp[3]);
+          } else if (epi == COCODR_EPI_ADD) {
+            if (p.drop.threshold) drop_apply<4>(v, (uint64_t)gm * p.N + (colw + b * 32 + 8 * rg), p.drop);
+            float r[4];
+            unpack4(rr[ai & 1][b][rg], r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += r[j];
+          } else if (epi == COCODR_EPI_DGELU) {
+            float r[4];
+            unpack4(rr[ai & 1][b][rg], r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= r[j];
+          }
+          w[g][0] = pack2bf(v[0], v[1]);
+          w[g][1] = pack2bf(v[2], v[3]);
+        }
+        swap_halves(w[0][0], w[1][0]);
+        swap_halves(w[0][1], w[1][1]);
+        const size_t o = (size_t)gm * p.ldc + (n0 + wc * 32 * NB + b * 32 + 16 * k + 8 * hh);
+#if defined(COCODR_ABL_EPI_NOSTORE)  // ablation: everything but the global stores
+        asm volatile("" ::"v"(w[0][0]), "v"(w[0][1]), "v"(w[1][0]), "v"(w[1][1]), "v"(o));
+        if (epi == COCODR_EPI_GELU && C2 != nullptr) asm volatile("" ::"v"(w2[0][0]), "v"(w2[0][1]), "v"(w2[1][0]), "v"(w2[1][1]));
+#else
+        if (ok) *reinterpret_cast<uint4*>(C + o) = make_uint4(w[0][0], w[0][1], w[1][0], w[1][1]);
+        if (epi == COCODR_EPI_GELU && C2 != nullptr) {
+          swap_halves(w2[0][0], w2[1][0]);
+          swap_halves(w2[0][1], w2[1][1]);
+          if (ok) *reinterpret_cast<uint4*>(C2 + o) = make_uint4(w2[0][0], w2[0][1], w2[1][0], w2[1][1]);
+        }
+#endif
+      }
+  }
+}
+
 // VAR (experiment builds, -DCOCODR_PP_VARIANTS, tools/gemm_bench.py --impls 13,15,16): 0 = DMA pieces requested in the load
 // segment behind the fragment reads; 2 = as 0 without s_setprio (-15 %); 3 = requested in front of the fragment reads (=).
 // Requesting them inside the MFMA segment instead cost 10-14 % (profiles/r02_gemm_pp_variants.txt).
@@ -152,9 +254,10 @@ struct MultiArgs {
 constexpr int SPLIT_TILE = BM * 256;  // floats of one partial tile
 template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std::conditional<MULTI, MultiArgs, cocodr_gemm_args>::type pa,
-                                                              const int flat) {
+                                                              const int flags) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using S = Shape<NB>;
+  const int flat = flags & 1;  // bit 1: register-direct epilogue (bf16 results without fused column sums)
   constexpr int BN = S::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -305,8 +408,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     else wait_vmcnt<(j == 0 ? 2 : 0)>();
   };
 
-  for (int t = 0; t < nt; ++t) {
-    const int rem = nt - t;
+  // One K-tile.  STEADY: at least two more K-tiles follow (rem >= 3) - every request exists and every wait is vmcnt(8), so the
+  // steady-state loop carries no scalar compare / branch at all (the rem-dependent forms cost 3-6 branches per load segment,
+  // a fifth of its 256-cycle budget); the last two K-tiles run the general form.
+  auto ktile = [&](auto steady_c, const int t, const int rem_in) {
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const int rem = STEADY ? 3 : rem_in;
     const uint32_t kb = lds_base + (uint32_t)((t & 1) * S::KT_BYTES);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + kb; curB[i] = adB[i] + kb; }
@@ -368,6 +475,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       phase(std::integral_constant<int, 2>{}, [&]() { pp_read_sub<TA, 2, 3 * HALF_BYTES>(curA, fa); }, fb1, acc[2][1], acc[3][1]);   // (A1, B1)
       phase(std::integral_constant<int, 3>{}, [&]() {}, fb0, acc[2][0], acc[3][0]);                      // (A1, B0): all in registers
     }
+  };
+  if constexpr (VAR == 0 && NB == 2) {
+    int t = 0;
+    if (!(flags & 4))  // (bit 2: A/B switch COCODR_PP_NOPEEL - every K-tile in the general form)
+      for (; t < nt - 2; ++t) ktile(std::true_type{}, t, 3);
+    for (; t < nt; ++t) ktile(std::false_type{}, t, nt - t);
+  } else {
+    for (int t = 0; t < nt; ++t) ktile(std::false_type{}, t, nt - t);
   }
 #if defined(COCODR_ABL_TIMELINE)
   if (tid == 0) tl[2] = wall_clock64();
@@ -390,6 +505,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     }
   }
 
+  if constexpr (!OUT_F32) {
+    if ((flags & 2) && p.colsum_partial == nullptr) {
+      pp_reg_epilogue<NB>(p, z, acc, m0, n0, wr, wc, lane);
+      return;
+    }
+  }
   // ---- epilogue (gemm.hip's, for this geometry): two 128-row passes of the fp32 tile through LDS, row-major 16-B stores
   const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
   const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
@@ -496,6 +617,9 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
     flat_env = e ? atoi(e) : 1;
   }
   const int flat = (a.batch > 1 && flat_env) ? 1 : 0;
+  static const int regepi = getenv("COCODR_PP_REGEPI") ? atoi(getenv("COCODR_PP_REGEPI")) : 0;  // A/B switch: 1 = the register-direct epilogue (measured 4 % slower in the step, see pp_reg_epilogue)
+  static const int nopeel = getenv("COCODR_PP_NOPEEL") ? atoi(getenv("COCODR_PP_NOPEEL")) : 0;  // A/B switch of the branch-free steady-state loop
+  const int flags = flat | (regepi ? 2 : 0) | (nopeel ? 4 : 0);
   dim3 grid(flat ? ntm * ntn * a.batch : ntm * ntn, flat ? 1 : a.batch);
   static bool attr_done = false;
   if (!attr_done) {
@@ -504,9 +628,9 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
     attr_done = true;
   }
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flags);
   else
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flags);
 }
 
 }  // namespace cocodr_gemm_pp
@@ -571,7 +695,8 @@ void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, hi
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
+  static const int nopeel = getenv("COCODR_PP_NOPEEL") ? atoi(getenv("COCODR_PP_NOPEEL")) : 0;
+  hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1 | (nopeel ? 4 : 0));
   if (split) hipLaunchKernelGGL(gemm_pp_split_finish, dim3(r, SPLIT_TILE / 4 / 256), dim3(256), 0, st, ma, r);
 }
 

@@ -196,6 +196,10 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= r[j];
   }
+#if defined(COCODR_ABL_EPI_NOSTORE)  // ablation: everything but the result store
+  asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+  return;
+#endif
   if (OUT_F32) {
     float* C = reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn;
     *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);

@@ -626,8 +626,8 @@ class CocoBertModel(nn.Module):
             raise RuntimeError("CocoBertModel runs on an MI355X only: move it with .to('cuda') (there is no CPU fallback)")
         B, L = ids.shape
         self._refresh_shadow()
-        if training and getattr(self, "_dp_enabled", False):
-            self._dp_fwd_live += 1
+        if training:
+            self._dp_note_forward()
         lay = self._layout_for(B, L, training)
         arena = torch.empty(lay.total_bytes, dtype=torch.uint8, device=ids.device)
         emb, arr, _, _ = self._param_structs()
@@ -641,8 +641,8 @@ class CocoBertModel(nn.Module):
         if not self.flat_decay.is_cuda:
             raise RuntimeError("CocoBertModel runs on an MI355X only: move it with .to('cuda') (there is no CPU fallback)")
         self._refresh_shadow()
-        if training and getattr(self, "_dp_enabled", False):
-            self._dp_fwd_live += 1
+        if training:
+            self._dp_note_forward()
         lay = N.EncoderLayout()
         arena_drop = self._next_dropout(training)
         cfg = self._c_config(arena_drop)
@@ -667,8 +667,7 @@ class CocoBertModel(nn.Module):
                                                   ptr(d_in) if d_in is not None else None, ptr(arena), arena.numel(), l_hi, l_lo,
                                                   int(do_embed), stream_ptr()), "encoder_bwd_packed")
 
-        dp = getattr(self, "_dp_enabled", False)
-        if not dp or self._dp_fwd_live != 1:
+        if not self._dp_overlap_ok():
             call(NL, 0, d16, True)
             return gd, gn
         bounds = self._dp_bounds()
@@ -678,7 +677,7 @@ class CocoBertModel(nn.Module):
             call(l_hi, l_lo, d16 if l_hi == NL else None, l_lo == 0)
             works += self._dp_reduce_async(self._grad_range(gd, gn, l_lo, l_hi))
         self._dp_finish(works)
-        self._dp_skip_hooks = 2
+        self._dp_mark_reduced(self.flat_decay, self.flat_nodecay)
         return gd, gn
 
     def _dp_bounds(self):
@@ -690,7 +689,7 @@ class CocoBertModel(nn.Module):
         bounds = [0] + [min(NL, max(1, round(i * (NL + emb_units) / nchunk - emb_units))) for i in range(1, nchunk)] + [NL]
         return sorted(set(bounds))
 
-    def enable_grad_allreduce(self, group=None, chunks: int = 4) -> None:
+    def enable_grad_allreduce(self, group=None, chunks: int = 4, extra_params=()) -> None:
         """Data-parallel gradient averaging without DDP (ANCE/drivers/run_ann.py:177-184, HF Trainer for COCO).
 
         * ONE encoder pass in the step (the COCO contrastive step): the backward walks the layer stack in ``chunks``
@@ -701,15 +700,46 @@ class CocoBertModel(nn.Module):
           never one all-reduce of the whole model per pass.
         * the full coCondenser step reduces the head's gradients under the backbone's backward and the upper backbone range
           under the lower one (condenser._CondenserStepFn.backward).
-        ``no_sync()`` suspends all of it for gradient-accumulation micro-steps."""
+        ``no_sync()`` suspends all of it for gradient-accumulation micro-steps (DDP semantics, the pattern of
+        ANCE/drivers/run_ann.py:318-341): gradients of those micro-steps stay local and un-reduced in ``.grad``; the next
+        synchronised backward then does NOT reduce in flight (that would average only its own share) but lets the
+        post-accumulate hook reduce the accumulated ``.grad`` once.
+        ``extra_params``: further flat parameters that take part (the Condenser head's; ``condenser_step`` adopts them itself)."""
         self._dp_group = group
         self._dp_chunks = max(1, int(chunks))
         self._dp_enabled = True
-        self._dp_fwd_live = 0     # training forwards since the last completed backward
-        self._dp_skip_hooks = 0   # hook calls to skip because the backward already reduced in flight
+        self._dp_fwd_live = 0        # training forwards of the current step (since the parameters last changed) without a backward
+        self._dp_live_version = -1   # flat_decay._version those forwards were counted at
+        self._dp_skip = set()        # id(param): its next hook call is a no-op, the backward reduced this pass in flight
+        self._dp_unsynced = set()    # id(param): .grad holds local gradient of no_sync micro-steps
         if not getattr(self, "_dp_hooks", None):
-            self._dp_hooks = [p.register_post_accumulate_grad_hook(self._dp_post_accumulate)
-                              for p in (self.flat_decay, self.flat_nodecay)]
+            self._dp_hooks = {}
+        self._dp_adopt(self.flat_decay, self.flat_nodecay, *extra_params)
+
+    def _dp_adopt(self, *params) -> None:
+        """register the reduce-on-accumulate hook on flat parameters that do not have it yet (idempotent)"""
+        for p in params:
+            if id(p) not in self._dp_hooks:
+                self._dp_hooks[id(p)] = p.register_post_accumulate_grad_hook(self._dp_post_accumulate)
+
+    def _dp_note_forward(self) -> None:
+        """count a training forward of the current step; the count restarts whenever the parameters have changed since the last
+        counted forward (an optimizer step: a forward whose backward never ran must not haunt the next step)"""
+        if not getattr(self, "_dp_enabled", False):
+            return
+        v = self.flat_decay._version
+        if v != self._dp_live_version:
+            self._dp_live_version, self._dp_fwd_live = v, 0
+            self._dp_skip.clear()
+        self._dp_fwd_live += 1
+
+    def _dp_overlap_ok(self) -> bool:
+        """may this backward all-reduce its own gradient ranges in flight?  Only when it is the step's single pass through the
+        weights AND no local, un-reduced gradient of earlier no_sync micro-steps sits in ``.grad``."""
+        return bool(getattr(self, "_dp_enabled", False) and self._dp_fwd_live == 1 and not self._dp_unsynced)
+
+    def _dp_mark_reduced(self, *params) -> None:
+        self._dp_skip = {id(p) for p in params}
 
     def no_sync(self):
         """Context manager: gradients accumulate locally (DDP's ``no_sync`` for accumulation micro-steps)."""
@@ -741,12 +771,16 @@ class CocoBertModel(nn.Module):
                 t.div_(W)
 
     def _dp_post_accumulate(self, p) -> None:
-        if not getattr(self, "_dp_enabled", False) or p.grad is None:
+        if p.grad is None or not hasattr(self, "_dp_unsynced"):
+            return
+        if not getattr(self, "_dp_enabled", False):  # under no_sync(): remember that .grad now holds local gradient
+            self._dp_unsynced.add(id(p))
             return
         self._dp_fwd_live = 0
-        if self._dp_skip_hooks > 0:
-            self._dp_skip_hooks -= 1
+        if id(p) in self._dp_skip:  # this pass was reduced in flight (only possible with nothing un-reduced in .grad)
+            self._dp_skip.discard(id(p))
             return
+        self._dp_unsynced.discard(id(p))
         n, k = p.grad.numel(), self._dp_chunks
         step = (n // k + 1023) // 1024 * 1024 if k > 1 else n
         self._dp_finish(self._dp_reduce_async([p.grad[a:a + step] for a in range(0, n, max(step, 1))]))
@@ -760,8 +794,7 @@ class CocoBertModel(nn.Module):
         gd[:lo.mat_begin].zero_()  # embedding tables: sparse word rows are accumulated, unused position rows stay zero
         emb, arr, eg, garr = self._param_structs((gd, gn))
         cfg = self._c_config(getattr(arena, "_cocodr_drop", None))
-        dp = getattr(self, "_dp_enabled", False)
-        if not dp or self._dp_fwd_live != 1:  # several passes share the weights: reduced once, from the hook
+        if not self._dp_overlap_ok():  # several passes share the weights / local gradient pending: reduced once, from the hook
             check(lib().cocodr_encoder_bwd(C.byref(cfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ids), ptr(mask), ptr(d_last16),
                                            B, L, ptr(arena), arena.numel(), stream_ptr()), "encoder_bwd")
             return gd, gn
@@ -776,7 +809,7 @@ class CocoBertModel(nn.Module):
                                                  int(l_lo == 0), stream_ptr()), "encoder_bwd_range")
             works += self._dp_reduce_async(self._grad_range(gd, gn, l_lo, l_hi))
         self._dp_finish(works)
-        self._dp_skip_hooks = 2
+        self._dp_mark_reduced(self.flat_decay, self.flat_nodecay)
         return gd, gn
 
     def _run_backward_taps(self, ids, mask, d_last16, arena, lay, taps: Dict[int, torch.Tensor]):

@@ -22,14 +22,17 @@ VARIANTS = {
     "no_dma": ["-DCOCODR_ABL_NO_DMA"],
     "dma_only": ["-DCOCODR_ABL_NO_MFMA", "-DCOCODR_ABL_NO_LDSREAD"],
     "mfma_only": ["-DCOCODR_ABL_NO_DMA", "-DCOCODR_ABL_NO_LDSREAD"],
+    "epi_nostore": ["-DCOCODR_ABL_EPI_NOSTORE"],
 }
 TIMELINE = {"timeline": ["-DCOCODR_ABL_TIMELINE"]}
 
 
-def build():
+def build(only=None):
     os.makedirs(OUT, exist_ok=True)
     csrc = os.path.join(ROOT, "coco-dr_amd", "csrc")
     for name, defs in {**VARIANTS, **TIMELINE}.items():
+        if only and name not in only:
+            continue
         lib = os.path.join(OUT, f"libabl_{name}.so")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                "-DCOCODR_ABL_ALIAS_LD"] + defs + [
@@ -95,7 +98,7 @@ def main():
     ap.add_argument("--shapes", default="", help="comma separated indices into tools/gemm_bench.py SHAPES")
     args = ap.parse_args()
     if args.build:
-        return build()
+        return build(args.variants.split(",") if args.variants else None)
     import torch
     from cocodr_amd import _native
     from tools.gemm_bench import SHAPES
