@@ -28,6 +28,7 @@ from torch import nn
 from . import _native as N
 from . import ops
 from ._native import check, lib, ptr, stream_ptr
+from .flatparams import FlatParamsMixin
 from .modeling import CocoBertConfig, CocoBertModel, _Layout
 
 __all__ = ["CondenserHead", "condenser_step"]
@@ -35,7 +36,7 @@ __all__ = ["CondenserHead", "condenser_step"]
 _NEG = -1e30
 
 
-class CondenserHead(nn.Module):
+class CondenserHead(FlatParamsMixin, nn.Module):
     """Parameters of `c_head` (COCO/modeling.py:43-46) and of `lm.cls` (hf BertOnlyMLMHead) in two flat tensors.
     State-dict names follow the reference: ``c_head.{i}.attention.self.query.weight`` ...,
     ``cls.predictions.transform.dense.weight`` ..., ``cls.predictions.bias`` (the decoder weight is the backbone's
@@ -55,6 +56,7 @@ class CondenserHead(nn.Module):
         self.dropout_seed = None  # None: torch.initial_seed() at the first dropout forward
         self._dropout_calls = 0
         self.reset_parameters()
+        self._build_views()
 
     def _build_layout(self):
         H, V = self.config.hidden_size, self.config.vocab_size
@@ -80,6 +82,7 @@ class CondenserHead(nn.Module):
                 else:
                     dst.copy_(keep[name])
         self._shadow_version = -1
+        self._build_views()
 
     def reset_parameters(self):
         with torch.no_grad():
@@ -142,9 +145,9 @@ class CondenserHead(nn.Module):
 
     def _refresh_shadow(self):
         self._shadow_target()
-        if self._shadow_version != self.flat_decay._version:
+        if self._shadow_version != self._params_version():
             ops.cast_f32_bf16(self.flat_decay.data, self._shadow)
-            self._shadow_version = self.flat_decay._version
+            self._shadow_version = self._params_version()
 
 
 class _CondenserStepFn(torch.autograd.Function):

@@ -38,6 +38,7 @@ from torch import nn
 from . import _native as N
 from . import ops
 from ._native import check, lib, ptr, stream_ptr
+from .flatparams import FlatParamsMixin
 
 __all__ = ["CocoBertConfig", "CocoBertModel", "BertDotNLL", "CoCondenserForPretraining", "EncoderOutput"]
 
@@ -392,7 +393,7 @@ def _resize_rows(t: torch.Tensor, n: int) -> torch.Tensor:
     return out
 
 
-class CocoBertModel(nn.Module):
+class CocoBertModel(FlatParamsMixin, nn.Module):
     """BertModel (no pooler) on the native gfx950 kernels.  HF-compatible: ``from_pretrained``,
     ``save_pretrained``, ``state_dict`` key names, ``forward(input_ids=, attention_mask=)`` ->
     object with ``[0]`` / ``.last_hidden_state`` / ``.hidden_states``."""
@@ -415,6 +416,7 @@ class CocoBertModel(nn.Module):
         # outputs at the real tokens, ~1/3 fewer rows on MS MARCO-shaped batches (include/cocodr.h "Packed batches")
         self.pack_sequences = False
         self.reset_parameters()
+        self._build_views()  # HF-named nn.Parameter views of the flats: what parameters() / named_parameters() yield
 
     # ---------------------------------------------------------------- init / HF naming
     def reset_parameters(self):
@@ -434,7 +436,8 @@ class CocoBertModel(nn.Module):
         return self.layout.view((self.flat_decay.data, self.flat_nodecay.data), name)
 
     def hf_named_parameters(self):
-        """(HF name, view into the flat parameter) pairs - what ``named_parameters()`` of BertModel yields."""
+        """(HF name, plain tensor view into the flat parameter) pairs.  ``named_parameters()`` yields the same names with
+        ``nn.Parameter`` views (cocodr_amd.flatparams) whose ``.grad`` aliases the flat gradient."""
         for name in self.layout.names:
             yield name, self.hf_view(name)
 
@@ -544,6 +547,7 @@ class CocoBertModel(nn.Module):
         if bias is not None and bias.shape[0] == old:
             self._extra_state["cls.predictions.bias"] = _resize_rows(bias, n)
         self._shadow, self._shadow_version = None, -1
+        self._build_views()
         for fn in getattr(self, "_vocab_listeners", []):
             fn(old, n)
         return self
@@ -595,9 +599,9 @@ class CocoBertModel(nn.Module):
     def _refresh_shadow(self):
         lo = self.layout
         self._ensure_shadow()
-        if self._shadow_version != self.flat_decay._version:
+        if self._shadow_version != self._params_version():
             ops.cast_f32_bf16(self.flat_decay.data[lo.mat_begin:], self._shadow)
-            self._shadow_version = self.flat_decay._version
+            self._shadow_version = self._params_version()
 
     def _param_structs(self, grads: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         lo, cfg = self.layout, self.config

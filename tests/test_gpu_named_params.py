@@ -1,0 +1,80 @@
+"""The reference's per-tensor optimizer code on the HF-named parameter views (cocodr_amd.flatparams), after REAL native
+backward passes: it must land where the fused flat optimizers land, and the next forward must see the update (the bf16
+weight shadow follows per-tensor in-place updates).  ANCE/drivers/run_ann.py:128-147, 345-352; COCO/trainer.py:66-70."""
+import numpy as np
+import pytest
+import torch
+
+import cocodr_amd  # noqa: F401
+from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertConfig, CocoBertModel
+from cocodr_amd.optim import FlatAdamW, FlatLamb, clip_grad_norm_
+from tests.test_named_params_cpu import _RefLamb, _hf_decay_groups
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _pair():
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=500, hidden_size=128, num_hidden_layers=3,
+                         num_attention_heads=2, intermediate_size=256, max_position_embeddings=64)
+    torch.manual_seed(0)
+    a = CocoBertModel(cfg).to(DEV)
+    b = CocoBertModel(cfg).to(DEV)
+    b.load_state_dict(a.state_dict())
+    return a, b
+
+
+def _batch(seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(5, 500, (8, 32), generator=g)
+    mask = torch.ones(8, 32, dtype=torch.long)
+    mask[3, 20:] = 0
+    return {"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV)}
+
+
+def _rel(x, y):
+    return float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30))
+
+
+def test_name_grouped_torch_adamw_on_views_tracks_flat_adamw():
+    a, b = _pair()
+    ma, mb = CoCondenserForPretraining(a), CoCondenserForPretraining(b)
+    opt_a = torch.optim.AdamW(_hf_decay_groups(a, 0.01), lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    opt_b = FlatAdamW.for_model(b, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for step in range(3):
+        la = ma(_batch(step), None)
+        lb = mb(_batch(step), None)
+        assert abs(float(la.detach()) - float(lb.detach())) < 2e-3 * abs(float(lb.detach())), (step, float(la.detach()), float(lb.detach()))
+        la.backward()
+        lb.backward()
+        # run_ann.py:345-347 on the views; the device-side clip on the flats
+        torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0)
+        clip = clip_grad_norm_(b.flat_parameters(), 1.0)
+        opt_a.step()
+        opt_b.step(clip=clip)
+        opt_a.zero_grad()
+        opt_b.zero_grad()
+        assert a.flat_decay.grad is None and b.flat_decay.grad is None
+    for name in a.layout.names:
+        assert _rel(a.hf_view(name), b.hf_view(name)) < 2e-3, (name, _rel(a.hf_view(name), b.hf_view(name)))
+
+
+def test_per_tensor_lamb_on_views_tracks_flat_lamb():
+    a, b = _pair()
+    ma, mb = CoCondenserForPretraining(a), CoCondenserForPretraining(b)
+    opt_a = _RefLamb(a.parameters(), lr=2e-3, eps=1e-6, weight_decay=0.0)
+    opt_b = FlatLamb.for_model(b, lr=2e-3, eps=1e-6)
+    for step in range(2):
+        ma(_batch(10 + step), None).backward()
+        mb(_batch(10 + step), None).backward()
+        opt_a.step()
+        opt_b.step()
+        a.zero_grad()
+        b.zero_grad()
+    for name in a.layout.names:
+        assert _rel(a.hf_view(name), b.hf_view(name)) < 2e-3, (name, _rel(a.hf_view(name), b.hf_view(name)))
+    # the forward after a per-tensor update reads the updated weights (shadow refreshed from the views' version counter)
+    with torch.no_grad():
+        ea = a.encode_cls(**_batch(99))
+        eb = b.encode_cls(**_batch(99))
+    assert _rel(ea, eb) < 5e-3
