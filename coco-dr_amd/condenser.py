@@ -145,9 +145,9 @@ class CondenserHead(FlatParamsMixin, nn.Module):
 
     def _refresh_shadow(self):
         self._shadow_target()
-        if self._shadow_version != self._params_version():
+        if self._shadow_stale():
             ops.cast_f32_bf16(self.flat_decay.data, self._shadow)
-            self._shadow_version = self._params_version()
+            self._shadow_mark_fresh()
 
 
 class _CondenserStepFn(torch.autograd.Function):

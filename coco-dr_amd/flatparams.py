@@ -73,11 +73,28 @@ class ViewParameter(nn.Parameter):
         reset.discard(self._index)
         flat.grad[self._off:self._off + self.numel()].view(self.shape).copy_(value)
 
+    # ``p.data`` writes (the reference's Lamb updates ``p.data.add_(...)``, ANCE/utils/lamb.py:120) bypass torch's version
+    # counters, which is how the owner knows that its bf16 weight shadow is stale: handing out ``.data`` marks it dirty.
+    @property
+    def data(self):
+        owner = self._owner() if self._owner is not None else None
+        if owner is not None:
+            owner.__dict__["_views_dirty"] = True
+        return torch.Tensor.data.__get__(self)
+
+    @data.setter
+    def data(self, value):  # keep aliasing the flat: copy instead of re-binding the storage
+        owner = self._owner() if self._owner is not None else None
+        if owner is not None:
+            owner.__dict__["_views_dirty"] = True
+        with torch.no_grad():
+            torch.Tensor.data.__get__(self).copy_(value)
+
     def __deepcopy__(self, memo):  # a detached plain parameter (deep copies of the owning module rebuild their own views)
-        return nn.Parameter(self.data.clone(), self.requires_grad)
+        return nn.Parameter(torch.Tensor.data.__get__(self).clone(), self.requires_grad)
 
     def __reduce_ex__(self, proto):
-        return (nn.Parameter, (self.data.clone(), self.requires_grad))
+        return (nn.Parameter, (torch.Tensor.data.__get__(self).clone(), self.requires_grad))
 
 
 class _Shell(nn.Module):
@@ -196,10 +213,17 @@ class FlatParamsMixin:
 
     def _params_version(self):
         """changes whenever the flat storage was written in place - through a flat (``FlatAdamW``, ``load_state_dict``) or
-        through any view (a per-tensor optimizer)"""
+        through any view (a per-tensor torch optimizer); ``.data`` writes through a view set ``_views_dirty`` instead"""
         fd = self.__dict__[FLAT_NAMES[0]]
         vb = self.__dict__.get("_vbase", (None, None))[0]
         return (fd._version, vb._version if vb is not None else -1)
+
+    def _shadow_stale(self) -> bool:
+        return self._shadow_version != self._params_version() or self.__dict__.get("_views_dirty", False)
+
+    def _shadow_mark_fresh(self) -> None:
+        self._shadow_version = self._params_version()
+        self.__dict__["_views_dirty"] = False
 
     # ---------------------------------------------------------------- nn.Module plumbing that must see the flats
     def _apply(self, fn, recurse=True):

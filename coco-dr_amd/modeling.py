@@ -599,9 +599,9 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
     def _refresh_shadow(self):
         lo = self.layout
         self._ensure_shadow()
-        if self._shadow_version != self._params_version():
+        if self._shadow_stale():
             ops.cast_f32_bf16(self.flat_decay.data[lo.mat_begin:], self._shadow)
-            self._shadow_version = self._params_version()
+            self._shadow_mark_fresh()
 
     def _param_structs(self, grads: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         lo, cfg = self.layout, self.config

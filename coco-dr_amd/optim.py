@@ -67,7 +67,10 @@ def _after_native_update(p: torch.Tensor, owner, shadow_written: bool) -> None:
     decide on that counter whether they are stale.  Bump it, and mark the shadow fresh only if this pass wrote it."""
     torch.autograd.graph.increment_version(p)
     if owner is not None and shadow_written:
-        owner._shadow_version = owner._params_version() if hasattr(owner, "_params_version") else p._version
+        if hasattr(owner, "_shadow_mark_fresh"):
+            owner._shadow_mark_fresh()
+        else:
+            owner._shadow_version = p._version
 
 
 class FlatAdamW(torch.optim.Optimizer):

@@ -408,7 +408,8 @@ def _nosync_rank(rank, world, ids, mask, packed):
     # (b) reference: both micro-steps without any reduction, then one explicit mean over ranks
     ref_b, ref_m = make()
     ref_m({"input_ids": t(ids, 0), "attention_mask": t(mask, 0)}, None).backward()
-    same_local = all(torch.equal(a, b.grad) for a, b in zip(local1, (ref_b.flat_decay, ref_b.flat_nodecay)))
+    # (equal up to the order of the embedding-row atomics)
+    same_local = all(float((a - b.grad).norm() / (b.grad.norm() + 1e-30)) < 1e-5 for a, b in zip(local1, (ref_b.flat_decay, ref_b.flat_nodecay)))
     ref_m({"input_ids": t(ids, 1), "attention_mask": t(mask, 1)}, None).backward()
     want = []
     for p in (ref_b.flat_decay, ref_b.flat_nodecay):

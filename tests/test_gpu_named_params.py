@@ -55,8 +55,13 @@ def test_name_grouped_torch_adamw_on_views_tracks_flat_adamw():
         opt_a.zero_grad()
         opt_b.zero_grad()
         assert a.flat_decay.grad is None and b.flat_decay.grad is None
+    # (what this test pins is the plumbing - real backward -> view gradients -> per-tensor update -> refreshed bf16 shadow; the
+    # exact grouping / arithmetic is pinned on CPU with identical gradients, tests/test_named_params_cpu.py.  Here the two
+    # models drift apart chaotically: a 1e-7 difference between the two AdamW implementations flips a bf16 ulp of a shadow
+    # weight, the next gradients differ by 1e-3, and Adam's normalised step carries that into the weights)
     for name in a.layout.names:
-        assert _rel(a.hf_view(name), b.hf_view(name)) < 2e-3, (name, _rel(a.hf_view(name), b.hf_view(name)))
+        assert _rel(a.hf_view(name), b.hf_view(name)) < 1e-2, (name, _rel(a.hf_view(name), b.hf_view(name)))
+    assert _rel(a.flat_decay.data, b.flat_decay.data) < 2e-3
 
 
 def test_per_tensor_lamb_on_views_tracks_flat_lamb():
@@ -72,9 +77,18 @@ def test_per_tensor_lamb_on_views_tracks_flat_lamb():
         a.zero_grad()
         b.zero_grad()
     for name in a.layout.names:
-        assert _rel(a.hf_view(name), b.hf_view(name)) < 2e-3, (name, _rel(a.hf_view(name), b.hf_view(name)))
-    # the forward after a per-tensor update reads the updated weights (shadow refreshed from the views' version counter)
+        assert _rel(a.hf_view(name), b.hf_view(name)) < 1e-2, (name, _rel(a.hf_view(name), b.hf_view(name)))
+    assert _rel(a.flat_decay.data, b.flat_decay.data) < 2e-3
+    # the forward after a per-tensor in-place update reads the updated weights: the bf16 shadow follows both kinds of write (version
+    # counter shared by the views; `.data` hand-outs).  Decisive form: scale one matrix through its view on `a`, through the flat on `b`.
+    assert a._shadow_stale()  # the per-tensor optimizer wrote (through p.data, invisible to version counters) since the last cast
     with torch.no_grad():
+        before = a.encode_cls(**_batch(99)).clone()
+        assert not a._shadow_stale()
+        dict(a.named_parameters())["encoder.layer.2.output.dense.weight"].mul_(8.0)
+        b.hf_view("encoder.layer.2.output.dense.weight").mul_(8.0)
+        b._shadow_version = -1
         ea = a.encode_cls(**_batch(99))
         eb = b.encode_cls(**_batch(99))
-    assert _rel(ea, eb) < 5e-3
+    assert _rel(ea, before) > 5 * _rel(ea, eb)  # the change is visible ...
+    assert _rel(ea, eb) < 2e-2     # ... and is the same change on both models (bf16 tolerance)

@@ -156,7 +156,9 @@ def test_per_tensor_lamb_over_parameters_matches_the_oracle_per_tensor():
     for step in range(2):
         _fill_grads(m, 20 + step)
         G = [p.grad.detach().double().numpy().copy() for p in m.parameters()]
+        m.__dict__["_views_dirty"] = False
         opt.step()
+        assert m._shadow_stale()  # the reference's `p.data.add_` bypasses version counters: handing out .data marks the shadow stale
         trust_seen = OO.lamb_step(P, G, M, V, lr=1e-3, weight_decay=0.01)
         m.zero_grad()
         assert m.flat_decay.grad is None
