@@ -130,6 +130,7 @@ SIGNATURES = {
     "cocodr_score_set_mode": (c_int, [c_int]),
     "cocodr_score_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
+    "cocodr_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_int, c_void_p]),
     "cocodr_encoder_layout": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),
     "cocodr_encoder_bwd_layout": (c_int, [C.POINTER(Config), c_int, c_int, C.POINTER(EncoderBwdLayout)]),
     "cocodr_encoder_fwd": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), c_void_p, c_void_p,

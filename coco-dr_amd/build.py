@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcocodr_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "loss.hip", "score.hip", "encoder.hip", "collate.hip", "probe.hip", "comm.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "loss.hip", "score.hip", "merge.hip", "encoder.hip", "collate.hip", "probe.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 FLAGS += os.environ.get("COCODR_EXTRA_FLAGS", "").split()  # experiment builds only (e.g. -DCOCODR_PP_VARIANTS)
 

@@ -329,6 +329,20 @@ def score_topk(Q: torch.Tensor, P: torch.Tensor, k: int, id_offset: int = 0, wor
     return D, I
 
 
+def topk_merge(D: torch.Tensor, I: torch.Tensor, shard_offset: torch.Tensor, k_out: int):
+    """Merge W sorted per-shard top-k lists per query (cocodr_topk_merge): D fp32 / I int32 [W, Nq, k] with shard-local
+    positions, shard_offset int64 [W] -> (D [Nq, k_out] fp32, I [Nq, k_out] int64 global positions)."""
+    _req(D, F32, "D", 3); _req(I, I32, "I", 3); _req(shard_offset, I64, "shard_offset", 1)
+    if D.shape != I.shape or shard_offset.shape[0] != D.shape[0]:
+        raise ValueError("topk_merge: D / I must be [W, Nq, k] and shard_offset [W]")
+    W, Nq, k = D.shape
+    outD = torch.empty((Nq, k_out), dtype=F32, device=D.device)
+    outI = torch.empty((Nq, k_out), dtype=I64, device=D.device)
+    check(lib().cocodr_topk_merge(ptr(D), ptr(I), ptr(shard_offset), W, Nq, k, Nq * k, ptr(outD), ptr(outI), int(k_out), stream_ptr()),
+          "topk_merge")
+    return outD, outI
+
+
 def score_set_mode(mode: int) -> None:
     """0 = split-precision scores on the 16-bit matrix pipe (default), 1 = exact fp32 MFMA scores (include/cocodr.h)."""
     check(lib().cocodr_score_set_mode(int(mode)), "score_set_mode")

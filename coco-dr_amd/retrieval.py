@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 
-__all__ = ["shard_indices", "merged_order", "encode_corpus", "search", "sharded_search", "merge_topk", "eval_dev_query",
+__all__ = ["shard_indices", "merged_order", "encode_corpus", "search", "sharded_search", "merge_topk", "merge_shard_lists", "eval_dev_query",
            "EvalDevQuery", "generate_negatives", "ndcg_at_10", "map_at_10", "recall_at", "mrr_at_10", "build_ann_training_data"]
 
 
@@ -70,7 +70,9 @@ def search(Q: torch.Tensor, P: torch.Tensor, k: int, id_offset: int = 0) -> Tupl
 
 
 def merge_topk(D: torch.Tensor, I: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Merge candidate lists [Nq, C] into the top k by (score descending, position ascending); -1 ids last."""
+    """Host-side utility (tests, small glue): merge UNSORTED candidate lists [Nq, C] into the top k by (score descending,
+    position ascending); -1 ids last.  The search path itself merges per-shard lists with the native kernel
+    (``merge_shard_lists`` -> cocodr_topk_merge)."""
     big = torch.iinfo(torch.int64).max
     key_i = torch.where(I < 0, torch.full_like(I, big), I)
     o1 = torch.argsort(key_i, dim=1, stable=True)
@@ -79,16 +81,32 @@ def merge_topk(D: torch.Tensor, I: torch.Tensor, k: int) -> Tuple[torch.Tensor, 
     return torch.gather(D1, 1, o2), torch.gather(I1, 1, o2)
 
 
-def sharded_search(Q_local: torch.Tensor, P_local: torch.Tensor, k: int,
-                   local_search: Optional[Callable] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Search ALL queries against the corpus sharded over the ranks: all-gather the queries, search the
-    resident shard, all-gather the per-shard (score, position) lists, merge.  Positions are indices into the
-    rank-major merged corpus (what ``barrier_array_merge`` + ``IndexFlatIP`` would produce); map them through
-    ``merged_order`` / ``passage_embedding2id`` for record ids.  Every rank returns the full [Nq_total, k] result."""
+def merge_shard_lists(D: torch.Tensor, I: torch.Tensor, shard_offset: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """W sorted per-shard top-k lists per query -> the top k of the merged corpus (native: cocodr_topk_merge).
+    D fp32 / I int32 [W, Nq, k'] with shard-local positions, shard_offset int64 [W]; returns (D [Nq, k], I int64 [Nq, k])."""
+    return ops.topk_merge(D.contiguous(), I.contiguous(), shard_offset.contiguous(), k)
+
+
+def sharded_search(Q_local: torch.Tensor, P_local: torch.Tensor, k: int, local_search: Optional[Callable] = None,
+                   local_merge: Optional[Callable] = None, gather: bool = True):
+    """Search ALL queries against the corpus sharded over the ranks: all-gather the queries (Nq x H fp32), search
+    the resident shard, hand every rank the W per-shard lists of ITS block of ceil(Nq / W) queries (one all-to-all: scores
+    fp32 + shard-local positions int32, Nq k 8 bytes per rank in total - an all-gather of the lists would move W times
+    that and make every rank merge everything), merge that block natively (``merge_shard_lists``).  Positions are indices
+    into the rank-major merged corpus (what ``barrier_array_merge`` + ``IndexFlatIP`` would produce); map them through
+    ``merged_order`` / ``passage_embedding2id`` for record ids.
+
+    ``gather=True``: every rank returns the full ``(D, I)`` [Nq_total, k] (one all-gather of the merged blocks).
+    ``gather=False``: returns ``(D_block, I_block, (q_lo, q_hi))`` - this rank's query block only, for per-query work that
+    stays sharded (nDCG, hard negatives).  ``local_search`` / ``local_merge`` replace the native kernels (CPU tests)."""
     import torch.distributed as dist
     fn = local_search or search
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return fn(Q_local, P_local, k, 0)
+    merge = local_merge or merge_shard_lists
+    import os
+    force = bool(os.environ.get("COCODR_FORCE_DIST")) and dist.is_available() and dist.is_initialized()  # 1-rank test of the N > 1 path
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
+        D, I = fn(Q_local, P_local, k, 0)
+        return (D, I) if gather else (D, I, (0, Q_local.shape[0]))
     W, r = dist.get_world_size(), dist.get_rank()
     dev = Q_local.device
     counts = torch.tensor([Q_local.shape[0], P_local.shape[0]], dtype=torch.int64, device=dev)
@@ -103,15 +121,36 @@ def sharded_search(Q_local: torch.Tensor, P_local: torch.Tensor, k: int,
     qall = torch.empty((W * qmax, H), dtype=Q_local.dtype, device=dev)
     dist.all_gather_into_tensor(qall, qpad)
     Q = torch.cat([qall[i * qmax:i * qmax + nq[i]] for i in range(W)])
-    offset = sum(npass[:r])
-    D, I = fn(Q, P_local, k, offset)
-    Dall = torch.empty((W,) + tuple(D.shape), dtype=D.dtype, device=dev)
-    Iall = torch.empty((W,) + tuple(I.shape), dtype=I.dtype, device=dev)
-    dist.all_gather_into_tensor(Dall.view(-1, D.shape[1]), D.contiguous())
-    dist.all_gather_into_tensor(Iall.view(-1, I.shape[1]), I.contiguous())
-    Dc = Dall.permute(1, 0, 2).reshape(D.shape[0], -1)
-    Ic = Iall.permute(1, 0, 2).reshape(I.shape[0], -1)
-    return merge_topk(Dc, Ic, k)
+    Nq = Q.shape[0]
+    D, I = fn(Q, P_local, k, 0)  # positions local to this shard
+    kk = D.shape[1]
+    bq = (Nq + W - 1) // W       # queries per block; the last block may be short (padded rows are empty lists)
+    Dp = torch.full((W * bq, kk), float("-inf"), dtype=torch.float32, device=dev)
+    Ip = torch.full((W * bq, kk), -1, dtype=torch.int32, device=dev)
+    Dp[:Nq] = D
+    Ip[:Nq] = I.to(torch.int32)
+    Dr = torch.empty((W, bq, kk), dtype=torch.float32, device=dev)
+    Ir = torch.empty((W, bq, kk), dtype=torch.int32, device=dev)
+    if dist.get_backend() == "nccl":  # RCCL: block j of my lists goes to rank j, I receive everybody's lists of block r
+        dist.all_to_all_single(Dr.view(-1), Dp.view(-1))
+        dist.all_to_all_single(Ir.view(-1), Ip.view(-1))
+    else:  # gloo has no all-to-all: gather everything, keep my block (CPU / shared-GPU test path; same result)
+        Dall = torch.empty((W, W * bq, kk), dtype=torch.float32, device=dev)
+        Iall = torch.empty((W, W * bq, kk), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(Dall.view(-1, kk), Dp)
+        dist.all_gather_into_tensor(Iall.view(-1, kk), Ip)
+        Dr.copy_(Dall[:, r * bq:(r + 1) * bq])
+        Ir.copy_(Iall[:, r * bq:(r + 1) * bq])
+    offs = torch.tensor([sum(npass[:w]) for w in range(W)], dtype=torch.int64, device=dev)
+    Dm, Im = merge(Dr, Ir, offs, min(k, W * kk))
+    q_lo, q_hi = min(r * bq, Nq), min((r + 1) * bq, Nq)
+    if not gather:
+        return Dm[:q_hi - q_lo], Im[:q_hi - q_lo], (q_lo, q_hi)
+    Df = torch.empty((W * bq, Dm.shape[1]), dtype=Dm.dtype, device=dev)
+    If = torch.empty((W * bq, Im.shape[1]), dtype=Im.dtype, device=dev)
+    dist.all_gather_into_tensor(Df, Dm.contiguous())
+    dist.all_gather_into_tensor(If, Im.contiguous())
+    return Df[:Nq], If[:Nq]
 
 
 # ----------------------------------------------------------------------------------------------- metrics

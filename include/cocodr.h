@@ -308,6 +308,18 @@ int cocodr_score_set_mode(int mode);
 int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset,
                       float* D, long long* I, void* workspace, size_t workspace_bytes, cocodr_stream_t stream);
 
+/* k-way merge of per-shard top-k lists into the list ONE search over the rank-major merged corpus would return - what
+ * replaces the reference's gather-everything-then-search (ANCE/utils/util.py:117-155 barrier_array_merge +
+ * evaluate/evaluation/evaluate_beir.py:200-224 IndexFlatIP over the concatenated shards) when the corpus stays sharded in
+ * HBM (each rank merges its Nq / W query block).
+ * D fp32 / I int32 [W][Nq][k] (shard w's lists start at w * stride_w elements): for every query W lists sorted by
+ * (score descending, position ascending) - cocodr_score_topk's output with id_offset 0, positions LOCAL to the shard and
+ * narrowed to int32, empty slots (I < 0) at the end.  shard_offset int64 [W] (device): first global position of shard w,
+ * ascending in w.  outD fp32 / outI int64 [Nq][k_out], k_out <= W * k: (score descending, global position ascending),
+ * (-inf, -1) padding.  W <= 64, W * k <= 39936.  Deterministic, no workspace. */
+int cocodr_topk_merge(const float* D, const int32_t* I, const long long* shard_offset, int W, int Nq, int k,
+                      long long stride_w, float* outD, long long* outI, int k_out, cocodr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Whole-encoder entry points: the layer loop lives in native code so one host call enqueues every
  * kernel of BertModel.forward (COCO/modeling.py:199-204, ANCE/model/models.py:225-229) or of its

@@ -118,9 +118,18 @@ def _sharded(rank, world, Q, P, k):
         I = np.where(I >= 0, I + off, I)
         return torch.from_numpy(D), torch.from_numpy(I)
 
+    def numpy_merge(Dw, Iw, offs, kk):  # stands in for cocodr_topk_merge: [W, Nq, k] sorted lists, shard-local int32 positions
+        Dw, Iw, offs = Dw.numpy(), Iw.numpy().astype(np.int64), offs.numpy()
+        Ig = [np.where(Iw[w] >= 0, Iw[w] + offs[w], -1) for w in range(Dw.shape[0])]
+        D, I = O.merge_topk([Dw[w] for w in range(Dw.shape[0])], Ig, kk)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
     qi = R.shard_indices(Q.shape[0], rank, world)
     pi = R.shard_indices(P.shape[0], rank, world)
-    D, I = R.sharded_search(torch.from_numpy(Q)[qi], torch.from_numpy(P)[pi], k, local_search=numpy_search)
+    D, I = R.sharded_search(torch.from_numpy(Q)[qi], torch.from_numpy(P)[pi], k, local_search=numpy_search, local_merge=numpy_merge)
+    Db, Ib, (lo, hi) = R.sharded_search(torch.from_numpy(Q)[qi], torch.from_numpy(P)[pi], k, local_search=numpy_search,
+                                        local_merge=numpy_merge, gather=False)
+    assert np.array_equal(Db.numpy(), D.numpy()[lo:hi]) and np.array_equal(Ib.numpy(), I.numpy()[lo:hi])  # the block form
     return D.numpy(), I.numpy()
 
 

@@ -565,3 +565,53 @@ def test_config3_eight_ranks_at_256_sequences_equal_the_single_process_m2048_ste
         float(np.abs(np.concatenate([emb.ravel(), mat.ravel()]).astype(np.float64)).sum())
     for r in range(1, world):
         assert abs(out[r][1] - s_gd) <= 1e-6 * a_gd and abs(out[r][2] - s_gn) <= 1e-6 * (abs(s_gn) + 1.0) and abs(out[r][3] - a_gd) <= 1e-9 * a_gd
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# sharded search with the native kernels (score_topk per shard, query-block exchange, cocodr_topk_merge): what one
+# IndexFlatIP search over the rank-major merged corpus returns (evaluate/evaluation/evaluate_beir.py:200-224)
+def _sharded_search_rank(rank, world, Q, P, k):
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd import retrieval as R
+    qi = R.shard_indices(Q.shape[0], rank, world)
+    pi = R.shard_indices(P.shape[0], rank, world)
+    Ql, Pl = torch.from_numpy(Q)[qi].cuda(), torch.from_numpy(P)[pi].cuda()
+    D, I = R.sharded_search(Ql, Pl, k)
+    Db, Ib, (lo, hi) = R.sharded_search(Ql, Pl, k, gather=False)
+    assert torch.equal(Db, D[lo:hi]) and torch.equal(Ib, I[lo:hi])
+    return D.cpu().numpy(), I.cpu().numpy(), (lo, hi)
+
+
+@pytest.mark.parametrize("world,nq,npass,k", [(2, 37, 5001, 100), (3, 10, 700, 300)])
+def test_sharded_search_native_equals_one_search_over_the_merged_corpus(world, nq, npass, k):
+    rng = np.random.Generator(np.random.PCG64(npass))
+    Q = (rng.standard_normal((nq, 128)) / 11).astype(np.float32)
+    P = (rng.standard_normal((npass, 128)) / 11).astype(np.float32)
+    P[17] = P[18]  # an exact tie between two shards (records 17 and 18 live on different ranks)
+    out = _spawn(_sharded_search_rank, world, "gloo", Q, P, k)
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd import retrieval as R
+    op, oq = R.merged_order(npass, world).numpy(), R.merged_order(nq, world).numpy()
+    D, I = R.search(torch.from_numpy(Q[oq]).cuda(), torch.from_numpy(P[op]).cuda(), k)
+    blocks = []
+    for r in range(world):
+        assert np.array_equal(out[r][1], I.cpu().numpy()) and np.array_equal(out[r][0], D.cpu().numpy()), r
+        blocks.append(out[r][2])
+    assert blocks[0][0] == 0 and blocks[-1][1] == nq and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))  # a partition
+
+
+def _sharded_search_one_rank_rccl(rank, world, Q, P, k):
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd import retrieval as R
+    os.environ["COCODR_FORCE_DIST"] = "1"  # the N > 1 path (all_to_all_single + merge) on a 1-rank RCCL group
+    Ql, Pl = torch.from_numpy(Q).cuda(), torch.from_numpy(P).cuda()
+    D, I = R.sharded_search(Ql, Pl, k)
+    D0, I0 = R.search(Ql, Pl, k)
+    return bool(torch.equal(D, D0) and torch.equal(I, I0))
+
+
+def test_sharded_search_exchange_runs_on_rccl():
+    rng = np.random.Generator(np.random.PCG64(5))
+    Q = (rng.standard_normal((21, 128)) / 11).astype(np.float32)
+    P = (rng.standard_normal((3000, 128)) / 11).astype(np.float32)
+    assert _spawn(_sharded_search_one_rank_rccl, 1, "nccl", Q, P, 50)[0]
