@@ -281,20 +281,24 @@ def eval_search(dev, nq: int = 10000, npass: int = 125000, dim: int = 1024, k: i
     return out
 
 
-def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3):
+def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int = 0, world: int = 1, fence=None, dp_chunks: int = 2):
     """BASELINE config 4 (ANCE/drivers/run_ann.py:293-356): BERT-large triplet step, 32 rows/GPU = queries [32,64] +
     positives / negatives [32,128], backward, clip_grad_norm_(1.0), LAMB (the reference's default optimizer), linear
-    schedule.  One training row = 3 sequences."""
+    schedule.  One training row = 3 sequences.  ``world > 1``: the data-parallel step - every rank its own rows
+    (the reference strides them by rank, ANCE/utils/util.py:390-392), the summed gradient of the query and passage passes
+    averaged ONCE over RCCL (DDP in the reference, run_ann.py:177-184), timed between fences, whole-job rows per second."""
     from cocodr_amd.modeling import BertDotNLL, CocoBertConfig
     from cocodr_amd.optim import FlatLamb, clip_grad_norm_
     cfg = CocoBertConfig.large()
     torch.manual_seed(0)
     model = BertDotNLL(cfg).to(dev)
+    if world > 1:
+        model.bert.enable_grad_allreduce(chunks=dp_chunks)
     opt = FlatLamb.for_model(model.bert, lr=5e-6, eps=1e-8)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: max(0.0, 1.0 - s / 1000.0))
-    q, qm = synth_batch(0, rows, 64, cfg.vocab_size, dev)
-    a, am = synth_batch(1, rows, 128, cfg.vocab_size, dev)
-    b, bm = synth_batch(2, rows, 128, cfg.vocab_size, dev)
+    q, qm = synth_batch(3 * rank, rows, 64, cfg.vocab_size, dev)
+    a, am = synth_batch(3 * rank + 1, rows, 128, cfg.vocab_size, dev)
+    b, bm = synth_batch(3 * rank + 2, rows, 128, cfg.vocab_size, dev)
     flats = [model.bert.flat_decay, model.bert.flat_nodecay]
 
     def step():
@@ -307,6 +311,13 @@ def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3):
 
     for _ in range(warmup):
         loss = step()
+    if world > 1:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        fence()
+        return (time.perf_counter() - t0) / steps, float(loss.detach())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -382,6 +393,70 @@ def corpus_encode(cfg, dev, n: int = 8192, seq_len: int = 128, batch: int = 512,
             "packed_sequences_per_sec": round(n / dtp, 1), "packed_equals_padded": bool(torch.equal(emb_p, emb)),
             "workload": f"{n} passages x L{seq_len}, batch {batch}, BertDot_NLL_LN body_emb (last-layer [CLS]), bf16 encoder, eval mode; "
                         "packed = the same batches stored back to back (32-row alignment), same embeddings"}
+
+
+def multi_gpu_legs(dev, rank: int, world: int, fence, tmax, shared: bool, dp_chunks: int):
+    """What BASELINE configs[3] / [4] name beyond the contrastive step, on all ranks of the job:
+      * sharded corpus encode - every rank encodes its shard (record i -> rank i % W, ANCE/utils/util.py:390-392;
+        ANCE/drivers/run_ann_data_gen.py:157-212), embeddings stay in HBM;
+      * sharded search - 10 000 queries x (125 000 x W) passages x 1024, k = 1000: query all-gather, per-shard score + top-k,
+        query-block exchange, native k-way merge, gather of the merged blocks ALL inside the timed region
+        (evaluate/evaluation/evaluate_beir.py:220-224 on the rank-major merged corpus);
+      * the data-parallel ANCE triplet step (ANCE/drivers/run_ann.py:293-356), BERT-large, 32 rows per GPU.
+    Every number is whole-job work / max-over-ranks time between fences.  ``shared`` (ranks share a GPU over gloo: a code-path
+    check) runs reduced sizes."""
+    from cocodr_amd import retrieval
+    from cocodr_amd.modeling import BertDotNLL, CocoBertConfig
+    out = {"note": "reduced sizes: the ranks share GPUs over gloo (code-path check, not a scaling number)" if shared else
+                   "whole-job work / max-over-ranks time between barrier + synchronize fences"}
+    # ---- sharded corpus encode (cocodr-large, the config-5 encoder)
+    cfg = CocoBertConfig.large()
+    torch.manual_seed(0)
+    enc = BertDotNLL(cfg).to(dev).eval()
+    n_local, batch = (1024, 256) if shared else (8192, 512)
+    ids, mask = synth_batch(100 + rank, n_local, SEQ_LEN, cfg.vocab_size, dev)
+    retrieval.encode_corpus(enc, ids[:batch], mask[:batch], batch_size=batch, pack=False)
+    fence()
+    t0 = time.perf_counter()
+    emb, _ = retrieval.encode_corpus(enc, ids, mask, batch_size=batch, pack=False)
+    fence()
+    dt = tmax(time.perf_counter() - t0)
+    out["sharded_corpus_encode"] = {"sequences_per_sec": round(n_local * world / dt, 1), "ms": round(dt * 1e3, 2),
+                                    "workload": f"cocodr-large body_emb, {n_local} passages x L{SEQ_LEN} per rank (record i -> rank i % W), batch {batch}, "
+                                                "padded batches, embeddings kept in HBM; BASELINE configs[4] encode half"}
+    del enc, ids, mask, emb
+    torch.cuda.empty_cache()
+    # ---- sharded search
+    nq, np_local, dim, k = (2000, 20000, 1024, 100) if shared else (10000, 125000, 1024, 1000)
+    g = torch.Generator().manual_seed(7 + rank)
+    nq_local = len(range(rank, nq, world))
+    Ql = (torch.randn(nq_local, dim, generator=g) / dim ** 0.5).to(dev)
+    Pl = (torch.randn(np_local, dim, generator=g) / dim ** 0.5).to(dev)
+    retrieval.sharded_search(Ql, Pl, k)
+    iters = 3
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        D, I = retrieval.sharded_search(Ql, Pl, k)
+    fence()
+    dt = tmax((time.perf_counter() - t0) / iters)
+    out["sharded_search"] = {"dot_products_per_sec": round(nq * np_local * world / dt), "ms": round(dt * 1e3, 2),
+                             "workload": f"{nq} queries x ({np_local} x {world}) passages x {dim} fp32, k = {k}: query all-gather + per-shard "
+                                         "split-precision scores + exact top-k + query-block exchange (fp32 scores, int32 shard-local "
+                                         "positions) + native k-way merge + gather of the merged blocks, all timed; BASELINE configs[4] search half",
+                             "result_rows": int(D.shape[0])}
+    del Ql, Pl, D, I
+    torch.cuda.empty_cache()
+    # ---- data-parallel ANCE step
+    rows = 32
+    adt, aloss = ance_step(dev, rows=rows, steps=3 if shared else 8, warmup=2 if shared else 3, rank=rank, world=world, fence=fence,
+                           dp_chunks=dp_chunks)
+    adt = tmax(adt)
+    out["ance_triplet_step"] = {"rows_per_sec": round(rows * world / adt, 1), "sequences_per_sec": round(3 * rows * world / adt, 1),
+                                "ms_per_step": round(adt * 1e3, 3), "loss": round(aloss, 4),
+                                "scope": f"cocodr-large triplet step, {rows} rows per GPU (q L64 + pos/neg L128), summed gradient of the two "
+                                         "passes averaged once over the ranks, clip_grad_norm_(1.0) + LAMB; BASELINE configs[3]"}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------- the timed step
@@ -503,7 +578,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="base", choices=["base", "large"])
-    ap.add_argument("--seq-per-gpu", type=int, default=SEQ_PER_GPU)
+    ap.add_argument("--seq-per-gpu", type=int, default=0,
+                    help="sequences per GPU and step; default 64 (BASELINE configs[1]), and 256 for cocodr-base at 8 GPUs = configs[2]'s "
+                         "global batch 2048 (COCO/README.md:55 NPROC x BATCH_SIZE)")
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
     ap.add_argument("--dense", action="store_true", help="every synthetic sequence fills seq_len (SURVEY 8d's roofline variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -519,6 +596,9 @@ def main():
         raise SystemExit(_self_launch(args))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    config3 = args.seq_per_gpu == 0 and world == 8 and args.model == "base"  # BASELINE configs[2]: global batch 2048 on 8 GPUs
+    if args.seq_per_gpu == 0:
+        args.seq_per_gpu = 256 if config3 else SEQ_PER_GPU
 
     import torch.distributed as dist
     import cocodr_amd  # noqa: F401
@@ -583,10 +663,31 @@ def main():
             extras["ance_triplet_step"] = ance_step(dev)
         extras["corpus_encode"] = corpus_encode(cfg, dev, seq_len=args.seq_len)
         extras["eval_search"] = eval_search(dev)
-    if use_dist:
-        tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def tmax(x: float) -> float:
+        if not use_dist:
+            return x
+        t = torch.tensor([x], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+    dt = tmax(dt)
+    if world > 1 and not args.no_full_step:
+        if config3:  # the weak-scaling point that keeps N = 1's per-GPU batch (the headline of this line is configs[2]'s 256 per GPU)
+            wdt, wloss, _, _, _ = contrastive_leg(args.model, SEQ_PER_GPU, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
+                                                  args.dp_chunks, False, args.dense)
+            wdt = tmax(wdt)
+            extras["same_per_gpu_batch_as_n1"] = {"sequences_per_sec": round(SEQ_PER_GPU * world * args.steps / wdt, 2),
+                                                  "ms_per_step": round(wdt / args.steps * 1e3, 3), "global_batch": SEQ_PER_GPU * world,
+                                                  "loss": round(wloss, 4),
+                                                  "note": "64 sequences per GPU as at N = 1, 2, 4: the point to use for weak-scaling efficiency "
+                                                          "against those lines"}
+        extras["multi_gpu"] = multi_gpu_legs(dev, rank, world, fence, tmax, shared, args.dp_chunks)
 
     if rank == 0:
         n_seq = args.seq_per_gpu * world * args.steps
@@ -602,7 +703,8 @@ def main():
             "config": {"workload": f"cocodr-{args.model} contrastive step (COCO in-batch negatives), seq_len={args.seq_len}, "
                                    f"{args.seq_per_gpu} sequences/GPU, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW; "
                                    + ("BASELINE configs[1]" if args.model == "base" and world == 1 else
-                                      "BASELINE configs[1]'s batch on every GPU, negatives all-gathered as in configs[2] (whose 2048 global batch at 8 GPUs is --seq-per-gpu 256)" if args.model == "base" else "north_star BERT-large target shape"),
+                                      "BASELINE configs[2] (8 GPUs, RCCL all_gather negatives, global batch 2048)" if config3 else
+                                      "BASELINE configs[1]'s batch on every GPU, negatives all-gathered as in configs[2] (whose 2048 global batch at 8 GPUs is 256 per GPU, the default at --gpus 8)" if args.model == "base" else "north_star BERT-large target shape"),
                        "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len,
                        "batches": "8 pre-generated synthetic batches per rank, resident in HBM, visited round-robin",
                        "parallelism": par},

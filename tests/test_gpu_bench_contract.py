@@ -44,3 +44,9 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
     assert "gloo" in d["config"]["parallelism"] or "RCCL" in d["config"]["parallelism"]
     assert d["value"] > 0
+    # N > 1 also measures what BASELINE configs[3] / [4] name: sharded encode, sharded search (merge inside the timed region)
+    # and the data-parallel ANCE step
+    m = d["multi_gpu"]
+    assert m["sharded_corpus_encode"]["sequences_per_sec"] > 0
+    assert m["sharded_search"]["dot_products_per_sec"] > 0 and m["sharded_search"]["result_rows"] == 2000
+    assert m["ance_triplet_step"]["rows_per_sec"] > 0 and m["ance_triplet_step"]["loss"] > 0
