@@ -80,6 +80,7 @@ SIGNATURES = {
     "cocodr_build_info": (C.c_char_p, []),
     "cocodr_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
     "cocodr_gemm_multi_workspace_floats": (c_size_t, []),
+    "cocodr_gemm_multi_workspace_floats_for": (c_size_t, [c_void_p, c_int]),
     "cocodr_gemm_multi": (c_int, [C.POINTER(GemmArgs), c_int, c_void_p, c_size_t, c_void_p]),
     "cocodr_gemm_set_impl": (c_int, [c_int]),
     "cocodr_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -12,11 +12,18 @@ typedef int (*allgather_fn)(const void*, void*, size_t, int /* ncclDataType_t */
 typedef const char* (*errstr_fn)(int);
 constexpr int kNcclFloat32 = 7;  // rccl.h: ncclFloat32 = 7
 
+// the loader's message of the last failed dlopen / dlsym (dlerror() clears its state when read: read it exactly once, right
+// after the failing call)
+const char* g_dl_error = nullptr;
 void* rccl_handle() {
   static void* h = nullptr;
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // the copy this process already uses
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
-  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) {
+    dlerror();  // drop the NOLOAD probes' messages
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) g_dl_error = dlerror();
+  }
   return h;
 }
 }  // namespace
@@ -26,9 +33,15 @@ extern "C" int cocodr_allgather_rows(const float* local_rows, float* gathered, i
   CK_ARG(local_rows && gathered && nccl_comm, "allgather_rows: null pointer");
   CK_ARG(rows > 0 && H > 0, "allgather_rows: bad shape rows=%d H=%d", rows, H);
   void* h = rccl_handle();
-  allgather_fn ag = h ? (allgather_fn)dlsym(h, "ncclAllGather") : nullptr;
+  if (!h) {
+    cocodr_set_error("allgather_rows: RCCL (librccl.so.1) is not loadable in this process: %s", g_dl_error ? g_dl_error : "dlopen failed");
+    return COCODR_ERR_LAUNCH;
+  }
+  dlerror();
+  allgather_fn ag = (allgather_fn)dlsym(h, "ncclAllGather");
   if (!ag) {
-    cocodr_set_error("allgather_rows: RCCL (librccl.so.1) is not loadable in this process: %s", dlerror() ? dlerror() : "symbol ncclAllGather missing");
+    const char* e = dlerror();
+    cocodr_set_error("allgather_rows: the loaded RCCL has no ncclAllGather: %s", e ? e : "symbol ncclAllGather missing");
     return COCODR_ERR_LAUNCH;
   }
   const int rc = ag(local_rows, gathered, (size_t)rows * H, kNcclFloat32, nccl_comm, (hipStream_t)stream);

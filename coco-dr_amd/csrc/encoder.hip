@@ -10,6 +10,8 @@
 // atomics, deterministic, fp32 results written straight into the caller's gradient buffers.
 #include <algorithm>
 
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -32,8 +34,21 @@ struct BwdLayout {
   size_t ln_partial, colsum_partial, emb_partial;  // fp32
   size_t ln2_slots, ln1_slots, b1_slots, bv_slots, bqk_slots;  // fp32 per-layer partial rows of the deferred reductions
   size_t multi_ws;  // fp32 partial tiles of the merged weight-gradient launch's cut last round (cocodr_gemm_multi)
+  size_t multi_ws_floats;
   size_t total;
 };
+
+// shapes (no pointers) of the four grouped weight-gradient problems of a backward range of ng layers over M token rows:
+// dWqkv [3H,H], dWo [H,H], dW1 [I,H], dW2 [H,I] = dY^T X, contraction over the tokens, batch = layer
+void weight_grad_shapes(cocodr_gemm_args (&wg)[4], int M, int H, int I, int ng) {
+  const int rows[4] = {3 * H, H, I, H}, cols[4] = {H, H, H, I};
+  for (int q = 0; q < 4; ++q) {
+    memset(&wg[q], 0, sizeof(wg[q]));
+    wg[q].M = rows[q]; wg[q].N = cols[q]; wg[q].K = M;
+    wg[q].lda = rows[q]; wg[q].ldb = cols[q]; wg[q].ldc = cols[q];
+    wg[q].trans_a = wg[q].trans_b = 1; wg[q].out_f32 = 1; wg[q].batch = ng; wg[q].epi = COCODR_EPI_NONE;
+  }
+}
 
 BwdLayout bwd_layout_m(const cocodr_config* c, size_t M, int B, int L) {
   const size_t H = c->hidden, I = c->inter, N = c->layers;
@@ -56,7 +71,16 @@ BwdLayout bwd_layout_m(const cocodr_config* c, size_t M, int B, int L) {
   b.b1_slots = cv.take(N * cocodr_gemm_colsum_partial_floats((int)M, (int)I) * 4);
   b.bv_slots = cv.take(N * cocodr_gemm_colsum_partial_floats((int)M, (int)H) * 4);
   b.bqk_slots = cv.take(N * (size_t)4 * B * 2 * H * 4);  // attention backward: 4 B partial rows of dQ | dK column sums
-  b.multi_ws = cv.take(cocodr_gemm_multi_workspace_floats() * 4);
+  // the merged weight-gradient launch of a backward range [lo, hi) cuts its last partial round into contraction slices: the
+  // partial tiles of the largest cut over all range lengths (0 - not 64 MiB - where no range is merged or none leaves a tail)
+  size_t ws = 0;
+  for (size_t ng = 1; ng <= N; ++ng) {
+    cocodr_gemm_args wg[4];
+    weight_grad_shapes(wg, (int)M, (int)H, (int)I, (int)ng);
+    ws = std::max(ws, cocodr_gemm_multi_workspace_floats_for(wg, 4));
+  }
+  b.multi_ws_floats = ws;
+  b.multi_ws = cv.take(ws * 4);
   b.total = cv.off;
   return b;
 }
@@ -479,7 +503,7 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   wg[2].out_f32 = 1; wg[2].batch = NG; wg[2].strideA = sMI; wg[2].strideB = sMH; wg[2].strideC = s_w1;
   wg[3] = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
   wg[3].out_f32 = 1; wg[3].batch = NG; wg[3].strideA = sMH; wg[3].strideB = sMI; wg[3].strideC = s_w2;
-  TRY(cocodr_gemm_multi(wg, 4, (float*)(bb + bl.multi_ws), cocodr_gemm_multi_workspace_floats(), stream));
+  TRY(cocodr_gemm_multi(wg, 4, bl.multi_ws_floats ? (float*)(bb + bl.multi_ws) : nullptr, bl.multi_ws_floats, stream));
   // ---- deferred reductions of the range (LayerNorm weight / bias + the Linear bias in front of it; b1; value bias)
   if (defer) {
     cocodr_reduce_job jobs[5];  // one launch for all of them

@@ -583,8 +583,9 @@ void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
 }  // namespace cocodr_gemm_v2
 using cocodr_gemm_v2::launch_glds_any;
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st);  // gemm_pp.hip: the ping-pong pipeline
-void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, hipStream_t st);
+void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, size_t ws_floats, hipStream_t st);
 size_t cocodr_gemm_pp_multi_ws_floats();
+size_t cocodr_gemm_pp_multi_ws_floats_for(const cocodr_gemm_args* a, int n);
 
 namespace {
 
@@ -752,24 +753,47 @@ extern "C" size_t cocodr_gemm_colsum_partial_floats(int M, int N) {
 // when together they fill it (>= 400 tiles of 256 x 256); otherwise, or when a problem does not fit that form, n plain calls.
 extern "C" size_t cocodr_gemm_multi_workspace_floats(void) { return cocodr_gemm_pp_multi_ws_floats(); }
 
-extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, float* workspace, size_t workspace_floats,
-                                 cocodr_stream_t stream) {
-  CK_ARG(problems != nullptr && n >= 1 && n <= 4, "gemm_multi: 1..4 problems");
-  CK_ARG(workspace == nullptr || (((uintptr_t)workspace & 15) == 0), "gemm_multi: workspace must be 16-byte aligned");
-  if (workspace_floats < cocodr_gemm_pp_multi_ws_floats()) workspace = nullptr;  // too small: whole tiles only
+namespace {
+long long multi_min_tiles() {
+  static const long long v = getenv("COCODR_GEMM_MULTI_MIN") ? atoll(getenv("COCODR_GEMM_MULTI_MIN")) : 400;  // tuning hook
+  return v;
+}
+// tiles of the merged launch; *form_ok: every problem has the form the merged launch takes (and nothing switched it off)
+long long multi_tiles(const cocodr_gemm_args* problems, int n, bool* form_ok) {
   static const bool off = getenv("COCODR_GEMM_NOMULTI") != nullptr;  // A/B switch
   bool ok = !off && n > 1 && gemm_impl_override() == 0;
   long long tiles = 0;
   for (int q = 0; q < n && ok; ++q) {
     const cocodr_gemm_args& a = problems[q];
-    ok = a.A && a.B && a.C && a.trans_a && a.trans_b && a.out_f32 && a.epi == COCODR_EPI_NONE && !a.bias && !a.colsum &&
+    ok = a.trans_a && a.trans_b && a.out_f32 && a.epi == COCODR_EPI_NONE && !a.bias && !a.colsum &&
          !a.colsum_partial && !a.drop.threshold && !a.ab_f16 && a.M > 0 && a.N > 0 && a.K == problems[0].K && a.K > 0 &&
          a.N % 256 == 0 && a.M % 8 == 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && a.lda >= a.M &&
          a.ldb >= a.N && a.ldc >= a.N && (size_t)a.K * a.lda * 2 < (1ull << 32) && (size_t)a.K * a.ldb * 2 < (1ull << 32);
     tiles += (long long)((a.M + 255) / 256) * (a.N / 256) * (a.batch > 0 ? a.batch : 1);
   }
-  static const long long min_tiles = getenv("COCODR_GEMM_MULTI_MIN") ? atoll(getenv("COCODR_GEMM_MULTI_MIN")) : 400;  // tuning hook
-  if (ok && tiles >= min_tiles && tiles < (1ll << 30)) {
+  *form_ok = ok;
+  return tiles;
+}
+}  // namespace
+
+// workspace floats THIS call would use (0: the problems do not run merged, or the merged launch has no last round to cut);
+// pointers are not examined, so layouts can ask with shapes alone
+extern "C" size_t cocodr_gemm_multi_workspace_floats_for(const cocodr_gemm_args* problems, int n) {
+  if (!problems || n < 1 || n > 4) return 0;
+  bool ok = false;
+  const long long tiles = multi_tiles(problems, n, &ok);
+  if (!(ok && tiles >= multi_min_tiles() && tiles < (1ll << 30))) return 0;
+  return cocodr_gemm_pp_multi_ws_floats_for(problems, n);
+}
+
+extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, float* workspace, size_t workspace_floats,
+                                 cocodr_stream_t stream) {
+  CK_ARG(problems != nullptr && n >= 1 && n <= 4, "gemm_multi: 1..4 problems");
+  CK_ARG(workspace == nullptr || (((uintptr_t)workspace & 15) == 0), "gemm_multi: workspace must be 16-byte aligned");
+  bool ok = false;
+  const long long tiles = multi_tiles(problems, n, &ok);
+  for (int q = 0; q < n && ok; ++q) ok = problems[q].A && problems[q].B && problems[q].C;
+  if (ok && tiles >= multi_min_tiles() && tiles < (1ll << 30)) {
     cocodr_gemm_args copy[4];
     double flops = 0.0;
     for (int q = 0; q < n; ++q) {
@@ -778,7 +802,7 @@ extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, float*
       flops += 2.0 * copy[q].M * copy[q].N * (double)copy[q].K * copy[q].batch;
     }
     ProfScope prof(PROF_GEMM, (hipStream_t)stream, flops);  // bench.py's roofline sample: one launch, the FLOPs of all problems
-    cocodr_gemm_pp_launch_multi(copy, n, workspace, (hipStream_t)stream);
+    cocodr_gemm_pp_launch_multi(copy, n, workspace, workspace_floats, (hipStream_t)stream);
     CK_LAUNCH("gemm_multi");
     return COCODR_OK;
   }

@@ -659,12 +659,46 @@ __global__ __launch_bounds__(256) void gemm_pp_split_finish(const MultiArgs ma, 
 }
 }  // namespace cocodr_gemm_pp
 
-// floats of workspace the cut last round of a merged launch may need (see MultiArgs)
+// floats of workspace the cut last round of ANY merged launch may need (see MultiArgs)
 size_t cocodr_gemm_pp_multi_ws_floats() { return (size_t)256 * cocodr_gemm_pp::SPLIT_TILE; }
 
+namespace {
+// compute units the cut is planned for: the device's (a multiple of 8), or 256 (MI355X) where no device can be asked -
+// layout functions run on the host alone
+int multi_n_cu() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+      n_cu = 256;
+    if (n_cu % 8 != 0) n_cu = -1;
+  }
+  return n_cu;
+}
+// the cut of the last partial round: r tiles in s contraction slices each (s = 0: no cut)
+void multi_split_plan(const cocodr_gemm_args* a, int n, int& total, int& r, int& s) {
+  using namespace cocodr_gemm_pp;
+  total = 0;
+  for (int q = 0; q < n; ++q) total += ((a[q].M + BM - 1) / BM) * (a[q].N / Shape<2>::BN) * (a[q].batch > 0 ? a[q].batch : 1);
+  const int n_cu = multi_n_cu();
+  r = n_cu > 0 ? total % n_cu : 0;
+  const int nt_min = (a[0].K + BK - 1) / BK;
+  s = r > 0 ? n_cu / r : 0;
+  if (s > nt_min) s = nt_min;
+  if (!(r > 0 && total > n_cu && s >= 4 && (size_t)r * s <= 256)) s = 0;
+}
+}  // namespace
+
+// floats of workspace THIS merged launch needs for its cut last round (0: it runs whole tiles only)
+size_t cocodr_gemm_pp_multi_ws_floats_for(const cocodr_gemm_args* a, int n) {
+  int total, r, s;
+  multi_split_plan(a, n, total, r, s);
+  return s ? (size_t)r * s * cocodr_gemm_pp::SPLIT_TILE : 0;
+}
+
 // n <= 4 batched TN problems with fp32 results (validated by cocodr_gemm_multi) as one launch; ws: optional workspace of
-// cocodr_gemm_pp_multi_ws_floats() floats for the cut last round (NULL: whole tiles only)
-void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, hipStream_t st) {
+// ws_floats >= cocodr_gemm_pp_multi_ws_floats_for(a, n) floats for the cut last round (NULL / smaller: whole tiles only)
+void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, size_t ws_floats, hipStream_t st) {
   using namespace cocodr_gemm_pp;
   MultiArgs ma;
   int total = 0;
@@ -673,19 +707,10 @@ void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, hi
     if (q < n) total += ((a[q].M + BM - 1) / BM) * (a[q].N / Shape<2>::BN) * (a[q].batch > 0 ? a[q].batch : 1);
     ma.tile_end[q] = total;
   }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0 || n_cu % 8 != 0) n_cu = -1;
-  }
   static const bool nosplit = getenv("COCODR_GEMM_NOSPLIT") != nullptr;  // A/B switch
-  const int r = n_cu > 0 ? total % n_cu : 0;
-  const int nt_min = (a[0].K + BK - 1) / BK;
-  int s = r > 0 ? n_cu / r : 0;
-  if (s > nt_min) s = nt_min;
-  const bool split = ws != nullptr && !nosplit && r > 0 && total > n_cu && s >= 4 && (size_t)r * s <= 256;
+  int r, s, total2;
+  multi_split_plan(a, n, total2, r, s);
+  const bool split = ws != nullptr && !nosplit && s > 0 && ws_floats >= (size_t)r * s * SPLIT_TILE;
   ma.split_first = split ? total - r : total;
   ma.split_s = split ? s : 1;
   ma.split_ws = ws;

@@ -892,6 +892,11 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
             raise ValueError(f"packed_index describes a {pk.B} x {pk.L} batch, the inputs are {tuple(ids.shape)}")
         if pk is None and self.pack_sequences:
             pk = PackedIndex.build(ids, mask)
+        if pk is not None and output_hidden_states and torch.is_grad_enabled() and self.flat_decay.requires_grad:
+            # a training forward whose caller may read (and back-propagate through) ANY hidden_states[i] - the Condenser head
+            # under the reference wrapper reads hidden_states[skip_from], COCO/modeling.py:212-216: only the padded Function
+            # makes the intermediate states differentiable outputs ("taps"), so this call runs padded
+            pk = None
         if pk is not None:
             last, cls = _PackedEncoderFn.apply(self.flat_decay, self.flat_nodecay, self, pk, torch.is_grad_enabled())
         else:

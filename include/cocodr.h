@@ -123,6 +123,9 @@ int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream);
  * last partial round of the 256 CUs into contraction slices (fp32 partial tiles, added in a fixed order by a second small
  * kernel) instead of running one more nearly empty round of whole tiles; NULL / too small: whole tiles only. */
 size_t cocodr_gemm_multi_workspace_floats(void);
+/* what THIS call would use of it (0: the problems do not run merged, or their tiles leave no last round to cut); only the
+ * shapes of `problems` are read, so an arena layout can ask before any buffer exists */
+size_t cocodr_gemm_multi_workspace_floats_for(const cocodr_gemm_args* problems, int n);
 int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, float* workspace, size_t workspace_floats, cocodr_stream_t stream);
 /* tuning / test hook: 0 = auto, 1 = register-staged pipeline,
  * direct-to-LDS <BM,BK,wave rows/32>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile,

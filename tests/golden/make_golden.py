@@ -2,7 +2,8 @@
 """Generate the golden vectors under tests/golden/ by running the REFERENCE in the build
 container (CPU, fp32).  Run once from the repo root:
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py            # every target, each in its own interpreter
+    python tests/golden/make_golden.py coco ance  # selected targets in this interpreter
 
 It imports /root/reference/COCO/modeling.py and /root/reference/ANCE/model/models.py
 (read-only) on top of the installed transformers BertModel (eager attention, fp32, eval),
@@ -29,7 +30,7 @@ sys.path.insert(0, ROOT)
 from oracle import OracleConfig, make_params  # noqa: E402
 
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("COCODR_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))  # (tests regenerate into a scratch directory)
 STD = 0.08  # larger than HF's 0.02 so that [CLS] rows differ visibly between inputs
 # The [CLS] embedding is a LayerNorm output: |q|^2 ~ H whatever the weight scale, so raw dot-product logits sit near 130
 # at H = 128 and a bf16-vs-fp32 comparison of them says little about the loss.  The triplet / DRO fixtures therefore
@@ -853,7 +854,21 @@ def golden_negatives():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate", "evaldev", "negatives", "dropout", "training_rows", "coco_dataset"]
+    ALL = ["coco", "ance", "mrr", "condenser", "cache", "lamb", "idro", "dro_greedy", "collate", "evaldev", "negatives", "dropout",
+           "training_rows", "coco_dataset"]
+    which = sys.argv[1:]
+    if not which:
+        # every target in its own interpreter: the reference trees shadow each other's top-level modules (COCO/data.py vs
+        # ANCE/data/, two different `model` / `utils` packages), and a target that has imported one poisons sys.modules for the next
+        import subprocess
+        for t in ALL:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), t])
+            if r.returncode != 0:
+                sys.exit(f"make_golden: target {t!r} failed with exit code {r.returncode}")
+        sys.exit(0)
+    unknown = [t for t in which if t not in ALL]
+    if unknown:
+        sys.exit(f"make_golden: unknown target(s) {unknown}; known: {ALL}")
     if "evaldev" in which:
         golden_evaldev()
     if "negatives" in which:

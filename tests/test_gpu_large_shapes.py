@@ -95,7 +95,7 @@ def _np_rel(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-def _contrastive_step_vs_oracle(ocfg, P, B, L, seed, grad_tol):
+def _contrastive_step_vs_oracle(ocfg, P, B, L, seed, grad_tol, max_escapes=0):
     # [CLS] is a LayerNorm output: |e|^2 ~ H, so the raw dot-product logits of the InfoNCE are O(H) and its softmax is
     # saturated - a loss that magnifies bf16 rounding of the hidden states by H.  As in the triplet / DRO fixtures
     # (tests/golden/make_golden.py) the LAST LayerNorm is shrunk so that the logits are O(5) and loss and gradients are
@@ -132,22 +132,32 @@ def _contrastive_step_vs_oracle(ocfg, P, B, L, seed, grad_tol):
     loss.backward()
     assert abs(float(loss) - ref_loss) < 1e-2 * abs(ref_loss) + 1e-3, (float(loss), ref_loss)
     G = {k: v.detach().float().cpu().numpy() for k, v in m.hf_named_grads()}
-    # Per tensor: rel-L2 <= grad_tol.  At random init every token row of a deep stack looks alike, so a few gradients
-    # (query / key projections of the top layers, the last LayerNorm's bias) are small residuals of cancelling terms whose
-    # bf16 noise is measured against the rest of their layer instead: error <= grad_tol / 4 of the layer's gradient norm.
+    # Per tensor: rel-L2 <= grad_tol.  At random init every token row of a deep stack looks alike, so a FEW gradients are small
+    # residuals of cancelling terms (the softmax is nearly uniform: dS ~ 0) whose bf16 noise has nothing to do with their own
+    # size.  Only those - query / key projections and the bias of the last (shrunk) LayerNorm - may instead be measured
+    # against their whole layer's gradient (error <= grad_tol / 4 of the layer norm), and only `max_escapes` of them.
     def group(n):
         return n.split(".")[2] if n.startswith("encoder.layer.") else "embeddings"
     gnorm = {}
     for n in Gref:
         gnorm[group(n)] = gnorm.get(group(n), 0.0) + float(np.sum(np.asarray(Gref[n], np.float64) ** 2))
-    bad = {}
+    may_escape = lambda n: ".attention.self.query." in n or ".attention.self.key." in n or n == last + "bias"
+    bad, escaped = {}, {}
     for n in Gref:
         if n.endswith("key.bias"):
-            continue
+            continue  # identically zero (softmax rows are shift-invariant): written as zeros, nothing to compare relatively
         err = float(np.linalg.norm(np.asarray(G[n], np.float64) - Gref[n]))
-        if err > grad_tol * float(np.linalg.norm(Gref[n])) and err > 0.25 * grad_tol * np.sqrt(gnorm[group(n)]):
-            bad[n] = (err / float(np.linalg.norm(Gref[n])), err / np.sqrt(gnorm[group(n)]))
+        rel = err / float(np.linalg.norm(Gref[n]))
+        if rel <= grad_tol:
+            continue
+        rel_layer = err / np.sqrt(gnorm[group(n)])
+        if may_escape(n) and rel_layer <= 0.25 * grad_tol:
+            escaped[n] = (rel, rel_layer)
+        else:
+            bad[n] = (rel, rel_layer)
+    print(f"gradient check: {len(Gref)} tensors, {len(escaped)} measured against their layer: {sorted(escaped)}")
     assert not bad, bad
+    assert len(escaped) <= max_escapes, escaped
 
 
 @pytest.mark.parametrize("B,L", [(4, 128), (4, 64)])
@@ -156,7 +166,7 @@ def test_bert_large_two_layers_vs_oracle(B, L):
     sequence lengths of configs 4 / 5, forward + InfoNCE + backward"""
     ocfg = O.OracleConfig(vocab_size=2000, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
                           max_position_embeddings=128)
-    _contrastive_step_vs_oracle(ocfg, O.make_params(ocfg, 21, std=0.04), B, L, seed=6, grad_tol=8e-2)
+    _contrastive_step_vs_oracle(ocfg, O.make_params(ocfg, 21, std=0.04), B, L, seed=6, grad_tol=8e-2, max_escapes=2)
 
 
 def test_config1_real_shape_vs_oracle():
@@ -164,4 +174,4 @@ def test_config1_real_shape_vs_oracle():
     path that config is defined on)"""
     ocfg = O.OracleConfig(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                           max_position_embeddings=512)
-    _contrastive_step_vs_oracle(ocfg, O.make_params(ocfg, 0, std=0.03), 8, 64, seed=7, grad_tol=1e-1)
+    _contrastive_step_vs_oracle(ocfg, O.make_params(ocfg, 0, std=0.03), 8, 64, seed=7, grad_tol=8e-2, max_escapes=6)

@@ -83,7 +83,16 @@ def test_score_topk_vs_oracle(Nq, Np, H, k, score_mode):
     gap_ok[:, 1:] &= d
     gap_ok[:, :-1] &= d
     assert np.array_equal(I[:, :kk][gap_ok], (Ir[:, :kk] + 7)[gap_ok])
-    assert (np.sort(I[:, :kk], 1) == np.sort(I[:, :kk], 1)).all() and all(len(set(r)) == kk for r in I[:, :kk])
+    assert all(len(set(r)) == kk for r in I[:, :kk])  # no position twice
+    # the SET of returned positions is the oracle's on every row whose k-th and (k+1)-th best scores are separated by more
+    # than fp32 round-off (near-ties inside the list may permute, near-ties at the cut may swap one member)
+    if Np > kk:
+        D2, _ = O.score_topk(Q, P, kk + 1)
+        clear_cut = (D2[:, kk - 1] - D2[:, kk]) > 1e-6
+    else:
+        clear_cut = np.ones(Nq, bool)
+    assert clear_cut.sum() >= 0.9 * Nq
+    assert np.array_equal(np.sort(I[:, :kk], 1)[clear_cut], np.sort(Ir[:, :kk] + 7, 1)[clear_cut])
     if k > Np:
         assert (I[:, Np:] == -1).all() and np.isneginf(D[:, Np:]).all()
 
