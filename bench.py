@@ -464,7 +464,7 @@ def _traffic_for(model_name: str, seq_per_gpu: int, seq_len: int):
     """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
     corrected as MI355X_MICROARCH.md prescribes) of THIS workload shape, with the file it came from; None when no pass was
     taken on the shape."""
-    path = os.path.join(ROOT, "profiles", f"r02_gemm_pmc_{model_name}_{seq_per_gpu}x{seq_len}.json")
+    path = os.path.join(ROOT, "profiles", f"gemm_pmc_{model_name}_{seq_per_gpu}x{seq_len}.json")
     try:
         with open(path) as f:
             d = json.load(f)

@@ -2,8 +2,10 @@
 # One GPU visit: parity suite, the default bench line, kernel-trace stats and HBM-traffic PMC passes for the base and
 # large contrastive steps.  Usage (on the GPU box, from the repo root): tools/gpu_round.sh <tag> [commit] [stages]
 # stages: any of t (tests) b (bench) k (kernel stats) p (PMC traffic); default tbkp
+# The PMC stage writes gemm_pmc_<model>_<seq>x128.json; copy them to profiles/ (bench.py's roofline.traffic reads profiles/gemm_pmc_*.json
+# and reports the commit recorded inside).
 set -u
-tag=${1:-r02}; commit=${2:-unknown}; stages=${3:-tbkp}
+tag=${1:-r03}; commit=${2:-unknown}; stages=${3:-tbkp}
 export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/$tag
@@ -18,7 +20,7 @@ if [[ $stages == *b* ]]; then
   echo "bench exit $?"; tail -c 600 $out/bench.json
 fi
 prof_args="--steps 10 --warmup 3 --no-cpu-baseline --no-full-step"
-for cfg in "base 64" "large 64" "large 200"; do
+for cfg in "base 64" "large 64" "large 200" "large 256"; do
   set -- $cfg; model=$1; nseq=$2
   name=${model}_${nseq}x128
   if [[ $stages == *k* ]]; then
@@ -34,7 +36,7 @@ for cfg in "base 64" "large 64" "large 200"; do
     done
     f=$(find $out/pmc_${name}_FETCH_SIZE -name "*counter_collection.csv" | head -1)
     w=$(find $out/pmc_${name}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-    if [ -n "$f" ] && [ -n "$w" ]; then python tools/pmc_traffic.py $f $w $out/r02_gemm_pmc_$name.json "$pmc_cmd" $commit; fi
+    if [ -n "$f" ] && [ -n "$w" ]; then python tools/pmc_traffic.py $f $w $out/gemm_pmc_$name.json "$pmc_cmd" $commit; fi
   fi
 done
 # keep the merged-back payload small: drop raw traces
