@@ -396,16 +396,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // two half-tiles in flight the operand stream ran at ~50 GB/s per CU - the latency of a loaded L2 times the bytes in
   // flight - and bounded the whole loop (DMA-only ablation, profiles/r02_gemm_pp_ablation.txt).
   // rem = K-tiles left including this one: the request exists while its K-tile does; the wait count shrinks with the queue.
+  // VAR 6 (experiment): the same request sequence issued in TWO bursts per K-tile instead of one half-tile per phase - nothing in
+  // the phases that carry the most fragment reads ((A0, B0): 12, (A1, B1): 8), two half-tiles in the two light ones ((A0, B1): 4
+  // reads requests B1 and A1 of K-tile t + 1, (A1, B0): none requests A0 and B0 of K-tile t + 2).  Same slots, same margins.
   auto request = [&](auto jc, int t, int rem) {
     constexpr int j = decltype(jc)::value;
-    if constexpr (j < 2) { if (rem >= 2) stage(std::integral_constant<int, j + 2>{}, t + 1); }
-    else { if (rem >= 3) stage(std::integral_constant<int, j - 2>{}, t + 2); }
+    if constexpr (VAR == 6) {
+      if constexpr (j == 1) { if (rem >= 2) { stage(std::integral_constant<int, 2>{}, t + 1); stage(std::integral_constant<int, 3>{}, t + 1); } }
+      if constexpr (j == 3) { if (rem >= 3) { stage(std::integral_constant<int, 0>{}, t + 2); stage(std::integral_constant<int, 1>{}, t + 2); } }
+    } else {
+      if constexpr (j < 2) { if (rem >= 2) stage(std::integral_constant<int, j + 2>{}, t + 1); }
+      else { if (rem >= 3) stage(std::integral_constant<int, j - 2>{}, t + 2); }
+    }
   };
   auto wait_stage = [&](auto jc, int rem) {
     constexpr int j = decltype(jc)::value;
-    if (rem >= 3) wait_vmcnt<8>();
-    else if (rem == 2) wait_vmcnt<(j < 2 ? 8 : (j == 2 ? 6 : 4))>();
-    else wait_vmcnt<(j == 0 ? 2 : 0)>();
+    if constexpr (VAR == 6) {  // what the NEXT phase reads must have landed; everything requested behind it may stay in flight
+      if constexpr (j == 0) { if (rem >= 2) wait_vmcnt<6>(); else wait_vmcnt<2>(); }          // B1(t); behind it A1(t), A0 B0(t+1)
+      if constexpr (j == 1) { if (rem >= 2) wait_vmcnt<8>(); else wait_vmcnt<0>(); }          // A1(t); behind it A0 B0 B1 A1(t+1)
+      if constexpr (j == 3) { if (rem >= 3) wait_vmcnt<8>(); else if (rem == 2) wait_vmcnt<4>(); else wait_vmcnt<0>(); }  // A0 B0(t+1)
+    } else {
+      if (rem >= 3) wait_vmcnt<8>();
+      else if (rem == 2) wait_vmcnt<(j < 2 ? 8 : (j == 2 ? 6 : 4))>();
+      else wait_vmcnt<(j == 0 ? 2 : 0)>();
+    }
   };
 
   // One K-tile.  STEADY: at least two more K-tiles follow (rem >= 3) - every request exists and every wait is vmcnt(8), so the
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       auto none = []() {};
       if constexpr (VAR == 3) req();
       reads();
-      if constexpr (VAR == 0 || VAR == 2) req();
+      if constexpr (VAR == 0 || VAR == 2 || VAR == 6) req();
       wait_stage(tyc, rem);
       __builtin_amdgcn_s_barrier();
       wait_lgkmcnt<0>();
@@ -476,7 +490,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       phase(std::integral_constant<int, 3>{}, [&]() {}, fb0, acc[2][0], acc[3][0]);                      // (A1, B0): all in registers
     }
   };
-  if constexpr (VAR == 0 && NB == 2) {
+  if constexpr ((VAR == 0 || VAR == 6) && NB == 2) {
     int t = 0;
     if (!(flags & 4))  // (bit 2: A/B switch COCODR_PP_NOPEEL - every K-tile in the general form)
       for (; t < nt - 2; ++t) ktile(std::true_type{}, t, 3);
@@ -736,12 +750,16 @@ static void launch_any(const cocodr_gemm_args& a, hipStream_t st) {
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st) {
   static const int fat = getenv("COCODR_PP_FAT") ? atoi(getenv("COCODR_PP_FAT")) : 0;  // A/B switch: 1 = fat phases everywhere,
   if (nb == 2 && (fat == 1 || (fat == 2 && !a.trans_a) || (fat == 3 && a.trans_a))) launch_any<5>(a, st);  // 2 = forward / dgrad only, 3 = wgrads only
+#if defined(COCODR_PP_VARIANTS)
+  else if (nb == 2 && getenv("COCODR_PP_VAR") && atoi(getenv("COCODR_PP_VAR")) == 6) launch_any<6>(a, st);  // in-step A/B of VAR 6
+#endif
   else if (nb == 2) launch_any<0>(a, st);                                        // four thin phases per K-tile (the default)
   else if (nb == 104) cocodr_gemm_pp::launch_form<2, 0, 0, 5, true>(a, st);      // IEEE-half operands (the search): fat phases
   else if (nb == 105) launch_any<5>(a, st);                                      // impl 18: two fat phases per K-tile
 #if defined(COCODR_PP_VARIANTS)
   else if (nb == 102) launch_any<2>(a, st);
   else if (nb == 103) launch_any<3>(a, st);
+  else if (nb == 106) launch_any<6>(a, st);
 #endif
   else launch_any<0>(a, st);
 }

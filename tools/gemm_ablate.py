@@ -23,6 +23,8 @@ VARIANTS = {
     "dma_only": ["-DCOCODR_ABL_NO_MFMA", "-DCOCODR_ABL_NO_LDSREAD"],
     "mfma_only": ["-DCOCODR_ABL_NO_DMA", "-DCOCODR_ABL_NO_LDSREAD"],
     "epi_nostore": ["-DCOCODR_ABL_EPI_NOSTORE"],
+    "no_barrier": ["-DCOCODR_ABL_NO_BARRIER"],
+    "w4_burst": ["-DCOCODR_ABL_W4_BURST"],
 }
 TIMELINE = {"timeline": ["-DCOCODR_ABL_TIMELINE"]}
 
@@ -35,8 +37,8 @@ def build(only=None):
             continue
         lib = os.path.join(OUT, f"libabl_{name}.so")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-               "-DCOCODR_ABL_ALIAS_LD"] + defs + [
-            os.path.join(csrc, "gemm.hip"), os.path.join(csrc, "gemm_pp.hip"), os.path.join(csrc, "core.hip"), os.path.join(csrc, "rowops.hip"), "-o", lib]
+               "-DCOCODR_ABL_ALIAS_LD", "-DCOCODR_W4"] + defs + [
+            os.path.join(csrc, "gemm.hip"), os.path.join(csrc, "gemm_pp.hip"), os.path.join(csrc, "gemm_w4.hip"), os.path.join(csrc, "core.hip"), os.path.join(csrc, "rowops.hip"), "-o", lib]
         subprocess.run(cmd, check=True)
         print("built", lib)
 

@@ -78,6 +78,8 @@ SHAPES = [  # (name, M, N, K, ta, tb, batch, out_f32)
     ("pkXL dgrad ffn2 17896x4096x1024", 17896, 4096, 1024, 0, 1, 1, 0),
     ("pkXL dgrad ffn1 17896x1024x4096", 17896, 1024, 4096, 0, 1, 1, 0),
     ("pkXL dgrad qkv 17896x1024x3072", 17896, 1024, 3072, 0, 1, 1, 0),
+    # 61: one query chunk of the config-5 search: 2048 queries x 125 184 passages, depth 3 x 1024 (split precision), fp32 slab out
+    ("score chunk 2048x125184x3072 f32", 2048, 125184, 3072, 0, 0, 1, 1),
 ]
 
 
