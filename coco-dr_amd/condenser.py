@@ -275,7 +275,7 @@ class _CondenserStepFn(torch.autograd.Function):
         # ---- backbone backward in two ranges; the head's gradient joins at hidden_states[skip_from]
         bgd = torch.empty_like(bert.flat_decay.data)
         bgn = torch.empty_like(bert.flat_nodecay.data)
-        bgd[:lo.mat_begin].zero_()
+        ops.zero_f32(bgd[:lo.mat_begin])
         emb, arr, eg, garr = bert._param_structs((bgd, bgn))
         bcfg = bert._c_config(getattr(ctx.arena, "_cocodr_drop", None))
         d_last16 = d_last.to(torch.bfloat16)

@@ -816,6 +816,25 @@ extern "C" int cocodr_cast_f32_bf16(const float* src, uint16_t* dst, size_t n, c
   return COCODR_OK;
 }
 
+// zero fill of a gradient block (the embedding tables' gradient, 94 - 125 MB per backward: rows are accumulated with atomics,
+// so the block has to start from zero; torch's fill kernel measured 1.5 TB/s on it, this one streams 16-B stores from 2048
+// workgroups)
+__global__ __launch_bounds__(256) void zero_kernel(float4* __restrict__ dst, size_t n4, float* __restrict__ tail, int ntail) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+extern "C" int cocodr_zero_f32(float* dst, size_t n, cocodr_stream_t stream) {
+  CK_ARG(dst != nullptr || n == 0, "zero_f32: null pointer");
+  CK_ARG(((uintptr_t)dst & 15) == 0, "zero_f32: pointer must be 16-byte aligned");
+  if (n == 0) return COCODR_OK;
+  const size_t n4 = n / 4;
+  const int grid = (int)std::min((size_t)2048, n4 / 256 + 1);
+  hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(dst), n4, dst + 4 * n4, (int)(n - 4 * n4));
+  CK_LAUNCH("zero_f32");
+  return COCODR_OK;
+}
+
 extern "C" int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int H, cocodr_stream_t stream) {
   CK_ARG(dE && d_last, "scatter_cls_grad: null pointer");
   CK_ARG(B > 0 && L > 0 && row_shape_ok(H), "scatter_cls_grad: bad shape");

@@ -662,7 +662,7 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         lo, NL = self.layout, self.config.num_hidden_layers
         gd = torch.empty_like(self.flat_decay.data)
         gn = torch.empty_like(self.flat_nodecay.data)
-        gd[:lo.mat_begin].zero_()
+        ops.zero_f32(gd[:lo.mat_begin])
         emb, arr, eg, garr = self._param_structs((gd, gn))
         cfg = self._c_config(getattr(arena, "_cocodr_drop", None))
 
@@ -795,7 +795,7 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         NL = self.config.num_hidden_layers
         gd = torch.empty_like(self.flat_decay.data)
         gn = torch.empty_like(self.flat_nodecay.data)
-        gd[:lo.mat_begin].zero_()  # embedding tables: sparse word rows are accumulated, unused position rows stay zero
+        ops.zero_f32(gd[:lo.mat_begin])  # embedding tables: sparse word rows are accumulated, unused position rows stay zero
         emb, arr, eg, garr = self._param_structs((gd, gn))
         cfg = self._c_config(getattr(arena, "_cocodr_drop", None))
         if not self._dp_overlap_ok():  # several passes share the weights / local gradient pending: reduced once, from the hook
@@ -826,7 +826,7 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         M = B * L
         gd = torch.empty_like(self.flat_decay.data)
         gn = torch.empty_like(self.flat_nodecay.data)
-        gd[:lo.mat_begin].zero_()
+        ops.zero_f32(gd[:lo.mat_begin])
         emb, arr, eg, garr = self._param_structs((gd, gn))
         cfg = self._c_config(getattr(arena, "_cocodr_drop", None))
         dx_view = arena[lay.bwd_dx: lay.bwd_dx + M * H * 2].view(torch.bfloat16).view(B, L, H)

@@ -256,6 +256,13 @@ def gram(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def zero_f32(t: torch.Tensor) -> torch.Tensor:
+    """t[...] = 0 for a contiguous fp32 CUDA tensor (cocodr_zero_f32)."""
+    _req(t, F32, "t")
+    check(lib().cocodr_zero_f32(ptr(t), t.numel(), stream_ptr()), "zero_f32")
+    return t
+
+
 def cast_f32_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(src, F32, "src")
     if dst is None:

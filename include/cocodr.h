@@ -210,6 +210,9 @@ size_t cocodr_colsum_partial_floats(int M, int N, int batch);
 int cocodr_colsum(const uint16_t* X, float* out, float* partial, int M, int N, int ldx, int batch,
                   long long strideX, long long strideOut, cocodr_stream_t stream);
 int cocodr_cast_f32_bf16(const float* src, uint16_t* dst, size_t n, cocodr_stream_t stream);
+/* dst[0 .. n) = 0 (fp32, 16-byte aligned): the embedding tables' gradient block, which the embedding backward accumulates into
+ * with atomics (what autograd's zero-initialised sparse-to-dense embedding gradient is in the reference, hf BertEmbeddings) */
+int cocodr_zero_f32(float* dst, size_t n, cocodr_stream_t stream);
 /* d_last[b*L + 0, :] = bf16(dE[b, :]), all other rows zero (gradient enters at [CLS] only) */
 int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int H, cocodr_stream_t stream);
 
