@@ -117,6 +117,9 @@ SIGNATURES = {
     "cocodr_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
     "cocodr_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "cocodr_zero_f32": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "cocodr_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "cocodr_scatter_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cocodr_mul_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cocodr_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_float, c_float,
                                   c_float, c_float, c_int, c_float, c_void_p, c_void_p]),
     "cocodr_grad_norm_clip": (c_int, [C.POINTER(c_void_p), C.POINTER(c_size_t), c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -193,10 +193,11 @@ class _CondenserStepFn(torch.autograd.Function):
         lab_p = torch.cat([lab, lab.new_zeros(n_pad - n_lab)])
         scale_p = torch.zeros(n_pad, dtype=torch.float32, device=dev)
         scale_p[:n_lab] = 1.0 / n_lab
-        xg = head_out.reshape(M, H).index_select(0, rows_p)
+        n2 = 2 * n_pad if late_mlm else n_pad
+        xg = torch.empty((n2, H), dtype=torch.bfloat16, device=dev)  # labelled rows of the head output [| of the last backbone layer]
+        ops.gather_rows(head_out.reshape(M, H), rows_p, xg[:n_pad])
         if late_mlm:
-            xg = torch.cat([xg, last.reshape(M, H).index_select(0, rows_p)])
-        n2 = xg.shape[0]
+            ops.gather_rows(last.reshape(M, H), rows_p, xg[n_pad:])
         wt = head._shadow[: H * H].view(H, H)
         b_t = head.hf_view("cls.predictions.transform.dense.bias")
         g_act, a_pre = ops.gemm(xg.contiguous(), wt, bias=b_t, epi=N.EPI_GELU)
@@ -250,14 +251,14 @@ class _CondenserStepFn(torch.autograd.Function):
             dg, dlnw, dlnb = ops.ln_bwd(dt, g_act, head.hf_view("cls.predictions.transform.LayerNorm.weight"), t_mean, t_rstd)
             gv("cls.predictions.transform.LayerNorm.weight").copy_(dlnw)
             gv("cls.predictions.transform.LayerNorm.bias").copy_(dlnb)
-            da = (dg.float() * a_pre.float()).to(torch.bfloat16)  # a_pre holds GELU'(pre-activation) (EPI_GELU's C2)
+            da = ops.mul_bf16(dg, a_pre)  # a_pre holds GELU'(pre-activation) (EPI_GELU's C2)
             gv("cls.predictions.transform.dense.weight").copy_(ops.gemm(da, xg, trans_a=True, trans_b=True, out_f32=True))
             gv("cls.predictions.transform.dense.bias").copy_(ops.colsum(da))
             wt = head._shadow[: H * H].view(H, H)
             dxg = ops.gemm(da, wt, trans_b=True)                                        # [n2,H]
-            d_head_out.index_copy_(0, rows, dxg[:n_lab])
+            ops.scatter_rows(dxg[:n_lab], rows, d_head_out)
             if ctx.late_mlm:
-                d_last.index_add_(0, rows, dxg[ctx.n_pad:ctx.n_pad + n_lab].float())
+                ops.scatter_rows(dxg[ctx.n_pad:ctx.n_pad + n_lab], rows, d_last)
         # ---- Condenser head backward (layers nh-1 .. 0), input gradient left at hlay.bwd_dx
         harr, hgarr = hlo.layer_structs(head._shadow.data_ptr(), 0, head.flat_nodecay.data_ptr(), (ghd.data_ptr(), ghn.data_ptr()))
         check(lib().cocodr_encoder_bwd_range(C.byref(ctx.hcfg), None, harr, None, hgarr, None, ptr(ctx.mask), ptr(d_head_out), B, L,

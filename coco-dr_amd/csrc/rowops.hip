@@ -835,6 +835,81 @@ extern "C" int cocodr_zero_f32(float* dst, size_t n, cocodr_stream_t stream) {
   return COCODR_OK;
 }
 
+// ------------------------------------------------------------------ row plumbing of the label-sparse MLM head
+// The Condenser / MLM head runs on the ~15 % labelled rows only (COCO/modeling.py:87-93, 222-224 form the full [B L, V] logits and let
+// the cross entropy ignore -100): gather those rows, scatter their gradients back, and the GELU' product of the transform's backward.
+// One wave per row, 8-byte lanes (H % 4 == 0); idx int64 (what torch.nonzero returns).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint16_t* __restrict__ src, const long long* __restrict__ idx, uint16_t* __restrict__ dst,
+                                                          int n, int H) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
+    const uint2* s = reinterpret_cast<const uint2*>(src + (size_t)idx[r] * H);
+    uint2* d = reinterpret_cast<uint2*>(dst + (size_t)r * H);
+    for (int c = lane; c < H / 4; c += 64) d[c] = s[c];
+  }
+}
+// MODE 0: dst bf16 [M,H] row idx[r] = src row r (rows not named stay as they are: the caller zero-fills);
+// MODE 1: dst fp32 [M,H] row idx[r] += src row r (idx unique: no atomics)
+template <int MODE>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const uint16_t* __restrict__ src, const long long* __restrict__ idx, void* __restrict__ dst,
+                                                           int n, int H) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
+    const uint2* s = reinterpret_cast<const uint2*>(src + (size_t)r * H);
+    if (MODE == 0) {
+      uint2* d = reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + (size_t)idx[r] * H);
+      for (int c = lane; c < H / 4; c += 64) d[c] = s[c];
+    } else {
+      float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + (size_t)idx[r] * H);
+      for (int c = lane; c < H / 4; c += 64) {
+        float f[4];
+        unpack4(s[c], f);
+        float4 v = d[c];
+        v.x += f[0]; v.y += f[1]; v.z += f[2]; v.w += f[3];
+        d[c] = v;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void mul_bf16_kernel(const uint2* __restrict__ a, const uint2* __restrict__ b, uint2* __restrict__ out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float x[4], y[4];
+    unpack4(a[i], x);
+    unpack4(b[i], y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] *= y[e];
+    out[i] = pack4(x);
+  }
+}
+extern "C" int cocodr_gather_rows(const uint16_t* src, const long long* idx, uint16_t* dst, int n, int H, cocodr_stream_t stream) {
+  CK_ARG(src && idx && dst, "gather_rows: null pointer");
+  CK_ARG(n >= 0 && H > 0 && H % 4 == 0, "gather_rows: bad shape n=%d H=%d", n, H);
+  if (n == 0) return COCODR_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(std::min(2048, (n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, H);
+  CK_LAUNCH("gather_rows");
+  return COCODR_OK;
+}
+extern "C" int cocodr_scatter_rows(const uint16_t* src, const long long* idx, void* dst, int n, int H, int add_f32, cocodr_stream_t stream) {
+  CK_ARG(src && idx && dst, "scatter_rows: null pointer");
+  CK_ARG(n >= 0 && H > 0 && H % 4 == 0, "scatter_rows: bad shape n=%d H=%d", n, H);
+  if (n == 0) return COCODR_OK;
+  const dim3 grid(std::min(2048, (n + 3) / 4));
+  if (add_f32) hipLaunchKernelGGL(scatter_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, H);
+  else hipLaunchKernelGGL(scatter_rows_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, H);
+  CK_LAUNCH("scatter_rows");
+  return COCODR_OK;
+}
+extern "C" int cocodr_mul_bf16(const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n, cocodr_stream_t stream) {
+  CK_ARG(a && b && out, "mul_bf16: null pointer");
+  CK_ARG(n % 4 == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 7) == 0), "mul_bf16: n %% 4 == 0 and 8-byte aligned pointers");
+  if (n == 0) return COCODR_OK;
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(mul_bf16_kernel, dim3((int)std::min((size_t)2048, n4 / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const uint2*>(a), reinterpret_cast<const uint2*>(b), reinterpret_cast<uint2*>(out), n4);
+  CK_LAUNCH("mul_bf16");
+  return COCODR_OK;
+}
+
 extern "C" int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int H, cocodr_stream_t stream) {
   CK_ARG(dE && d_last, "scatter_cls_grad: null pointer");
   CK_ARG(B > 0 && L > 0 && row_shape_ok(H), "scatter_cls_grad: bad shape");

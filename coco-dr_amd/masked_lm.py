@@ -68,7 +68,7 @@ class _MLMHeadFn(torch.autograd.Function):
         dg, dlnw, dlnb = ops.ln_bwd(dt, g_act, head.hf_view("cls.predictions.transform.LayerNorm.weight"), t_mean, t_rstd)
         gv("cls.predictions.transform.LayerNorm.weight").copy_(dlnw)
         gv("cls.predictions.transform.LayerNorm.bias").copy_(dlnb)
-        da = (dg.float() * a_pre.float()).to(torch.bfloat16)  # a_pre holds GELU'(pre-activation) (EPI_GELU's second output)
+        da = ops.mul_bf16(dg, a_pre)  # a_pre holds GELU'(pre-activation) (EPI_GELU's second output)
         gv("cls.predictions.transform.dense.weight").copy_(ops.gemm(da, x, trans_a=True, trans_b=True, out_f32=True))
         gv("cls.predictions.transform.dense.bias").copy_(ops.colsum(da))
         dx = ops.gemm(da, head._shadow[: H * H].view(H, H), trans_b=True)

@@ -263,6 +263,41 @@ def zero_f32(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r] = src[idx[r]]: bf16 rows [*, H], idx int64 [n] (cocodr_gather_rows)."""
+    _req(src, BF16, "src", 2); _req(idx, I64, "idx", 1)
+    n, H = idx.shape[0], src.shape[1]
+    if out is None:
+        out = torch.empty((n, H), dtype=BF16, device=src.device)
+    else:
+        _req(out, BF16, "out", 2)
+        if tuple(out.shape) != (n, H):
+            raise ValueError("gather_rows: out shape mismatch")
+    check(lib().cocodr_gather_rows(ptr(src), ptr(idx), ptr(out), n, H, stream_ptr()), "gather_rows")
+    return out
+
+
+def scatter_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[idx[r]] = src[r] (dst bf16) or dst[idx[r]] += src[r] (dst fp32; idx unique) - cocodr_scatter_rows."""
+    _req(src, BF16, "src", 2); _req(idx, I64, "idx", 1)
+    if dst.dtype not in (BF16, F32) or not dst.is_cuda or not dst.is_contiguous() or dst.dim() != 2 or dst.shape[1] != src.shape[1]:
+        raise ValueError("scatter_rows: dst must be a contiguous CUDA [M, H] tensor (bf16 or fp32) of src's width")
+    if idx.shape[0] > src.shape[0]:
+        raise ValueError("scatter_rows: more indices than source rows")
+    check(lib().cocodr_scatter_rows(ptr(src), ptr(idx), ptr(dst), idx.shape[0], src.shape[1], int(dst.dtype == F32), stream_ptr()), "scatter_rows")
+    return dst
+
+
+def mul_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """element-wise bf16 product (fp32 multiply, one rounding) - cocodr_mul_bf16."""
+    _req(a, BF16, "a"); _req(b, BF16, "b")
+    if a.shape != b.shape:
+        raise ValueError("mul_bf16: shape mismatch")
+    out = torch.empty_like(a)
+    check(lib().cocodr_mul_bf16(ptr(a), ptr(b), ptr(out), a.numel(), stream_ptr()), "mul_bf16")
+    return out
+
+
 def cast_f32_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(src, F32, "src")
     if dst is None:

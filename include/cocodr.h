@@ -213,6 +213,13 @@ int cocodr_cast_f32_bf16(const float* src, uint16_t* dst, size_t n, cocodr_strea
 /* dst[0 .. n) = 0 (fp32, 16-byte aligned): the embedding tables' gradient block, which the embedding backward accumulates into
  * with atomics (what autograd's zero-initialised sparse-to-dense embedding gradient is in the reference, hf BertEmbeddings) */
 int cocodr_zero_f32(float* dst, size_t n, cocodr_stream_t stream);
+/* Row plumbing of the label-sparse MLM head (COCO/modeling.py:87-93, 222-224 run lm.cls on all B L rows and let the cross entropy
+ * ignore -100; here only the labelled rows go through it): dst[r] = src[idx[r]] (bf16 rows of width H, idx int64 [n]);
+ * scatter: dst[idx[r]] = src[r] (bf16) or, add_f32 != 0, dst fp32 [.,H] row idx[r] += src[r] (idx unique); and the element-wise
+ * bf16 product of the transform's backward (dense-output gradient = LayerNorm-input gradient x saved GELU'). */
+int cocodr_gather_rows(const uint16_t* src, const long long* idx, uint16_t* dst, int n, int H, cocodr_stream_t stream);
+int cocodr_scatter_rows(const uint16_t* src, const long long* idx, void* dst, int n, int H, int add_f32, cocodr_stream_t stream);
+int cocodr_mul_bf16(const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n, cocodr_stream_t stream);
 /* d_last[b*L + 0, :] = bf16(dE[b, :]), all other rows zero (gradient enters at [CLS] only) */
 int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int H, cocodr_stream_t stream);
 

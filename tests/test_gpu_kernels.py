@@ -402,3 +402,29 @@ def test_gemm_multi_weight_gradients_in_one_launch(layers, M, H, I):
     check(lib().cocodr_gemm_multi(arr, 4, ptr(ws), nws, stream_ptr()), "gemm_multi")
     for o, o2 in zip(outs, outs2):
         assert float((o - o2).norm() / o2.norm()) < 1e-6
+
+
+def test_row_gather_scatter_and_bf16_product_are_exact():
+    """cocodr_gather_rows / cocodr_scatter_rows / cocodr_mul_bf16 (the label-sparse MLM head's plumbing) against torch indexing:
+    copies are bit-exact, the fp32 scatter-add adds exactly the bf16 values, the product is one fp32 multiply rounded once."""
+    g = torch.Generator().manual_seed(4)
+    M, H, n = 700, 768, 131
+    src = torch.randn(M, H, generator=g).to(torch.bfloat16).to(DEV)
+    idx = torch.randperm(M, generator=g)[:n].to(DEV)
+    got = ops.gather_rows(src, idx)
+    assert torch.equal(got, src.index_select(0, idx))
+    rows = torch.randn(n, H, generator=g).to(torch.bfloat16).to(DEV)
+    dst = torch.zeros(M, H, dtype=torch.bfloat16, device=DEV)
+    ops.scatter_rows(rows, idx, dst)
+    want = torch.zeros_like(dst)
+    want.index_copy_(0, idx, rows)
+    assert torch.equal(dst, want)
+    acc = torch.randn(M, H, generator=g).to(DEV)
+    ref = acc.clone()
+    ref.index_add_(0, idx, rows.float())
+    ops.scatter_rows(rows, idx, acc)
+    assert torch.equal(acc, ref)
+    a = torch.randn(n, H, generator=g).to(torch.bfloat16).to(DEV)
+    assert torch.equal(ops.mul_bf16(a, rows), (a.float() * rows.float()).to(torch.bfloat16))
+    with pytest.raises(ValueError):
+        ops.gather_rows(src, idx.to(torch.int32))
