@@ -610,7 +610,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG(impl >= 0 && impl <= 20 && impl != 17, "gemm_set_impl: impl must be in [0,13] or 18 (ping-pong with two fat phases per K-tile); 14-16, 19: schedule variants of experiment builds");
+  CK_ARG(impl >= 0 && impl <= 21 && impl != 17, "gemm_set_impl: impl must be in [0,13] or 18 (ping-pong with two fat phases per K-tile); 14-16, 19: schedule variants of experiment builds");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -724,7 +724,7 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
 #if defined(COCODR_W4)  // experiment builds (COCODR_EXPERIMENTAL=1 python coco-dr_amd/build.py): gemm_w4.hip, impl 20
   if (impl == 20 && cocodr_gemm_w4_launch(a, st)) { /* one wave per SIMD */ } else
 #endif
-  if (impl >= 13) cocodr_gemm_pp_launch(a, impl == 20 ? 2 : (impl == 13 ? 2 : 100 + impl - 13), st);
+  if (impl >= 13) cocodr_gemm_pp_launch(a, impl == 20 ? 2 : (impl == 21 ? 107 : (impl == 13 ? 2 : 100 + impl - 13)), st);
   else if (impl == 12) launch_glds_any<256, 64, 2, 1, 4, 3>(a, st);
   else if (impl == 11) launch_glds_any<256, 32, 2, 4>(a, st);
   else if (impl == 10) launch_glds_any<256, 64, 4, 2, 4>(a, st);

@@ -415,6 +415,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       if constexpr (j == 0) { if (rem >= 2) wait_vmcnt<6>(); else wait_vmcnt<2>(); }          // B1(t); behind it A1(t), A0 B0(t+1)
       if constexpr (j == 1) { if (rem >= 2) wait_vmcnt<8>(); else wait_vmcnt<0>(); }          // A1(t); behind it A0 B0 B1 A1(t+1)
       if constexpr (j == 3) { if (rem >= 3) wait_vmcnt<8>(); else if (rem == 2) wait_vmcnt<4>(); else wait_vmcnt<0>(); }  // A0 B0(t+1)
+    } else if constexpr (VAR == 7) {  // as VAR 0, but B0 of K-tile t + 1 is read one phase early (phase 3): phase 2's wait retires it
+      if (rem >= 3) wait_vmcnt<(j == 2 ? 6 : 8)>();
+      else if (rem == 2) wait_vmcnt<(j < 2 ? 8 : 4)>();
+      else wait_vmcnt<(j == 0 ? 2 : 0)>();
     } else {
       if (rem >= 3) wait_vmcnt<8>();
       else if (rem == 2) wait_vmcnt<(j < 2 ? 8 : (j == 2 ? 6 : 4))>();
@@ -425,7 +429,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // One K-tile.  STEADY: at least two more K-tiles follow (rem >= 3) - every request exists and every wait is vmcnt(8), so the
   // steady-state loop carries no scalar compare / branch at all (the rem-dependent forms cost 3-6 branches per load segment,
   // a fifth of its 256-cycle budget); the last two K-tiles run the general form.
-  auto ktile = [&](auto steady_c, const int t, const int rem_in) {
+  // (VAR 7 passes the two B fragment buffers in alternating roles: fbx holds B0 of this K-tile, fby receives B1 and, in phase 3,
+  // B0 of the next K-tile)
+  auto ktile = [&](auto steady_c, const int t, const int rem_in, FragSet<TB, 1> (&fbx)[4], FragSet<TB, 1> (&fby)[4]) {
     constexpr bool STEADY = decltype(steady_c)::value;
     const int rem = STEADY ? 3 : rem_in;
     const uint32_t kb = lds_base + (uint32_t)((t & 1) * S::KT_BYTES);
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       auto none = []() {};
       if constexpr (VAR == 3) req();
       reads();
-      if constexpr (VAR == 0 || VAR == 2 || VAR == 6) req();
+      if constexpr (VAR == 0 || VAR == 2 || VAR == 6 || VAR == 7) req();
       wait_stage(tyc, rem);
       __builtin_amdgcn_s_barrier();
       wait_lgkmcnt<0>();
@@ -482,6 +488,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       pp_mfma<TA, TB, F16>(fa, fb0, acc[2][0], acc[3][0], none);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
+    } else if constexpr (NB == 2 && VAR == 7) {
+      // (experiment builds) Fragment reads per phase 8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0: B0 of K-tile t + 1 is read in phase 3 of
+      // K-tile t - which reads nothing otherwise - into the buffer B1 left in phase 2, so the heaviest load segment (A0 + B0 = 12
+      // reads) shrinks to A0 alone.  Bit-identical; measured: NO gain where the steady state is all there is (grouped weight
+      // gradient, K = 25 600: 1301 vs 1297 TFLOP/s) - the 12-read phase is not what the loop waits for - and the role swap of the
+      // two B buffers costs hipcc ~65 register moves per K-tile and spills in the tail K-tiles (profiles/r03_gemm_experiments.md).
+      uint32_t curBn[4];
+      const uint32_t kbn = lds_base + (uint32_t)(((t + 1) & 1) * S::KT_BYTES);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) curBn[i] = adB[i] + kbn;
+      phase(std::integral_constant<int, 0>{}, [&]() { pp_read_sub<TA, 2, 0 * HALF_BYTES>(curA, fa); }, fbx, acc[0][0], acc[1][0]);    // (A0, B0)
+      phase(std::integral_constant<int, 1>{}, [&]() { pp_read_sub<TB, 1, 2 * HALF_BYTES>(curB, fby); }, fby, acc[0][1], acc[1][1]);   // (A0, B1)
+      phase(std::integral_constant<int, 2>{}, [&]() { pp_read_sub<TA, 2, 3 * HALF_BYTES>(curA, fa); }, fby, acc[2][1], acc[3][1]);    // (A1, B1)
+      phase(std::integral_constant<int, 3>{}, [&]() { if (rem >= 2) pp_read_sub<TB, 1, 1 * HALF_BYTES>(curBn, fby); },                // (A1, B0)
+            fbx, acc[2][0], acc[3][0]);
     } else if constexpr (NB == 2) {
       phase(std::integral_constant<int, 0>{}, [&]() { pp_read_sub<TA, 2, 0 * HALF_BYTES>(curA, fa); pp_read_sub<TB, 1, 1 * HALF_BYTES>(curB, fb0); },
             fb0, acc[0][0], acc[1][0]);                                                                  // (A0, B0)
@@ -490,13 +511,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       phase(std::integral_constant<int, 3>{}, [&]() {}, fb0, acc[2][0], acc[3][0]);                      // (A1, B0): all in registers
     }
   };
-  if constexpr ((VAR == 0 || VAR == 6) && NB == 2) {
+  if constexpr (VAR == 7 && NB == 2) {
+    {  // B0 of K-tile 0 (landed: the prologue waited for A0 and B0)
+      uint32_t c0[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c0[i] = adB[i] + lds_base;
+      pp_read_sub<TB, 1, 1 * HALF_BYTES>(c0, fb0);
+    }
+    // the B fragment buffers swap roles every K-tile: pairs of K-tiles with static roles, the parity of what is left decided
+    // once (a role picked at run time per K-tile puts the fragment arrays in scratch)
+    const int ns = nt > 2 ? nt - 2 : 0;  // K-tiles in the branch-free steady form
+    int t = 0;
+    for (; t + 1 < ns; t += 2) {
+      ktile(std::true_type{}, t, 3, fb0, fb1);
+      ktile(std::true_type{}, t + 1, 3, fb1, fb0);
+    }
+    if (ns & 1) {
+      ktile(std::true_type{}, t, 3, fb0, fb1);
+      ++t;
+      ktile(std::false_type{}, t, nt - t, fb1, fb0);
+      if (t + 1 < nt) ktile(std::false_type{}, t + 1, nt - t - 1, fb0, fb1);
+    } else {
+      ktile(std::false_type{}, t, nt - t, fb0, fb1);
+      if (t + 1 < nt) ktile(std::false_type{}, t + 1, nt - t - 1, fb1, fb0);
+    }
+  } else if constexpr ((VAR == 0 || VAR == 6) && NB == 2) {
     int t = 0;
     if (!(flags & 4))  // (bit 2: A/B switch COCODR_PP_NOPEEL - every K-tile in the general form)
-      for (; t < nt - 2; ++t) ktile(std::true_type{}, t, 3);
-    for (; t < nt; ++t) ktile(std::false_type{}, t, nt - t);
+      for (; t < nt - 2; ++t) ktile(std::true_type{}, t, 3, fb0, fb1);
+    for (; t < nt; ++t) ktile(std::false_type{}, t, nt - t, fb0, fb1);
   } else {
-    for (int t = 0; t < nt; ++t) ktile(std::false_type{}, t, nt - t);
+    for (int t = 0; t < nt; ++t) ktile(std::false_type{}, t, nt - t, fb0, fb1);
   }
 #if defined(COCODR_ABL_TIMELINE)
   if (tid == 0) tl[2] = wall_clock64();
@@ -748,10 +793,12 @@ static void launch_any(const cocodr_gemm_args& a, hipStream_t st) {
   else launch_form<2, 1, 1, VAR>(a, st);
 }
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st) {
+  static const int b0early = getenv("COCODR_PP_B0EARLY") ? atoi(getenv("COCODR_PP_B0EARLY")) : 0;  // A/B switch of VAR 7
   static const int fat = getenv("COCODR_PP_FAT") ? atoi(getenv("COCODR_PP_FAT")) : 0;  // A/B switch: 1 = fat phases everywhere,
   if (nb == 2 && (fat == 1 || (fat == 2 && !a.trans_a) || (fat == 3 && a.trans_a))) launch_any<5>(a, st);  // 2 = forward / dgrad only, 3 = wgrads only
 #if defined(COCODR_PP_VARIANTS)
   else if (nb == 2 && getenv("COCODR_PP_VAR") && atoi(getenv("COCODR_PP_VAR")) == 6) launch_any<6>(a, st);  // in-step A/B of VAR 6
+  else if (nb == 107 || (nb == 2 && b0early)) launch_any<7>(a, st);              // B0 fragments read one phase early (8 / 4 / 8 / 4 reads)
 #endif
   else if (nb == 2) launch_any<0>(a, st);                                        // four thin phases per K-tile (the default)
   else if (nb == 104) cocodr_gemm_pp::launch_form<2, 0, 0, 5, true>(a, st);      // IEEE-half operands (the search): fat phases
