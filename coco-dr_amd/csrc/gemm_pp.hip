@@ -260,6 +260,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   const int flat = flags & 1;  // bit 1: register-direct epilogue (bf16 results without fused column sums)
   constexpr int BN = S::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // bits 8-15 (COCODR_PP_STAGGER, experiment): the first round's workgroups start phase x units x 512 clocks late, phase =
+  // (id / 8) % 8 (neighbours on one XCD differ), so that the 256 CUs do not reach their epilogues - a burst of 33 MB of
+  // stores per round - at the same moment for the rest of the launch
+  if (const int stag = (flags >> 8) & 255; stag != 0 && blockIdx.x < 256 && blockIdx.y == 0) {
+    const int nph = ((flags >> 16) & 31) + 1;  // phases - 1 in bits 16-20 (a power of two)
+    const int units = (((int)blockIdx.x >> 3) & (nph - 1)) * stag;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;  // waves 0-3 (one per SIMD) form group 0, waves 4-7 group 1
@@ -678,7 +686,18 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
   const int flat = (a.batch > 1 && flat_env) ? 1 : 0;
   static const int regepi = getenv("COCODR_PP_REGEPI") ? atoi(getenv("COCODR_PP_REGEPI")) : 0;  // A/B switch: 1 = the register-direct epilogue (measured 4 % slower in the step, see pp_reg_epilogue)
   static const int nopeel = getenv("COCODR_PP_NOPEEL") ? atoi(getenv("COCODR_PP_NOPEEL")) : 0;  // A/B switch of the branch-free steady-state loop
-  const int flags = flat | (regepi ? 2 : 0) | (nopeel ? 4 : 0);
+  // first-round stagger (see the kernel; experiment, off unless COCODR_PP_STAGGER=units): 32 phases x units x 512 clocks.  Only
+  // from four rounds of tiles on and where the last round is partly empty - the late starters then take no tile of that round,
+  // while with whole rounds the launch ends as much later as it started (8192 x 4096 x 1024, two whole rounds: -8 %).  In the
+  // BERT-large step at 200 sequences units = 2 measured +1.4 ... +2.2 % on three boxes and -0.4 % on a fourth, nothing elsewhere
+  // (profiles/r03_gemm_pp_stagger.md): not shipped as a default.
+  static const int stagger_env = getenv("COCODR_PP_STAGGER") ? atoi(getenv("COCODR_PP_STAGGER")) & 255 : 0;
+  static const int stagger_ph = getenv("COCODR_PP_STAGGER_PH") ? atoi(getenv("COCODR_PP_STAGGER_PH")) : 32;
+  static const int stagger_all = getenv("COCODR_PP_STAGGER_ALL") != nullptr;  // A/B: also launches of whole rounds
+  const long long tiles = (long long)ntm * ntn * (a.batch > 0 ? a.batch : 1);
+  const int rem = (int)(tiles % 256);
+  const int stagger = (stagger_all || (tiles >= 1024 && rem >= 1 && rem <= 208)) ? stagger_env : 0;
+  const int flags = flat | (regepi ? 2 : 0) | (nopeel ? 4 : 0) | (stagger << 8) | (((stagger_ph - 1) & 31) << 16);
   dim3 grid(flat ? ntm * ntn * a.batch : ntm * ntn, flat ? 1 : a.batch);
   static bool attr_done = false;
   if (!attr_done) {
