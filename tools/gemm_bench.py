@@ -146,7 +146,8 @@ def main():
     if args.epi:
         return epi_bench(args, impls)
     dev = "cuda"
-    print(f"{'shape':34s} " + " ".join(f"impl{i:d} TF/s(us)".rjust(18) for i in impls))
+    # impl -1 = torch.matmul (hipBLASLt / rocBLAS) on the same operands: the vendor library's rate on this box, as a yardstick only
+    print(f"{'shape':34s} " + " ".join((f"impl{i:d} TF/s(us)" if i >= 0 else "torch TF/s(us)").rjust(18) for i in impls))
     sel = [int(x) for x in args.shapes.split(',')] if args.shapes else range(len(SHAPES))
     for name, M, N, K, ta, tb, nb, f32 in [SHAPES[i] for i in sel]:
         g = torch.Generator().manual_seed(0)
@@ -160,11 +161,19 @@ def main():
         best = {i: 1e9 for i in impls}
         for r in range(args.rounds + 1):
             for i in impls:
-                ops.gemm_set_impl(i)
+                if i >= 0:
+                    ops.gemm_set_impl(i)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if i < 0:
+                    at = a.transpose(-1, -2) if ta else a
+                    bt = b if tb else b.transpose(-1, -2)
+                    lib_out = out if not f32 else torch.empty(out.shape, dtype=torch.bfloat16, device=dev)  # (bf16 result: no fp32-out library form via torch)
                 e0.record()
                 for _ in range(5):
-                    ops.gemm(a, b, trans_a=bool(ta), trans_b=bool(tb), out_f32=bool(f32), out=out)
+                    if i < 0:
+                        torch.matmul(at, bt, out=lib_out)
+                    else:
+                        ops.gemm(a, b, trans_a=bool(ta), trans_b=bool(tb), out_f32=bool(f32), out=out)
                 e1.record()
                 torch.cuda.synchronize()
                 if r > 0:
