@@ -228,6 +228,97 @@ __device__ __forceinline__ void pp_reg_epilogue(const cocodr_gemm_args& p, const
   }
 }
 
+// ---- epilogue of the persistent walk: four 64-row passes of the fp32 tile through the TOP 64 KiB of the LDS ([96 K, 160 K): the
+// ring's buffer-1 slots B1 / A1 plus the 32 KiB behind the ring), so that the next tile's K-tile 0 (buffer 0) and the first
+// half of its K-tile 1 (buffer-1 slots A0 / B0) stay in flight underneath.  64 rows x 256 floats fill the region exactly: no
+// padding, the 16-B blocks of a row are XOR-swizzled with row & 15 instead (writes: 8 consecutive rows per LDS cycle hit 8
+// different blocks; reads: a row's 32 lanes cover all 64 banks).  Row-major 16-B global accesses as in the two-pass epilogue.
+// Every LDS access is inline assembly: hipcc orders the LDS accesses it can see behind ALL outstanding LDS-DMA (vmcnt(0)).
+__device__ __forceinline__ void asm_ds_write_b128(uint32_t addr, float a, float b, float c, float d) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = {a, b, c, d};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void pp_lds4_epilogue(const cocodr_gemm_args& p, const int z, const f32x16 (&acc)[4][2], const int m0, const int n0,
+                                                 const int wr, const int wc, const int tid_in, const int lane_in, const uint32_t lds_base) {
+  constexpr int NCH = 4;  // 64 rows x 32 chunks of 8 columns over 512 threads
+  // opaque copies: every address below is a function of the thread id alone, i.e. invariant over the caller's tile loop - hoisted
+  // out of it, the ~20 of them are spilled over the main loop and reloaded per tile; a few integer operations per tile are cheaper
+  int tid = tid_in, lane = lane_in;
+  asm volatile("" : "+v"(tid), "+v"(lane));
+  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
+  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
+  const bool need_r = R_ != nullptr && (p.epi == COCODR_EPI_ADD || p.epi == COCODR_EPI_DGELU);
+  const int c8 = (tid & 31) << 3;  // this thread's 8 columns (512 % 32 == 0: the same in every chunk)
+  const int gn = n0 + c8;
+  uint4 rcur[NCH], rnext[NCH];
+  auto fetch_r = [&](int h, uint4 (&dst)[NCH]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int gm = m0 + h * 64 + ((tid + i * NTHREADS) >> 5);
+      dst[i] = make_uint4(0, 0, 0, 0);
+      if (need_r && gm < p.M) dst[i] = *reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn);
+    }
+  };
+  fetch_r(0, rcur);
+  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (bias != nullptr) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + gn);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+  const uint32_t ct = lds_base + 96u * 1024u;
+  const int hh = lane >> 5, rl = lane & 31;
+  static_for<0, 4>([&](auto hc) {
+    constexpr int h = decltype(hc)::value;
+    if constexpr (h < 3) fetch_r(h + 1, rnext);
+    if (wr == (h >> 1)) {
+#pragma unroll
+      for (int ai2 = 0; ai2 < 2; ++ai2)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            constexpr int dummy = 0; (void)dummy;
+            const int row = ai2 * 32 + rl;
+            const int blk = wc * 16 + b * 8 + 2 * rg + hh;  // 16-B block of columns wc 64 + b 32 + 8 rg + 4 hh
+            const f32x16& a = acc[2 * (h & 1) + ai2][b];
+            asm_ds_write_b128(ct + (uint32_t)(row * 1024 + ((blk ^ (row & 15)) << 4)), a[rg * 4 + 0], a[rg * 4 + 1], a[rg * 4 + 2], a[rg * 4 + 3]);
+          }
+    }
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i0 = 0; i0 < NCH; i0 += 2) {  // two chunks at a time (register budget)
+      v4i lo[2], hi[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = (tid + (i0 + i) * NTHREADS) >> 5;
+        const int blk = (tid & 31) << 1;
+        const uint32_t rb = ct + (uint32_t)(row * 1024);
+        asm_ds_read_b128<0>(lo[i], rb + (uint32_t)((blk ^ (row & 15)) << 4));
+        asm_ds_read_b128<0>(hi[i], rb + (uint32_t)(((blk + 1) ^ (row & 15)) << 4));
+      }
+      wait_lgkmcnt<0>();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int gm = m0 + h * 64 + ((tid + (i0 + i) * NTHREADS) >> 5);
+        if (gm < p.M) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] = __int_as_float(lo[i][j]); v[4 + j] = __int_as_float(hi[i][j]); }
+          epilogue_store8<false, true, true>(p, z, bias, R_, gm, gn, v, rcur[i0 + i], bias8);
+        }
+      }
+    }
+    if constexpr (h < 3) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rcur[i] = rnext[i];
+      __builtin_amdgcn_s_barrier();  // the next pass overwrites what this one read (the reads have returned: lgkmcnt(0) above)
+    }
+  });
+}
+
 // VAR (experiment builds, -DCOCODR_PP_VARIANTS, tools/gemm_bench.py --impls 13,15,16): 0 = DMA pieces requested in the load
 // segment behind the fragment reads; 2 = as 0 without s_setprio (-15 %); 3 = requested in front of the fragment reads (=).
 // Requesting them inside the MFMA segment instead cost 10-14 % (profiles/r02_gemm_pp_variants.txt).
@@ -252,7 +343,20 @@ struct MultiArgs {
   float* split_ws;
 };
 constexpr int SPLIT_TILE = BM * 256;  // floats of one partial tile
-template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false>
+// PERSIST (forward / dgrad forms with bf16 results and no fused column sums; opt-in, see launch_form): a grid of at most one
+// workgroup per CU walks the tiles, and the operand stream never stops at a tile boundary - the last two K-tiles of a tile
+// request the first 1.5 K-tiles of the workgroup's NEXT tile into the same ring slots, in the steady-state order and with the
+// steady-state waits, the register-direct epilogue (no LDS) runs with those requests in flight, and the next tile starts on
+// landed operands.  What this hides is the tile's fixed cost: workgroup launch, prologue latency, and the idle loaders under
+// the epilogue (profiles/r03_gemm_vs_library.md).  The epilogue's stores sit in the vmcnt queue between the prefetched pieces
+// and the next tile's first requests: K-tile 0 of a continued tile allows for them in its counted waits (gfx9 retires vector
+// memory loads and stores in issue order).  Needs an even number of K-tiles (the ring parity carries over).
+// MEASURED AND NOT ADOPTED (round 3, profiles/r03_gemm_pp_persistent.md; experiment builds with -DCOCODR_PP_PERSIST_BUILD, then
+// COCODR_PP_PERSIST=1 / 2): bit-identical on every form incl. ragged row counts; inside the BERT-large step the 1200-tile QKV
+// GEMM gains 3 % (162 -> 157 us) but the 400-tile long-K forms (two tiles per workgroup on 200 CUs) lose 14-17 % and the step
+// 4.7 %.  The tile's fixed cost turned out to be ~3.6 us of 32 (not the 8 assumed): the K-loop itself, 1.8 us per K-tile against
+// 1.0 of MFMA time, is where the library's hand-scheduled kernel (1.5) is ahead.
+template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false, int PERSIST = 0>  // PERSIST: 1 = LDS epilogue, 2 = register epilogue
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std::conditional<MULTI, MultiArgs, cocodr_gemm_args>::type pa,
                                                               const int flags) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -307,14 +411,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     z = id / per;
     tile = id - z * per;
   } else {
-    tile = xcd_remap(blockIdx.x, gridDim.x);
+    tile = xcd_remap(blockIdx.x, PERSIST ? ntm * ntn : (int)gridDim.x);
     z = blockIdx.y;
   }
   int tm_, tn_;
   if (TA == 0) grouped_tile(tile, ntm, ntn, 4, tm_, tn_);
   else if (flat) grouped_tile(tile, ntm, ntn, 8, tm_, tn_);
   else { tm_ = tile / ntn; tn_ = tile % ntn; }
-  const int m0 = tm_ * BM, n0 = tn_ * BN;
+  int m0 = tm_ * BM, n0 = tn_ * BN;  // (PERSIST: of the tile being computed; the DMA offsets below stay those of the first tile)
+  // PERSIST: virtual block id v = blockIdx.x + k gridDim.x walks this workgroup's tiles (gridDim.x % 8 == 0: v stays on the
+  // workgroup's XCD in xcd_remap, and the workgroups of an XCD hold consecutive tile ids at any time, as without the walk)
+  [[maybe_unused]] const int total_tiles = ntm * ntn;
+  [[maybe_unused]] auto tile_origin = [&](int v, int& mo, int& no) {
+    const int tl_ = xcd_remap(v, total_tiles);
+    int a_, b_;
+    if (TA == 0) grouped_tile(tl_, ntm, ntn, 4, a_, b_);
+    else { a_ = tl_ / ntn; b_ = tl_ % ntn; }
+    mo = a_ * BM; no = b_ * BN;
+  };
+  // byte offsets (mod 2^32) of the current / the next tile's operand panels relative to the first tile's
+  [[maybe_unused]] uint32_t curA_b = 0, curB_b = 0, nxtA_b = 0, nxtB_b = 0;
+  const int m0_first = m0, n0_first = n0;
   const uint16_t* A = p.A + (size_t)z * p.strideA;
   const uint16_t* B = p.B + (size_t)z * p.strideB;
   const uint32_t a_bytes = (uint32_t)((size_t)(TA ? p.K : p.M) * p.lda * 2);
@@ -342,20 +459,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     }
   }
 
-  auto stage = [&](auto tyc, int t) {  // request half-tile `ty` of K-tile t
+  auto stage_at = [&](auto tyc, int t, const uint32_t base_a, const uint32_t base_b) {  // request half-tile `ty` of K-tile t
     constexpr int ty = decltype(tyc)::value;
 #if defined(COCODR_ABL_NO_DMA)
     if (t > 0) return;
 #endif
     char* dst = smem + (t & 1) * S::KT_BYTES + ty * HALF_BYTES + wid * 2048;
     if constexpr (type_is_a<NB>(ty)) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))dst, 16, off[ty][0] + (t + t0) * stepa, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + (t + t0) * stepa, 0, 0, 0);
+      const uint32_t sb_ = base_a + (t + t0) * stepa;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))dst, 16, off[ty][0] + sb_, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + sb_, 0, 0, 0);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))dst, 16, off[ty][0] + (t + t0) * stepb, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + (t + t0) * stepb, 0, 0, 0);
+      const uint32_t sb_ = base_b + (t + t0) * stepb;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))dst, 16, off[ty][0] + sb_, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + sb_, 0, 0, 0);
     }
   };
+  auto stage = [&](auto tyc, int t) {  // ... of the tile being computed
+    if constexpr (PERSIST) stage_at(tyc, t, curA_b, curB_b);
+    else stage_at(tyc, t, 0u, 0u);
+  };
+  [[maybe_unused]] auto stage_next = [&](auto tyc, int k) { stage_at(tyc, k, nxtA_b, nxtB_b); };  // ... K-tile k of the next tile (PERSIST)
 
   f32x16 acc[4][NB];
 #pragma unroll
@@ -407,18 +531,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // VAR 6 (experiment): the same request sequence issued in TWO bursts per K-tile instead of one half-tile per phase - nothing in
   // the phases that carry the most fragment reads ((A0, B0): 12, (A1, B1): 8), two half-tiles in the two light ones ((A0, B1): 4
   // reads requests B1 and A1 of K-tile t + 1, (A1, B0): none requests A0 and B0 of K-tile t + 2).  Same slots, same margins.
-  auto request = [&](auto jc, int t, int rem) {
+  // (PERSIST, cont = this workgroup has another tile: where the tile's own request sequence ends, the next tile's begins -
+  //  its K-tile 0 lands in buffer 0 and the first half of its K-tile 1 in buffer 1, exactly the slots and margins of a K-tile
+  //  nt / nt + 1 of this tile; every wait keeps its steady-state count)
+  auto request = [&](auto jc, int t, int rem, [[maybe_unused]] bool cont) {
     constexpr int j = decltype(jc)::value;
     if constexpr (VAR == 6) {
       if constexpr (j == 1) { if (rem >= 2) { stage(std::integral_constant<int, 2>{}, t + 1); stage(std::integral_constant<int, 3>{}, t + 1); } }
       if constexpr (j == 3) { if (rem >= 3) { stage(std::integral_constant<int, 0>{}, t + 2); stage(std::integral_constant<int, 1>{}, t + 2); } }
+    } else if constexpr (PERSIST) {
+      if constexpr (j < 2) { if (rem >= 2) stage(std::integral_constant<int, j + 2>{}, t + 1); else if (cont) stage_next(std::integral_constant<int, j + 2>{}, 0); }
+      else { if (rem >= 3) stage(std::integral_constant<int, j - 2>{}, t + 2); else if (cont) stage_next(std::integral_constant<int, j - 2>{}, rem == 2 ? 0 : 1); }
     } else {
       if constexpr (j < 2) { if (rem >= 2) stage(std::integral_constant<int, j + 2>{}, t + 1); }
       else { if (rem >= 3) stage(std::integral_constant<int, j - 2>{}, t + 2); }
     }
   };
-  auto wait_stage = [&](auto jc, int rem) {
+  // sext (PERSIST, K-tile 0 of a continued tile): store instructions of the previous tile's epilogue that sit in the queue
+  // behind the pieces this K-tile waits for - 16 (one result) / 32 (GELU + GELU') per wave, or 0 = unknown (ragged tile: waves
+  // past the last row issue none), which makes the wait drain them
+  auto wait_stage = [&](auto jc, int rem, [[maybe_unused]] bool cont, [[maybe_unused]] int sext) {
     constexpr int j = decltype(jc)::value;
+    if constexpr (PERSIST) {
+      if (rem >= 3 || cont) {
+        if (sext == 0) wait_vmcnt<8>();
+        else if (sext == 16) wait_vmcnt<24>();
+        else wait_vmcnt<40>();
+        return;
+      }
+    }
     if constexpr (VAR == 6) {  // what the NEXT phase reads must have landed; everything requested behind it may stay in flight
       if constexpr (j == 0) { if (rem >= 2) wait_vmcnt<6>(); else wait_vmcnt<2>(); }          // B1(t); behind it A1(t), A0 B0(t+1)
       if constexpr (j == 1) { if (rem >= 2) wait_vmcnt<8>(); else wait_vmcnt<0>(); }          // A1(t); behind it A0 B0 B1 A1(t+1)
@@ -439,20 +580,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // a fifth of its 256-cycle budget); the last two K-tiles run the general form.
   // (VAR 7 passes the two B fragment buffers in alternating roles: fbx holds B0 of this K-tile, fby receives B1 and, in phase 3,
   // B0 of the next K-tile)
-  auto ktile = [&](auto steady_c, const int t, const int rem_in, FragSet<TB, 1> (&fbx)[4], FragSet<TB, 1> (&fby)[4]) {
+  auto ktile = [&](auto steady_c, const int t, const int rem_in, FragSet<TB, 1> (&fbx)[4], FragSet<TB, 1> (&fby)[4],
+                   [[maybe_unused]] const bool cont = false, [[maybe_unused]] const int sext_in = 0) {
     constexpr bool STEADY = decltype(steady_c)::value;
     const int rem = STEADY ? 3 : rem_in;
+    const int sext = STEADY ? 0 : sext_in;
     const uint32_t kb = lds_base + (uint32_t)((t & 1) * S::KT_BYTES);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + kb; curB[i] = adB[i] + kb; }
     // one phase; RD: this phase's fragment reads, TY: the half-tile type requested for K-tile t + 1
     auto phase = [&](auto tyc, auto&& reads, const FragSet<TB, 1> (&fb)[4], f32x16& c0, f32x16& c1) {
-      auto req = [&]() { request(tyc, t, rem); };
+      auto req = [&]() { request(tyc, t, rem, cont); };
       auto none = []() {};
       if constexpr (VAR == 3) req();
       reads();
       if constexpr (VAR == 0 || VAR == 2 || VAR == 6 || VAR == 7) req();
-      wait_stage(tyc, rem);
+      wait_stage(tyc, rem, cont, sext);
       __builtin_amdgcn_s_barrier();
       wait_lgkmcnt<0>();
       if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(1);
@@ -543,6 +686,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       ktile(std::false_type{}, t, nt - t, fb0, fb1);
       if (t + 1 < nt) ktile(std::false_type{}, t + 1, nt - t - 1, fb1, fb0);
     }
+  } else if constexpr (PERSIST) {
+    static_assert(VAR == 0 && NB == 2 && !OUT_F32 && !MULTI, "the persistent walk exists for the bf16-result forward / dgrad forms");
+    int vb = (int)blockIdx.x;
+    int sext = -1;  // < 0: the first tile (prologue above); else the store count of the previous epilogue for K-tile 0's waits
+    for (;;) {
+      const int vn = vb + (int)gridDim.x;
+      const bool cont = vn < total_tiles;
+      int m0n = 0, n0n = 0;
+      if (cont) {
+        tile_origin(vn, m0n, n0n);
+        nxtA_b = (uint32_t)(m0n - m0_first) * (TA ? 2u : (uint32_t)(p.lda * 2));
+        nxtB_b = (uint32_t)(n0n - n0_first) * (TB ? 2u : (uint32_t)(p.ldb * 2));
+      }
+      int t = 0;
+      if (sext >= 0) { ktile(std::false_type{}, 0, nt, fb0, fb1, cont, sext); t = 1; }
+      for (; t < nt - 2; ++t) ktile(std::true_type{}, t, 3, fb0, fb1);
+      for (; t < nt; ++t) ktile(std::false_type{}, t, nt - t, fb0, fb1, cont, 0);
+      if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 catches up with group 1's last barrier
+      if constexpr (PERSIST == 2) pp_reg_epilogue<NB>(p, z, acc, m0, n0, wr, wc, lane);  // (COCODR_PP_PERSIST=2: A/B switch)
+      else pp_lds4_epilogue(p, z, acc, m0, n0, wr, wc, tid, lane, lds_base);
+      if (!cont) break;
+      sext = (m0 + BM <= p.M) ? ((p.epi == COCODR_EPI_GELU && p.C2 != nullptr) ? 32 : 16) : 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      // A0, B0 of the next tile's K-tile 0 were retired by every wave's waits of the last K-tile: one barrier makes all of
+      // them visible, the second one puts group 1 a barrier behind group 0 again
+      __builtin_amdgcn_s_barrier();
+      if (wr == 1) __builtin_amdgcn_s_barrier();
+      vb = vn; m0 = m0n; n0 = n0n; curA_b = nxtA_b; curB_b = nxtB_b;
+    }
+    return;
   } else if constexpr ((VAR == 0 || VAR == 6) && NB == 2) {
     int t = 0;
     if (!(flags & 4))  // (bit 2: A/B switch COCODR_PP_NOPEEL - every K-tile in the general form)
@@ -705,6 +883,32 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
     hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+#if defined(COCODR_PP_PERSIST_BUILD)  // experiment builds (COCODR_EXTRA_FLAGS=-DCOCODR_PP_PERSIST_BUILD): measured, not adopted - see the kernel
+  if constexpr (NB == 2 && VAR == 0 && !F16) {
+    // persistent walk (see the kernel): bf16 results without fused column sums, more tiles than CUs, an even number (>= 4) of
+    // K-tiles.  Grid: the fewest workgroups that need no more rounds than 256 would, a multiple of 8 (1200 tiles -> 240 x 5).
+    static const int persist = getenv("COCODR_PP_PERSIST") ? atoi(getenv("COCODR_PP_PERSIST")) : 0;
+    const int nkt = (a.K + BK - 1) / BK;
+    if (persist && !a.out_f32 && a.batch <= 1 && a.colsum_partial == nullptr && a.colsum == nullptr && tiles > 256 && nkt >= 4 && nkt % 2 == 0 &&
+        a.K % BK == 0) {
+      const int rounds = (int)((tiles + 255) / 256);
+      int g = (int)((tiles + rounds - 1) / rounds);
+      g = (g + 7) & ~7;
+      if (g > 256) g = 256;
+      static bool attr_p = false;
+      if (!attr_p) {
+        hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_p = true;
+      }
+      if (persist == 2)
+        hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 2>), dim3(g), dim3(NTHREADS), 160 * 1024, st, a, flags & ~(255 << 8));
+      else
+        hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 1>), dim3(g), dim3(NTHREADS), 160 * 1024, st, a, flags & ~(255 << 8));
+      return;
+    }
+  }
+#endif
   if (a.out_f32)
     hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flags);
   else
