@@ -356,7 +356,16 @@ constexpr int SPLIT_TILE = BM * 256;  // floats of one partial tile
 // GEMM gains 3 % (162 -> 157 us) but the 400-tile long-K forms (two tiles per workgroup on 200 CUs) lose 14-17 % and the step
 // 4.7 %.  The tile's fixed cost turned out to be ~3.6 us of 32 (not the 8 assumed): the K-loop itself, 1.8 us per K-tile against
 // 1.0 of MFMA time, is where the library's hand-scheduled kernel (1.5) is ahead.
-template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false, int PERSIST = 0>  // PERSIST: 1 = LDS epilogue, 2 = register epilogue
+// NSLOT = 10 (VAR 0, NB = 2): the half-tile ring takes the whole 160 KiB of the CU's LDS - ten 16-KiB slots, half-tile s = 4 t + j
+// in slot s % 10 - instead of two K-tile buffers (eight slots).  Phase (t, j) then requests half-tile j of K-tile t + 2 (the
+// slot that half-tile (t, j) - 2 left in the previous phase), six half-tiles = 96 KiB per CU stay in flight instead of four,
+// and a request has two K-tiles instead of one and a half to land.  The loop's K-tile time is the latency of the operand
+// stream divided by its look-ahead (profiles/r03_load_rate_probe.txt: bytes in flight x 1 / latency), not the MFMA time - that
+// was the hypothesis.  MEASURED AND NOT ADOPTED (round 3, profiles/r03_gemm_pp_ring10.md; experiment builds with
+// -DCOCODR_PP_RING10_BUILD, then COCODR_PP_RING=10): bit-identical on every form and K-tile count, and 4-12 % SLOWER everywhere
+// (8192^3: 1263 -> 1182 TFLOP/s; the BERT-large step at 200 sequences -5 %).  Half again as many bytes in flight buy nothing:
+// the K-loop is not waiting for the operand stream's latency.
+template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false, int PERSIST = 0, int NSLOT = 8>  // PERSIST: 1 = LDS epilogue, 2 = register epilogue
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std::conditional<MULTI, MultiArgs, cocodr_gemm_args>::type pa,
                                                               const int flags) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
 #if defined(COCODR_ABL_NO_DMA)
     if (t > 0) return;
 #endif
-    char* dst = smem + (t & 1) * S::KT_BYTES + ty * HALF_BYTES + wid * 2048;
+    char* dst = smem + (NSLOT == 10 ? ((4 * t + ty) % 10) * HALF_BYTES : (t & 1) * S::KT_BYTES + ty * HALF_BYTES) + wid * 2048;
     if constexpr (type_is_a<NB>(ty)) {
       const uint32_t sb_ = base_a + (t + t0) * stepa;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))dst, 16, off[ty][0] + sb_, 0, 0, 0);
@@ -497,7 +506,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // ---- prologue: the half-tiles 0 .. LOOK-1 of the request sequence (K-tile 0 and the first two of K-tile 1); phase 0 needs
   // A0 and B0 of K-tile 0, everything behind them may stay in flight
   static_for<0, S::NTYPE>([&](auto tyc) { stage(tyc, 0); });
-  if (nt > 1) {
+  if (NSLOT == 10 && nt > 1) {  // the ten-slot ring starts two whole K-tiles deep
+    static_for<0, S::NTYPE>([&](auto tyc) { stage(tyc, 1); });
+    wait_vmcnt<12>();
+  } else if (nt > 1) {
     stage(std::integral_constant<int, 0>{}, 1);
     stage(std::integral_constant<int, 1>{}, 1);
     if constexpr (VAR == 5) wait_vmcnt<6>();  // the first fat phase reads A0, B0 and B1
@@ -539,6 +551,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     if constexpr (VAR == 6) {
       if constexpr (j == 1) { if (rem >= 2) { stage(std::integral_constant<int, 2>{}, t + 1); stage(std::integral_constant<int, 3>{}, t + 1); } }
       if constexpr (j == 3) { if (rem >= 3) { stage(std::integral_constant<int, 0>{}, t + 2); stage(std::integral_constant<int, 1>{}, t + 2); } }
+    } else if constexpr (NSLOT == 10) {
+      if (rem >= 3) stage(std::integral_constant<int, j>{}, t + 2);  // the same half-tile type, two K-tiles ahead
     } else if constexpr (PERSIST) {
       if constexpr (j < 2) { if (rem >= 2) stage(std::integral_constant<int, j + 2>{}, t + 1); else if (cont) stage_next(std::integral_constant<int, j + 2>{}, 0); }
       else { if (rem >= 3) stage(std::integral_constant<int, j - 2>{}, t + 2); else if (cont) stage_next(std::integral_constant<int, j - 2>{}, rem == 2 ? 0 : 1); }
@@ -552,6 +566,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // past the last row issue none), which makes the wait drain them
   auto wait_stage = [&](auto jc, int rem, [[maybe_unused]] bool cont, [[maybe_unused]] int sext) {
     constexpr int j = decltype(jc)::value;
+    if constexpr (NSLOT == 10) {
+      // after this phase's request the queue may keep what lies behind half-tile p + 2 (read from phase p + 3 on, retired one
+      // phase early as in the eight-slot ring): min(6, 4 rem - j - 3) half-tiles of two pieces each
+      if (rem >= 3) wait_vmcnt<12>();
+      else if (rem == 2) wait_vmcnt<(j == 0 ? 10 : (j == 1 ? 8 : (j == 2 ? 6 : 4)))>();
+      else wait_vmcnt<(j == 0 ? 2 : 0)>();
+      return;
+    }
     if constexpr (PERSIST) {
       if (rem >= 3 || cont) {
         if (sext == 0) wait_vmcnt<8>();
@@ -654,6 +676,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       phase(std::integral_constant<int, 2>{}, [&]() { pp_read_sub<TA, 2, 3 * HALF_BYTES>(curA, fa); }, fby, acc[2][1], acc[3][1]);    // (A1, B1)
       phase(std::integral_constant<int, 3>{}, [&]() { if (rem >= 2) pp_read_sub<TB, 1, 1 * HALF_BYTES>(curBn, fby); },                // (A1, B0)
             fbx, acc[2][0], acc[3][0]);
+    } else if constexpr (NB == 2 && NSLOT == 10) {
+      // fragment addresses per half-tile: its slot is (4 t + type) % 10, a different one every K-tile (period 5)
+      auto at = [&](const uint32_t (&ad)[4], int ty, uint32_t (&cur)[4]) {
+        const uint32_t b = lds_base + (uint32_t)(((4 * t + ty) % 10) * HALF_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = ad[i] + b;
+      };
+      phase(std::integral_constant<int, 0>{}, [&]() { at(adA, 0, curA); pp_read_sub<TA, 2, 0>(curA, fa); at(adB, 1, curB); pp_read_sub<TB, 1, 0>(curB, fb0); },
+            fb0, acc[0][0], acc[1][0]);                                                                  // (A0, B0)
+      phase(std::integral_constant<int, 1>{}, [&]() { at(adB, 2, curB); pp_read_sub<TB, 1, 0>(curB, fb1); }, fb1, acc[0][1], acc[1][1]);  // (A0, B1)
+      phase(std::integral_constant<int, 2>{}, [&]() { at(adA, 3, curA); pp_read_sub<TA, 2, 0>(curA, fa); }, fb1, acc[2][1], acc[3][1]);   // (A1, B1)
+      phase(std::integral_constant<int, 3>{}, [&]() {}, fb0, acc[2][0], acc[3][0]);                      // (A1, B0): all in registers
     } else if constexpr (NB == 2) {
       phase(std::integral_constant<int, 0>{}, [&]() { pp_read_sub<TA, 2, 0 * HALF_BYTES>(curA, fa); pp_read_sub<TB, 1, 1 * HALF_BYTES>(curB, fb0); },
             fb0, acc[0][0], acc[1][0]);                                                                  // (A0, B0)
@@ -909,6 +943,24 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
     }
   }
 #endif
+#if defined(COCODR_PP_RING10_BUILD)  // experiment builds (COCODR_EXTRA_FLAGS=-DCOCODR_PP_RING10_BUILD): measured, not adopted - see the kernel
+  if constexpr (NB == 2 && VAR == 0 && !F16) {
+    static const int ring = getenv("COCODR_PP_RING") ? atoi(getenv("COCODR_PP_RING")) : 8;  // A/B switch: 10 = the ten-slot ring (see the kernel)
+    if (ring == 10) {
+      static bool attr_r = false;
+      if (!attr_r) {
+        hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, true, VAR, F16, false, 0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_r = true;
+      }
+      if (a.out_f32)
+        hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16, false, 0, 10>), grid, dim3(NTHREADS), 160 * 1024, st, a, flags);
+      else
+        hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 0, 10>), grid, dim3(NTHREADS), 160 * 1024, st, a, flags);
+      return;
+    }
+  }
+#endif
   if (a.out_f32)
     hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flags);
   else
@@ -996,14 +1048,20 @@ void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, si
   ma.split_first = split ? total - r : total;
   ma.split_s = split ? s : 1;
   ma.split_ws = ws;
+#if defined(COCODR_PP_RING10_BUILD)
+  static const int ring = getenv("COCODR_PP_RING") ? atoi(getenv("COCODR_PP_RING")) : 8;  // A/B switch: 10 = the ten-slot ring (see the kernel)
+  auto kern = ring == 10 ? gemm_pp_kernel<2, 1, 1, true, 0, false, true, 0, 10> : gemm_pp_kernel<2, 1, 1, true, 0, false, true>;
+#else
+  constexpr int ring = 8;
   auto kern = gemm_pp_kernel<2, 1, 1, true, 0, false, true>;
+#endif
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   static const int nopeel = getenv("COCODR_PP_NOPEEL") ? atoi(getenv("COCODR_PP_NOPEEL")) : 0;
-  hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1 | (nopeel ? 4 : 0));
+  hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), ring == 10 ? 160 * 1024 : Shape<2>::LDS_BYTES, st, ma, 1 | (nopeel ? 4 : 0));
   if (split) hipLaunchKernelGGL(gemm_pp_split_finish, dim3(r, SPLIT_TILE / 4 / 256), dim3(256), 0, st, ma, r);
 }
 
