@@ -1053,6 +1053,8 @@ void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, si
   auto kern = ring == 10 ? gemm_pp_kernel<2, 1, 1, true, 0, false, true, 0, 10> : gemm_pp_kernel<2, 1, 1, true, 0, false, true>;
 #else
   constexpr int ring = 8;
+  // (two fat phases per K-tile for the merged launch, gemm_pp_kernel<2, 1, 1, true, 5, false, true>: measured +0.3 % on the
+  //  BERT-base step, -0.3 ... -0.5 % on the BERT-large ones; not kept)
   auto kern = gemm_pp_kernel<2, 1, 1, true, 0, false, true>;
 #endif
   static bool attr_done = false;
