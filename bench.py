@@ -60,6 +60,13 @@ def train_flops_per_seq(cfg, L: int) -> float:
     return 3.0 * L * N * (24.0 * H * H + 4.0 * L * H)
 
 
+def train_gemm_flops_per_seq(cfg, L: int) -> float:
+    """The GEMM class's share of it (QKV, attention output, FFN1, FFN2: 24 H^2 FLOP per token and layer, x3 for the step), on the
+    L padded tokens of a sequence - SURVEY 8(d) counts padded tokens: the reference computes on padding."""
+    H, N = cfg.hidden_size, cfg.num_hidden_layers
+    return 3.0 * L * N * 24.0 * H * H
+
+
 # ---------------------------------------------------------------------------------------------------------- CPU baselines
 def _cpu_model_name() -> str:
     try:
@@ -463,11 +470,11 @@ def multi_gpu_legs(dev, rank: int, world: int, fence, tmax, shared: bool, dp_chu
 
 
 # ---------------------------------------------------------------------------------------------------------- the timed step
-def _traffic_for(model_name: str, seq_per_gpu: int, seq_len: int):
+def _traffic_for(model_name: str, seq_per_gpu: int, seq_len: int, packed: bool = False):
     """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
-    corrected as MI355X_MICROARCH.md prescribes) of THIS workload shape, with the file it came from; None when no pass was
-    taken on the shape."""
-    path = os.path.join(ROOT, "profiles", f"gemm_pmc_{model_name}_{seq_per_gpu}x{seq_len}.json")
+    corrected as MI355X_MICROARCH.md prescribes) of THIS workload shape and execution (packed / padded), with the file it came
+    from; None when no pass was taken on it."""
+    path = os.path.join(ROOT, "profiles", f"gemm_pmc_{model_name}_{seq_per_gpu}x{seq_len}{'_packed' if packed else ''}.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -543,18 +550,28 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
         if n_launch and gemm_ms > 0:
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
             sampled = len(range(0, steps, PROF_EVERY))
-            traffic, src = _traffic_for(model_name, seq_per_gpu, seq_len)
-            roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+            traffic, src = _traffic_for(model_name, seq_per_gpu, seq_len, packed)
+            # algorithmic FLOPs of the class (padded tokens - what the reference's arithmetic costs) over the time of
+            # its launches; on padded batches that IS what the launches execute, on packed batches the launches execute the
+            # stored rows only (`executed_*`)
+            alg = train_gemm_flops_per_seq(cfg, seq_len) * seq_per_gpu * sampled / (gemm_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(alg, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(alg / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+                    "executed_achieved": round(ach, 1), "executed_frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "kernel": "bf16 MFMA GEMM class of coco-dr_amd/csrc/gemm.hip (all NT / NN / TN launches of the step)",
                     "launches_per_step": n_launch // max(1, sampled),
                     "sampled": f"every GEMM launch of every {PROF_EVERY}th timed step ({n_launch} launches)",
                     "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                     "gemm_share_of_step": round(gemm_ms / sampled / (dt / steps * 1e3), 3),
+                    "flops": "achieved / frac: the class's ALGORITHMIC FLOPs (24 H^2 per padded token and layer, x3: SURVEY 8d counts "
+                             "padded tokens, the reference computes on padding) / the time of its launches; executed_*: the FLOPs "
+                             "the launches carry out" + (" (stored rows only)" if packed else " (the same here)"),
                     "batches": "fully dense (every sequence fills L)" if dense else
-                               "MS MARCO-shaped lengths, padded to L; the kernels do not skip masked work, so FLOPs = the dense count"}
-    if packed and roof is not None:
-        roof["rows_per_step"] = int(np.mean([b_["packed_index"].T for b_ in batches]))
+                               ("MS MARCO-shaped lengths, stored back to back (32-row alignment): no work on padding rows, same loss and "
+                                "gradients as the padded execution (tests/test_gpu_packed.py)" if packed else
+                                "MS MARCO-shaped lengths, padded to L; the kernels do not skip masked work, so executed FLOPs = the dense count")}
+    if packed and roof is not None:  # (of the sampled steps: what executed_* was measured on)
+        roof["rows_per_step"] = int(np.mean([batches[(warmup + i) % len(batches)]["packed_index"].T for i in range(0, steps, PROF_EVERY)]))
         roof["rows_per_step_padded"] = seq_per_gpu * seq_len
     del opt, model, bert
     torch.cuda.empty_cache()
@@ -586,6 +603,9 @@ def main():
                          "global batch 2048 (COCO/README.md:55 NPROC x BATCH_SIZE)")
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
     ap.add_argument("--dense", action="store_true", help="every synthetic sequence fills seq_len (SURVEY 8d's roofline variant)")
+    ap.add_argument("--padded", action="store_true",
+                    help="headline on the padded execution (every GEMM over all B x L rows, as the reference computes); default: packed "
+                         "execution of the same padded batches - identical loss and gradients, no work on padding rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true", help="skip the extra legs (north-star large step, full coCondenser step, search, encode, ANCE)")
@@ -623,44 +643,43 @@ def main():
             dist.init_process_group("gloo")
 
     solo = not use_dist
+    packed = not args.padded
     dt, final_loss, roof, cfg, (ids, mask) = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, rank,
-                                                            world, use_dist, args.dp_chunks, not args.no_roofline, args.dense)
+                                                            world, use_dist, args.dp_chunks, not args.no_roofline, args.dense, packed=packed)
     extras = {}
     if solo and not args.no_full_step and rank == 0:
         # the north-star target shape (BASELINE.json north_star: ">= 50 % MFMA roofline on BERT-large seq128 contrastive step
         # at 1 GPU"): cocodr-large at this line's 64 sequences and at COCO/README.md:59-63's per-GPU batch for the large
         # model (100 documents = 200 spans), each with its own HIP-event roofline block
         large = {}
-        # (256 sequences: every GEMM of the step fills whole rounds of the 256 CUs - what the kernels reach without tile-count tails)
+        # (256 sequences: every GEMM of the padded step fills whole rounds of the 256 CUs - what the kernels reach without tile-count
+        # tails).  Each size in both executions: packed (this line's default) and padded (executed FLOPs = the dense count)
         for n_seq, k_steps in ((64, 10), (200, 6), (256, 5)):
-            ldt, lloss, lroof, lcfg, _ = contrastive_leg("large", n_seq, SEQ_LEN, k_steps, 3, dev, 0, 1, False, args.dp_chunks,
-                                                         not args.no_roofline, args.dense)
-            v = n_seq * k_steps / ldt
-            tf = v * train_flops_per_seq(lcfg, SEQ_LEN) / 1e12
-            large[f"{n_seq}_sequences"] = {"sequences_per_sec": round(v, 1), "ms_per_step": round(ldt / k_steps * 1e3, 3), "steps": k_steps,
-                                           "loss": round(lloss, 4), "algorithmic_tflops_whole_step": round(tf, 1),
-                                           "whole_step_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "roofline": lroof}
-        # and the 200-sequence step on packed batches (same loss and gradients, no work on padding rows; side number)
-        pdt, ploss, proof, _, _ = contrastive_leg("large", 200, SEQ_LEN, 6, 3, dev, 0, 1, False, args.dp_chunks, not args.no_roofline, args.dense,
-                                                  packed=True)
-        large["200_sequences_packed"] = {"sequences_per_sec": round(200 * 6 / pdt, 1), "ms_per_step": round(pdt / 6 * 1e3, 3), "steps": 6,
-                                         "loss": round(ploss, 4), "rows_per_step": proof.get("rows_per_step") if proof else None,
-                                         "rows_per_step_padded": 200 * SEQ_LEN, "gemm_tflops_on_stored_rows": proof.get("achieved") if proof else None,
-                                         "note": "sequences stored back to back (32-row alignment); FLOP fractions are not comparable with the padded legs"}
+            for pk_ in (True, False):
+                ldt, lloss, lroof, lcfg, _ = contrastive_leg("large", n_seq, SEQ_LEN, k_steps, 3, dev, 0, 1, False, args.dp_chunks,
+                                                             not args.no_roofline, args.dense, packed=pk_)
+                v = n_seq * k_steps / ldt
+                tf = v * train_flops_per_seq(lcfg, SEQ_LEN) / 1e12
+                large[f"{n_seq}_sequences" + ("" if pk_ else "_padded")] = {
+                    "sequences_per_sec": round(v, 1), "ms_per_step": round(ldt / k_steps * 1e3, 3), "steps": k_steps, "loss": round(lloss, 4),
+                    "algorithmic_tflops_whole_step": round(tf, 1), "whole_step_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "execution": "packed" if pk_ else "padded", "roofline": lroof}
         large["workload"] = "cocodr-large (BERT-large, 24 x 1024) contrastive step, seq_len 128, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW, 1 GPU"
         extras["north_star_large_step"] = large
-        # the same headline step on PACKED batches (SURVEY 7 iii): identical loss and gradients (tests/test_gpu_packed.py), the
-        # padding rows beyond 32-token alignment are simply not stored.  Reported next to the headline, never instead of it.
-        pdt, ploss, proof, _, _ = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
-                                                  args.dp_chunks, not args.no_roofline, args.dense, packed=True)
-        pv = args.seq_per_gpu * args.steps / pdt
-        extras["packed_contrastive_step"] = {
-            "sequences_per_sec": round(pv, 1), "ms_per_step": round(pdt / args.steps * 1e3, 3), "loss": round(ploss, 4),
-            "speedup_vs_padded": round(pv / (args.seq_per_gpu * args.steps / dt), 3),
-            "rows_per_step": proof.get("rows_per_step") if proof else None, "rows_per_step_padded": args.seq_per_gpu * args.seq_len,
-            "gemm_tflops_on_stored_rows": proof.get("achieved") if proof else None,
-            "note": "same batches, same loss and gradients as the headline step; sequences stored back to back with 32-row alignment "
-                    "(no work on padding rows); FLOP-based fractions are not comparable with the padded line (fewer rows)"}
+        # the same headline step in the other execution: padded (every GEMM over all B x L rows, executed FLOPs = the dense count: the
+        # line that is comparable kernel for kernel with rounds 1-2) when the headline is packed, and the other way round
+        odt, oloss, oroof, _, _ = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
+                                                  args.dp_chunks, not args.no_roofline, args.dense, packed=not packed)
+        ov = args.seq_per_gpu * args.steps / odt
+        otf = ov * train_flops_per_seq(cfg, args.seq_len) / 1e12
+        extras["padded_contrastive_step" if packed else "packed_contrastive_step"] = {
+            "sequences_per_sec": round(ov, 1), "ms_per_step": round(odt / args.steps * 1e3, 3), "loss": round(oloss, 4),
+            "headline_vs_this": round((args.seq_per_gpu * args.steps / dt) / ov, 3),
+            "algorithmic_tflops_whole_step": round(otf, 1), "whole_step_frac_of_mfma_peak": round(otf / MFMA_BF16_PEAK_TFLOPS, 4),
+            "roofline": oroof,
+            "note": "same batches, same loss and gradients as the headline step (tests/test_gpu_packed.py); "
+                    + ("here every kernel runs over all B x L rows, padding included, as the reference does" if packed else
+                       "here the sequences are stored back to back with 32-row alignment (no work on padding rows)")}
         if args.model == "base":
             extras["full_coco_step"] = full_coco_step(cfg, dev, ids, mask)  # second scope: what the reference's step really runs
             extras["ance_triplet_step"] = ance_step(dev)
@@ -683,7 +702,7 @@ def main():
     if world > 1 and not args.no_full_step:
         if config3:  # the weak-scaling point that keeps N = 1's per-GPU batch (the headline of this line is configs[2]'s 256 per GPU)
             wdt, wloss, _, _, _ = contrastive_leg(args.model, SEQ_PER_GPU, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
-                                                  args.dp_chunks, False, args.dense)
+                                                  args.dp_chunks, False, args.dense, packed=packed)
             wdt = tmax(wdt)
             extras["same_per_gpu_batch_as_n1"] = {"sequences_per_sec": round(SEQ_PER_GPU * world * args.steps / wdt, 2),
                                                   "ms_per_step": round(wdt / args.steps * 1e3, 3), "global_batch": SEQ_PER_GPU * world,
@@ -704,12 +723,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"cocodr-{args.model} contrastive step (COCO in-batch negatives), seq_len={args.seq_len}, "
-                                   f"{args.seq_per_gpu} sequences/GPU, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW; "
+                                   f"{args.seq_per_gpu} sequences/GPU padded to seq_len at the boundary (MS MARCO-shaped lengths), "
+                                   + ("executed packed (sequences stored back to back inside the encoder: no work on padding rows, "
+                                      "loss and gradients identical to the padded execution); " if packed else "executed padded (all B x L rows); ")
+                                   + "bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW; "
                                    + ("BASELINE configs[1]" if args.model == "base" and world == 1 else
                                       "BASELINE configs[2] (8 GPUs, RCCL all_gather negatives, global batch 2048)" if config3 else
                                       "BASELINE configs[1]'s batch on every GPU, negatives all-gathered as in configs[2] (whose 2048 global batch at 8 GPUs is 256 per GPU, the default at --gpus 8)" if args.model == "base" else "north_star BERT-large target shape"),
                        "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len,
-                       "batches": "8 pre-generated synthetic batches per rank, resident in HBM, visited round-robin",
+                       "batches": "8 pre-generated synthetic batches per rank, resident in HBM, visited round-robin"
+                                  + (" (each with its packed-layout description, built once from the lengths as a collator would)" if packed else ""),
+                       "execution": "packed" if packed else "padded",
                        "parallelism": par},
             "loss": round(final_loss, 4),
             "algorithmic_tflops_whole_step": round(step_tflops, 1),

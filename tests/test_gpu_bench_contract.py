@@ -37,6 +37,18 @@ def test_bench_line_has_the_contract_keys_and_a_measured_roofline():
     assert 0.05 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or r["traffic"] > 0
     assert 5000 < d["value"] < 50000  # an MI355X, not a fallback
+    # default execution: packed (no work on padding rows) - `achieved` counts the algorithmic FLOPs (padded tokens),
+    # `executed_*` what the launches carry out on the stored rows
+    assert d["config"]["execution"] == "packed" and "packed" in d["config"]["workload"]
+    assert 0.05 < r["executed_frac"] < r["frac"] and r["rows_per_step"] < r["rows_per_step_padded"] == 64 * 128
+    assert abs(r["executed_achieved"] / r["achieved"] - r["rows_per_step"] / r["rows_per_step_padded"]) < 0.03
+
+
+def test_bench_padded_execution_executes_the_algorithmic_flops():
+    d = _run("--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-full-step", "--padded")
+    r = d["roofline"]
+    assert d["config"]["execution"] == "padded"
+    assert abs(r["executed_achieved"] - r["achieved"]) < 0.01 * r["achieved"]  # every GEMM runs over all B x L rows
 
 
 def test_bench_multi_rank_path_on_one_gpu():

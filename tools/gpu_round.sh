@@ -2,7 +2,7 @@
 # One GPU visit: parity suite, the default bench line, kernel-trace stats and HBM-traffic PMC passes for the base and
 # large contrastive steps.  Usage (on the GPU box, from the repo root): tools/gpu_round.sh <tag> [commit] [stages]
 # stages: any of t (tests) b (bench) k (kernel stats) p (PMC traffic); default tbkp
-# The PMC stage writes gemm_pmc_<model>_<seq>x128.json; copy them to profiles/ (bench.py's roofline.traffic reads profiles/gemm_pmc_*.json
+# The PMC stage writes gemm_pmc_<model>_<seq>x128[_packed].json; copy them to profiles/ (bench.py's roofline.traffic reads profiles/gemm_pmc_*.json
 # and reports the commit recorded inside).
 set -u
 tag=${1:-r03}; commit=${2:-unknown}; stages=${3:-tbkp}
@@ -20,17 +20,20 @@ if [[ $stages == *b* ]]; then
   echo "bench exit $?"; tail -c 600 $out/bench.json
 fi
 prof_args="--steps 10 --warmup 3 --no-cpu-baseline --no-full-step"
+# every leg in both executions: packed (bench.py's default: no work on padding rows) and padded (--padded: all B x L rows)
 for cfg in "base 64" "large 64" "large 200" "large 256"; do
+ for ex in packed padded; do
   set -- $cfg; model=$1; nseq=$2
-  name=${model}_${nseq}x128
+  name=${model}_${nseq}x128; flag=""
+  if [ $ex = packed ]; then name=${name}_packed; else flag="--padded"; fi
   if [[ $stages == *k* ]]; then
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/kt_$name -o kt -- python $root/bench.py $prof_args --model $model --seq-per-gpu $nseq > $out/kt_$name.log 2>&1)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/kt_$name -o kt -- python $root/bench.py $prof_args $flag --model $model --seq-per-gpu $nseq > $out/kt_$name.log 2>&1)
     db=$(find $out/kt_$name -name "*.db" | head -1)
     if [ -n "$db" ]; then python tools/rocpd_stats.py $db > $out/kernel_stats_$name.md; fi
     grep '"metric"' $out/kt_$name.log > $out/kt_bench_$name.json
   fi
   if [[ $stages == *p* ]]; then
-    pmc_cmd="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-full-step --model $model --seq-per-gpu $nseq"
+    pmc_cmd="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-full-step $flag --model $model --seq-per-gpu $nseq"
     for c in FETCH_SIZE WRITE_SIZE; do
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${name}_$c -- python $root/$pmc_cmd > $out/pmc_${name}_$c.log 2>&1)
     done
@@ -38,6 +41,7 @@ for cfg in "base 64" "large 64" "large 200" "large 256"; do
     w=$(find $out/pmc_${name}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ] && [ -n "$w" ]; then python tools/pmc_traffic.py $f $w $out/gemm_pmc_$name.json "$pmc_cmd" $commit; fi
   fi
+ done
 done
 # keep the merged-back payload small: drop raw traces
 find $out -name "*.db" -size +20M -delete
