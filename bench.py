@@ -565,7 +565,8 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
                     "gemm_share_of_step": round(gemm_ms / sampled / (dt / steps * 1e3), 3),
                     "flops": "achieved / frac: the class's ALGORITHMIC FLOPs (24 H^2 per padded token and layer, x3: SURVEY 8d counts "
                              "padded tokens, the reference computes on padding) / the time of its launches; executed_*: the FLOPs "
-                             "the launches carry out" + (" (stored rows only)" if packed else " (the same here)"),
+                             "the launches carry out (" + ("stored rows only; " if packed else "") + "the last layer's output projection and FFN "
+                             "on the [CLS] rows alone - all the loss consumes, cocodr_config.cls_tail)",
                     "batches": "fully dense (every sequence fills L)" if dense else
                                ("MS MARCO-shaped lengths, stored back to back (32-row alignment): no work on padding rows, same loss and "
                                 "gradients as the padded execution (tests/test_gpu_packed.py)" if packed else

@@ -34,7 +34,8 @@ class GemmArgs(C.Structure):
 class Config(C.Structure):
     _fields_ = [("hidden", c_int), ("heads", c_int), ("layers", c_int), ("inter", c_int), ("vocab", c_int),
                 ("max_pos", c_int), ("ln_eps", c_float),
-                ("hidden_dropout", c_float), ("attn_dropout", c_float), ("drop_seed", C.c_ulonglong), ("drop_call", C.c_ulonglong)]
+                ("hidden_dropout", c_float), ("attn_dropout", c_float), ("drop_seed", C.c_ulonglong), ("drop_call", C.c_ulonglong),
+                ("cls_tail", c_int)]
 
 
 class LayerParams(C.Structure):
@@ -126,6 +127,7 @@ SIGNATURES = {
     "cocodr_lamb_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, C.POINTER(LambPlan), c_float,
                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_scatter_cls_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cocodr_cls_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "cocodr_simce_workspace_floats": (c_size_t, [c_int]),
     "cocodr_simce_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_allgather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -78,6 +78,12 @@ BwdLayout bwd_layout_m(const cocodr_config* c, size_t M, int B, int L) {
     cocodr_gemm_args wg[4];
     weight_grad_shapes(wg, (int)M, (int)H, (int)I, (int)ng);
     ws = std::max(ws, cocodr_gemm_multi_workspace_floats_for(wg, 4));
+    if (ng > 1) {  // a top range behind a [CLS] tail: the top layer's dWo, dW1, dW2 are not in the launch
+      wg[1].batch = wg[2].batch = wg[3].batch = (int)ng - 1;
+      ws = std::max(ws, cocodr_gemm_multi_workspace_floats_for(wg, 4));
+    } else {
+      ws = std::max(ws, cocodr_gemm_multi_workspace_floats_for(wg, 1));
+    }
   }
   b.multi_ws_floats = ws;
   b.multi_ws = cv.take(ws * 4);
@@ -95,6 +101,18 @@ int check_cfg(const cocodr_config* c, int B, int L) {
   CK_ARG(B > 0 && L >= 32 && L % 32 == 0 && L <= 512 && L <= c->max_pos, "encoder: L=%d must be a multiple of 32 in [32, min(512,%d)]", L, c->max_pos);
   CK_ARG(c->hidden_dropout >= 0.f && c->hidden_dropout < 1.f && c->attn_dropout >= 0.f && c->attn_dropout < 1.f, "encoder: dropout probabilities must be in [0, 1)");
   return COCODR_OK;
+}
+
+// [CLS] tail (cocodr_config.cls_tail): the carve-up of hidden_states[layers]'s slot, which such a forward does not fill
+struct TailScratch {
+  uint16_t *ctx_c, *xin_c, *out_c;  // bf16 [B,H] each: gathered attention context rows, gathered residual rows, LayerNorm output
+  long long* idx;                   // [B] first row of every sequence
+};
+TailScratch tail_scratch(uint16_t* slot, int B, int H) {  // M >= 32 B rows of H: 3 B H bf16 + B indices fit with room to spare
+  TailScratch t;
+  t.ctx_c = slot; t.xin_c = slot + (size_t)B * H; t.out_c = slot + (size_t)2 * B * H;
+  t.idx = reinterpret_cast<long long*>(slot + (size_t)3 * B * H);
+  return t;
 }
 
 #define TRY(expr)                \
@@ -252,6 +270,8 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   CK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= NL, "encoder_fwd: bad layer range [%d,%d)", layer_lo, layer_hi);
   // dropout (hf nn.Dropout under model.train()): only a training forward drops; the site keys follow (seed, call, layer, kind)
   const bool dropping = training && drop_active(c);
+  CK_ARG(!(c->cls_tail && dropping), "encoder_fwd: the [CLS] tail is not available with dropout (masks are indexed by token row)");
+  CK_ARG(!(c->cls_tail && training && B % 8 != 0), "encoder_fwd: the [CLS] tail of a training forward needs B %% 8 == 0 (its weight gradients contract over the B rows)");
   if (!from_hidden && layer_lo == 0) {  // a bare layer stack (Condenser head) starts from hidden slot 0, filled by the caller
     cocodr_dropout_mask de;
     TRY(cocodr_dropout_mask_for(dropping ? c->hidden_dropout : 0.0, c->drop_seed, c->drop_call, 0, COCODR_DROP_EMBED, &de));
@@ -289,6 +309,27 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     TRY(cocodr_gemm(&g, stream));
     if (pk) TRY(cocodr_attn_fwd_packed(qkv, mask, ctx, lse, pk->seq_off, B, M, pk->max_len, c->heads, &ld.probs, pk->drop_L, stream));
     else TRY(cocodr_attn_fwd_drop(qkv, mask, ctx, lse, B, L, c->heads, &ld.probs, stream));
+    if (c->cls_tail && l == NL - 1) {
+      // [CLS] tail (cocodr_config.cls_tail): everything behind the attention on the B first rows of the sequences only.  The
+      // per-layer slots keep their first B rows; hidden_states[NL]'s slot is scratch: the gathered context rows, the gathered
+      // residual rows, the bf16 LayerNorm output and the B row indices (the backward reads the first two and the indices)
+      const TailScratch ts = tail_scratch(x_out, B, H);
+      TRY(cocodr_cls_rows(pk ? pk->seq_off : nullptr, L, B, ts.idx, stream));
+      TRY(cocodr_gather_rows(ctx, ts.idx, ts.ctx_c, B, H, stream));
+      TRY(cocodr_gather_rows(x_in, ts.idx, ts.xin_c, B, H, stream));
+      g = gemm_base(ts.ctx_c, w.wo, y1, B, H, H, H, H, H, 0, 0);
+      g.bias = w.bo; g.epi = COCODR_EPI_ADD; g.R = ts.xin_c; g.ldr = H;
+      TRY(cocodr_gemm(&g, stream));
+      TRY(cocodr_ln_fwd(y1, w.ln1_g, w.ln1_b, x1, mean1, rstd1, nullptr, 0, B, H, c->ln_eps, stream));
+      g = gemm_base(x1, w.w1, h, B, I, H, H, H, I, 0, 0);
+      g.bias = w.b1; g.epi = COCODR_EPI_GELU; g.C2 = training ? u : nullptr;
+      TRY(cocodr_gemm(&g, stream));
+      g = gemm_base(h, w.w2, y2, B, H, I, I, I, H, 0, 0);
+      g.bias = w.b2; g.epi = COCODR_EPI_ADD; g.R = x1; g.ldr = H;
+      TRY(cocodr_gemm(&g, stream));
+      TRY(cocodr_ln_fwd(y2, w.ln2_g, w.ln2_b, ts.out_c, mean2, rstd2, cls, 1, B, H, c->ln_eps, stream));  // every row is a [CLS] row
+      continue;
+    }
     g = gemm_base(ctx, w.wo, y1, M, H, H, H, H, H, 0, 0);
     g.bias = w.bo; g.epi = COCODR_EPI_ADD; g.R = x_in; g.ldr = H; g.drop = ld.attn_out;
     TRY(cocodr_gemm(&g, stream));
@@ -442,24 +483,53 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     LayerDrop ld;
     TRY(layer_drop(c, dropping, l, &ld));
     const bool dh = ld.ffn_out.threshold != 0;  // hidden dropout on (both dense sites share the probability)
+    // [CLS] tail (cocodr_config.cls_tail): the top layer's FFN / LayerNorms / output projection ran on the B [CLS] rows only - their
+    // gradients live in the first B rows of the layer's slots, dx (d_in) is the [B,H] gradient of those rows, and the layer
+    // reduces its vector gradients at once (its partial rows do not have the range's common shape)
+    const bool tail = c->cls_tail != 0 && l == NL - 1;
+    const int Mr = tail ? B : M;
+    const bool dl = defer && !tail;
     uint16_t* res2 = dh ? dres : dy2;
-    if (defer) TRY(cocodr_ln_bwd_partials(dx, y2, w.ln2_g, mean2, rstd2, res2, ln2_slots + li * ln_slot, M, H, 3, hst, dy2, &ld.ffn_out));
-    else TRY(cocodr_ln_bwd_drop(dx, y2, w.ln2_g, mean2, rstd2, res2, dy2, gr.ln2_g, gr.ln2_b, gr.b2, ln_partial, M, H, &ld.ffn_out, stream));
-    cocodr_gemm_args g = gemm_base(dy2, w.w2, du, M, I, H, H, I, I, 0, 1);  // dh = dy2 W2, fused with GELU'(u)
+    if (dl) TRY(cocodr_ln_bwd_partials(dx, y2, w.ln2_g, mean2, rstd2, res2, ln2_slots + li * ln_slot, Mr, H, 3, hst, dy2, &ld.ffn_out));
+    else TRY(cocodr_ln_bwd_drop(dx, y2, w.ln2_g, mean2, rstd2, res2, dy2, gr.ln2_g, gr.ln2_b, gr.b2, ln_partial, Mr, H, &ld.ffn_out, stream));
+    cocodr_gemm_args g = gemm_base(dy2, w.w2, du, Mr, I, H, H, I, I, 0, 1);  // dh = dy2 W2, fused with GELU'(u)
     g.epi = COCODR_EPI_DGELU; g.R = u; g.ldr = I;
-    if (rows_b1 > 0) g.colsum_partial = b1_slots + li * rows_b1 * I;
+    if (dl && rows_b1 > 0) g.colsum_partial = b1_slots + li * rows_b1 * I;
     else { g.colsum = gr.b1; g.colsum_partial = cs_partial; }
     TRY(cocodr_gemm(&g, stream));
-    g = gemm_base(du, w.w1, dxa, M, H, I, I, H, H, 0, 1);  // dx1 = du W1 + dy2 (residual branch)
+    g = gemm_base(du, w.w1, dxa, Mr, H, I, I, H, H, 0, 1);  // dx1 = du W1 + dy2 (residual branch)
     g.epi = COCODR_EPI_ADD; g.R = res2; g.ldr = H;
     TRY(cocodr_gemm(&g, stream));
     uint16_t* res1 = dh ? dres : dy1;  // res2 has been consumed by the GEMM above (stream order)
-    if (defer) TRY(cocodr_ln_bwd_partials(dxa, y1, w.ln1_g, mean1, rstd1, res1, ln1_slots + li * ln_slot, M, H, 3, hst, dy1, &ld.attn_out));
-    else TRY(cocodr_ln_bwd_drop(dxa, y1, w.ln1_g, mean1, rstd1, res1, dy1, gr.ln1_g, gr.ln1_b, gr.bo, ln_partial, M, H, &ld.attn_out, stream));
-    g = gemm_base(dy1, w.wo, dctx, M, H, H, H, H, H, 0, 1);  // dctx = dy1 Wo
-    if (rows_bv > 0) g.colsum_partial = bv_slots + li * rows_bv * H;
+    if (dl) TRY(cocodr_ln_bwd_partials(dxa, y1, w.ln1_g, mean1, rstd1, res1, ln1_slots + li * ln_slot, Mr, H, 3, hst, dy1, &ld.attn_out));
+    else TRY(cocodr_ln_bwd_drop(dxa, y1, w.ln1_g, mean1, rstd1, res1, dy1, gr.ln1_g, gr.ln1_b, gr.bo, ln_partial, Mr, H, &ld.attn_out, stream));
+    uint16_t* dctx_rows = tail ? dxa : dctx;  // (tail: dxa is free again - B compact rows, scattered into the zeroed dctx below)
+    g = gemm_base(dy1, w.wo, dctx_rows, Mr, H, H, H, H, H, 0, 1);  // dctx = dy1 Wo
+    if (dl && rows_bv > 0) g.colsum_partial = bv_slots + li * rows_bv * H;
     else if (!drop_probs) { g.colsum = gr.bqkv + 2 * H; g.colsum_partial = cs_partial; }
     TRY(cocodr_gemm(&g, stream));
+    if (tail) {
+      // the attention backward and the QKV dgrad below see the layer as a whole again: context gradient and residual gradient are
+      // zero off the [CLS] rows (no dropout on this path, so dres is free)
+      const TailScratch ts = tail_scratch(hidden + (size_t)NL * M * H, B, H);
+      if (hipMemsetAsync(dctx, 0, (size_t)M * H * 2, hst) != hipSuccess || hipMemsetAsync(dres, 0, (size_t)M * H * 2, hst) != hipSuccess) {
+        cocodr_set_error("encoder_bwd: memset failed");
+        return COCODR_ERR_LAUNCH;
+      }
+      TRY(cocodr_scatter_rows(dxa, ts.idx, dctx, B, H, 0, stream));
+      TRY(cocodr_scatter_rows(dy1, ts.idx, dres, B, H, 0, stream));
+      res1 = dres;
+      // this layer's three weight gradients over the B rows (the grouped launch below takes the other layers of the range)
+      cocodr_gemm_args tw = gemm_base(dy1, ts.ctx_c, gr.wo, H, H, B, H, H, H, 1, 1);
+      tw.out_f32 = 1;
+      TRY(cocodr_gemm(&tw, stream));
+      tw = gemm_base(du, (const uint16_t*)(base + lay.x1) + lo * M * H, gr.w1, I, H, B, I, H, H, 1, 1);
+      tw.out_f32 = 1;
+      TRY(cocodr_gemm(&tw, stream));
+      tw = gemm_base(dy2, (const uint16_t*)(base + lay.h) + lo * M * I, gr.w2, H, I, B, H, I, I, 1, 1);
+      tw.out_f32 = 1;
+      TRY(cocodr_gemm(&tw, stream));
+    }
     // the query / key bias gradients are column sums of dQ | dK: the attention backward leaves four partial rows per sequence
     if (pk) TRY(cocodr_attn_bwd_packed(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, pk->seq_off, B, M, pk->max_len, c->heads,
                                        &ld.probs, pk->drop_L, stream));
@@ -494,24 +564,29 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   const cocodr_layer_grads& g0 = lg[layer_lo];
   // (the four matrices of the range in ONE launch where the pipeline allows - cocodr_gemm_multi: launched one after the other,
   // each of the four pays its own partial last round of the 256 CUs)
+  // ([CLS] tail: the top layer computed dWo, dW1, dW2 and its vector gradients itself - those three problems and the deferred
+  //  LayerNorm / b1 / value-bias jobs cover the range's other layers, which come first in it)
+  const int NGt = (c->cls_tail != 0 && layer_hi == NL) ? NG - 1 : NG;
   cocodr_gemm_args wg[4];
   wg[0] = gemm_base(dqkv_all + l0 * sM3H, hidden + l0 * sMH, g0.wqkv, 3 * H, H, M, 3 * H, H, H, 1, 1);
   wg[0].out_f32 = 1; wg[0].batch = NG; wg[0].strideA = sM3H; wg[0].strideB = sMH; wg[0].strideC = s_wqkv;
   wg[1] = gemm_base(dy1_all + l0 * sMH, (const uint16_t*)(base + lay.ctx) + l0 * sMH, g0.wo, H, H, M, H, H, H, 1, 1);
-  wg[1].out_f32 = 1; wg[1].batch = NG; wg[1].strideA = sMH; wg[1].strideB = sMH; wg[1].strideC = s_wo;
+  wg[1].out_f32 = 1; wg[1].batch = NGt; wg[1].strideA = sMH; wg[1].strideB = sMH; wg[1].strideC = s_wo;
   wg[2] = gemm_base(du_all + l0 * sMI, (const uint16_t*)(base + lay.x1) + l0 * sMH, g0.w1, I, H, M, I, H, H, 1, 1);
-  wg[2].out_f32 = 1; wg[2].batch = NG; wg[2].strideA = sMI; wg[2].strideB = sMH; wg[2].strideC = s_w1;
+  wg[2].out_f32 = 1; wg[2].batch = NGt; wg[2].strideA = sMI; wg[2].strideB = sMH; wg[2].strideC = s_w1;
   wg[3] = gemm_base(dy2_all + l0 * sMH, (const uint16_t*)(base + lay.h) + l0 * sMI, g0.w2, H, I, M, H, I, I, 1, 1);
-  wg[3].out_f32 = 1; wg[3].batch = NG; wg[3].strideA = sMH; wg[3].strideB = sMI; wg[3].strideC = s_w2;
-  TRY(cocodr_gemm_multi(wg, 4, bl.multi_ws_floats ? (float*)(bb + bl.multi_ws) : nullptr, bl.multi_ws_floats, stream));
+  wg[3].out_f32 = 1; wg[3].batch = NGt; wg[3].strideA = sMH; wg[3].strideB = sMI; wg[3].strideC = s_w2;
+  TRY(cocodr_gemm_multi(wg, NGt > 0 ? 4 : 1, bl.multi_ws_floats ? (float*)(bb + bl.multi_ws) : nullptr, bl.multi_ws_floats, stream));
   // ---- deferred reductions of the range (LayerNorm weight / bias + the Linear bias in front of it; b1; value bias)
   if (defer) {
     cocodr_reduce_job jobs[5];  // one launch for all of them
     int nj = 0;
-    jobs[nj++] = {ln2_slots, g0.ln2_g, g0.ln2_b, g0.b2, P_ln, 3, H, NG, s_vec};
-    jobs[nj++] = {ln1_slots, g0.ln1_g, g0.ln1_b, g0.bo, P_ln, 3, H, NG, s_vec};
-    if (rows_b1 > 0) jobs[nj++] = {b1_slots, g0.b1, nullptr, nullptr, rows_b1, 1, I, NG, s_vec};
-    if (rows_bv > 0) jobs[nj++] = {bv_slots, g0.bqkv + 2 * H, nullptr, nullptr, rows_bv, 1, H, NG, s_vec};
+    if (NGt > 0) {
+      jobs[nj++] = {ln2_slots, g0.ln2_g, g0.ln2_b, g0.b2, P_ln, 3, H, NGt, s_vec};
+      jobs[nj++] = {ln1_slots, g0.ln1_g, g0.ln1_b, g0.bo, P_ln, 3, H, NGt, s_vec};
+      if (rows_b1 > 0) jobs[nj++] = {b1_slots, g0.b1, nullptr, nullptr, rows_b1, 1, I, NGt, s_vec};
+      if (rows_bv > 0) jobs[nj++] = {bv_slots, g0.bqkv + 2 * H, nullptr, nullptr, rows_bv, 1, H, NGt, s_vec};
+    }
     jobs[nj++] = {bqk_slots, g0.bqkv, nullptr, nullptr, 4 * B, 1, 2 * H, NG, s_vec};
     TRY(cocodr_reduce_partials_multi(jobs, nj, hst));
   }

@@ -910,6 +910,19 @@ extern "C" int cocodr_mul_bf16(const uint16_t* a, const uint16_t* b, uint16_t* o
   return COCODR_OK;
 }
 
+namespace {
+__global__ void cls_rows_kernel(const int32_t* __restrict__ seq_off, int L, int B, long long* __restrict__ idx) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) idx[b] = seq_off ? (long long)seq_off[b] : (long long)b * L;
+}
+}  // namespace
+extern "C" int cocodr_cls_rows(const int32_t* seq_off, int L, int B, long long* idx, cocodr_stream_t stream) {
+  CK_ARG(idx && B > 0 && (seq_off || L > 0), "cls_rows: bad arguments");
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, seq_off, L, B, idx);
+  CK_LAUNCH("cls_rows");
+  return COCODR_OK;
+}
+
 extern "C" int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int H, cocodr_stream_t stream) {
   CK_ARG(dE && d_last, "scatter_cls_grad: null pointer");
   CK_ARG(B > 0 && L > 0 && row_shape_ok(H), "scatter_cls_grad: bad shape");

@@ -220,6 +220,8 @@ int cocodr_zero_f32(float* dst, size_t n, cocodr_stream_t stream);
 int cocodr_gather_rows(const uint16_t* src, const long long* idx, uint16_t* dst, int n, int H, cocodr_stream_t stream);
 int cocodr_scatter_rows(const uint16_t* src, const long long* idx, void* dst, int n, int H, int add_f32, cocodr_stream_t stream);
 int cocodr_mul_bf16(const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n, cocodr_stream_t stream);
+/* idx[b] = first row of sequence b: seq_off[b] (packed batches; seq_off int32 [B+1] on the device) or b * L (seq_off == NULL) */
+int cocodr_cls_rows(const int32_t* seq_off, int L, int B, long long* idx, cocodr_stream_t stream);
 /* d_last[b*L + 0, :] = bf16(dE[b, :]), all other rows zero (gradient enters at [CLS] only) */
 int cocodr_scatter_cls_grad(const float* dE, uint16_t* d_last, int B, int L, int H, cocodr_stream_t stream);
 
@@ -346,6 +348,14 @@ typedef struct {
    * backward of a forward must be given the same four values; 0 probabilities = no dropout (eval). */
   float hidden_dropout, attn_dropout;
   unsigned long long drop_seed, drop_call;
+  /* cls_tail != 0: the caller consumes the last layer's [CLS] rows only (every reference wrapper of the contrastive / ANCE /
+   * inference paths: COCO/modeling.py:199-204 hidden_states[-1][:, :1], ANCE/model/models.py:225-232 [0][:, 0]).  The last layer
+   * then computes QKV and the attention over all rows (its keys and values come from every token) but the attention output
+   * projection, both LayerNorms and the FFN on the B [CLS] rows alone; cls_f32 is identical, hidden_states[layers] is NOT
+   * produced (its arena slot is scratch), and the backward of such a forward takes the [B,H] bf16 gradient of the [CLS] rows as
+   * d_last and must be given the same flag.  Not available with dropout (the masks are indexed by token row); a training
+   * forward needs B % 8 == 0. */
+  int cls_tail;
 } cocodr_config;
 
 typedef struct { /* one BertLayer; w* are bf16 shadows [out,in], vectors are the fp32 masters */

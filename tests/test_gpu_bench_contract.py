@@ -41,14 +41,18 @@ def test_bench_line_has_the_contract_keys_and_a_measured_roofline():
     # `executed_*` what the launches carry out on the stored rows
     assert d["config"]["execution"] == "packed" and "packed" in d["config"]["workload"]
     assert 0.05 < r["executed_frac"] < r["frac"] and r["rows_per_step"] < r["rows_per_step_padded"] == 64 * 128
-    assert abs(r["executed_achieved"] / r["achieved"] - r["rows_per_step"] / r["rows_per_step_padded"]) < 0.03
+    # (executed: the stored rows, and in the last layer - whose [CLS] rows alone are consumed - 18 of the 24 H^2 per token on those
+    # rows only: (1 - 0.75 / 12) of the stored-row count for the 12 layers of BERT-base)
+    ratio = r["rows_per_step"] / r["rows_per_step_padded"] * (1 - 0.75 / 12)
+    assert abs(r["executed_achieved"] / r["achieved"] - ratio) < 0.03
 
 
 def test_bench_padded_execution_executes_the_algorithmic_flops():
     d = _run("--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-full-step", "--padded")
     r = d["roofline"]
     assert d["config"]["execution"] == "padded"
-    assert abs(r["executed_achieved"] - r["achieved"]) < 0.01 * r["achieved"]  # every GEMM runs over all B x L rows
+    # every GEMM runs over all B x L rows, but for the last layer's output projection and FFN ([CLS] rows only)
+    assert abs(r["executed_achieved"] / r["achieved"] - (1 - 0.75 / 12)) < 0.01
 
 
 def test_bench_multi_rank_path_on_one_gpu():
