@@ -39,10 +39,11 @@ SEQ_PER_GPU = 64
 SEQ_LEN = 128
 
 
-def synth_batch(rank: int, n_seq: int, L: int, vocab: int, device, dense: bool = False):
+def synth_batch_lens(rank: int, n_seq: int, L: int, vocab: int, device, dense: bool = False):
     """ids ~ U{1000..V-1}, seed 1234+rank, lengths ~ clip(round(N(76,30)), 8, L) (MS MARCO-shaped; (24, 8)
     at L <= 64), [CLS]=101 first, [SEP]=102 last, [PAD]=0 after.  ``dense``: every sequence fills L (the variant SURVEY
-    8(d) prescribes for roofline fractions; the kernels do not skip masked work, so the FLOPs are the same either way)."""
+    8(d) prescribes for roofline fractions).  Returns (ids, mask) on ``device`` and the lengths on the HOST - what a collator
+    that pads on the CPU knows (COCO/data.py:135-144)."""
     rng = np.random.Generator(np.random.PCG64(1234 + rank))
     ids = rng.integers(1000, vocab, (n_seq, L))
     mu, sd = (76, 30) if L > 64 else (24, 8)
@@ -51,7 +52,17 @@ def synth_batch(rank: int, n_seq: int, L: int, vocab: int, device, dense: bool =
     ids = ids * mask
     ids[:, 0] = 101
     ids[np.arange(n_seq), lens - 1] = 102
-    return torch.from_numpy(ids).to(device), torch.from_numpy(mask).to(device)
+    return torch.from_numpy(ids).to(device), torch.from_numpy(mask).to(device), torch.from_numpy(lens)
+
+
+def synth_batch(rank: int, n_seq: int, L: int, vocab: int, device, dense: bool = False):
+    return synth_batch_lens(rank, n_seq, L, vocab, device, dense)[:2]
+
+
+def attention_train_flops(cfg, extents) -> float:
+    """SURVEY 8(d)'s attention term for the rows a step executes: forward 4 ext^2 H per sequence and layer (QK^T and PV), x3."""
+    H, N = cfg.hidden_size, cfg.num_hidden_layers
+    return 3.0 * N * 4.0 * H * float(np.sum(np.asarray(extents, np.float64) ** 2))
 
 
 def train_flops_per_seq(cfg, L: int) -> float:
@@ -486,7 +497,7 @@ def _traffic_for(model_name: str, seq_per_gpu: int, seq_len: int, packed: bool =
 def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int, warmup: int, dev, rank: int, world: int, use_dist: bool,
                     dp_chunks: int, roofline: bool, dense: bool = False, packed: bool = False):
     """Build the model, run `warmup` untimed + exactly `steps` timed contrastive steps between two fences; returns
-    (seconds over the timed steps on this rank, final loss, roofline dict or None, cfg, one batch)."""
+    (seconds over the timed steps on this rank, final loss, roofline dict or None, cfg, one batch, what the steps executed)."""
     import torch.distributed as dist
     from cocodr_amd import ops
     from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertConfig, CocoBertModel
@@ -501,17 +512,24 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
     total = steps + warmup
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / max(1, int(0.1 * total))))
     # a small pool of different synthetic batches, resident in HBM before the timed region, visited round-robin (one
-    # repeated batch is memorised within a few steps and the loss saturates at 0)
-    pool = [synth_batch(rank + 10007 * i, seq_per_gpu, seq_len, cfg.vocab_size, dev, dense) for i in range(8)]
-    batches = [{"input_ids": i_, "attention_mask": m_} for i_, m_ in pool]
-    if packed:  # sequences back to back (32-row alignment) instead of padded to seq_len; the layout descriptions are built once per
-        for b_ in batches:  # batch here, as a collator that knows the lengths would (one device -> host copy of B integers otherwise)
-            b_["packed_index"] = bert.pack(b_["input_ids"], b_["attention_mask"])
+    # repeated batch is memorised within a few steps and the loss saturates at 0).  A batch is what the reference's collator
+    # hands the model - padded ids + attention mask (COCO/data.py:150-154) - plus the B lengths on the host, which a collator
+    # that pads on the CPU knows; NOTHING of the packed layout is prebuilt: every timed step builds its own from these inside
+    # model(batch) (one pinned copy of 2B+1 integers + one native launch, coco-dr_amd/modeling.py PackedIndex)
+    pool = [synth_batch_lens(rank + 10007 * i, seq_per_gpu, seq_len, cfg.vocab_size, dev, dense) for i in range(8)]
+    bert.pack_sequences = bool(packed)  # (True is the model's default)
+
+    def fresh_batch(i):  # a new dict per step: nothing a previous step attached can survive
+        ids_, mask_, lens_ = pool[i % len(pool)]
+        return {"input_ids": ids_, "attention_mask": mask_, "lengths": lens_}
+
     step_no = [0]
     flats = [bert.flat_decay, bert.flat_nodecay]
+    seen = []  # (id of the batch dict, had a prebuilt layout) per step: tests/test_gpu_bench_contract.py
 
     def step():
-        batch = batches[step_no[0] % len(batches)]
+        batch = fresh_batch(step_no[0])
+        seen.append((id(batch), "packed_index" in batch))
         step_no[0] += 1
         opt.zero_grad(set_to_none=True)
         loss = model(batch, None)
@@ -545,38 +563,67 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
     fence()
     dt = time.perf_counter() - t0
     roof = None
+    # rows and attention extents the timed steps executed (host arithmetic on the lengths the batches carry)
+    def extents_of(i):
+        lens_ = pool[(warmup + i) % len(pool)][2].numpy()
+        return (np.maximum(lens_, 1) + 31) // 32 * 32 if packed else np.full(seq_per_gpu, seq_len)
+    rows_per_step = float(np.mean([extents_of(i).sum() for i in range(steps)]))
+    attn_flops_per_step = float(np.mean([attention_train_flops(cfg, extents_of(i)) for i in range(steps)]))
+    exec_info = {"rows_per_step": int(round(rows_per_step)), "rows_per_step_padded": seq_per_gpu * seq_len}
     if prof:
         n_launch, gemm_ms, gemm_flops = ops.prof_end()
         if n_launch and gemm_ms > 0:
-            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12  # FLOPs the bracketed launches carried out / their summed duration
             sampled = len(range(0, steps, PROF_EVERY))
             traffic, src = _traffic_for(model_name, seq_per_gpu, seq_len, packed)
-            # algorithmic FLOPs of the class (padded tokens - what the reference's arithmetic costs) over the time of
-            # its launches; on padded batches that IS what the launches execute, on packed batches the launches execute the
-            # stored rows only (`executed_*`)
+            lps = n_launch // max(1, sampled)
+            gemm_ms_step = gemm_ms / sampled
             alg = train_gemm_flops_per_seq(cfg, seq_len) * seq_per_gpu * sampled / (gemm_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(alg, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(alg / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
-                    "executed_achieved": round(ach, 1), "executed_frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "kernel": "bf16 MFMA GEMM class of coco-dr_amd/csrc/gemm.hip (all NT / NN / TN launches of the step)",
-                    "launches_per_step": n_launch // max(1, sampled),
+            roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "traffic_unit": "HBM-side bytes per GEMM launch (FETCH_SIZE + WRITE_SIZE PMC passes, average over the class)",
+                    "traffic_per_step_bytes": None if traffic is None else int(traffic * lps),
+                    "traffic_gbps": None if traffic is None else round(traffic * lps / (gemm_ms_step * 1e-3) / 1e9, 1),
+                    "traffic_source": src,
+                    "algorithmic_achieved": round(alg, 1), "algorithmic_frac": round(alg / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "kernel": "bf16 MFMA GEMM class of coco-dr_amd/csrc/gemm.hip + gemm_pp.hip (all NT / NN / TN launches of the step)",
+                    "launches_per_step": lps,
                     "sampled": f"every GEMM launch of every {PROF_EVERY}th timed step ({n_launch} launches)",
                     "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
-                    "gemm_share_of_step": round(gemm_ms / sampled / (dt / steps * 1e3), 3),
-                    "flops": "achieved / frac: the class's ALGORITHMIC FLOPs (24 H^2 per padded token and layer, x3: SURVEY 8d counts "
-                             "padded tokens, the reference computes on padding) / the time of its launches; executed_*: the FLOPs "
-                             "the launches carry out (" + ("stored rows only; " if packed else "") + "the last layer's output projection and FFN "
-                             "on the [CLS] rows alone - all the loss consumes, cocodr_config.cls_tail)",
+                    "gemm_share_of_step": round(gemm_ms_step / (dt / steps * 1e3), 3),
+                    "executed_gemm_flops_per_step": gemm_flops / sampled,
+                    "flops": "achieved / frac: the FLOPs the timed launches EXECUTE (2 M N K of every launch: "
+                             + ("stored rows only, " if packed else "all B x L rows, ") +
+                             "the last layer's output projection and FFN on the [CLS] rows alone - cocodr_config.cls_tail) / the summed "
+                             "duration of those launches.  algorithmic_*: the class's FLOPs on the padded batch as the reference computes "
+                             "it (24 H^2 per padded token and layer, x3: SURVEY 8d) over the same time - a throughput figure, not a "
+                             "utilisation",
                     "batches": "fully dense (every sequence fills L)" if dense else
                                ("MS MARCO-shaped lengths, stored back to back (32-row alignment): no work on padding rows, same loss and "
                                 "gradients as the padded execution (tests/test_gpu_packed.py)" if packed else
-                                "MS MARCO-shaped lengths, padded to L; the kernels do not skip masked work, so executed FLOPs = the dense count")}
-    if packed and roof is not None:  # (of the sampled steps: what executed_* was measured on)
-        roof["rows_per_step"] = int(np.mean([batches[(warmup + i) % len(batches)]["packed_index"].T for i in range(0, steps, PROF_EVERY)]))
-        roof["rows_per_step_padded"] = seq_per_gpu * seq_len
+                                "MS MARCO-shaped lengths, padded to L; every kernel runs over all B x L rows")}
+            roof.update(exec_info)
+            exec_info["executed_flops_per_step"] = gemm_flops / sampled + attn_flops_per_step
+    exec_info["fresh_batches"] = bool(len({i for i, _ in seen}) == len(seen) and not any(p for _, p in seen))
     del opt, model, bert
     torch.cuda.empty_cache()
-    return dt, float(loss.detach()), roof, cfg, pool[0]
+    return dt, float(loss.detach()), roof, cfg, pool[0][:2], exec_info
+
+
+def whole_step_fracs(n_seq: int, steps: int, dt: float, cfg, seq_len: int, exec_info: dict, world: int = 1) -> dict:
+    """Whole-step rates against the MFMA peak.  executed_*: the FLOPs the step's launches carry out (GEMM class as bracketed by
+    the HIP events + the attention term on the executed extents) / step time - the utilisation figure.  algorithmic_*: SURVEY
+    8(d)'s count on the padded batch (the reference's arithmetic) / step time - a throughput figure."""
+    v = n_seq * steps / dt
+    alg = v * train_flops_per_seq(cfg, seq_len) / 1e12
+    d = {"algorithmic_tflops_whole_step": round(alg, 1), "algorithmic_whole_step_frac": round(alg / (MFMA_BF16_PEAK_TFLOPS * world), 4)}
+    if exec_info.get("executed_flops_per_step"):
+        ex = exec_info["executed_flops_per_step"] / (dt / steps) / 1e12
+        d["executed_tflops_whole_step"] = round(ex, 1)
+        d["executed_whole_step_frac"] = round(ex / MFMA_BF16_PEAK_TFLOPS, 4)
+    d["rows_per_step"] = exec_info.get("rows_per_step")
+    d["fresh_batches_every_step"] = exec_info.get("fresh_batches")
+    return d
 
 
 def _self_launch(args) -> int:
@@ -645,7 +692,7 @@ def main():
 
     solo = not use_dist
     packed = not args.padded
-    dt, final_loss, roof, cfg, (ids, mask) = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, rank,
+    dt, final_loss, roof, cfg, (ids, mask), xinfo = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, rank,
                                                             world, use_dist, args.dp_chunks, not args.no_roofline, args.dense, packed=packed)
     extras = {}
     if solo and not args.no_full_step and rank == 0:
@@ -657,30 +704,29 @@ def main():
         # tails).  Each size in both executions: packed (this line's default) and padded (executed FLOPs = the dense count)
         for n_seq, k_steps in ((64, 10), (200, 6), (256, 5)):
             for pk_ in (True, False):
-                ldt, lloss, lroof, lcfg, _ = contrastive_leg("large", n_seq, SEQ_LEN, k_steps, 3, dev, 0, 1, False, args.dp_chunks,
-                                                             not args.no_roofline, args.dense, packed=pk_)
+                ldt, lloss, lroof, lcfg, _, linfo = contrastive_leg("large", n_seq, SEQ_LEN, k_steps, 3, dev, 0, 1, False, args.dp_chunks,
+                                                                    not args.no_roofline, args.dense, packed=pk_)
                 v = n_seq * k_steps / ldt
-                tf = v * train_flops_per_seq(lcfg, SEQ_LEN) / 1e12
-                large[f"{n_seq}_sequences" + ("" if pk_ else "_padded")] = {
-                    "sequences_per_sec": round(v, 1), "ms_per_step": round(ldt / k_steps * 1e3, 3), "steps": k_steps, "loss": round(lloss, 4),
-                    "algorithmic_tflops_whole_step": round(tf, 1), "whole_step_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "execution": "packed" if pk_ else "padded", "roofline": lroof}
+                entry = {"sequences_per_sec": round(v, 1), "ms_per_step": round(ldt / k_steps * 1e3, 3), "steps": k_steps, "loss": round(lloss, 4)}
+                entry.update(whole_step_fracs(n_seq, k_steps, ldt, lcfg, SEQ_LEN, linfo))
+                entry.update({"execution": "packed" if pk_ else "padded", "roofline": lroof})
+                large[f"{n_seq}_sequences" + ("" if pk_ else "_padded")] = entry
         large["workload"] = "cocodr-large (BERT-large, 24 x 1024) contrastive step, seq_len 128, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW, 1 GPU"
         extras["north_star_large_step"] = large
         # the same headline step in the other execution: padded (every GEMM over all B x L rows, executed FLOPs = the dense count: the
         # line that is comparable kernel for kernel with rounds 1-2) when the headline is packed, and the other way round
-        odt, oloss, oroof, _, _ = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
-                                                  args.dp_chunks, not args.no_roofline, args.dense, packed=not packed)
+        odt, oloss, oroof, _, _, oinfo = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
+                                                         args.dp_chunks, not args.no_roofline, args.dense, packed=not packed)
         ov = args.seq_per_gpu * args.steps / odt
-        otf = ov * train_flops_per_seq(cfg, args.seq_len) / 1e12
-        extras["padded_contrastive_step" if packed else "packed_contrastive_step"] = {
-            "sequences_per_sec": round(ov, 1), "ms_per_step": round(odt / args.steps * 1e3, 3), "loss": round(oloss, 4),
-            "headline_vs_this": round((args.seq_per_gpu * args.steps / dt) / ov, 3),
-            "algorithmic_tflops_whole_step": round(otf, 1), "whole_step_frac_of_mfma_peak": round(otf / MFMA_BF16_PEAK_TFLOPS, 4),
-            "roofline": oroof,
-            "note": "same batches, same loss and gradients as the headline step (tests/test_gpu_packed.py); "
-                    + ("here every kernel runs over all B x L rows, padding included, as the reference does" if packed else
-                       "here the sequences are stored back to back with 32-row alignment (no work on padding rows)")}
+        other = {"sequences_per_sec": round(ov, 1), "ms_per_step": round(odt / args.steps * 1e3, 3), "loss": round(oloss, 4),
+                 "headline_vs_this": round((args.seq_per_gpu * args.steps / dt) / ov, 3)}
+        other.update(whole_step_fracs(args.seq_per_gpu, args.steps, odt, cfg, args.seq_len, oinfo))
+        other.update({"roofline": oroof,
+                      "note": "same batches, same loss and gradients as the headline step (tests/test_gpu_packed.py); "
+                              + ("here every kernel runs over all B x L rows, padding included, as the reference does "
+                                 "(CocoBertModel.pack_sequences = False)" if packed else
+                                 "here the sequences are stored back to back with 32-row alignment (no work on padding rows)")})
+        extras["padded_contrastive_step" if packed else "packed_contrastive_step"] = other
         if args.model == "base":
             extras["full_coco_step"] = full_coco_step(cfg, dev, ids, mask)  # second scope: what the reference's step really runs
             extras["ance_triplet_step"] = ance_step(dev)
@@ -702,7 +748,7 @@ def main():
     dt = tmax(dt)
     if world > 1 and not args.no_full_step:
         if config3:  # the weak-scaling point that keeps N = 1's per-GPU batch (the headline of this line is configs[2]'s 256 per GPU)
-            wdt, wloss, _, _, _ = contrastive_leg(args.model, SEQ_PER_GPU, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
+            wdt, wloss, _, _, _, _ = contrastive_leg(args.model, SEQ_PER_GPU, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
                                                   args.dp_chunks, False, args.dense, packed=packed)
             wdt = tmax(wdt)
             extras["same_per_gpu_batch_as_n1"] = {"sequences_per_sec": round(SEQ_PER_GPU * world * args.steps / wdt, 2),
@@ -715,7 +761,6 @@ def main():
     if rank == 0:
         n_seq = args.seq_per_gpu * world * args.steps
         value = n_seq / dt
-        step_tflops = value * train_flops_per_seq(cfg, args.seq_len) / 1e12
         par = f"dp{world}"
         if world > 1:
             par += " + RCCL all_gather negatives" if backend == "nccl" else f" over gloo ({world} ranks sharing {n_dev} GPU(s): code-path check, not a scaling number)"
@@ -732,14 +777,15 @@ def main():
                                       "BASELINE configs[2] (8 GPUs, RCCL all_gather negatives, global batch 2048)" if config3 else
                                       "BASELINE configs[1]'s batch on every GPU, negatives all-gathered as in configs[2] (whose 2048 global batch at 8 GPUs is 256 per GPU, the default at --gpus 8)" if args.model == "base" else "north_star BERT-large target shape"),
                        "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len,
-                       "batches": "8 pre-generated synthetic batches per rank, resident in HBM, visited round-robin"
-                                  + (" (each with its packed-layout description, built once from the lengths as a collator would)" if packed else ""),
+                       "batches": "8 pre-generated synthetic batches per rank (padded ids + attention mask in HBM, the B lengths on the "
+                                  "host as a collator that pads on the CPU has them), visited round-robin; every timed step gets a fresh "
+                                  "batch dict" + (" and builds its packed layout inside the step (one pinned copy of 2B+1 integers + "
+                                                  "one native launch; nothing prebuilt or hoisted)" if packed else ""),
                        "execution": "packed" if packed else "padded",
                        "parallelism": par},
             "loss": round(final_loss, 4),
-            "algorithmic_tflops_whole_step": round(step_tflops, 1),
-            "whole_step_frac_of_mfma_peak": round(step_tflops / (MFMA_BF16_PEAK_TFLOPS * world), 4),
         }
+        out.update(whole_step_fracs(args.seq_per_gpu * world, args.steps, dt, cfg, args.seq_len, xinfo, world))
         if roof is not None:
             out["roofline"] = roof
         out.update(extras)

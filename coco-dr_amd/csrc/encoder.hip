@@ -546,9 +546,9 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     cocodr_dropout_mask de;
     TRY(cocodr_dropout_mask_for(dropping ? c->hidden_dropout : 0.0, c->drop_seed, c->drop_call, 0, COCODR_DROP_EMBED, &de));
     if (pk) {
-      CK_ARG(pk->ids && pk->positions, "encoder_bwd(packed): the embedding needs ids and positions");
-      TRY(cocodr_embed_ln_bwd_packed(dx, pk->ids, pk->positions, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
-                                     (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial, M,
+      CK_ARG(pk->ids, "encoder_bwd(packed): the embedding needs the token ids");
+      TRY(cocodr_embed_ln_bwd_packed(dx, pk->ids, pk->seq_off, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),
+                                     (const float*)(base + lay.emb_rstd), eg->word, eg->pos, eg->type0, eg->ln_g, eg->ln_b, emb_partial, B, M,
                                      pk->max_len, H, c->vocab, &de, stream));
     } else {
       TRY(cocodr_embed_ln_bwd_drop(dx, ids, emb->word, emb->pos, emb->type0, emb->ln_g, (const float*)(base + lay.emb_mean),

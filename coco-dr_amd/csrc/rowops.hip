@@ -334,14 +334,16 @@ __global__ __launch_bounds__(RB_THREADS) void ln_bwd_kernel(const uint16_t* __re
 }
 
 // grid.x = L (one workgroup per position): the position-embedding gradient row is a plain sum over
-// the batch (no atomics); only the sparse word-embedding rows use fp32 atomics.
+// the batch (no atomics); only the sparse word-embedding rows use fp32 atomics.  Padded batches (row = b L + l) and packed
+// ones (row = seq_off[b] + l where sequence b is that long) alike - the packed form used to scatter the position rows by
+// atomics as well, twice the atomic traffic of the padded kernel on fewer rows.
 __global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_kernel(const uint16_t* __restrict__ dout, const int32_t* __restrict__ ids,
                                                            const float* __restrict__ word, const float* __restrict__ pos,
                                                            const float* __restrict__ type0, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                            float* __restrict__ dword, float* __restrict__ dpos,
                                                            float* __restrict__ partial, int B, int L, int H, int vocab,
-                                                           const cocodr_dropout_mask dm) {
+                                                           const cocodr_dropout_mask dm, const int32_t* __restrict__ seq_off) {
   __shared__ __attribute__((aligned(16))) float red[NW * MAXC * 256];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
   const int l = blockIdx.x;
@@ -352,7 +354,13 @@ __global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_kernel(const uint16_t
   const int b_per = (B + gridDim.y - 1) / gridDim.y;
   const int b_end = min(B, (int)(blockIdx.y + 1) * b_per);
   for (int b = blockIdx.y * b_per + wid; b < b_end; b += NW) {
-    const int row = b * L + l;
+    // packed batches (seq_off != NULL): sequence b owns rows [seq_off[b], seq_off[b + 1]); position l exists in it or not
+    int row = b * L + l;
+    if (seq_off != nullptr) {
+      const int r0 = seq_off[b];
+      if (l >= seq_off[b + 1] - r0) continue;
+      row = r0 + l;
+    }
     int id = ids[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     RowVec d, x;
@@ -386,58 +394,6 @@ __global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_kernel(const uint16_t
   block_reduce_store(dg, red, prow, nch, tid);
   block_reduce_store(db, red, prow + H, nch, tid);
   block_reduce_store(dp, red, prow + 2 * H, nch, tid);
-}
-
-// Packed batches: rows are tokens in arbitrary (sequence, position) order, so the position-embedding gradient goes by fp32
-// atomics like the word rows (dpos zeroed by the caller side of the entry point); partial rows [block][3][H] = dgamma,
-// dbeta, sum of dx (the segment-0 type embedding's gradient).
-__global__ __launch_bounds__(RB_THREADS) void embed_ln_bwd_packed_kernel(const uint16_t* __restrict__ dout, const int32_t* __restrict__ ids,
-                                                                  const int32_t* __restrict__ positions, const float* __restrict__ word,
-                                                                  const float* __restrict__ pos, const float* __restrict__ type0,
-                                                                  const float* __restrict__ gamma, const float* __restrict__ mean_i,
-                                                                  const float* __restrict__ rstd_i, float* __restrict__ dword,
-                                                                  float* __restrict__ dpos, float* __restrict__ partial, int T, int H,
-                                                                  int vocab, const cocodr_dropout_mask dm) {
-  __shared__ __attribute__((aligned(16))) float red[NW * MAXC * 256];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nch = H >> 2;
-  RowVec dg, db, dp;
-  zero_row(dg);
-  zero_row(db);
-  zero_row(dp);
-  for (int row = blockIdx.x * NW + wid; row < T; row += gridDim.x * NW) {
-    int id = ids[row];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    const int l = positions[row];
-    RowVec d, x;
-    load_bf16_row(dout + (size_t)row * H, nch, lane, d);
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(d.v[i][e]));
-    if (wave_max(amax) == 0.f) continue;  // alignment padding rows carry an exactly-zero gradient
-    embed_gather(word, pos, type0, id, l, H, nch, lane, x);
-    if (dm.threshold) drop_row(d, row, H, nch, lane, dm);
-    ln_bwd_row(d, x, gamma, nch, lane, H, mean_i[row], rstd_i[row], dg, db);
-    float* wrow = dword + (size_t)id * H;
-    float* prow = dpos + (size_t)l * H;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nch) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dp.v[i][e] += d.v[i][e];
-          atomicAdd(wrow + c * 4 + e, d.v[i][e]);
-          atomicAdd(prow + c * 4 + e, d.v[i][e]);
-        }
-      }
-    }
-  }
-  float* out = partial + (size_t)blockIdx.x * 3 * H;
-  block_reduce_store(dg, red, out, nch, tid);
-  block_reduce_store(db, red, out + H, nch, tid);
-  block_reduce_store(dp, red, out + 2 * H, nch, tid);
 }
 
 // dpos[l][:] = sum over batch splits of the position partial rows
@@ -726,7 +682,7 @@ extern "C" int cocodr_embed_ln_bwd_drop(const uint16_t* dout, const int32_t* ids
   hipStream_t st = (hipStream_t)stream;
   const int S = embed_bwd_splits(B);
   hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(L, S), dim3(RB_THREADS), 0, st, dout, ids, word, pos, type0, gamma, mean, rstd, dword, dpos,
-                     partial, B, L, H, vocab, drop_or_none(drop));
+                     partial, B, L, H, vocab, drop_or_none(drop), (const int32_t*)nullptr);
   CK_LAUNCH("embed_ln_bwd");
   hipLaunchKernelGGL(embed_dpos_kernel, dim3(L), dim3(256), 0, st, partial, dpos, L, H, S);
   CK_LAUNCH("embed_dpos");
@@ -750,25 +706,24 @@ extern "C" int cocodr_ln_fwd_slots(const uint16_t* y, const float* gamma, const 
   return COCODR_OK;
 }
 
-extern "C" size_t cocodr_embed_bwd_packed_partial_floats(int T, int H) { return (size_t)std::min(256, (T + NW - 1) / NW) * 3 * H; }
-extern "C" int cocodr_embed_ln_bwd_packed(const uint16_t* dout, const int32_t* ids, const int32_t* positions, const float* word,
+extern "C" size_t cocodr_embed_bwd_packed_partial_floats(int T, int H) { return (size_t)8 * std::min(512, T) * 3 * H; }
+extern "C" int cocodr_embed_ln_bwd_packed(const uint16_t* dout, const int32_t* ids, const int32_t* seq_off, const float* word,
                                           const float* pos, const float* type0, const float* gamma, const float* mean,
                                           const float* rstd, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
-                                          float* partial, int T, int max_len, int H, int vocab, const cocodr_dropout_mask* drop,
+                                          float* partial, int B, int T, int max_len, int H, int vocab, const cocodr_dropout_mask* drop,
                                           cocodr_stream_t stream) {
-  CK_ARG(dout && ids && positions && word && pos && type0 && gamma && mean && rstd && dword && dpos && dtype0 && dgamma && dbeta && partial,
+  CK_ARG(dout && ids && seq_off && word && pos && type0 && gamma && mean && rstd && dword && dpos && dtype0 && dgamma && dbeta && partial,
          "embed_ln_bwd(packed): null pointer");
-  CK_ARG(T > 0 && max_len > 0 && vocab > 0 && row_shape_ok(H), "embed_ln_bwd(packed): bad shape T=%d H=%d", T, H);
+  CK_ARG(B > 0 && T > 0 && max_len > 0 && max_len <= 512 && max_len <= T && vocab > 0 && row_shape_ok(H),
+         "embed_ln_bwd(packed): bad shape B=%d T=%d max_len=%d H=%d", B, T, max_len, H);
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = std::min(256, (T + NW - 1) / NW);
-  if (hipMemsetAsync(dpos, 0, (size_t)max_len * H * sizeof(float), st) != hipSuccess) {  // rows [0, max_len) are rewritten, as on the padded path
-    cocodr_set_error("embed_ln_bwd(packed): memset failed");
-    return COCODR_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(embed_ln_bwd_packed_kernel, dim3(nblk), dim3(RB_THREADS), 0, st, dout, ids, positions, word, pos, type0, gamma, mean,
-                     rstd, dword, dpos, partial, T, H, vocab, drop_or_none(drop));
+  const int S = embed_bwd_splits(B);
+  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(max_len, S), dim3(RB_THREADS), 0, st, dout, ids, word, pos, type0, gamma, mean, rstd, dword,
+                     dpos, partial, B, max_len, H, vocab, drop_or_none(drop), seq_off);
   CK_LAUNCH("embed_ln_bwd(packed)");
-  return launch_reduce(partial, dgamma, dbeta, dtype0, nblk, 3, H, 1, 0, st);
+  hipLaunchKernelGGL(embed_dpos_kernel, dim3(max_len), dim3(256), 0, st, partial, dpos, max_len, H, S);  // rows [0, max_len) rewritten, as on the padded path
+  CK_LAUNCH("embed_dpos(packed)");
+  return launch_reduce(partial, dgamma, dbeta, dtype0, max_len * S, 3, H, 1, 0, st);
 }
 
 extern "C" size_t cocodr_ln_bwd_partial_floats(int M, int H) { return (size_t)ln_bwd_blocks(M) * 3 * H; }
@@ -920,6 +875,65 @@ extern "C" int cocodr_cls_rows(const int32_t* seq_off, int L, int B, long long* 
   CK_ARG(idx && B > 0 && (seq_off || L > 0), "cls_rows: bad arguments");
   hipLaunchKernelGGL(cls_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, seq_off, L, B, idx);
   CK_LAUNCH("cls_rows");
+  return COCODR_OK;
+}
+
+// ------------------------------------------------------------------ packed-batch layout (include/cocodr.h "Packed batches")
+namespace {
+template <typename T>
+__device__ __forceinline__ int as_int(const void* p, size_t i) { return (int)reinterpret_cast<const T*>(p)[i]; }
+__device__ __forceinline__ int load_int(const void* p, size_t i, int bytes) {
+  return bytes == 8 ? as_int<long long>(p, i) : (bytes == 4 ? as_int<int32_t>(p, i) : as_int<uint8_t>(p, i));
+}
+// one wave per sequence: length = number of set mask entries; ok = the mask is a prefix mask (1 .. 1 0 .. 0)
+__global__ __launch_bounds__(256) void mask_lengths_kernel(const void* __restrict__ mask, int bytes, int B, int L, long long ld,
+                                                           int32_t* __restrict__ lens, int32_t* __restrict__ ok) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  int n = 0, last = -1;  // set entries seen by this lane, the highest position among them
+  for (int p = lane; p < L; p += 64)
+    if (load_int(mask, (size_t)b * ld + p, bytes) != 0) { ++n; last = p; }
+  for (int o = 32; o > 0; o >>= 1) {
+    n += __shfl_xor(n, o, 64);
+    last = max(last, __shfl_xor(last, o, 64));
+  }
+  if (lane == 0) { lens[b] = n; ok[b] = (last + 1 == n) ? 1 : 0; }
+}
+// one workgroup per sequence writes the rows of its extent
+__global__ __launch_bounds__(128) void pack_index_kernel(const void* __restrict__ ids, int bytes, long long ld, const int32_t* __restrict__ lens,
+                                                         const int32_t* __restrict__ seq_off, int L, int32_t* __restrict__ out_ids,
+                                                         int32_t* __restrict__ positions, int32_t* __restrict__ mask,
+                                                         int32_t* __restrict__ cls_slot, long long* __restrict__ src) {
+  const int b = blockIdx.x;
+  const int r0 = seq_off[b], ext = seq_off[b + 1] - r0, len = lens[b];
+  for (int p = threadIdx.x; p < ext; p += 128) {
+    const int m = p < len ? 1 : 0;
+    out_ids[r0 + p] = m ? load_int(ids, (size_t)b * ld + p, bytes) : 0;
+    positions[r0 + p] = p;
+    mask[r0 + p] = m;
+    cls_slot[r0 + p] = p == 0 ? b : -1;
+    if (src) src[r0 + p] = (long long)b * L + p;
+  }
+}
+}  // namespace
+
+extern "C" int cocodr_mask_lengths(const void* mask, int elem_bytes, int B, int L, long long row_stride, int32_t* lens, int32_t* prefix_ok,
+                                   cocodr_stream_t stream) {
+  CK_ARG(mask && lens && prefix_ok, "mask_lengths: null pointer");
+  CK_ARG(B > 0 && L > 0 && row_stride >= L && (elem_bytes == 1 || elem_bytes == 4 || elem_bytes == 8), "mask_lengths: bad arguments");
+  hipLaunchKernelGGL(mask_lengths_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask, elem_bytes, B, L, row_stride, lens, prefix_ok);
+  CK_LAUNCH("mask_lengths");
+  return COCODR_OK;
+}
+
+extern "C" int cocodr_pack_index(const void* ids, int elem_bytes, long long row_stride, const int32_t* lens, const int32_t* seq_off, int B,
+                                 int L, int32_t* out_ids, int32_t* positions, int32_t* mask, int32_t* cls_slot, long long* src,
+                                 cocodr_stream_t stream) {
+  CK_ARG(ids && lens && seq_off && out_ids && positions && mask && cls_slot, "pack_index: null pointer");
+  CK_ARG(B > 0 && L > 0 && L % 32 == 0 && (elem_bytes == 4 || elem_bytes == 8) && row_stride > 0, "pack_index: bad arguments (L must be a multiple of 32)");
+  hipLaunchKernelGGL(pack_index_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, ids, elem_bytes, row_stride, lens, seq_off, L, out_ids,
+                     positions, mask, cls_slot, src);
+  CK_LAUNCH("pack_index");
   return COCODR_OK;
 }
 

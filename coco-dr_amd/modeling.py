@@ -315,40 +315,87 @@ class _EncoderFn(torch.autograd.Function):
 
 
 # =============================================================================== packed (variable-length) batches
+def packed_extents(lengths, B: int, L: int):
+    """Host arithmetic of the packed layout: sequence b gets an extent of ceil32(max(len_b, 1)) rows (a fully masked sequence
+    keeps one masked block).  Returns (int32 [2B + 1] = lengths followed by the B + 1 row offsets, T, longest extent)."""
+    import numpy as np
+    lens = np.ascontiguousarray(np.asarray(lengths).reshape(-1), dtype=np.int64)
+    if lens.shape[0] != B or (lens < 0).any() or (lens > L).any():
+        raise ValueError(f"packed batch: lengths must be {B} integers in [0, {L}]")
+    ext = (np.maximum(lens, 1) + 31) // 32 * 32
+    host = np.zeros(2 * B + 1, np.int32)
+    host[:B] = lens
+    np.cumsum(ext, out=host[B + 1:])
+    return host, int(host[-1]), int(ext.max())
+
+
 class PackedIndex:
     """Device-side description of a batch stored back to back (include/cocodr.h "Packed batches"): sequence b owns rows
-    [seq_off[b], seq_off[b+1]), an extent of ceil32(length) rows.  ``src`` maps packed row -> row of the padded [B*L] layout."""
+    [seq_off[b], seq_off[b+1]), an extent of ceil32(length) rows.  ``src`` maps packed row -> row of the padded [B*L] layout.
 
-    def __init__(self, ids: torch.Tensor, mask: torch.Tensor, lens_host: torch.Tensor):
-        B, L = ids.shape
+    Built per batch by ONE native launch (``cocodr_pack_index``) from the padded ids and the B lengths.  The row count T must
+    reach the host (it sizes every GEMM of the step):
+      * ``lengths`` known on the host - the reference's collators pad on the CPU (COCO/data.py:135-144,
+        ANCE/data/msmarco_data.py:381-382), ``collate.CoCondenserCollator`` emits them - : extents and offsets are a numpy
+        cumsum, one small pinned host -> device copy, nothing waits for the device queue;
+      * only the device mask: ``cocodr_mask_lengths`` + a device -> host copy of 2 B integers, which waits for everything
+        queued on the stream before it (the cost of not knowing the lengths; results are the same)."""
+
+    def __init__(self, ids: torch.Tensor, lens_host, L: Optional[int] = None):
+        if ids.dim() != 2 or ids.dtype not in (torch.int32, torch.int64):
+            raise ValueError("PackedIndex: ids must be an int32 / int64 [B, L] tensor")
+        if not ids.is_cuda:
+            raise RuntimeError("PackedIndex describes a batch in HBM: move the ids with .to('cuda') (there is no CPU fallback)")
+        if ids.stride(1) != 1:
+            ids = ids.contiguous()
+        B, L_in = ids.shape
+        Lp = (L_in + 31) // 32 * 32 if L is None else int(L)
+        host, self.T, self.max_len = packed_extents(lens_host, B, L_in)
         dev = ids.device
-        ext_h = ((lens_host.clamp(min=1) + 31) // 32) * 32          # a fully masked sequence keeps one (masked) block
-        off_h = torch.zeros(B + 1, dtype=torch.int64)
-        off_h[1:] = torch.cumsum(ext_h, 0)
-        self.B, self.L, self.T, self.max_len = B, L, int(off_h[-1]), int(ext_h.max())
-        self.seq_off = off_h.to(torch.int32).to(dev)
-        ext_d, lens_d = ext_h.to(dev), lens_host.to(dev)
-        row_seq = torch.repeat_interleave(torch.arange(B, device=dev), ext_d, output_size=self.T)
-        pos = torch.arange(self.T, device=dev) - self.seq_off[row_seq].to(torch.int64)
-        self.src = row_seq * L + pos                                 # extents never exceed L (L % 32 == 0)
-        self.positions = pos.to(torch.int32)
-        self.mask = (pos < lens_d[row_seq]).to(torch.int32)
-        self.ids = (ids.reshape(-1)[self.src] * self.mask).contiguous()
-        self.cls_slot = torch.where(pos == 0, row_seq, torch.full_like(row_seq, -1)).to(torch.int32)
-        self.cls_rows = self.seq_off[:-1].to(torch.int64)
+        self.B, self.L = B, Lp
+        self.lengths = host[:B]
+        staged = torch.from_numpy(host).pin_memory().to(dev, non_blocking=True)
+        self.seq_off = staged[B:]
+        buf = torch.empty(4 * self.T, dtype=torch.int32, device=dev)
+        self.ids, self.positions, self.mask, self.cls_slot = buf[:self.T], buf[self.T:2 * self.T], buf[2 * self.T:3 * self.T], buf[3 * self.T:]
+        self.src = torch.empty(self.T, dtype=torch.int64, device=dev)
+        check(lib().cocodr_pack_index(ptr(ids), ids.element_size(), ids.stride(0), ptr(staged), ptr(self.seq_off), B, Lp, ptr(self.ids),
+                                      ptr(self.positions), ptr(self.mask), ptr(self.cls_slot), ptr(self.src), stream_ptr()), "pack_index")
+        self._keep = (staged, buf)
         self.c_struct = N.PackedBatch(self.ids.data_ptr(), self.positions.data_ptr(), self.mask.data_ptr(), self.seq_off.data_ptr(),
-                                      self.cls_slot.data_ptr(), B, self.T, self.max_len, L)
+                                      self.cls_slot.data_ptr(), B, self.T, self.max_len, Lp)
+
+    @property
+    def cls_rows(self) -> torch.Tensor:
+        return self.seq_off[:-1].to(torch.int64)
 
     @staticmethod
-    def build(ids: torch.Tensor, mask: torch.Tensor) -> Optional["PackedIndex"]:
-        """None when a mask is not a prefix mask (the reference pads at the end, COCO/data.py:135-144; anything else runs padded).
-        One device -> host copy of B + 1 integers: the GEMM row count must be known to the host."""
-        lens = mask.sum(1)
-        prefix = (mask[:, 1:] <= mask[:, :-1]).all().to(lens.dtype)
-        host = torch.cat([lens, prefix[None]]).cpu()
-        if int(host[-1]) == 0:
+    def build(ids: torch.Tensor, mask: Optional[torch.Tensor] = None, lengths=None) -> Optional["PackedIndex"]:
+        """``lengths`` (host integers, = attention_mask.sum(1) of prefix masks): no device -> host traffic.  Otherwise the lengths
+        are read back from the device mask (a stream synchronisation); None when a mask is not a prefix mask (the reference pads
+        at the end, COCO/data.py:135-144; anything else runs padded)."""
+        if lengths is not None:
+            if torch.is_tensor(lengths):
+                if lengths.is_cuda:
+                    raise ValueError("lengths must live on the host (a CPU tensor, list or numpy array); on the device pass the mask alone")
+                lengths = lengths.numpy()
+            return PackedIndex(ids, lengths)
+        B, L = ids.shape
+        if mask is None:
+            import numpy as np
+            return PackedIndex(ids, np.full(B, L, np.int64))
+        if mask.shape != ids.shape:
+            raise ValueError("attention_mask shape must match input_ids")
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        if mask.element_size() not in (1, 4, 8) or mask.is_floating_point() or mask.stride(1) != 1:
+            mask = mask.to(torch.int32).contiguous()
+        out = torch.empty(2 * B, dtype=torch.int32, device=ids.device)
+        check(lib().cocodr_mask_lengths(ptr(mask), mask.element_size(), B, L, mask.stride(0), ptr(out), ptr(out[B:]), stream_ptr()), "mask_lengths")
+        host = out.cpu().numpy()
+        if not host[B:].all():
             return None
-        return PackedIndex(ids, mask, host[:-1].to(torch.int64))
+        return PackedIndex(ids, host[:B])
 
     def unpack(self, x: torch.Tensor) -> torch.Tensor:
         """[T, H] -> padded [B, L, H]; rows past a sequence's extent are zeros (the padded path leaves masked garbage there)."""
@@ -431,8 +478,9 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         self.dropout_seed: Optional[int] = None  # None: torch.initial_seed() at the first dropout forward
         self._dropout_calls = 0
         # store batches back to back (no padding rows beyond 32-token alignment) instead of padded to one length: same
-        # outputs at the real tokens, ~1/3 fewer rows on MS MARCO-shaped batches (include/cocodr.h "Packed batches")
-        self.pack_sequences = False
+        # outputs at the real tokens, ~1/3 fewer rows on MS MARCO-shaped batches (include/cocodr.h "Packed batches").  The
+        # default since round 4; False = every kernel over all B x L rows, as the reference computes
+        self.pack_sequences = True
         self.cls_tail = True  # encode_cls(): last layer on the [CLS] rows only (cocodr_config.cls_tail); False = always the full layer
         self.reset_parameters()
         self._build_views()  # HF-named nn.Parameter views of the flats: what parameters() / named_parameters() yield
@@ -894,41 +942,55 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
             mask = torch.nn.functional.pad(mask, (0, Lp - L))
         return ids.contiguous(), mask.contiguous(), L
 
-    def pack(self, input_ids, attention_mask=None) -> Optional["PackedIndex"]:
-        """The packed-layout description of a batch (or None when its masks are not prefix masks), for callers that reuse a batch
-        or know the lengths already: building it costs one device -> host copy of the B lengths, which ``forward`` otherwise
-        pays on every call when ``pack_sequences`` is set."""
-        ids, mask, _ = self._prep(input_ids, attention_mask)
-        return PackedIndex.build(ids, mask)
+    def pack(self, input_ids, attention_mask=None, lengths=None) -> Optional["PackedIndex"]:
+        """The packed-layout description of a batch (or None when its masks are not prefix masks), for callers that reuse a
+        batch: ``forward`` builds it per call when ``pack_sequences`` is set (one native launch; see ``PackedIndex`` for what
+        knowing the ``lengths`` on the host saves)."""
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [B, L], got {tuple(input_ids.shape)}")
+        if input_ids.dtype not in (torch.int32, torch.int64):
+            input_ids = input_ids.to(torch.int32)
+        return PackedIndex.build(input_ids, attention_mask, lengths)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None,
                 output_hidden_states: bool = False, return_dict: bool = True, packed_index: Optional["PackedIndex"] = None,
-                cls_only: bool = False, **unused):
+                cls_only: bool = False, lengths=None, **unused):
         """``cls_only`` (what ``encode_cls`` passes): the caller reads ``cls_fp32`` alone - the last layer then runs its output
         projection, LayerNorms and FFN on the [CLS] rows only (identical values, ~6 % less work; not with dropout, where the full
-        layer runs); ``last_hidden_state`` / ``hidden_states`` are None."""
+        layer runs); ``last_hidden_state`` / ``hidden_states`` are None.
+        ``lengths``: the B sequence lengths on the HOST (= attention_mask.sum(1); what a collator that pads on the CPU knows) -
+        with ``pack_sequences`` the packed layout is then built without reading anything back from the device."""
         if token_type_ids is not None and bool(token_type_ids.any()):
             raise NotImplementedError("token_type_ids != 0: the reference never passes segment ids (COCO/data.py:140)")
         if position_ids is not None:
             raise NotImplementedError("custom position_ids are not on the reference path")
-        ids, mask, L = self._prep(input_ids, attention_mask)
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [B, L], got {tuple(input_ids.shape)}")
+        B, L = input_ids.shape
         if L > self.config.max_position_embeddings:
             raise ValueError(f"sequence length {L} exceeds max_position_embeddings={self.config.max_position_embeddings}")
+        if attention_mask is not None and attention_mask.shape != input_ids.shape:
+            raise ValueError("attention_mask shape must match input_ids")
         pk = packed_index
-        if pk is not None and (pk.B, pk.L) != tuple(ids.shape):
-            raise ValueError(f"packed_index describes a {pk.B} x {pk.L} batch, the inputs are {tuple(ids.shape)}")
-        if pk is None and self.pack_sequences:
-            pk = PackedIndex.build(ids, mask)
-        if pk is not None and output_hidden_states and torch.is_grad_enabled() and self.flat_decay.requires_grad:
-            # a training forward whose caller may read (and back-propagate through) ANY hidden_states[i] - the Condenser head
-            # under the reference wrapper reads hidden_states[skip_from], COCO/modeling.py:212-216: only the padded Function
-            # makes the intermediate states differentiable outputs ("taps"), so this call runs padded
+        if pk is not None and (pk.B, pk.L) != (B, (L + 31) // 32 * 32):
+            raise ValueError(f"packed_index describes a {pk.B} x {pk.L} batch, the inputs are {tuple(input_ids.shape)}")
+        # a training forward whose caller may read (and back-propagate through) ANY hidden_states[i] - the Condenser head under
+        # the reference wrapper reads hidden_states[skip_from], COCO/modeling.py:212-216: only the padded Function makes the
+        # intermediate states differentiable outputs ("taps"), so such a call runs padded
+        want_taps = bool(output_hidden_states and torch.is_grad_enabled() and self.flat_decay.requires_grad)
+        if want_taps:
             pk = None
+        elif pk is None and self.pack_sequences:
+            if not self.flat_decay.is_cuda:
+                raise RuntimeError("CocoBertModel runs on an MI355X only: move it with .to('cuda') (there is no CPU fallback)")
+            pk = self.pack(input_ids, attention_mask, lengths)  # None: not prefix masks -> padded
+        ids = mask = None
+        if pk is None:
+            ids, mask, L = self._prep(input_ids, attention_mask)
         cls_only = bool(cls_only and not output_hidden_states and self.cls_tail)
         if pk is not None:
             last, cls = _PackedEncoderFn.apply(self.flat_decay, self.flat_nodecay, self, pk, torch.is_grad_enabled(), cls_only)
         else:
-            want_taps = bool(output_hidden_states and torch.is_grad_enabled() and self.flat_decay.requires_grad)
             outs = _EncoderFn.apply(self.flat_decay, self.flat_nodecay, ids, mask, self, torch.is_grad_enabled(), want_taps, cls_only)
             last, cls, taps = outs[0], outs[1], outs[2:]
         if last is None:  # [CLS] tail
@@ -951,9 +1013,9 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         self._last_hidden_states = None
         return out if return_dict else (out.last_hidden_state, None)
 
-    def encode_cls(self, input_ids, attention_mask=None, packed_index=None) -> torch.Tensor:
+    def encode_cls(self, input_ids, attention_mask=None, packed_index=None, lengths=None) -> torch.Tensor:
         """fp32 last-layer [CLS] rows [B,H] with autograd (what every reference wrapper consumes)."""
-        return self.forward(input_ids, attention_mask, packed_index=packed_index, cls_only=True).cls_fp32
+        return self.forward(input_ids, attention_mask, packed_index=packed_index, cls_only=True, lengths=lengths).cls_fp32
 
 
 # =============================================================================== ANCE wrapper
@@ -1215,7 +1277,7 @@ class CoCondenserForPretraining(nn.Module):
             late_mlm = bool(getattr(self.model_args, "late_mlm", False))
             mlm_loss, cls = condenser_step(self.lm, self.c_head, ids, mask, labels, skip_from, late_mlm)
         else:
-            cls = self.lm.encode_cls(ids, mask, packed_index=model_input.get("packed_index"))  # [2b, H] fp32
+            cls = self.lm.encode_cls(ids, mask, packed_index=model_input.get("packed_index"), lengths=model_input.get("lengths"))  # [2b, H] fp32
         W = self._world_size()
         force = bool(os.environ.get("COCODR_FORCE_DIST")) and torch.distributed.is_initialized()  # 1-rank test of the N>1 path
         if W > 1 or force:

@@ -469,10 +469,26 @@ int cocodr_embed_ln_fwd_packed(const int32_t* ids, const int32_t* positions, con
                                float* rstd, int T, int H, int vocab, float eps, const cocodr_dropout_mask* drop,
                                cocodr_stream_t stream);
 size_t cocodr_embed_bwd_packed_partial_floats(int T, int H);
-int cocodr_embed_ln_bwd_packed(const uint16_t* dout, const int32_t* ids, const int32_t* positions, const float* word,
+/* one workgroup per position (as on the padded path: the position rows are plain sums over the sequences that reach that
+ * position, only the sparse word rows are fp32 atomics); ids int32 [T], seq_off int32 [B+1] */
+int cocodr_embed_ln_bwd_packed(const uint16_t* dout, const int32_t* ids, const int32_t* seq_off, const float* word,
                                const float* pos, const float* type0, const float* gamma, const float* mean, const float* rstd,
-                               float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta, float* partial, int T,
+                               float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta, float* partial, int B, int T,
                                int max_len, int H, int vocab, const cocodr_dropout_mask* drop, cocodr_stream_t stream);
+/* The packed-layout description of a padded batch, built on the device in ONE launch (the collator of the reference pads on
+ * the CPU - COCO/data.py:135-144, ANCE/data/msmarco_data.py:381-382 - so a host that keeps the lengths passes them; one that
+ * has only the device mask asks cocodr_mask_lengths first and reads 2 B integers back).
+ *   cocodr_mask_lengths: mask [B, L] with elem_bytes 1 / 4 / 8 per entry, rows row_stride entries apart -> lens[b] = set
+ *     entries of row b, prefix_ok[b] = 1 when they are exactly the first lens[b] (only such batches can be packed).
+ *   cocodr_pack_index: ids [B, .] (int32 or int64: elem_bytes 4 / 8; rows row_stride entries apart), lens int32 [B] (<= row
+ *     length), seq_off int32 [B+1] = running sum of the extents ceil32(max(len, 1)); writes the int32 [T] arrays of
+ *     cocodr_packed_batch (token id or 0 on alignment rows, position, mask, cls_slot) and, when src != NULL, the row of the
+ *     padded [B, L] layout every packed row came from (int64 [T]; L % 32 == 0 is that layout's row length). */
+int cocodr_mask_lengths(const void* mask, int elem_bytes, int B, int L, long long row_stride, int32_t* lens, int32_t* prefix_ok,
+                        cocodr_stream_t stream);
+int cocodr_pack_index(const void* ids, int elem_bytes, long long row_stride, const int32_t* lens, const int32_t* seq_off, int B,
+                      int L, int32_t* out_ids, int32_t* positions, int32_t* mask, int32_t* cls_slot, long long* src,
+                      cocodr_stream_t stream);
 /* cocodr_ln_fwd whose fp32 [CLS] copies are named row by row: cls_slot int32 [M], -1 or the row of cls_out a row goes to */
 int cocodr_ln_fwd_slots(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean, float* rstd,
                         float* cls_out, int cls_stride, const int32_t* cls_slot, int M, int H, float eps,

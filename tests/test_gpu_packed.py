@@ -105,6 +105,7 @@ def test_packed_forward_equals_padded_forward(L):
     m = build(cfgd, P).eval()
     ids, mask, lens = ragged_batch(9, L, cfgd["vocab_size"], 3)
     with torch.no_grad():
+        m.pack_sequences = False
         ref = m(input_ids=t(ids), attention_mask=t(mask), output_hidden_states=True)
         m.pack_sequences = True
         got = m(input_ids=t(ids), attention_mask=t(mask), output_hidden_states=True)
