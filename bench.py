@@ -525,11 +525,12 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
 
     step_no = [0]
     flats = [bert.flat_decay, bert.flat_nodecay]
-    seen = []  # (id of the batch dict, had a prebuilt layout) per step: tests/test_gpu_bench_contract.py
+    seen, last = [], [None]  # per step: (a dict the previous step did not see, without a prebuilt layout); tests/test_gpu_bench_contract.py
 
     def step():
         batch = fresh_batch(step_no[0])
-        seen.append((id(batch), "packed_index" in batch))
+        seen.append(batch is not last[0] and "packed_index" not in batch)
+        last[0] = batch
         step_no[0] += 1
         opt.zero_grad(set_to_none=True)
         loss = model(batch, None)
@@ -604,7 +605,7 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
                                 "MS MARCO-shaped lengths, padded to L; every kernel runs over all B x L rows")}
             roof.update(exec_info)
             exec_info["executed_flops_per_step"] = gemm_flops / sampled + attn_flops_per_step
-    exec_info["fresh_batches"] = bool(len({i for i, _ in seen}) == len(seen) and not any(p for _, p in seen))
+    exec_info["fresh_batches"] = bool(seen and all(seen))
     del opt, model, bert
     torch.cuda.empty_cache()
     return dt, float(loss.detach()), roof, cfg, pool[0][:2], exec_info
@@ -680,7 +681,7 @@ def main():
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    use_dist = world > 1 or bool(os.environ.get("COCODR_FORCE_DIST"))  # FORCE: exercise the N>1 path on one GPU
+    use_dist = world > 1
     backend = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -14,10 +14,7 @@ BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcocodr_hip.so")
 SOURCES = ["core.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "loss.hip", "score.hip", "merge.hip", "encoder.hip", "collate.hip", "probe.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
-FLAGS += os.environ.get("COCODR_EXTRA_FLAGS", "").split()  # experiment builds only (e.g. -DCOCODR_PP_VARIANTS)
-if os.environ.get("COCODR_EXPERIMENTAL"):  # measured-and-not-adopted pipelines (gemm_w4.hip: one wave per SIMD, impl 20)
-    SOURCES.append("gemm_w4.hip")
-    FLAGS.append("-DCOCODR_W4")
+FLAGS += os.environ.get("COCODR_EXTRA_FLAGS", "").split()  # measurement builds only (tools/gemm_ablate.py: -DCOCODR_ABL_*)
 
 
 def _hipcc() -> str:

@@ -321,6 +321,8 @@ def condenser_step(bert: CocoBertModel, head: CondenserHead, input_ids, attentio
         labels = torch.nn.functional.pad(labels, (0, ids.shape[1] - L), value=-100)
     if not (0 <= skip_from <= bert.config.num_hidden_layers):
         raise ValueError(f"skip_from={skip_from} outside [0, {bert.config.num_hidden_layers}]")
+    if torch.is_grad_enabled():
+        bert._dp_adopt_ddp_wrapper()  # (a torch DistributedDataParallel wrapper around the model: the model reduces, see there)
     if getattr(bert, "_dp_hooks", None) is not None and hasattr(bert, "_dp_unsynced"):
         bert._dp_adopt(head.flat_decay, head.flat_nodecay)  # the head's gradients are averaged with the backbone's, in flight or by hook
     return _CondenserStepFn.apply(bert.flat_decay, bert.flat_nodecay, head.flat_decay, head.flat_nodecay, ids, mask,

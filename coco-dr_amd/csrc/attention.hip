@@ -751,11 +751,11 @@ int attn_fwd_any(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float*
          "attn_fwd: dropout indexes at most 2^33 probabilities");
   const int H = heads * 64;
   const size_t lds = (size_t)2 * L * 128 + (size_t)L * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static cocodr_lds_once attr_done;
+  if (attr_done.pending()) {
     lds_attr(attn_fwd_kernel<false>);
     lds_attr(attn_fwd_kernel<true>);
-    attr_done = true;
+    attr_done.done();
   }
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_ATTN, st, 4.0 * B * heads * (double)L * L * 64);
@@ -800,14 +800,14 @@ int attn_bwd_any(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, 
   const cocodr_dropout_mask dm = dropping ? *drop : kNoDrop;
   const int H = heads * 64;
   const size_t lds = (size_t)4 * L * 128 + (size_t)3 * L * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static cocodr_lds_once attr_done;
+  if (attr_done.pending()) {
     lds_attr(attn_bwd_kernel<false, false>); lds_attr(attn_bwd_kernel<true, false>);
     lds_attr(attn_bwd_kernel<false, true>); lds_attr(attn_bwd_kernel<true, true>);
     lds_attr(attn_bwd_dq_kernel<false, false>); lds_attr(attn_bwd_dq_kernel<true, false>);
     lds_attr(attn_bwd_dq_kernel<false, true>); lds_attr(attn_bwd_dq_kernel<true, true>);
     lds_attr(attn_bwd_dkv_kernel<false>); lds_attr(attn_bwd_dkv_kernel<true>);
-    attr_done = true;
+    attr_done.done();
   }
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(PROF_ATTN, st, 10.0 * B * heads * (double)L * L * 64);

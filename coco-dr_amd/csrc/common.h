@@ -134,6 +134,20 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& gp) {
   gp = fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a call site keeps one of these (static) and
+// raises the limit once per device it launches on (a bit per device ordinal; a second thread at worst repeats the idempotent call)
+#include <atomic>
+struct cocodr_lds_once {
+  std::atomic<unsigned long long> mask{0};
+  static unsigned long long bit() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return 1ull << (dev & 63);
+  }
+  bool pending() const { return (mask.load(std::memory_order_acquire) & bit()) == 0; }
+  void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
+
 // ------------------------------------------------------------------ dropout masks (cocodr_dropout_mask, include/cocodr.h)
 // One 32-bit word per PAIR of adjacent elements of the site's tensor: w = lowbias32(pair ^ k0) ^ k1, element 2 pair takes
 // the low 16 bits, element 2 pair + 1 the high 16 bits, keep iff the 16-bit value >= threshold (= round(p * 65536)).

@@ -555,11 +555,11 @@ void launch_glds(const cocodr_gemm_args& a, hipStream_t st) {
   const int flat = (a.batch > 1 && flat_env) ? 1 : 0;
   dim3 grid(flat ? ntm * ntn * a.batch : ntm * ntn, flat ? 1 : a.batch);
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static cocodr_lds_once attr_done;
+  if (attr_done.pending()) {
     hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, true, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)gemm_glds_kernel<BMv, BKv, WTM, WTN, LD, TA, TB, false, WC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done.done();
   }
   static int stagger = -1;  // x 4096 clocks; COCODR_GEMM_STAGGER overrides (0 disables)
   if (stagger < 0) {
@@ -583,7 +583,6 @@ void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
 }  // namespace cocodr_gemm_v2
 using cocodr_gemm_v2::launch_glds_any;
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st);  // gemm_pp.hip: the ping-pong pipeline
-bool cocodr_gemm_w4_launch(const cocodr_gemm_args& a, hipStream_t st);         // gemm_w4.hip: one wave per SIMD, 128 x 128 wave tiles
 void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, size_t ws_floats, hipStream_t st);
 size_t cocodr_gemm_pp_multi_ws_floats();
 size_t cocodr_gemm_pp_multi_ws_floats_for(const cocodr_gemm_args* a, int n);
@@ -610,7 +609,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG(impl >= 0 && impl <= 21 && impl != 17, "gemm_set_impl: impl must be in [0,13] or 18 (ping-pong with two fat phases per K-tile); 14-16, 19: schedule variants of experiment builds");
+  CK_ARG((impl >= 0 && impl <= 13) || impl == 18, "gemm_set_impl: impl must be in [0,13] or 18 (ping-pong with two fat phases per K-tile)");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -721,10 +720,7 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   const int cs_rows = colsum_rows(impl, a.M);  // the kernels with 128-column tiles reduce in their epilogue
   CK_ARG(!cs_part || cs_out || cs_rows > 0, "gemm: deferred column sums (colsum == NULL) are not available on this pipeline; ask cocodr_gemm_colsum_rows first");
   if (cs_rows == 0) a.colsum_partial = nullptr;
-#if defined(COCODR_W4)  // experiment builds (COCODR_EXPERIMENTAL=1 python coco-dr_amd/build.py): gemm_w4.hip, impl 20
-  if (impl == 20 && cocodr_gemm_w4_launch(a, st)) { /* one wave per SIMD */ } else
-#endif
-  if (impl >= 13) cocodr_gemm_pp_launch(a, impl == 20 ? 2 : (impl == 21 ? 107 : (impl == 13 ? 2 : 100 + impl - 13)), st);
+  if (impl >= 13) cocodr_gemm_pp_launch(a, impl == 18 ? 105 : 2, st);
   else if (impl == 12) launch_glds_any<256, 64, 2, 1, 4, 3>(a, st);
   else if (impl == 11) launch_glds_any<256, 32, 2, 4>(a, st);
   else if (impl == 10) launch_glds_any<256, 64, 4, 2, 4>(a, st);

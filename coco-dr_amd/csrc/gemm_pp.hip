@@ -126,203 +126,14 @@ __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const Fra
   }
 }
 
-// ---- register-direct epilogue (bf16 results): the accumulators never pass through LDS.
-// With the operands swapped a lane holds, per 32 x 32 block, ONE output row (lane & 31) and the 4-column groups
-// 8 rg + 4 (lane >> 5) .. + 3, rg = 0..3.  Bias / GELU / residual / dropout are applied there in fp32; after the bf16 pack one
-// v_permlane32_swap per dword hands the upper half-wave's group rg to the lower lane and the lower half-wave's group rg + 1 to
-// the upper lane, so every lane ends with 8 consecutive columns = one 16-B store (lanes 0-31: columns 16 k .. + 7,
-// lanes 32-63: 16 k + 8 .. + 15 of the same row).  No barrier, no LDS pass, no second wave-row pass.
-// The residual / GELU' operand is read in the same layout (8 B per lane and group), one 32-row block ahead.
-// MEASURED AND NOT ADOPTED (round 3, profiles/r03_gemm_pp_reg_epilogue.md; opt-in with COCODR_PP_REGEPI=1): in the BERT-large
-// training step it is 4 % SLOWER at 200 sequences and 1-2 % slower at 64 (the residual / GELU' reads in this layout expose their
-// latency; 32-B row segments per store instruction); with the stores compiled out the kernels lose only 4-7 % with EITHER
-// epilogue - the "5.3 us per tile" of the LDS-staged form is the memory system taking the tile's 128 KB, not the LDS passes.
-__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
-  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-  a = r[0];
-  b = r[1];
-}
-template <int NB>
-__device__ __forceinline__ void pp_reg_epilogue(const cocodr_gemm_args& p, const int z, const f32x16 (&acc)[4][NB], const int m0,
-                                                const int n0, const int wr, const int wc, const int lane) {
-  const int rl = lane & 31, hh = lane >> 5;
-  const int colw = n0 + wc * 32 * NB + 4 * hh;  // this lane's first column (block 0, group 0)
-  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
-  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
-  uint16_t* __restrict__ C = reinterpret_cast<uint16_t*>(p.C) + (size_t)z * p.strideC;
-  uint16_t* __restrict__ C2 = p.C2 ? p.C2 + (size_t)z * p.strideC : nullptr;
-  const int epi = p.epi;
-  const bool need_r = R_ != nullptr && (epi == COCODR_EPI_ADD || epi == COCODR_EPI_DGELU);
-  float4 bv[NB][4];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg)
-      bv[b][rg] = bias ? *reinterpret_cast<const float4*>(bias + colw + b * 32 + 8 * rg) : make_float4(0.f, 0.f, 0.f, 0.f);
-  uint2 rr[2][NB][4];
-  auto fetch_r = [&](int ai, uint2 (&dst)[NB][4]) {
-    const int gm = m0 + wr * 128 + ai * 32 + rl;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        dst[b][rg] = make_uint2(0, 0);
-        if (need_r && gm < p.M) dst[b][rg] = *reinterpret_cast<const uint2*>(R_ + (size_t)gm * p.ldr + colw + b * 32 + 8 * rg);
-      }
-  };
-  fetch_r(0, rr[0]);
-#pragma unroll
-  for (int ai = 0; ai < 4; ++ai) {
-    if (ai + 1 < 4) fetch_r(ai + 1, rr[(ai + 1) & 1]);
-    const int gm = m0 + wr * 128 + ai * 32 + rl;
-    const bool ok = gm < p.M;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        uint32_t w[2][2], w2[2][2];  // [group 2k / 2k + 1][dword] packed bf16 pairs of the result (and of GELU')
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int rg = 2 * k + g;
-          float v[4] = {acc[ai][b][rg * 4 + 0] + bv[b][rg].x, acc[ai][b][rg * 4 + 1] + bv[b][rg].y,
-                        acc[ai][b][rg * 4 + 2] + bv[b][rg].z, acc[ai][b][rg * 4 + 3] + bv[b][rg].w};
-          if (epi == COCODR_EPI_GELU && C2 == nullptr) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-          } else if (epi == COCODR_EPI_GELU) {
-            float gp[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gelu_erf_both(v[j], v[j], gp[j]);
-            w2[g][0] = pack2bf(gp[0], gp[1]);
-            w2[g][1] = pack2bf(gp[2], gp[3]);
-          } else if (epi == COCODR_EPI_ADD) {
-            if (p.drop.threshold) drop_apply<4>(v, (uint64_t)gm * p.N + (colw + b * 32 + 8 * rg), p.drop);
-            float r[4];
-            unpack4(rr[ai & 1][b][rg], r);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += r[j];
-          } else if (epi == COCODR_EPI_DGELU) {
-            float r[4];
-            unpack4(rr[ai & 1][b][rg], r);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= r[j];
-          }
-          w[g][0] = pack2bf(v[0], v[1]);
-          w[g][1] = pack2bf(v[2], v[3]);
-        }
-        swap_halves(w[0][0], w[1][0]);
-        swap_halves(w[0][1], w[1][1]);
-        const size_t o = (size_t)gm * p.ldc + (n0 + wc * 32 * NB + b * 32 + 16 * k + 8 * hh);
-#if defined(COCODR_ABL_EPI_NOSTORE)  // ablation: everything but the global stores
-        asm volatile("" ::"v"(w[0][0]), "v"(w[0][1]), "v"(w[1][0]), "v"(w[1][1]), "v"(o));
-        if (epi == COCODR_EPI_GELU && C2 != nullptr) asm volatile("" ::"v"(w2[0][0]), "v"(w2[0][1]), "v"(w2[1][0]), "v"(w2[1][1]));
-#else
-        if (ok) *reinterpret_cast<uint4*>(C + o) = make_uint4(w[0][0], w[0][1], w[1][0], w[1][1]);
-        if (epi == COCODR_EPI_GELU && C2 != nullptr) {
-          swap_halves(w2[0][0], w2[1][0]);
-          swap_halves(w2[0][1], w2[1][1]);
-          if (ok) *reinterpret_cast<uint4*>(C2 + o) = make_uint4(w2[0][0], w2[0][1], w2[1][0], w2[1][1]);
-        }
-#endif
-      }
-  }
-}
-
-// ---- epilogue of the persistent walk: four 64-row passes of the fp32 tile through the TOP 64 KiB of the LDS ([96 K, 160 K): the
-// ring's buffer-1 slots B1 / A1 plus the 32 KiB behind the ring), so that the next tile's K-tile 0 (buffer 0) and the first
-// half of its K-tile 1 (buffer-1 slots A0 / B0) stay in flight underneath.  64 rows x 256 floats fill the region exactly: no
-// padding, the 16-B blocks of a row are XOR-swizzled with row & 15 instead (writes: 8 consecutive rows per LDS cycle hit 8
-// different blocks; reads: a row's 32 lanes cover all 64 banks).  Row-major 16-B global accesses as in the two-pass epilogue.
-// Every LDS access is inline assembly: hipcc orders the LDS accesses it can see behind ALL outstanding LDS-DMA (vmcnt(0)).
-__device__ __forceinline__ void asm_ds_write_b128(uint32_t addr, float a, float b, float c, float d) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  const v4f v = {a, b, c, d};
-  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void pp_lds4_epilogue(const cocodr_gemm_args& p, const int z, const f32x16 (&acc)[4][2], const int m0, const int n0,
-                                                 const int wr, const int wc, const int tid_in, const int lane_in, const uint32_t lds_base) {
-  constexpr int NCH = 4;  // 64 rows x 32 chunks of 8 columns over 512 threads
-  // opaque copies: every address below is a function of the thread id alone, i.e. invariant over the caller's tile loop - hoisted
-  // out of it, the ~20 of them are spilled over the main loop and reloaded per tile; a few integer operations per tile are cheaper
-  int tid = tid_in, lane = lane_in;
-  asm volatile("" : "+v"(tid), "+v"(lane));
-  const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
-  const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
-  const bool need_r = R_ != nullptr && (p.epi == COCODR_EPI_ADD || p.epi == COCODR_EPI_DGELU);
-  const int c8 = (tid & 31) << 3;  // this thread's 8 columns (512 % 32 == 0: the same in every chunk)
-  const int gn = n0 + c8;
-  uint4 rcur[NCH], rnext[NCH];
-  auto fetch_r = [&](int h, uint4 (&dst)[NCH]) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int gm = m0 + h * 64 + ((tid + i * NTHREADS) >> 5);
-      dst[i] = make_uint4(0, 0, 0, 0);
-      if (need_r && gm < p.M) dst[i] = *reinterpret_cast<const uint4*>(R_ + (size_t)gm * p.ldr + gn);
-    }
-  };
-  fetch_r(0, rcur);
-  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (bias != nullptr) {
-    const float4 b0 = *reinterpret_cast<const float4*>(bias + gn);
-    const float4 b1 = *reinterpret_cast<const float4*>(bias + gn + 4);
-    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-  }
-  const uint32_t ct = lds_base + 96u * 1024u;
-  const int hh = lane >> 5, rl = lane & 31;
-  static_for<0, 4>([&](auto hc) {
-    constexpr int h = decltype(hc)::value;
-    if constexpr (h < 3) fetch_r(h + 1, rnext);
-    if (wr == (h >> 1)) {
-#pragma unroll
-      for (int ai2 = 0; ai2 < 2; ++ai2)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            constexpr int dummy = 0; (void)dummy;
-            const int row = ai2 * 32 + rl;
-            const int blk = wc * 16 + b * 8 + 2 * rg + hh;  // 16-B block of columns wc 64 + b 32 + 8 rg + 4 hh
-            const f32x16& a = acc[2 * (h & 1) + ai2][b];
-            asm_ds_write_b128(ct + (uint32_t)(row * 1024 + ((blk ^ (row & 15)) << 4)), a[rg * 4 + 0], a[rg * 4 + 1], a[rg * 4 + 2], a[rg * 4 + 3]);
-          }
-    }
-    wait_lgkmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i0 = 0; i0 < NCH; i0 += 2) {  // two chunks at a time (register budget)
-      v4i lo[2], hi[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = (tid + (i0 + i) * NTHREADS) >> 5;
-        const int blk = (tid & 31) << 1;
-        const uint32_t rb = ct + (uint32_t)(row * 1024);
-        asm_ds_read_b128<0>(lo[i], rb + (uint32_t)((blk ^ (row & 15)) << 4));
-        asm_ds_read_b128<0>(hi[i], rb + (uint32_t)(((blk + 1) ^ (row & 15)) << 4));
-      }
-      wait_lgkmcnt<0>();
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int gm = m0 + h * 64 + ((tid + (i0 + i) * NTHREADS) >> 5);
-        if (gm < p.M) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v[j] = __int_as_float(lo[i][j]); v[4 + j] = __int_as_float(hi[i][j]); }
-          epilogue_store8<false, true, true>(p, z, bias, R_, gm, gn, v, rcur[i0 + i], bias8);
-        }
-      }
-    }
-    if constexpr (h < 3) {
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) rcur[i] = rnext[i];
-      __builtin_amdgcn_s_barrier();  // the next pass overwrites what this one read (the reads have returned: lgkmcnt(0) above)
-    }
-  });
-}
-
-// VAR (experiment builds, -DCOCODR_PP_VARIANTS, tools/gemm_bench.py --impls 13,15,16): 0 = DMA pieces requested in the load
-// segment behind the fragment reads; 2 = as 0 without s_setprio (-15 %); 3 = requested in front of the fragment reads (=).
-// Requesting them inside the MFMA segment instead cost 10-14 % (profiles/r02_gemm_pp_variants.txt).
-// VAR 5 (impl 18; the search's score GEMM): "fat" phases - two per K-tile of 16 MFMAs each, (A0: B0, B1) and (A1: B1, B0), i.e.
+// Measured in rounds 2-3 and NOT part of this kernel any more (sources in the history up to commit 78acbbd, results in profiles/):
+// a register-direct epilogue (permlane32_swap instead of the LDS passes: -4 % in the BERT-large step, r03_gemm_pp_reg_epilogue.md),
+// a persistent tile walk whose operand stream crosses tile boundaries (-4.7 %, r03_gemm_pp_persistent.md), a ten-slot operand ring
+// over all 160 KiB (-4 ... -12 %, r03_gemm_pp_ring10.md), a first-round stagger (+-, r03_gemm_pp_stagger.md), DMA requests in two
+// bursts per K-tile and B fragments read a phase early (VAR 6 / 7, r03_gemm_experiments.md), DMA requests in front of the
+// fragment reads / no s_setprio (VAR 3 / 2, r02_gemm_pp_variants.txt), one wave per SIMD with 128 x 128 wave tiles in HIP C++
+// (tools/experiments/gemm_w4.hip, r03_gemm_experiments.md section 3).
+// VAR 0: four thin phases per K-tile (8 MFMAs each; the encoder).  VAR 5 (impl 18; the search's score GEMM): "fat" phases - two per K-tile of 16 MFMAs each, (A0: B0, B1) and (A1: B1, B0), i.e.
 // half the barriers per MFMA.  The fragment reads of a phase are retired (lgkmcnt) in FRONT of its first barrier, so that a
 // half-tile may be requested one phase after its last read even by the group that runs a barrier ahead.  Back to back in
 // tools/gemm_bench.py it is 3-9 % faster than VAR 0 on every shape (profiles/r02_gemm_pp_fat.txt), inside the BERT-large
@@ -343,44 +154,15 @@ struct MultiArgs {
   float* split_ws;
 };
 constexpr int SPLIT_TILE = BM * 256;  // floats of one partial tile
-// PERSIST (forward / dgrad forms with bf16 results and no fused column sums; opt-in, see launch_form): a grid of at most one
-// workgroup per CU walks the tiles, and the operand stream never stops at a tile boundary - the last two K-tiles of a tile
-// request the first 1.5 K-tiles of the workgroup's NEXT tile into the same ring slots, in the steady-state order and with the
-// steady-state waits, the register-direct epilogue (no LDS) runs with those requests in flight, and the next tile starts on
-// landed operands.  What this hides is the tile's fixed cost: workgroup launch, prologue latency, and the idle loaders under
-// the epilogue (profiles/r03_gemm_vs_library.md).  The epilogue's stores sit in the vmcnt queue between the prefetched pieces
-// and the next tile's first requests: K-tile 0 of a continued tile allows for them in its counted waits (gfx9 retires vector
-// memory loads and stores in issue order).  Needs an even number of K-tiles (the ring parity carries over).
-// MEASURED AND NOT ADOPTED (round 3, profiles/r03_gemm_pp_persistent.md; experiment builds with -DCOCODR_PP_PERSIST_BUILD, then
-// COCODR_PP_PERSIST=1 / 2): bit-identical on every form incl. ragged row counts; inside the BERT-large step the 1200-tile QKV
-// GEMM gains 3 % (162 -> 157 us) but the 400-tile long-K forms (two tiles per workgroup on 200 CUs) lose 14-17 % and the step
-// 4.7 %.  The tile's fixed cost turned out to be ~3.6 us of 32 (not the 8 assumed): the K-loop itself, 1.8 us per K-tile against
-// 1.0 of MFMA time, is where the library's hand-scheduled kernel (1.5) is ahead.
-// NSLOT = 10 (VAR 0, NB = 2): the half-tile ring takes the whole 160 KiB of the CU's LDS - ten 16-KiB slots, half-tile s = 4 t + j
-// in slot s % 10 - instead of two K-tile buffers (eight slots).  Phase (t, j) then requests half-tile j of K-tile t + 2 (the
-// slot that half-tile (t, j) - 2 left in the previous phase), six half-tiles = 96 KiB per CU stay in flight instead of four,
-// and a request has two K-tiles instead of one and a half to land.  The loop's K-tile time is the latency of the operand
-// stream divided by its look-ahead (profiles/r03_load_rate_probe.txt: bytes in flight x 1 / latency), not the MFMA time - that
-// was the hypothesis.  MEASURED AND NOT ADOPTED (round 3, profiles/r03_gemm_pp_ring10.md; experiment builds with
-// -DCOCODR_PP_RING10_BUILD, then COCODR_PP_RING=10): bit-identical on every form and K-tile count, and 4-12 % SLOWER everywhere
-// (8192^3: 1263 -> 1182 TFLOP/s; the BERT-large step at 200 sequences -5 %).  Half again as many bytes in flight buy nothing:
-// the K-loop is not waiting for the operand stream's latency.
-template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false, int PERSIST = 0, int NSLOT = 8>  // PERSIST: 1 = LDS epilogue, 2 = register epilogue
+template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std::conditional<MULTI, MultiArgs, cocodr_gemm_args>::type pa,
                                                               const int flags) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using S = Shape<NB>;
-  const int flat = flags & 1;  // bit 1: register-direct epilogue (bf16 results without fused column sums)
+  static_assert(VAR == 0 || VAR == 5, "VAR 0: four thin phases per K-tile, VAR 5: two fat ones");
+  const int flat = flags & 1;
   constexpr int BN = S::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // bits 8-15 (COCODR_PP_STAGGER, experiment): the first round's workgroups start phase x units x 512 clocks late, phase =
-  // (id / 8) % 8 (neighbours on one XCD differ), so that the 256 CUs do not reach their epilogues - a burst of 33 MB of
-  // stores per round - at the same moment for the rest of the launch
-  if (const int stag = (flags >> 8) & 255; stag != 0 && blockIdx.x < 256 && blockIdx.y == 0) {
-    const int nph = ((flags >> 16) & 31) + 1;  // phases - 1 in bits 16-20 (a power of two)
-    const int units = (((int)blockIdx.x >> 3) & (nph - 1)) * stag;
-    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;  // waves 0-3 (one per SIMD) form group 0, waves 4-7 group 1
@@ -420,27 +202,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     z = id / per;
     tile = id - z * per;
   } else {
-    tile = xcd_remap(blockIdx.x, PERSIST ? ntm * ntn : (int)gridDim.x);
+    tile = xcd_remap(blockIdx.x, (int)gridDim.x);
     z = blockIdx.y;
   }
   int tm_, tn_;
   if (TA == 0) grouped_tile(tile, ntm, ntn, 4, tm_, tn_);
   else if (flat) grouped_tile(tile, ntm, ntn, 8, tm_, tn_);
   else { tm_ = tile / ntn; tn_ = tile % ntn; }
-  int m0 = tm_ * BM, n0 = tn_ * BN;  // (PERSIST: of the tile being computed; the DMA offsets below stay those of the first tile)
-  // PERSIST: virtual block id v = blockIdx.x + k gridDim.x walks this workgroup's tiles (gridDim.x % 8 == 0: v stays on the
-  // workgroup's XCD in xcd_remap, and the workgroups of an XCD hold consecutive tile ids at any time, as without the walk)
-  [[maybe_unused]] const int total_tiles = ntm * ntn;
-  [[maybe_unused]] auto tile_origin = [&](int v, int& mo, int& no) {
-    const int tl_ = xcd_remap(v, total_tiles);
-    int a_, b_;
-    if (TA == 0) grouped_tile(tl_, ntm, ntn, 4, a_, b_);
-    else { a_ = tl_ / ntn; b_ = tl_ % ntn; }
-    mo = a_ * BM; no = b_ * BN;
-  };
-  // byte offsets (mod 2^32) of the current / the next tile's operand panels relative to the first tile's
-  [[maybe_unused]] uint32_t curA_b = 0, curB_b = 0, nxtA_b = 0, nxtB_b = 0;
-  const int m0_first = m0, n0_first = n0;
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
   const uint16_t* A = p.A + (size_t)z * p.strideA;
   const uint16_t* B = p.B + (size_t)z * p.strideB;
   const uint32_t a_bytes = (uint32_t)((size_t)(TA ? p.K : p.M) * p.lda * 2);
@@ -468,28 +237,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     }
   }
 
-  auto stage_at = [&](auto tyc, int t, const uint32_t base_a, const uint32_t base_b) {  // request half-tile `ty` of K-tile t
+  auto stage = [&](auto tyc, int t) {  // request half-tile `ty` of K-tile t
     constexpr int ty = decltype(tyc)::value;
 #if defined(COCODR_ABL_NO_DMA)
     if (t > 0) return;
 #endif
-    char* dst = smem + (NSLOT == 10 ? ((4 * t + ty) % 10) * HALF_BYTES : (t & 1) * S::KT_BYTES + ty * HALF_BYTES) + wid * 2048;
+    char* dst = smem + (t & 1) * S::KT_BYTES + ty * HALF_BYTES + wid * 2048;
     if constexpr (type_is_a<NB>(ty)) {
-      const uint32_t sb_ = base_a + (t + t0) * stepa;
+      const uint32_t sb_ = (t + t0) * stepa;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))dst, 16, off[ty][0] + sb_, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + sb_, 0, 0, 0);
     } else {
-      const uint32_t sb_ = base_b + (t + t0) * stepb;
+      const uint32_t sb_ = (t + t0) * stepb;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))dst, 16, off[ty][0] + sb_, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_PTR(void))(dst + 1024), 16, off[ty][1] + sb_, 0, 0, 0);
     }
   };
-  auto stage = [&](auto tyc, int t) {  // ... of the tile being computed
-    if constexpr (PERSIST) stage_at(tyc, t, curA_b, curB_b);
-    else stage_at(tyc, t, 0u, 0u);
-  };
-  [[maybe_unused]] auto stage_next = [&](auto tyc, int k) { stage_at(tyc, k, nxtA_b, nxtB_b); };  // ... K-tile k of the next tile (PERSIST)
-
   f32x16 acc[4][NB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -506,10 +269,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // ---- prologue: the half-tiles 0 .. LOOK-1 of the request sequence (K-tile 0 and the first two of K-tile 1); phase 0 needs
   // A0 and B0 of K-tile 0, everything behind them may stay in flight
   static_for<0, S::NTYPE>([&](auto tyc) { stage(tyc, 0); });
-  if (NSLOT == 10 && nt > 1) {  // the ten-slot ring starts two whole K-tiles deep
-    static_for<0, S::NTYPE>([&](auto tyc) { stage(tyc, 1); });
-    wait_vmcnt<12>();
-  } else if (nt > 1) {
+  if (nt > 1) {
     stage(std::integral_constant<int, 0>{}, 1);
     stage(std::integral_constant<int, 1>{}, 1);
     if constexpr (VAR == 5) wait_vmcnt<6>();  // the first fat phase reads A0, B0 and B1
@@ -540,89 +300,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // two half-tiles in flight the operand stream ran at ~50 GB/s per CU - the latency of a loaded L2 times the bytes in
   // flight - and bounded the whole loop (DMA-only ablation, profiles/r02_gemm_pp_ablation.txt).
   // rem = K-tiles left including this one: the request exists while its K-tile does; the wait count shrinks with the queue.
-  // VAR 6 (experiment): the same request sequence issued in TWO bursts per K-tile instead of one half-tile per phase - nothing in
-  // the phases that carry the most fragment reads ((A0, B0): 12, (A1, B1): 8), two half-tiles in the two light ones ((A0, B1): 4
-  // reads requests B1 and A1 of K-tile t + 1, (A1, B0): none requests A0 and B0 of K-tile t + 2).  Same slots, same margins.
-  // (PERSIST, cont = this workgroup has another tile: where the tile's own request sequence ends, the next tile's begins -
-  //  its K-tile 0 lands in buffer 0 and the first half of its K-tile 1 in buffer 1, exactly the slots and margins of a K-tile
-  //  nt / nt + 1 of this tile; every wait keeps its steady-state count)
-  auto request = [&](auto jc, int t, int rem, [[maybe_unused]] bool cont) {
+  auto request = [&](auto jc, int t, int rem) {
     constexpr int j = decltype(jc)::value;
-    if constexpr (VAR == 6) {
-      if constexpr (j == 1) { if (rem >= 2) { stage(std::integral_constant<int, 2>{}, t + 1); stage(std::integral_constant<int, 3>{}, t + 1); } }
-      if constexpr (j == 3) { if (rem >= 3) { stage(std::integral_constant<int, 0>{}, t + 2); stage(std::integral_constant<int, 1>{}, t + 2); } }
-    } else if constexpr (NSLOT == 10) {
-      if (rem >= 3) stage(std::integral_constant<int, j>{}, t + 2);  // the same half-tile type, two K-tiles ahead
-    } else if constexpr (PERSIST) {
-      if constexpr (j < 2) { if (rem >= 2) stage(std::integral_constant<int, j + 2>{}, t + 1); else if (cont) stage_next(std::integral_constant<int, j + 2>{}, 0); }
-      else { if (rem >= 3) stage(std::integral_constant<int, j - 2>{}, t + 2); else if (cont) stage_next(std::integral_constant<int, j - 2>{}, rem == 2 ? 0 : 1); }
-    } else {
-      if constexpr (j < 2) { if (rem >= 2) stage(std::integral_constant<int, j + 2>{}, t + 1); }
-      else { if (rem >= 3) stage(std::integral_constant<int, j - 2>{}, t + 2); }
-    }
+    if constexpr (j < 2) { if (rem >= 2) stage(std::integral_constant<int, j + 2>{}, t + 1); }
+    else { if (rem >= 3) stage(std::integral_constant<int, j - 2>{}, t + 2); }
   };
-  // sext (PERSIST, K-tile 0 of a continued tile): store instructions of the previous tile's epilogue that sit in the queue
-  // behind the pieces this K-tile waits for - 16 (one result) / 32 (GELU + GELU') per wave, or 0 = unknown (ragged tile: waves
-  // past the last row issue none), which makes the wait drain them
-  auto wait_stage = [&](auto jc, int rem, [[maybe_unused]] bool cont, [[maybe_unused]] int sext) {
+  auto wait_stage = [&](auto jc, int rem) {
     constexpr int j = decltype(jc)::value;
-    if constexpr (NSLOT == 10) {
-      // after this phase's request the queue may keep what lies behind half-tile p + 2 (read from phase p + 3 on, retired one
-      // phase early as in the eight-slot ring): min(6, 4 rem - j - 3) half-tiles of two pieces each
-      if (rem >= 3) wait_vmcnt<12>();
-      else if (rem == 2) wait_vmcnt<(j == 0 ? 10 : (j == 1 ? 8 : (j == 2 ? 6 : 4)))>();
-      else wait_vmcnt<(j == 0 ? 2 : 0)>();
-      return;
-    }
-    if constexpr (PERSIST) {
-      if (rem >= 3 || cont) {
-        if (sext == 0) wait_vmcnt<8>();
-        else if (sext == 16) wait_vmcnt<24>();
-        else wait_vmcnt<40>();
-        return;
-      }
-    }
-    if constexpr (VAR == 6) {  // what the NEXT phase reads must have landed; everything requested behind it may stay in flight
-      if constexpr (j == 0) { if (rem >= 2) wait_vmcnt<6>(); else wait_vmcnt<2>(); }          // B1(t); behind it A1(t), A0 B0(t+1)
-      if constexpr (j == 1) { if (rem >= 2) wait_vmcnt<8>(); else wait_vmcnt<0>(); }          // A1(t); behind it A0 B0 B1 A1(t+1)
-      if constexpr (j == 3) { if (rem >= 3) wait_vmcnt<8>(); else if (rem == 2) wait_vmcnt<4>(); else wait_vmcnt<0>(); }  // A0 B0(t+1)
-    } else if constexpr (VAR == 7) {  // as VAR 0, but B0 of K-tile t + 1 is read one phase early (phase 3): phase 2's wait retires it
-      if (rem >= 3) wait_vmcnt<(j == 2 ? 6 : 8)>();
-      else if (rem == 2) wait_vmcnt<(j < 2 ? 8 : 4)>();
-      else wait_vmcnt<(j == 0 ? 2 : 0)>();
-    } else {
-      if (rem >= 3) wait_vmcnt<8>();
-      else if (rem == 2) wait_vmcnt<(j < 2 ? 8 : (j == 2 ? 6 : 4))>();
-      else wait_vmcnt<(j == 0 ? 2 : 0)>();
-    }
+    if (rem >= 3) wait_vmcnt<8>();
+    else if (rem == 2) wait_vmcnt<(j < 2 ? 8 : (j == 2 ? 6 : 4))>();
+    else wait_vmcnt<(j == 0 ? 2 : 0)>();
   };
 
   // One K-tile.  STEADY: at least two more K-tiles follow (rem >= 3) - every request exists and every wait is vmcnt(8), so the
   // steady-state loop carries no scalar compare / branch at all (the rem-dependent forms cost 3-6 branches per load segment,
   // a fifth of its 256-cycle budget); the last two K-tiles run the general form.
-  // (VAR 7 passes the two B fragment buffers in alternating roles: fbx holds B0 of this K-tile, fby receives B1 and, in phase 3,
-  // B0 of the next K-tile)
-  auto ktile = [&](auto steady_c, const int t, const int rem_in, FragSet<TB, 1> (&fbx)[4], FragSet<TB, 1> (&fby)[4],
-                   [[maybe_unused]] const bool cont = false, [[maybe_unused]] const int sext_in = 0) {
+  auto ktile = [&](auto steady_c, const int t, const int rem_in) {
     constexpr bool STEADY = decltype(steady_c)::value;
     const int rem = STEADY ? 3 : rem_in;
-    const int sext = STEADY ? 0 : sext_in;
     const uint32_t kb = lds_base + (uint32_t)((t & 1) * S::KT_BYTES);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { curA[i] = adA[i] + kb; curB[i] = adB[i] + kb; }
     // one phase; RD: this phase's fragment reads, TY: the half-tile type requested for K-tile t + 1
     auto phase = [&](auto tyc, auto&& reads, const FragSet<TB, 1> (&fb)[4], f32x16& c0, f32x16& c1) {
-      auto req = [&]() { request(tyc, t, rem, cont); };
       auto none = []() {};
-      if constexpr (VAR == 3) req();
       reads();
-      if constexpr (VAR == 0 || VAR == 2 || VAR == 6 || VAR == 7) req();
-      wait_stage(tyc, rem, cont, sext);
+      request(tyc, t, rem);  // the DMA pieces go out in the load segment, behind the fragment reads
+      wait_stage(tyc, rem);
       __builtin_amdgcn_s_barrier();
       wait_lgkmcnt<0>();
-      if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(1);
       pp_mfma<TA, TB, F16>(fa, fb, c0, c1, none);
-      if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
     };
     if constexpr (NB == 2 && VAR == 5) {
@@ -661,33 +370,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       pp_mfma<TA, TB, F16>(fa, fb0, acc[2][0], acc[3][0], none);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
-    } else if constexpr (NB == 2 && VAR == 7) {
-      // (experiment builds) Fragment reads per phase 8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0: B0 of K-tile t + 1 is read in phase 3 of
-      // K-tile t - which reads nothing otherwise - into the buffer B1 left in phase 2, so the heaviest load segment (A0 + B0 = 12
-      // reads) shrinks to A0 alone.  Bit-identical; measured: NO gain where the steady state is all there is (grouped weight
-      // gradient, K = 25 600: 1301 vs 1297 TFLOP/s) - the 12-read phase is not what the loop waits for - and the role swap of the
-      // two B buffers costs hipcc ~65 register moves per K-tile and spills in the tail K-tiles (profiles/r03_gemm_experiments.md).
-      uint32_t curBn[4];
-      const uint32_t kbn = lds_base + (uint32_t)(((t + 1) & 1) * S::KT_BYTES);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) curBn[i] = adB[i] + kbn;
-      phase(std::integral_constant<int, 0>{}, [&]() { pp_read_sub<TA, 2, 0 * HALF_BYTES>(curA, fa); }, fbx, acc[0][0], acc[1][0]);    // (A0, B0)
-      phase(std::integral_constant<int, 1>{}, [&]() { pp_read_sub<TB, 1, 2 * HALF_BYTES>(curB, fby); }, fby, acc[0][1], acc[1][1]);   // (A0, B1)
-      phase(std::integral_constant<int, 2>{}, [&]() { pp_read_sub<TA, 2, 3 * HALF_BYTES>(curA, fa); }, fby, acc[2][1], acc[3][1]);    // (A1, B1)
-      phase(std::integral_constant<int, 3>{}, [&]() { if (rem >= 2) pp_read_sub<TB, 1, 1 * HALF_BYTES>(curBn, fby); },                // (A1, B0)
-            fbx, acc[2][0], acc[3][0]);
-    } else if constexpr (NB == 2 && NSLOT == 10) {
-      // fragment addresses per half-tile: its slot is (4 t + type) % 10, a different one every K-tile (period 5)
-      auto at = [&](const uint32_t (&ad)[4], int ty, uint32_t (&cur)[4]) {
-        const uint32_t b = lds_base + (uint32_t)(((4 * t + ty) % 10) * HALF_BYTES);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cur[i] = ad[i] + b;
-      };
-      phase(std::integral_constant<int, 0>{}, [&]() { at(adA, 0, curA); pp_read_sub<TA, 2, 0>(curA, fa); at(adB, 1, curB); pp_read_sub<TB, 1, 0>(curB, fb0); },
-            fb0, acc[0][0], acc[1][0]);                                                                  // (A0, B0)
-      phase(std::integral_constant<int, 1>{}, [&]() { at(adB, 2, curB); pp_read_sub<TB, 1, 0>(curB, fb1); }, fb1, acc[0][1], acc[1][1]);  // (A0, B1)
-      phase(std::integral_constant<int, 2>{}, [&]() { at(adA, 3, curA); pp_read_sub<TA, 2, 0>(curA, fa); }, fb1, acc[2][1], acc[3][1]);   // (A1, B1)
-      phase(std::integral_constant<int, 3>{}, [&]() {}, fb0, acc[2][0], acc[3][0]);                      // (A1, B0): all in registers
     } else if constexpr (NB == 2) {
       phase(std::integral_constant<int, 0>{}, [&]() { pp_read_sub<TA, 2, 0 * HALF_BYTES>(curA, fa); pp_read_sub<TB, 1, 1 * HALF_BYTES>(curB, fb0); },
             fb0, acc[0][0], acc[1][0]);                                                                  // (A0, B0)
@@ -696,72 +378,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
       phase(std::integral_constant<int, 3>{}, [&]() {}, fb0, acc[2][0], acc[3][0]);                      // (A1, B0): all in registers
     }
   };
-  if constexpr (VAR == 7 && NB == 2) {
-    {  // B0 of K-tile 0 (landed: the prologue waited for A0 and B0)
-      uint32_t c0[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) c0[i] = adB[i] + lds_base;
-      pp_read_sub<TB, 1, 1 * HALF_BYTES>(c0, fb0);
-    }
-    // the B fragment buffers swap roles every K-tile: pairs of K-tiles with static roles, the parity of what is left decided
-    // once (a role picked at run time per K-tile puts the fragment arrays in scratch)
-    const int ns = nt > 2 ? nt - 2 : 0;  // K-tiles in the branch-free steady form
+  if constexpr (VAR == 0 && NB == 2) {
     int t = 0;
-    for (; t + 1 < ns; t += 2) {
-      ktile(std::true_type{}, t, 3, fb0, fb1);
-      ktile(std::true_type{}, t + 1, 3, fb1, fb0);
-    }
-    if (ns & 1) {
-      ktile(std::true_type{}, t, 3, fb0, fb1);
-      ++t;
-      ktile(std::false_type{}, t, nt - t, fb1, fb0);
-      if (t + 1 < nt) ktile(std::false_type{}, t + 1, nt - t - 1, fb0, fb1);
-    } else {
-      ktile(std::false_type{}, t, nt - t, fb0, fb1);
-      if (t + 1 < nt) ktile(std::false_type{}, t + 1, nt - t - 1, fb1, fb0);
-    }
-  } else if constexpr (PERSIST) {
-    static_assert(VAR == 0 && NB == 2 && !OUT_F32 && !MULTI, "the persistent walk exists for the bf16-result forward / dgrad forms");
-    int vb = (int)blockIdx.x;
-    int sext = -1;  // < 0: the first tile (prologue above); else the store count of the previous epilogue for K-tile 0's waits
-    for (;;) {
-      const int vn = vb + (int)gridDim.x;
-      const bool cont = vn < total_tiles;
-      int m0n = 0, n0n = 0;
-      if (cont) {
-        tile_origin(vn, m0n, n0n);
-        nxtA_b = (uint32_t)(m0n - m0_first) * (TA ? 2u : (uint32_t)(p.lda * 2));
-        nxtB_b = (uint32_t)(n0n - n0_first) * (TB ? 2u : (uint32_t)(p.ldb * 2));
-      }
-      int t = 0;
-      if (sext >= 0) { ktile(std::false_type{}, 0, nt, fb0, fb1, cont, sext); t = 1; }
-      for (; t < nt - 2; ++t) ktile(std::true_type{}, t, 3, fb0, fb1);
-      for (; t < nt; ++t) ktile(std::false_type{}, t, nt - t, fb0, fb1, cont, 0);
-      if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 catches up with group 1's last barrier
-      if constexpr (PERSIST == 2) pp_reg_epilogue<NB>(p, z, acc, m0, n0, wr, wc, lane);  // (COCODR_PP_PERSIST=2: A/B switch)
-      else pp_lds4_epilogue(p, z, acc, m0, n0, wr, wc, tid, lane, lds_base);
-      if (!cont) break;
-      sext = (m0 + BM <= p.M) ? ((p.epi == COCODR_EPI_GELU && p.C2 != nullptr) ? 32 : 16) : 0;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-      // A0, B0 of the next tile's K-tile 0 were retired by every wave's waits of the last K-tile: one barrier makes all of
-      // them visible, the second one puts group 1 a barrier behind group 0 again
-      __builtin_amdgcn_s_barrier();
-      if (wr == 1) __builtin_amdgcn_s_barrier();
-      vb = vn; m0 = m0n; n0 = n0n; curA_b = nxtA_b; curB_b = nxtB_b;
-    }
-    return;
-  } else if constexpr ((VAR == 0 || VAR == 6) && NB == 2) {
-    int t = 0;
-    if (!(flags & 4))  // (bit 2: A/B switch COCODR_PP_NOPEEL - every K-tile in the general form)
-      for (; t < nt - 2; ++t) ktile(std::true_type{}, t, 3, fb0, fb1);
-    for (; t < nt; ++t) ktile(std::false_type{}, t, nt - t, fb0, fb1);
+    for (; t < nt - 2; ++t) ktile(std::true_type{}, t, 3);
+    for (; t < nt; ++t) ktile(std::false_type{}, t, nt - t);
   } else {
-    for (int t = 0; t < nt; ++t) ktile(std::false_type{}, t, nt - t, fb0, fb1);
+    for (int t = 0; t < nt; ++t) ktile(std::false_type{}, t, nt - t);
   }
 #if defined(COCODR_ABL_TIMELINE)
   if (tid == 0) tl[2] = wall_clock64();
@@ -784,12 +406,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     }
   }
 
-  if constexpr (!OUT_F32) {
-    if ((flags & 2) && p.colsum_partial == nullptr) {
-      pp_reg_epilogue<NB>(p, z, acc, m0, n0, wr, wc, lane);
-      return;
-    }
-  }
   // ---- epilogue (gemm.hip's, for this geometry): two 128-row passes of the fp32 tile through LDS, row-major 16-B stores
   const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
   const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
@@ -890,81 +506,18 @@ template <int NB, int TA, int TB, int VAR = 5, bool F16 = false>
 void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
   using S = Shape<NB>;
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / S::BN;
-  static int flat_env = -1;  // COCODR_PP_FLAT=0 keeps the per-item remap (A/B switch)
-  if (flat_env < 0) {
-    const char* e = getenv("COCODR_PP_FLAT");
-    flat_env = e ? atoi(e) : 1;
-  }
-  const int flat = (a.batch > 1 && flat_env) ? 1 : 0;
-  static const int regepi = getenv("COCODR_PP_REGEPI") ? atoi(getenv("COCODR_PP_REGEPI")) : 0;  // A/B switch: 1 = the register-direct epilogue (measured 4 % slower in the step, see pp_reg_epilogue)
-  static const int nopeel = getenv("COCODR_PP_NOPEEL") ? atoi(getenv("COCODR_PP_NOPEEL")) : 0;  // A/B switch of the branch-free steady-state loop
-  // first-round stagger (see the kernel; experiment, off unless COCODR_PP_STAGGER=units): 32 phases x units x 512 clocks.  Only
-  // from four rounds of tiles on and where the last round is partly empty - the late starters then take no tile of that round,
-  // while with whole rounds the launch ends as much later as it started (8192 x 4096 x 1024, two whole rounds: -8 %).  In the
-  // BERT-large step at 200 sequences units = 2 measured +1.4 ... +2.2 % on three boxes and -0.4 % on a fourth, nothing elsewhere
-  // (profiles/r03_gemm_pp_stagger.md): not shipped as a default.
-  static const int stagger_env = getenv("COCODR_PP_STAGGER") ? atoi(getenv("COCODR_PP_STAGGER")) & 255 : 0;
-  static const int stagger_ph = getenv("COCODR_PP_STAGGER_PH") ? atoi(getenv("COCODR_PP_STAGGER_PH")) : 32;
-  static const int stagger_all = getenv("COCODR_PP_STAGGER_ALL") != nullptr;  // A/B: also launches of whole rounds
-  const long long tiles = (long long)ntm * ntn * (a.batch > 0 ? a.batch : 1);
-  const int rem = (int)(tiles % 256);
-  const int stagger = (stagger_all || (tiles >= 1024 && rem >= 1 && rem <= 208)) ? stagger_env : 0;
-  const int flags = flat | (regepi ? 2 : 0) | (nopeel ? 4 : 0) | (stagger << 8) | (((stagger_ph - 1) & 31) << 16);
+  const int flat = a.batch > 1 ? 1 : 0;  // batched launches walk (item, tile) in one XCD-remapped grid axis (see the kernel)
   dim3 grid(flat ? ntm * ntn * a.batch : ntm * ntn, flat ? 1 : a.batch);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static cocodr_lds_once attr_done;
+  if (attr_done.pending()) {
     hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, true, VAR, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done.done();
   }
-#if defined(COCODR_PP_PERSIST_BUILD)  // experiment builds (COCODR_EXTRA_FLAGS=-DCOCODR_PP_PERSIST_BUILD): measured, not adopted - see the kernel
-  if constexpr (NB == 2 && VAR == 0 && !F16) {
-    // persistent walk (see the kernel): bf16 results without fused column sums, more tiles than CUs, an even number (>= 4) of
-    // K-tiles.  Grid: the fewest workgroups that need no more rounds than 256 would, a multiple of 8 (1200 tiles -> 240 x 5).
-    static const int persist = getenv("COCODR_PP_PERSIST") ? atoi(getenv("COCODR_PP_PERSIST")) : 0;
-    const int nkt = (a.K + BK - 1) / BK;
-    if (persist && !a.out_f32 && a.batch <= 1 && a.colsum_partial == nullptr && a.colsum == nullptr && tiles > 256 && nkt >= 4 && nkt % 2 == 0 &&
-        a.K % BK == 0) {
-      const int rounds = (int)((tiles + 255) / 256);
-      int g = (int)((tiles + rounds - 1) / rounds);
-      g = (g + 7) & ~7;
-      if (g > 256) g = 256;
-      static bool attr_p = false;
-      if (!attr_p) {
-        hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_p = true;
-      }
-      if (persist == 2)
-        hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 2>), dim3(g), dim3(NTHREADS), 160 * 1024, st, a, flags & ~(255 << 8));
-      else
-        hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 1>), dim3(g), dim3(NTHREADS), 160 * 1024, st, a, flags & ~(255 << 8));
-      return;
-    }
-  }
-#endif
-#if defined(COCODR_PP_RING10_BUILD)  // experiment builds (COCODR_EXTRA_FLAGS=-DCOCODR_PP_RING10_BUILD): measured, not adopted - see the kernel
-  if constexpr (NB == 2 && VAR == 0 && !F16) {
-    static const int ring = getenv("COCODR_PP_RING") ? atoi(getenv("COCODR_PP_RING")) : 8;  // A/B switch: 10 = the ten-slot ring (see the kernel)
-    if (ring == 10) {
-      static bool attr_r = false;
-      if (!attr_r) {
-        hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, true, VAR, F16, false, 0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_r = true;
-      }
-      if (a.out_f32)
-        hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16, false, 0, 10>), grid, dim3(NTHREADS), 160 * 1024, st, a, flags);
-      else
-        hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16, false, 0, 10>), grid, dim3(NTHREADS), 160 * 1024, st, a, flags);
-      return;
-    }
-  }
-#endif
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flags);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
   else
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flags);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
 }
 
 }  // namespace cocodr_gemm_pp
@@ -1048,26 +601,20 @@ void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, si
   ma.split_first = split ? total - r : total;
   ma.split_s = split ? s : 1;
   ma.split_ws = ws;
-#if defined(COCODR_PP_RING10_BUILD)
-  static const int ring = getenv("COCODR_PP_RING") ? atoi(getenv("COCODR_PP_RING")) : 8;  // A/B switch: 10 = the ten-slot ring (see the kernel)
-  auto kern = ring == 10 ? gemm_pp_kernel<2, 1, 1, true, 0, false, true, 0, 10> : gemm_pp_kernel<2, 1, 1, true, 0, false, true>;
-#else
-  constexpr int ring = 8;
   // (two fat phases per K-tile for the merged launch, gemm_pp_kernel<2, 1, 1, true, 5, false, true>: measured +0.3 % on the
   //  BERT-base step, -0.3 ... -0.5 % on the BERT-large ones; not kept)
   auto kern = gemm_pp_kernel<2, 1, 1, true, 0, false, true>;
-#endif
-  static bool attr_done = false;
-  if (!attr_done) {
+  static cocodr_lds_once attr_done;
+  if (attr_done.pending()) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done.done();
   }
-  static const int nopeel = getenv("COCODR_PP_NOPEEL") ? atoi(getenv("COCODR_PP_NOPEEL")) : 0;
-  hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), ring == 10 ? 160 * 1024 : Shape<2>::LDS_BYTES, st, ma, 1 | (nopeel ? 4 : 0));
+  hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
   if (split) hipLaunchKernelGGL(gemm_pp_split_finish, dim3(r, SPLIT_TILE / 4 / 256), dim3(256), 0, st, ma, r);
 }
 
-// nb = 2: 256 x 256 tile (N % 256 == 0), nb = 1: 256 x 128 tile; the caller has validated the arguments (cocodr_gemm)
+// nb = 2: four thin phases per K-tile (the encoder's default), 105: two fat phases per K-tile (impl 18), 104: IEEE-half operands
+// with fat phases (the search's split-precision score GEMM); the caller has validated the arguments (cocodr_gemm)
 template <int VAR>
 static void launch_any(const cocodr_gemm_args& a, hipStream_t st) {
   using namespace cocodr_gemm_pp;
@@ -1076,20 +623,7 @@ static void launch_any(const cocodr_gemm_args& a, hipStream_t st) {
   else launch_form<2, 1, 1, VAR>(a, st);
 }
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st) {
-  static const int b0early = getenv("COCODR_PP_B0EARLY") ? atoi(getenv("COCODR_PP_B0EARLY")) : 0;  // A/B switch of VAR 7
-  static const int fat = getenv("COCODR_PP_FAT") ? atoi(getenv("COCODR_PP_FAT")) : 0;  // A/B switch: 1 = fat phases everywhere,
-  if (nb == 2 && (fat == 1 || (fat == 2 && !a.trans_a) || (fat == 3 && a.trans_a))) launch_any<5>(a, st);  // 2 = forward / dgrad only, 3 = wgrads only
-#if defined(COCODR_PP_VARIANTS)
-  else if (nb == 2 && getenv("COCODR_PP_VAR") && atoi(getenv("COCODR_PP_VAR")) == 6) launch_any<6>(a, st);  // in-step A/B of VAR 6
-  else if (nb == 107 || (nb == 2 && b0early)) launch_any<7>(a, st);              // B0 fragments read one phase early (8 / 4 / 8 / 4 reads)
-#endif
-  else if (nb == 2) launch_any<0>(a, st);                                        // four thin phases per K-tile (the default)
-  else if (nb == 104) cocodr_gemm_pp::launch_form<2, 0, 0, 5, true>(a, st);      // IEEE-half operands (the search): fat phases
-  else if (nb == 105) launch_any<5>(a, st);                                      // impl 18: two fat phases per K-tile
-#if defined(COCODR_PP_VARIANTS)
-  else if (nb == 102) launch_any<2>(a, st);
-  else if (nb == 103) launch_any<3>(a, st);
-  else if (nb == 106) launch_any<6>(a, st);
-#endif
+  if (nb == 104) cocodr_gemm_pp::launch_form<2, 0, 0, 5, true>(a, st);
+  else if (nb == 105) launch_any<5>(a, st);
   else launch_any<0>(a, st);
 }

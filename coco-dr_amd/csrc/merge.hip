@@ -24,36 +24,37 @@ struct MergeArgs {
 };
 
 __global__ __launch_bounds__(256) void topk_merge_kernel(const MergeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sc[];  // [W][k] scores, -inf where the slot is empty
+  extern __shared__ __attribute__((aligned(16))) float sc[];  // [W][k] scores
   __shared__ int n_valid[64];
   const int q = blockIdx.x, tid = threadIdx.x;
   const int W = a.W, k = a.k, n = W * k;
   const float NEG = -INFINITY;
-  for (int e = tid; e < n; e += 256) {
-    const int w = e / k, i = e - w * k;
-    const size_t g = (size_t)w * a.stride_w + (size_t)q * k + i;
-    sc[e] = a.I[g] < 0 ? NEG : a.D[g];
-  }
-  __syncthreads();
-  if (tid < W) {  // valid prefix of list tid (empty slots sit at the end)
-    const float* L = sc + tid * k;
+  // validity comes from the POSITION alone (I < 0 = empty slot, at the end of a list): a real candidate whose score is -inf is a
+  // candidate like any other.  (NaN scores are not supported: they break the order the lists are sorted by - include/cocodr.h.)
+  if (tid < W) {
+    const int32_t* Iw = a.I + (size_t)tid * a.stride_w + (size_t)q * k;
     int lo = 0, hi = k;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (L[mid] != NEG) lo = mid + 1;
+      if (Iw[mid] >= 0) lo = mid + 1;
       else hi = mid;
     }
     n_valid[tid] = lo;
   }
   for (int e = tid; e < n; e += 256) {
     const int w = e / k, i = e - w * k;
+    sc[e] = a.D[(size_t)w * a.stride_w + (size_t)q * k + i];
+  }
+  __syncthreads();
+  for (int e = tid; e < n; e += 256) {
+    const int w = e / k, i = e - w * k;
+    if (i >= n_valid[w]) continue;
     const float s = sc[e];
-    if (s == NEG) continue;
     int rank = i;
     for (int w2 = 0; w2 < W && rank < a.k_out; ++w2) {
       if (w2 == w) continue;
       const float* L = sc + w2 * k;
-      int lo = 0, hi = k;
+      int lo = 0, hi = n_valid[w2];
       if (w2 < w) {  // a lower shard wins ties: count its elements >= s
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
@@ -75,7 +76,6 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const MergeArgs a) {
       a.outI[(size_t)q * a.k_out + rank] = a.shard_off[w] + (long long)a.I[g];
     }
   }
-  __syncthreads();
   int total = 0;
   for (int w = 0; w < W; ++w) total += n_valid[w];
   for (int r = total + tid; r < a.k_out; r += 256) {  // fewer candidates than k_out: (-inf, -1) padding, as cocodr_score_topk
@@ -94,10 +94,10 @@ extern "C" int cocodr_topk_merge(const float* D, const int32_t* I, const long lo
   const size_t lds = (size_t)W * k * sizeof(float);
   CK_ARG(lds <= 156 * 1024, "topk_merge: W * k = %d candidates per query exceed the LDS (max 39936)", W * k);
   if (Nq == 0) return COCODR_OK;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static cocodr_lds_once attr_once;  // (the raised LDS limit is a per-device attribute)
+  if (attr_once.pending()) {
     hipFuncSetAttribute((const void*)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    attr_done = true;
+    attr_once.done();
   }
   MergeArgs a{D, I, shard_offset, outD, outI, W, Nq, k, k_out, stride_w};
   hipLaunchKernelGGL(topk_merge_kernel, dim3(Nq), dim3(256), lds, (hipStream_t)stream, a);

@@ -547,8 +547,8 @@ int ln_bwd_blocks(int M) { return M >= 256 * NW ? 256 : (M + NW - 1) / NW; }
 int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd, uint16_t* dy,
                   float* partial, int M, int H, int nseg, hipStream_t st, uint16_t* dy_drop = nullptr,
                   const cocodr_dropout_mask* dm = nullptr) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static cocodr_lds_once attr_done;
+  if (attr_done.pending()) {
     hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -557,7 +557,7 @@ int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, c
     hipFuncSetAttribute((const void*)&ln_bwd_kernel<3, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)&ln_bwd_kernel<MAXC, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done.done();
   }
   const size_t row_bytes = (size_t)NW * H * 4;  // one accumulator row of every wave
   const int per_pass = std::max(1, std::min(nseg, (int)((160 * 1024) / row_bytes)));

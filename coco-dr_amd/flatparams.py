@@ -73,28 +73,24 @@ class ViewParameter(nn.Parameter):
         reset.discard(self._index)
         flat.grad[self._off:self._off + self.numel()].view(self.shape).copy_(value)
 
-    # ``p.data`` writes (the reference's Lamb updates ``p.data.add_(...)``, ANCE/utils/lamb.py:120) bypass torch's version
-    # counters, which is how the owner knows that its bf16 weight shadow is stale: handing out ``.data`` marks it dirty.
+    # ``p.data`` (the reference's Lamb reads and writes ``p.data``, ANCE/utils/lamb.py:97-120): what is handed out is a detached
+    # alias that SHARES the version counter of the flat's view base (every view derives from that one alias), so an in-place write
+    # through it - now or through an alias a helper cached across steps (EMA / SWA, an optimizer keeping ``p.data`` in its state) -
+    # is seen by ``_params_version`` and refreshes the bf16 weight shadow; merely reading ``p.data`` (logging, norms) costs nothing.
     @property
     def data(self):
-        owner = self._owner() if self._owner is not None else None
-        if owner is not None:
-            owner.__dict__["_views_dirty"] = True
-        return torch.Tensor.data.__get__(self)
+        return self.detach()
 
     @data.setter
     def data(self, value):  # keep aliasing the flat: copy instead of re-binding the storage
-        owner = self._owner() if self._owner is not None else None
-        if owner is not None:
-            owner.__dict__["_views_dirty"] = True
         with torch.no_grad():
-            torch.Tensor.data.__get__(self).copy_(value)
+            self.detach().copy_(value)
 
     def __deepcopy__(self, memo):  # a detached plain parameter (deep copies of the owning module rebuild their own views)
-        return nn.Parameter(torch.Tensor.data.__get__(self).clone(), self.requires_grad)
+        return nn.Parameter(self.detach().clone(), self.requires_grad)
 
     def __reduce_ex__(self, proto):
-        return (nn.Parameter, (torch.Tensor.data.__get__(self).clone(), self.requires_grad))
+        return (nn.Parameter, (self.detach().clone(), self.requires_grad))
 
 
 class _Shell(nn.Module):
@@ -212,18 +208,17 @@ class FlatParamsMixin:
         self.__dict__["_grad_reset"] = [set(), set()]
 
     def _params_version(self):
-        """changes whenever the flat storage was written in place - through a flat (``FlatAdamW``, ``load_state_dict``) or
-        through any view (a per-tensor torch optimizer); ``.data`` writes through a view set ``_views_dirty`` instead"""
+        """changes whenever the flat storage was written in place - through a flat (``FlatAdamW``, ``load_state_dict``), through
+        any view (a per-tensor torch optimizer) or through an alias ``view.data`` handed out at any time"""
         fd = self.__dict__[FLAT_NAMES[0]]
         vb = self.__dict__.get("_vbase", (None, None))[0]
         return (fd._version, vb._version if vb is not None else -1)
 
     def _shadow_stale(self) -> bool:
-        return self._shadow_version != self._params_version() or self.__dict__.get("_views_dirty", False)
+        return self._shadow_version != self._params_version()
 
     def _shadow_mark_fresh(self) -> None:
         self._shadow_version = self._params_version()
-        self.__dict__["_views_dirty"] = False
 
     # ---------------------------------------------------------------- nn.Module plumbing that must see the flats
     def _apply(self, fn, recurse=True):

@@ -797,9 +797,56 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
             if id(p) not in self._dp_hooks:
                 self._dp_hooks[id(p)] = p.register_post_accumulate_grad_hook(self._dp_post_accumulate)
 
+    def _dp_adopt_ddp_wrapper(self) -> None:
+        """``torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+        find_unused_parameters=True)`` is how every reference driver makes the model data-parallel
+        (ANCE/drivers/run_ann.py:177-184, ANCE/drivers/run_ann_data_gen.py:146-153; HF Trainer for COCO, COCO/trainer.py:181-182).
+        torch's reducer hangs its hooks on the per-tensor parameters - here HF-named VIEWS of two flat tensors that autograd never
+        visits (the native backward writes the flat gradients), so on its own the wrapper would reduce nothing and the ranks would
+        drift apart without an error.  When a training forward finds itself inside such a wrapper (DDP publishes the running
+        wrapper in ``_active_ddp_module``) the model therefore takes the job over: ``enable_grad_allreduce`` on the wrapper's
+        process group (same averaged gradients, reduced range by range under the backward), the wrapper's own reducer is switched
+        to its pass-through state (``require_backward_grad_sync = False``: what its ``no_sync()`` sets), and the wrapper's
+        ``no_sync()`` is rebound to this model's, so gradient-accumulation loops written against DDP
+        (ANCE/drivers/run_ann.py:318-341) keep their meaning.  tests/test_gpu_distributed.py::test_reference_ddp_wrap_line_*."""
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        ddp = getattr(DDP, "_active_ddp_module", None)
+        if ddp is None:
+            return
+        adopted = ddp.__dict__.get("_cocodr_adopted")
+        if adopted is None:
+            adopted = ddp.__dict__["_cocodr_adopted"] = {"models": [], "in_no_sync": False}
+            import contextlib
+
+            @contextlib.contextmanager
+            def no_sync(_state=adopted):
+                with contextlib.ExitStack() as stack:
+                    for m in _state["models"]:
+                        stack.enter_context(m.no_sync())
+                    _state["in_no_sync"] = True
+                    try:
+                        yield
+                    finally:
+                        _state["in_no_sync"] = False
+            in_no_sync = not ddp.require_backward_grad_sync  # a first forward already inside the wrapper's own no_sync()
+            ddp.no_sync = no_sync
+        else:
+            in_no_sync = adopted["in_no_sync"]
+        if not any(m is self for m in adopted["models"]):
+            adopted["models"].append(self)
+            if not hasattr(self, "_dp_unsynced"):
+                self.enable_grad_allreduce(group=ddp.process_group, chunks=2)
+            elif self._dp_group is not ddp.process_group and self._dp_group is not None:
+                raise RuntimeError("CocoBertModel: enable_grad_allreduce() was set up on a different process group than the "
+                                   "DistributedDataParallel wrapper around this model")
+        ddp.require_backward_grad_sync = False  # the wrapper's reducer has nothing to reduce: keep it passive
+        if not adopted["in_no_sync"]:
+            self._dp_enabled = not in_no_sync
+
     def _dp_note_forward(self) -> None:
         """count a training forward of the current step; the count restarts whenever the parameters have changed since the last
         counted forward (an optimizer step: a forward whose backward never ran must not haunt the next step)"""
+        self._dp_adopt_ddp_wrapper()
         if not getattr(self, "_dp_enabled", False):
             return
         v = self.flat_decay._version
@@ -1279,7 +1326,7 @@ class CoCondenserForPretraining(nn.Module):
         else:
             cls = self.lm.encode_cls(ids, mask, packed_index=model_input.get("packed_index"), lengths=model_input.get("lengths"))  # [2b, H] fp32
         W = self._world_size()
-        force = bool(os.environ.get("COCODR_FORCE_DIST")) and torch.distributed.is_initialized()  # 1-rank test of the N>1 path
+        force = bool(getattr(self, "force_gather", False)) and torch.distributed.is_initialized()  # (tests: the N > 1 path on a 1-rank group)
         if W > 1 or force:
             import torch.distributed as dist
             E = _GatherRows.apply(cls)

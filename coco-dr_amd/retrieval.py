@@ -88,7 +88,7 @@ def merge_shard_lists(D: torch.Tensor, I: torch.Tensor, shard_offset: torch.Tens
 
 
 def sharded_search(Q_local: torch.Tensor, P_local: torch.Tensor, k: int, local_search: Optional[Callable] = None,
-                   local_merge: Optional[Callable] = None, gather: bool = True):
+                   local_merge: Optional[Callable] = None, gather: bool = True, force_distributed: bool = False):
     """Search ALL queries against the corpus sharded over the ranks: all-gather the queries (Nq x H fp32), search
     the resident shard, hand every rank the W per-shard lists of ITS block of ceil(Nq / W) queries (one all-to-all: scores
     fp32 + shard-local positions int32, Nq k 8 bytes per rank in total - an all-gather of the lists would move W times
@@ -98,12 +98,12 @@ def sharded_search(Q_local: torch.Tensor, P_local: torch.Tensor, k: int, local_s
 
     ``gather=True``: every rank returns the full ``(D, I)`` [Nq_total, k] (one all-gather of the merged blocks).
     ``gather=False``: returns ``(D_block, I_block, (q_lo, q_hi))`` - this rank's query block only, for per-query work that
-    stays sharded (nDCG, hard negatives).  ``local_search`` / ``local_merge`` replace the native kernels (CPU tests)."""
+    stays sharded (nDCG, hard negatives).  ``local_search`` / ``local_merge`` replace the native kernels (CPU tests);
+    ``force_distributed`` takes the exchange + merge path on a 1-rank process group as well (tests of that path)."""
     import torch.distributed as dist
     fn = local_search or search
     merge = local_merge or merge_shard_lists
-    import os
-    force = bool(os.environ.get("COCODR_FORCE_DIST")) and dist.is_available() and dist.is_initialized()  # 1-rank test of the N > 1 path
+    force = bool(force_distributed) and dist.is_available() and dist.is_initialized()
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         D, I = fn(Q_local, P_local, k, 0)
         return (D, I) if gather else (D, I, (0, Q_local.shape[0]))
@@ -128,19 +128,18 @@ def sharded_search(Q_local: torch.Tensor, P_local: torch.Tensor, k: int, local_s
     Dp = torch.full((W * bq, kk), float("-inf"), dtype=torch.float32, device=dev)
     Ip = torch.full((W * bq, kk), -1, dtype=torch.int32, device=dev)
     Dp[:Nq] = D
+    if P_local.shape[0] >= 2 ** 31:
+        raise ValueError("sharded_search: a shard holds 2^31 or more passages; shard-local positions travel as int32")
     Ip[:Nq] = I.to(torch.int32)
     Dr = torch.empty((W, bq, kk), dtype=torch.float32, device=dev)
     Ir = torch.empty((W, bq, kk), dtype=torch.int32, device=dev)
     if dist.get_backend() == "nccl":  # RCCL: block j of my lists goes to rank j, I receive everybody's lists of block r
         dist.all_to_all_single(Dr.view(-1), Dp.view(-1))
         dist.all_to_all_single(Ir.view(-1), Ip.view(-1))
-    else:  # gloo has no all-to-all: gather everything, keep my block (CPU / shared-GPU test path; same result)
-        Dall = torch.empty((W, W * bq, kk), dtype=torch.float32, device=dev)
-        Iall = torch.empty((W, W * bq, kk), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(Dall.view(-1, kk), Dp)
-        dist.all_gather_into_tensor(Iall.view(-1, kk), Ip)
-        Dr.copy_(Dall[:, r * bq:(r + 1) * bq])
-        Ir.copy_(Iall[:, r * bq:(r + 1) * bq])
+    else:  # gloo has no all-to-all: W gathers, rank j collecting everybody's lists of block j (CPU / shared-GPU test path; same result)
+        for j in range(W):
+            dist.gather(Dp[j * bq:(j + 1) * bq], gather_list=list(Dr.unbind(0)) if r == j else None, dst=j)
+            dist.gather(Ip[j * bq:(j + 1) * bq], gather_list=list(Ir.unbind(0)) if r == j else None, dst=j)
     offs = torch.tensor([sum(npass[:w]) for w in range(W)], dtype=torch.int64, device=dev)
     Dm, Im = merge(Dr, Ir, offs, min(k, W * kk))
     q_lo, q_hi = min(r * bq, Nq), min((r + 1) * bq, Nq)

@@ -331,7 +331,8 @@ int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int
  * (score descending, position ascending) - cocodr_score_topk's output with id_offset 0, positions LOCAL to the shard and
  * narrowed to int32, empty slots (I < 0) at the end.  shard_offset int64 [W] (device): first global position of shard w,
  * ascending in w.  outD fp32 / outI int64 [Nq][k_out], k_out <= W * k: (score descending, global position ascending),
- * (-inf, -1) padding.  W <= 64, W * k <= 39936.  Deterministic, no workspace. */
+ * (-inf, -1) padding.  W <= 64, W * k <= 39936.  Deterministic, no workspace.  A slot is empty iff its position is negative - a
+ * candidate whose score is -inf is a candidate; NaN scores are not supported (they have no place in the order). */
 int cocodr_topk_merge(const float* D, const int32_t* I, const long long* shard_offset, int W, int Nq, int k,
                       long long stride_w, float* outD, long long* outI, int k_out, cocodr_stream_t stream);
 

@@ -282,10 +282,10 @@ def _nccl_one_rank(rank, world, ids, mask):
     import torch.distributed as dist
     import cocodr_amd  # noqa: F401
     from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
-    os.environ["COCODR_FORCE_DIST"] = "1"  # take the N > 1 code path with one rank: gather + ranged all-reduce run on RCCL
     torch.manual_seed(0)
     bert = CocoBertModel(_small_cfg()).to("cuda")
     model = CoCondenserForPretraining(bert)
+    model.force_gather = True  # take the N > 1 code path with one rank: gather + ranged all-reduce run on RCCL
     bert.enable_grad_allreduce(chunks=2)
     assert dist.get_backend() == "nccl"
     loss = model({"input_ids": torch.from_numpy(ids).cuda(), "attention_mask": torch.from_numpy(mask).cuda()}, None)
@@ -447,6 +447,103 @@ def test_two_rank_no_sync_accumulation_then_synchronised_step(packed):
         assert np.array_equal(a, b)  # both ranks hold the same average
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's own data-parallel line, kept verbatim (ANCE/drivers/run_ann.py:177-184):
+#     model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.local_rank], output_device=args.local_rank,
+#                                                       find_unused_parameters=True)
+# torch's reducer sees only HF-named views that autograd never visits; the model notices the wrapper and reduces its flat
+# gradients itself on the wrapper's process group (CocoBertModel._dp_adopt_ddp_wrapper).  The gradients after a plain step, after
+# a DDP no_sync() accumulation step + a synchronised step, and the parameters after two optimizer steps must be those of an
+# explicit mean over ranks - on BOTH ranks, bit for bit equal to each other (nothing may drift).
+def _ddp_wrap_rank(rank, world, batches, find_unused):
+    import torch.distributed as dist
+    import cocodr_amd  # noqa: F401
+    from cocodr_amd.modeling import BertDotNLL
+    from cocodr_amd.optim import FlatAdamW
+
+    def make():
+        torch.manual_seed(0)
+        m = BertDotNLL(_small_cfg()).to("cuda").eval()  # (eval: no dropout, so the explicit reference below sees the same arithmetic)
+        return m
+
+    def args_of(b):
+        return [torch.from_numpy(x[rank::world].copy()).cuda() for x in b]
+
+    model = make()
+    if rank == 1:  # a rank that starts from different weights: the wrapper's constructor broadcasts rank 0's (DDP semantics)
+        with torch.no_grad():
+            model.bert.flat_decay.add_(0.01)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, find_unused_parameters=find_unused)
+    opt = FlatAdamW.for_model(model.bert, lr=1e-3)
+    flats = (model.bert.flat_decay, model.bert.flat_nodecay)
+    out = {}
+    # step 1: plain synchronised step through the WRAPPER
+    loss, _, _ = ddp(*args_of(batches[0]))
+    loss.backward()
+    out["g1"] = [p.grad.cpu().numpy().copy() for p in flats]
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    # step 2: accumulation micro-step under the wrapper's no_sync(), then a synchronised micro-step (run_ann.py:318-341)
+    with ddp.no_sync():
+        loss, _, _ = ddp(*args_of(batches[1]))
+        loss.backward()
+    out["local"] = [p.grad.cpu().numpy().copy() for p in flats]
+    loss, _, _ = ddp(*args_of(batches[2]))
+    loss.backward()
+    out["g2"] = [p.grad.cpu().numpy().copy() for p in flats]
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    # step 3: a third forward / backward (torch's reducer raises here if it believes a reduction is pending)
+    loss, _, _ = ddp(*args_of(batches[0]))
+    loss.backward()
+    out["params"] = [p.detach().cpu().numpy().copy() for p in flats]
+    out["passive"] = ddp.require_backward_grad_sync is False
+    # ---- reference: no wrapper, no reduction machinery; explicit means
+    ref = make()
+    ropt = FlatAdamW.for_model(ref.bert, lr=1e-3)
+    rflats = (ref.bert.flat_decay, ref.bert.flat_nodecay)
+
+    def mean_grads():
+        res = []
+        for p in rflats:
+            g = p.grad.clone()
+            dist.all_reduce(g)
+            p.grad.copy_(g / world)
+            res.append(p.grad.cpu().numpy().copy())
+        return res
+
+    l, _, _ = ref(*args_of(batches[0]))
+    l.backward()
+    out["r1"] = mean_grads()
+    ropt.step()
+    ropt.zero_grad(set_to_none=True)
+    l, _, _ = ref(*args_of(batches[1]))
+    l.backward()
+    out["rlocal"] = [p.grad.cpu().numpy().copy() for p in rflats]
+    l, _, _ = ref(*args_of(batches[2]))
+    l.backward()
+    out["r2"] = mean_grads()
+    ropt.step()
+    out["rparams"] = [p.detach().cpu().numpy().copy() for p in rflats]
+    return out
+
+
+@pytest.mark.parametrize("find_unused", [True, False])
+def test_reference_ddp_wrap_line_reduces_the_flat_gradients_and_ranks_stay_equal(find_unused):
+    batches = [_triplet_batch(40 + i, 8) for i in range(3)]
+    out = _spawn(_ddp_wrap_rank, 2, "gloo", batches, find_unused)
+    for r in (0, 1):
+        o = out[r]
+        assert o["passive"]
+        for k_got, k_ref, tol in (("g1", "r1", 1e-5), ("local", "rlocal", 1e-5), ("g2", "r2", 1e-5), ("params", "rparams", 1e-5)):
+            for g, w in zip(o[k_got], o[k_ref]):
+                assert _rel(g, w) < tol, (k_got, _rel(g, w))
+    for k in ("g1", "g2", "params"):  # the two ranks hold identical averaged gradients and identical weights: nothing drifts
+        for a, b in zip(out[0][k], out[1][k]):
+            assert np.array_equal(a, b), k
+    assert not np.array_equal(out[0]["local"][0], out[1]["local"][0])  # (the no_sync micro-step really stayed local)
+
+
 def _condenser_stale_rank(rank, world, ids, mask, labels):
     """A training-mode forward whose backward never runs (its count would have forced the hook path for the backbone and, before
     round 3, left the head un-reduced), then a real step: backbone AND head gradients must still be the mean over ranks."""
@@ -603,9 +700,8 @@ def test_sharded_search_native_equals_one_search_over_the_merged_corpus(world, n
 def _sharded_search_one_rank_rccl(rank, world, Q, P, k):
     import cocodr_amd  # noqa: F401
     from cocodr_amd import retrieval as R
-    os.environ["COCODR_FORCE_DIST"] = "1"  # the N > 1 path (all_to_all_single + merge) on a 1-rank RCCL group
     Ql, Pl = torch.from_numpy(Q).cuda(), torch.from_numpy(P).cuda()
-    D, I = R.sharded_search(Ql, Pl, k)
+    D, I = R.sharded_search(Ql, Pl, k, force_distributed=True)  # the N > 1 path (all_to_all_single + merge) on a 1-rank RCCL group
     D0, I0 = R.search(Ql, Pl, k)
     return bool(torch.equal(D, D0) and torch.equal(I, I0))
 

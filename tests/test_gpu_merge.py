@@ -89,3 +89,16 @@ def test_merge_rejects_bad_arguments():
         ops.topk_merge(D, I.to(torch.int64), offs, 4)
     with pytest.raises(ValueError):
         ops.topk_merge(D.cpu(), I.cpu(), offs.cpu(), 4)  # no CPU path
+
+
+def test_a_real_candidate_scoring_minus_infinity_is_a_candidate():
+    """Validity is the position (I < 0 = empty slot), never the score: a passage whose score is -inf keeps its rank behind every
+    finite score and ahead of the padding (the C twin `cocodr_topk_merge_ref` has always read it that way)."""
+    D = np.full((2, 1, 4), -np.inf, np.float32)
+    I = np.full((2, 1, 4), -1, np.int32)
+    D[0, 0, :3], I[0, 0, :3] = [2.0, 1.0, -np.inf], [5, 1, 3]       # three candidates, the last one scores -inf
+    D[1, 0, :2], I[1, 0, :2] = [1.5, -np.inf], [0, 2]
+    offs = np.array([0, 10], np.int64)
+    Dm, Im = ops.topk_merge(torch.from_numpy(D).to(DEV), torch.from_numpy(I).to(DEV), torch.from_numpy(offs).to(DEV), 7)
+    assert Im.cpu().numpy()[0].tolist() == [5, 10, 1, 3, 12, -1, -1]
+    assert Dm.cpu().numpy()[0, :3].tolist() == [2.0, 1.5, 1.0] and np.isneginf(Dm.cpu().numpy()[0, 3:]).all()

@@ -232,11 +232,11 @@ template <int TA, int TB>
 void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
   const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
   dim3 grid(ntm * ntn, a.batch);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static cocodr_lds_once attr_done;
+  if (attr_done.pending()) {
     hipFuncSetAttribute((const void*)gemm_w4_kernel<TA, TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)gemm_w4_kernel<TA, TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_done = true;
+    attr_done.done();
   }
   if (a.out_f32) hipLaunchKernelGGL((gemm_w4_kernel<TA, TB, true>), grid, dim3(NTHREADS), LDS_BYTES, st, a);
   else hipLaunchKernelGGL((gemm_w4_kernel<TA, TB, false>), grid, dim3(NTHREADS), LDS_BYTES, st, a);
