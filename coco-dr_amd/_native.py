@@ -28,6 +28,7 @@ class GemmArgs(C.Structure):
         ("colsum", c_void_p), ("colsum_partial", c_void_p),
         ("drop", DropoutMask),
         ("ab_f16", c_int),
+        ("split_ws", c_void_p), ("split_ws_floats", c_size_t),
     ]
 
 
@@ -57,7 +58,7 @@ class EmbedGrads(C.Structure):
 class EncoderLayout(C.Structure):
     _fields_ = [(n, c_size_t) for n in (
         "total_bytes", "hidden", "cls_f32", "qkv", "ctx", "y1", "x1", "u", "h", "y2", "lse", "mean1", "rstd1", "mean2",
-        "rstd2", "emb_mean", "emb_rstd", "bwd_scratch", "bwd_bytes", "bwd_dx")]
+        "rstd2", "emb_mean", "emb_rstd", "bwd_scratch", "bwd_bytes", "bwd_dx", "split_ws", "split_ws_floats")]
 
 
 class PackedBatch(C.Structure):  # mirrors cocodr_packed_batch
@@ -81,6 +82,7 @@ SIGNATURES = {
     "cocodr_build_info": (C.c_char_p, []),
     "cocodr_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
     "cocodr_gemm_multi_workspace_floats": (c_size_t, []),
+    "cocodr_gemm_split_workspace_floats": (c_size_t, []),
     "cocodr_gemm_multi_workspace_floats_for": (c_size_t, [c_void_p, c_int]),
     "cocodr_gemm_multi": (c_int, [C.POINTER(GemmArgs), c_int, c_void_p, c_size_t, c_void_p]),
     "cocodr_gemm_set_impl": (c_int, [c_int]),

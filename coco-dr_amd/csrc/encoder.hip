@@ -134,8 +134,13 @@ int layer_drop(const cocodr_config* c, bool active, int l, LayerDrop* d) {
   return COCODR_OK;
 }
 
+// (split workspace of the arena the current call works on: set by encoder_fwd_impl / encoder_bwd_impl before their first GEMM;
+//  the library is single-threaded per call chain - one host thread enqueues a pass - and every gemm_base call re-reads it)
+thread_local float* t_split_ws = nullptr;
+thread_local size_t t_split_ws_floats = 0;
 cocodr_gemm_args gemm_base(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb) {
   cocodr_gemm_args g = {};
+  g.split_ws = t_split_ws; g.split_ws_floats = t_split_ws_floats;
   g.A = (const uint16_t*)A; g.B = (const uint16_t*)B; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.trans_a = ta; g.trans_b = tb; g.epi = COCODR_EPI_NONE; g.batch = 1;
@@ -188,6 +193,10 @@ int layout_m(const cocodr_config* c, size_t M, int B, int L, int training, cocod
   out->rstd2 = cv.take(NL * M * 4);
   out->emb_mean = cv.take(M * 4);
   out->emb_rstd = cv.take(M * 4);
+  // the widest GEMM of a layer has more 256 x 256 tiles than the chip has compute units: a workspace lets every forward / dgrad
+  // launch cut its last partial round into contraction slices (gemm_pp.hip launch_split)
+  out->split_ws_floats = ((M + 255) / 256) * (std::max(I, 3 * H) / 256) > 256 ? cocodr_gemm_split_workspace_floats() : 0;
+  out->split_ws = cv.take(out->split_ws_floats * 4);
   out->bwd_scratch = cv.off;
   out->bwd_bytes = training ? bwd_layout_m(c, M, B, L).total : 0;
   out->bwd_dx = training ? cv.off + bwd_layout_m(c, M, B, L).dxb : 0;
@@ -262,6 +271,8 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
   CK_ARG(((uintptr_t)arena & 255) == 0, "encoder_fwd: arena must be 256-byte aligned");
   char* base = (char*)arena;
   const int M = pk ? pk->T : B * L, H = c->hidden, I = c->inter, NL = c->layers;
+  t_split_ws = lay.split_ws_floats ? (float*)(base + lay.split_ws) : nullptr;
+  t_split_ws_floats = lay.split_ws_floats;
   const size_t ls = training ? 1 : 0;  // per-layer stride multiplier
   uint16_t* hidden = (uint16_t*)(base + lay.hidden);
   float* cls = (float*)(base + lay.cls_f32);
@@ -400,6 +411,8 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     }
   }
   char* base = (char*)arena;
+  t_split_ws = lay.split_ws_floats ? (float*)(base + lay.split_ws) : nullptr;
+  t_split_ws_floats = lay.split_ws_floats;
   const BwdLayout bl = pk ? bwd_layout_m(c, (size_t)M, B, 32) : bwd_layout(c, B, L);
   char* bb = base + lay.bwd_scratch;
   uint16_t* hidden = (uint16_t*)(base + lay.hidden);

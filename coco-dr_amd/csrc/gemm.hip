@@ -583,6 +583,9 @@ void launch_glds_any(const cocodr_gemm_args& a, hipStream_t st) {
 }  // namespace cocodr_gemm_v2
 using cocodr_gemm_v2::launch_glds_any;
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st);  // gemm_pp.hip: the ping-pong pipeline
+bool cocodr_gemm_pp_launch_split(const cocodr_gemm_args& a, hipStream_t st);    // ... with its last partial round cut into contraction slices
+void cocodr_gemm_pp_split_plan(const cocodr_gemm_args& a, int& total, int& r, int& s);
+size_t cocodr_gemm_pp_split_ws_floats();
 void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, size_t ws_floats, hipStream_t st);
 size_t cocodr_gemm_pp_multi_ws_floats();
 size_t cocodr_gemm_pp_multi_ws_floats_for(const cocodr_gemm_args* a, int n);
@@ -647,7 +650,18 @@ int select_impl(const cocodr_gemm_args& a) {
     const long long roundspp = (tilespp + 255) / 256;
     static const bool nopp = getenv("COCODR_GEMM_NOPP") != nullptr;  // A/B switch of this rule
     // (with two fat phases per K-tile the grouped weight gradients gain from ~400 tiles as well: profiles/r02_gemm_pp_fat.txt)
-    const bool pp_fills = !nopp && tilespp >= 400 && tilespp * 100 >= roundspp * 256 * 78;
+    bool pp_fills = !nopp && tilespp >= 400 && tilespp * 100 >= roundspp * 256 * 78;
+    // with a split workspace the last partial round can run as contraction slices (gemm_pp.hip launch_split).  Measured over
+    // packed row counts 4 416 ... 26 016 (profiles/r04_gemm_tail_sweep.txt): it beats every other pipeline only where the
+    // tail is short and the contraction long - r <= 64 tiles in s >= 4 slices at K >= 2048 (17 888 rows x 1024 x 4096: 145 us
+    // against 163 for the 256 x 128 tiles and 180 for whole 256 x 256 tiles; the same shape at K = 1024: 64 against 55) - and
+    // loses wherever the tail is long (368 tiles: 200 against 180) because two slices of a tile cost a ramp, a 256 KB fp32
+    // partial tile each way and the finishing pass.  So: exactly that window.
+    if (!nopp && !pp_fills && tilespp > 256 && a.split_ws != nullptr && batch == 1 && a.K >= 2048) {
+      int total, r, sl;
+      cocodr_gemm_pp_split_plan(a, total, r, sl);
+      if (sl >= 4 && r <= 64) pp_fills = true;
+    }
     if (!(k_ok && small)) impl = 1;
     else if (pp_fills) impl = 13;
     else if (fewer_rounds && !a.trans_a && tiles256 >= 128 && !a.colsum && !a.colsum_partial) impl = 12;
@@ -700,6 +714,7 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   if (a.epi != COCODR_EPI_ADD && a.epi != COCODR_EPI_DGELU) a.R = nullptr;
   CK_ARG(a.drop.threshold == 0 || (a.epi == COCODR_EPI_ADD && a.batch == 1 && !a.colsum && !a.colsum_partial && a.drop.threshold < 65536),
          "gemm: dropout belongs to an EPI_ADD call with batch == 1 and no column sums");
+  CK_ARG(a.split_ws == nullptr || (((uintptr_t)a.split_ws & 15) == 0), "gemm: split_ws must be 16-byte aligned");
   CK_ARG(!(a.colsum || a.colsum_partial) || (a.colsum_partial && a.batch == 1 && !a.out_f32),
          "gemm: column sums need colsum_partial, batch == 1 and a bf16 output");
   float* const cs_out = a.colsum;
@@ -720,7 +735,8 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   const int cs_rows = colsum_rows(impl, a.M);  // the kernels with 128-column tiles reduce in their epilogue
   CK_ARG(!cs_part || cs_out || cs_rows > 0, "gemm: deferred column sums (colsum == NULL) are not available on this pipeline; ask cocodr_gemm_colsum_rows first");
   if (cs_rows == 0) a.colsum_partial = nullptr;
-  if (impl >= 13) cocodr_gemm_pp_launch(a, impl == 18 ? 105 : 2, st);
+  if (impl == 13 && cocodr_gemm_pp_launch_split(a, st)) { /* whole rounds + a cut last round */ }
+  else if (impl >= 13) cocodr_gemm_pp_launch(a, impl == 18 ? 105 : 2, st);
   else if (impl == 12) launch_glds_any<256, 64, 2, 1, 4, 3>(a, st);
   else if (impl == 11) launch_glds_any<256, 32, 2, 4>(a, st);
   else if (impl == 10) launch_glds_any<256, 64, 4, 2, 4>(a, st);
@@ -742,6 +758,8 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   }
   return COCODR_OK;
 }
+
+extern "C" size_t cocodr_gemm_split_workspace_floats(void) { return cocodr_gemm_pp_split_ws_floats(); }
 
 extern "C" size_t cocodr_gemm_colsum_partial_floats(int M, int N) {
   const size_t panels = (size_t)(M + 127) / 128;

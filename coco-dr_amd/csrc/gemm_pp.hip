@@ -544,6 +544,53 @@ __global__ __launch_bounds__(256) void gemm_pp_split_finish(const MultiArgs ma, 
   const int gm = tm_ * BM + row, gn = tn_ * 256 + col;
   if (gm < p.M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC + (size_t)gm * p.ldc + gn) = acc;
 }
+
+// The same for ONE problem of any form with its epilogue (bias / GELU + GELU' / residual (+ dropout) / x GELU', bf16 or fp32 result,
+// optional per-row-panel column sums): grid = (r tiles, 8 strips of 32 columns), 256 threads = 64 row lanes x 4 chunks of 8 columns;
+// a thread walks rows lane, lane + 64, ... of its chunk, so a wave reads 16 rows x 128 contiguous bytes per slice.
+template <bool OUT_F32, int TA>
+__global__ __launch_bounds__(256) void gemm_pp_split_finish_epi(const MultiArgs ma) {
+  __shared__ float cred[4][8][64];
+  const cocodr_gemm_args& p = ma.p[0];
+  const int lt = blockIdx.x, id = ma.split_first + lt;
+  const int ntn = p.N / 256, ntm = (p.M + BM - 1) / BM;
+  int tm_, tn_;
+  if (TA == 0) cocodr_gemm_v2::grouped_tile(id, ntm, ntn, 4, tm_, tn_);
+  else cocodr_gemm_v2::grouped_tile(id, ntm, ntn, 8, tm_, tn_);
+  const int tid = threadIdx.x, ch = tid & 3, rl = tid >> 2;
+  const int col = blockIdx.y * 32 + ch * 8, gn = tn_ * 256 + col;
+  const float* __restrict__ bias = p.bias;
+  const uint16_t* __restrict__ R_ = p.R;
+  const float* src = ma.split_ws + (size_t)lt * ma.split_s * SPLIT_TILE + col;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int row = rl; row < BM; row += 64) {
+    const int gm = tm_ * BM + row;
+    if (gm >= p.M) break;
+    float v[8];
+    const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)row * 256);
+    const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)row * 256 + 4);
+    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    for (int c = 1; c < ma.split_s; ++c) {
+      const float4 b0 = *reinterpret_cast<const float4*>(src + (size_t)c * SPLIT_TILE + (size_t)row * 256);
+      const float4 b1 = *reinterpret_cast<const float4*>(src + (size_t)c * SPLIT_TILE + (size_t)row * 256 + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    epilogue_store8<OUT_F32>(p, 0, bias, R_, gm, gn, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) csum[j] += v[j];
+  }
+  if (p.colsum_partial != nullptr) {  // the tile's column sums (workgroup-uniform branch), one row per row panel as in the whole-tile epilogue
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cred[ch][j][rl] = csum[j];
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+      for (int i = 0; i < 64; ++i) t += cred[tid >> 3][tid & 7][i];
+      p.colsum_partial[(size_t)tm_ * p.N + tn_ * 256 + blockIdx.y * 32 + tid] = t;
+    }
+  }
+}
 }  // namespace cocodr_gemm_pp
 
 // floats of workspace the cut last round of ANY merged launch may need (see MultiArgs)
@@ -611,6 +658,60 @@ void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, si
   }
   hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
   if (split) hipLaunchKernelGGL(gemm_pp_split_finish, dim3(r, SPLIT_TILE / 4 / 256), dim3(256), 0, st, ma, r);
+}
+
+// ---- ONE forward / dgrad / weight-gradient problem (batch == 1) whose tiles leave a partial last round of the compute units: the
+// r tiles of that round run as r x s contraction slices (see MultiArgs) and gemm_pp_split_finish_epi adds them and applies the
+// epilogue.  Keeps arbitrary row counts (packed batches: T changes with every batch) on this pipeline: 280 tiles are 256 whole
+// tiles + 24 tiles x 4 slices instead of two rounds, the second one with 9 % of the CUs at work.
+size_t cocodr_gemm_pp_split_ws_floats() { return (size_t)256 * cocodr_gemm_pp::SPLIT_TILE; }
+// the cut this problem would get: r tiles in s slices (s = 0: none)
+void cocodr_gemm_pp_split_plan(const cocodr_gemm_args& a, int& total, int& r, int& s) {
+  using namespace cocodr_gemm_pp;
+  total = ((a.M + BM - 1) / BM) * (a.N / Shape<2>::BN);
+  const int n_cu = multi_n_cu();
+  const int nkt = (a.K + BK - 1) / BK;
+  r = s = 0;
+  static const int off = getenv("COCODR_GEMM_NOTAIL") ? 1 : 0;  // A/B switch
+  if (off || n_cu <= 0 || a.batch > 1 || a.split_ws == nullptr || a.ab_f16 || a.drop.threshold >= 65536) return;
+  r = total % n_cu;
+  if (total <= n_cu || r == 0 || r > n_cu / 2) { r = 0; return; }
+  s = n_cu / r;
+  if (s > 8) s = 8;                // (fp32 partial tiles: 256 KB each way per slice)
+  if (s > nkt / 2) s = nkt / 2;    // at least two K-tiles per slice
+  if (s < 2 || (size_t)r * s * SPLIT_TILE > a.split_ws_floats) { r = s = 0; }
+}
+template <int TA, int TB>
+static void launch_split(const cocodr_gemm_args& a, int total, int r, int s, hipStream_t st) {
+  using namespace cocodr_gemm_pp;
+  MultiArgs ma;
+  for (int q = 0; q < 4; ++q) { ma.p[q] = a; ma.tile_end[q] = total; }
+  ma.split_first = total - r;
+  ma.split_s = s;
+  ma.split_ws = a.split_ws;
+  static cocodr_lds_once attr_done;
+  if (attr_done.pending()) {
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<2, TA, TB, true, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<2, TA, TB, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done.done();
+  }
+  const dim3 grid(total - r + r * s);
+  if (a.out_f32) {
+    hipLaunchKernelGGL((gemm_pp_kernel<2, TA, TB, true, 0, false, true>), grid, dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
+    hipLaunchKernelGGL((gemm_pp_split_finish_epi<true, TA>), dim3(r, 8), dim3(256), 0, st, ma);
+  } else {
+    hipLaunchKernelGGL((gemm_pp_kernel<2, TA, TB, false, 0, false, true>), grid, dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
+    hipLaunchKernelGGL((gemm_pp_split_finish_epi<false, TA>), dim3(r, 8), dim3(256), 0, st, ma);
+  }
+}
+bool cocodr_gemm_pp_launch_split(const cocodr_gemm_args& a, hipStream_t st) {
+  int total, r, s;
+  cocodr_gemm_pp_split_plan(a, total, r, s);
+  if (s == 0) return false;
+  if (!a.trans_a && !a.trans_b) launch_split<0, 0>(a, total, r, s, st);
+  else if (!a.trans_a && a.trans_b) launch_split<0, 1>(a, total, r, s, st);
+  else launch_split<1, 1>(a, total, r, s, st);
+  return true;
 }
 
 // nb = 2: four thin phases per K-tile (the encoder's default), 105: two fat phases per K-tile (impl 18), 104: IEEE-half operands

@@ -52,7 +52,7 @@ def _dm_ref(drop: Optional[N.DropoutMask]):
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          bias: Optional[torch.Tensor] = None, epi: int = N.EPI_NONE, r: Optional[torch.Tensor] = None,
          out_f32: bool = False, out: Optional[torch.Tensor] = None, colsum: bool = False, split_k: int = 1,
-         drop: Optional[N.DropoutMask] = None):
+         drop: Optional[N.DropoutMask] = None, split_ws: Optional[torch.Tensor] = None):
     """C = epi(op(a) @ op(b)); a, b bf16 2-D (or 3-D batched with equal batch).  See cocodr_gemm.
     colsum=True (unbatched) also returns the fp32 column sums of C as the last element of the result tuple.
     split_k > 1 (plain 2-D product, trans_a=False): the contraction is cut into split_k slices that run as the batch items of
@@ -102,6 +102,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
     g.strideA, g.strideB, g.strideC = a2.numel(), b2.numel(), M * Nn
     if drop is not None:  # EPI_ADD: out = dropout(a @ b + bias) + r
         g.drop = drop
+    if split_ws is not None:  # fp32 workspace: the 256 x 256-tile pipeline may cut its last partial round into contraction slices
+        _req(split_ws, F32, "split_ws")
+        g.split_ws, g.split_ws_floats = split_ws.data_ptr(), split_ws.numel()
     cs = None
     if colsum:
         if batched:

@@ -107,7 +107,14 @@ typedef struct {
   /* non-zero: A and B hold IEEE half instead of bfloat16 (plain NT form with an fp32 result only: trans_a = trans_b = 0,
    * out_f32 = 1, no epilogue / bias / column sums, N % 256 == 0, K % 64 == 0) - the split-precision score GEMM of the search */
   int ab_f16;
+  /* optional workspace (16-byte aligned, batch == 1): lets a launch on the 256 x 256-tile pipeline cut the tiles of its last
+   * partial round of the compute units into contraction slices (fp32 partial tiles; a second small kernel adds them in a fixed
+   * order and applies the epilogue) instead of running one more nearly empty round of whole tiles - what keeps arbitrary row
+   * counts (packed batches) on that pipeline.  cocodr_gemm_split_workspace_floats() floats serve any call; NULL: whole tiles. */
+  float* split_ws;
+  size_t split_ws_floats;
 } cocodr_gemm_args;
+size_t cocodr_gemm_split_workspace_floats(void);
 size_t cocodr_gemm_colsum_partial_floats(int M, int N);
 /* Deferred form: with colsum == NULL and colsum_partial != NULL the call only leaves its per-row-panel sums
  * [rows][N] in colsum_partial (rows = cocodr_gemm_colsum_rows(args), which is 0 when the call would not run on a
@@ -388,6 +395,8 @@ typedef struct { /* byte offsets into the arena, filled by cocodr_encoder_layout
   size_t bwd_scratch;  /* backward-only region (dgrad chain, saved dY for the grouped wgrad) */
   size_t bwd_bytes;
   size_t bwd_dx;       /* bf16 [M,H]: where a backward range leaves dL/d(hidden_states[layer_lo]) */
+  size_t split_ws;     /* fp32 workspace the forward / dgrad GEMMs may cut their last partial round into (cocodr_gemm_args.split_ws) */
+  size_t split_ws_floats; /* 0: no GEMM of this shape has more tiles than compute units */
 } cocodr_encoder_layout_t;
 
 /* training = 0 keeps only what inference needs (hidden states + one layer of scratch) */
