@@ -721,7 +721,12 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         tail = bool(cls_tail and arena_drop is None and (not training or pk.B % 8 == 0))
         cfg = self._c_config(arena_drop, tail)
         check(lib().cocodr_encoder_layout_packed(C.byref(cfg), pk.T, pk.B, int(training), C.byref(lay)), "encoder_layout_packed")
-        arena = torch.empty(lay.total_bytes, dtype=torch.uint8, device=pk.ids.device)
+        # T changes with every batch; the arena is allocated at the size of the PADDED batch (B x L rows, the upper bound of T) so
+        # that the caching allocator hands back the same block step after step instead of growing / splitting a 10-20 GB block
+        # whenever a batch is a little longer than any before it (a hipMalloc of that size inside a step costs tens of ms)
+        cap = N.EncoderLayout()
+        check(lib().cocodr_encoder_layout_packed(C.byref(cfg), pk.B * pk.L, pk.B, int(training), C.byref(cap)), "encoder_layout_packed")
+        arena = torch.empty(max(cap.total_bytes, lay.total_bytes), dtype=torch.uint8, device=pk.ids.device)
         arena._cocodr_drop = arena_drop
         arena._cocodr_tail = tail
         emb, arr, _, _ = self._param_structs()

@@ -5,7 +5,7 @@
 # The PMC stage writes gemm_pmc_<model>_<seq>x128[_packed].json; copy them to profiles/ (bench.py's roofline.traffic reads profiles/gemm_pmc_*.json
 # and reports the commit recorded inside).
 set -u
-tag=${1:-r03}; commit=${2:-unknown}; stages=${3:-tbkp}
+tag=${1:-r04}; commit=${2:-unknown}; stages=${3:-tbkp}
 export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/$tag
