@@ -200,7 +200,7 @@ def cpu_baseline():
 
 
 # ---------------------------------------------------------------------------------------------------------- side legs
-def full_coco_step(cfg, dev, ids, mask, steps: int = 8, warmup: int = 3):
+def full_coco_step(cfg, dev, ids, mask, lens=None, steps: int = 8, warmup: int = 3):
     """The reference's whole pre-training step (COCO/modeling.py:192-235 with COCO/README.md:49 settings: 2 Condenser
     head layers, skip_from 6, late MLM): backbone + head + two label-sparse MLM losses + contrastive + AdamW.
     Reported next to the headline metric, never instead of it."""
@@ -218,6 +218,8 @@ def full_coco_step(cfg, dev, ids, mask, steps: int = 8, warmup: int = 3):
     labels = torch.where(pick, ids, torch.full_like(ids, -100))
     inp = torch.where(pick, torch.full_like(ids, 103), ids)  # [MASK]
     batch = {"input_ids": inp, "attention_mask": mask}
+    if lens is not None:
+        batch["lengths"] = lens  # host-known lengths: the packed layout (the default execution) is built without a read-back
     all_flats = [bert.flat_decay, bert.flat_nodecay, model.c_head.flat_decay, model.c_head.flat_nodecay]
 
     def step():
@@ -235,7 +237,17 @@ def full_coco_step(cfg, dev, ids, mask, steps: int = 8, warmup: int = 3):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    bert.pack_sequences = False  # the same step on the padded layout (all B x L rows)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    pdt = (time.perf_counter() - t0) / steps
     return {"sequences_per_sec": round(ids.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss.detach()), 3),
+            "execution": "packed (backbone and Condenser head on the stored rows)", "padded_ms_per_step": round(pdt * 1e3, 3),
             "scope": "backbone + 2 Condenser head layers (skip_from 6) + head & late MLM losses (label-sparse, 15 %) + contrastive + clip_grad_norm_(1.0) + AdamW"}
 
 
@@ -608,7 +620,7 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
     exec_info["fresh_batches"] = bool(seen and all(seen))
     del opt, model, bert
     torch.cuda.empty_cache()
-    return dt, float(loss.detach()), roof, cfg, pool[0][:2], exec_info
+    return dt, float(loss.detach()), roof, cfg, pool[0], exec_info
 
 
 def whole_step_fracs(n_seq: int, steps: int, dt: float, cfg, seq_len: int, exec_info: dict, world: int = 1) -> dict:
@@ -693,7 +705,7 @@ def main():
 
     solo = not use_dist
     packed = not args.padded
-    dt, final_loss, roof, cfg, (ids, mask), xinfo = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, rank,
+    dt, final_loss, roof, cfg, (ids, mask, lens), xinfo = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, rank,
                                                             world, use_dist, args.dp_chunks, not args.no_roofline, args.dense, packed=packed)
     extras = {}
     if solo and not args.no_full_step and rank == 0:
@@ -729,7 +741,7 @@ def main():
                                  "here the sequences are stored back to back with 32-row alignment (no work on padding rows)")})
         extras["padded_contrastive_step" if packed else "packed_contrastive_step"] = other
         if args.model == "base":
-            extras["full_coco_step"] = full_coco_step(cfg, dev, ids, mask)  # second scope: what the reference's step really runs
+            extras["full_coco_step"] = full_coco_step(cfg, dev, ids, mask, lens)  # second scope: what the reference's step really runs
             extras["ance_triplet_step"] = ance_step(dev)
         extras["corpus_encode"] = corpus_encode(cfg, dev, seq_len=args.seq_len)
         extras["eval_search"] = eval_search(dev)

@@ -105,6 +105,7 @@ SIGNATURES = {
     "cocodr_encoder_layout_packed": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),
     "cocodr_encoder_fwd_packed": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), C.POINTER(PackedBatch), c_int,
                                           c_void_p, c_size_t, c_void_p]),
+    "cocodr_stack_fwd_packed": (c_int, [C.POINTER(Config), C.POINTER(LayerParams), C.POINTER(PackedBatch), c_int, c_void_p, c_size_t, c_void_p]),
     "cocodr_encoder_bwd_packed": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), C.POINTER(EmbedGrads),
                                           C.POINTER(LayerGrads), C.POINTER(PackedBatch), c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
                                           c_void_p]),

@@ -155,10 +155,13 @@ class _CondenserStepFn(torch.autograd.Function):
     is applied on the returned [CLS] rows by the caller (it needs the cross-rank gather)."""
 
     @staticmethod
-    def forward(ctx, fd, fn, hd, hn, ids, mask, labels, bert: CocoBertModel, head: CondenserHead, skip_from: int, late_mlm: bool):
+    def forward(ctx, fd, fn, hd, hn, ids, mask, labels, bert: CocoBertModel, head: CondenserHead, skip_from: int, late_mlm: bool, pk=None):
+        """``pk`` (a PackedIndex): backbone and head run on the packed layout - T stored rows instead of B x L; ``labels`` are
+        then the labels of the packed rows [T].  Same arithmetic per real token, same losses and gradients."""
         cfg = bert.config
         B, L = ids.shape
-        M, H, V, NL = B * L, cfg.hidden_size, cfg.vocab_size, cfg.num_hidden_layers
+        H, V, NL = cfg.hidden_size, cfg.vocab_size, cfg.num_hidden_layers
+        M = pk.T if pk is not None else B * L
         nh = head.n_head_layers
         dev = ids.device
         rows = torch.nonzero(labels.reshape(-1) != -100).squeeze(1)  # host sync: the GEMM row count must be known
@@ -166,9 +169,14 @@ class _CondenserStepFn(torch.autograd.Function):
         if n_lab == 0:
             raise ValueError("condenser step: no labelled positions in the batch (cross_entropy would be NaN)")
         lab = labels.reshape(-1)[rows].to(torch.int32)
+        # first row of every sequence in the [M, H] activations
+        cls_rows = pk.cls_rows if pk is not None else torch.arange(B, device=dev, dtype=torch.int64) * L
         # ---- backbone
-        arena, lay = bert._run_forward(ids, mask, True)
-        hidden = arena[lay.hidden: lay.hidden + (NL + 1) * M * H * 2].view(torch.bfloat16).view(NL + 1, B, L, H)
+        if pk is not None:
+            arena, lay = bert._run_forward_packed(pk, True)
+        else:
+            arena, lay = bert._run_forward(ids, mask, True)
+        hidden = arena[lay.hidden: lay.hidden + (NL + 1) * M * H * 2].view(torch.bfloat16).view(NL + 1, M, H)
         cls = arena[lay.cls_f32: lay.cls_f32 + B * H * 4].view(torch.float32).view(B, H).clone()
         last = hidden[NL]
         # ---- Condenser head on cat(cls of the last layer, skip_from states without their first token)
@@ -176,14 +184,23 @@ class _CondenserStepFn(torch.autograd.Function):
         hdrop = head._next_dropout() or (0.0, 0.0, 0, 0)
         hcfg = N.Config(H, cfg.num_attention_heads, nh, cfg.intermediate_size, V, cfg.max_position_embeddings, cfg.layer_norm_eps, *hdrop)
         hlay = N.EncoderLayout()
-        check(lib().cocodr_encoder_layout(C.byref(hcfg), B, L, 1, C.byref(hlay)), "encoder_layout(head)")
-        harena = torch.empty(hlay.total_bytes, dtype=torch.uint8, device=dev)
-        hhidden = harena[hlay.hidden: hlay.hidden + (nh + 1) * M * H * 2].view(torch.bfloat16).view(nh + 1, B, L, H)
+        if pk is not None:
+            check(lib().cocodr_encoder_layout_packed(C.byref(hcfg), pk.T, B, 1, C.byref(hlay)), "encoder_layout_packed(head)")
+            hcap = N.EncoderLayout()  # (allocated at the padded upper bound, as the backbone's arena: CocoBertModel._run_forward_packed)
+            check(lib().cocodr_encoder_layout_packed(C.byref(hcfg), B * pk.L, B, 1, C.byref(hcap)), "encoder_layout_packed(head)")
+            harena = torch.empty(max(hlay.total_bytes, hcap.total_bytes), dtype=torch.uint8, device=dev)
+        else:
+            check(lib().cocodr_encoder_layout(C.byref(hcfg), B, L, 1, C.byref(hlay)), "encoder_layout(head)")
+            harena = torch.empty(hlay.total_bytes, dtype=torch.uint8, device=dev)
+        hhidden = harena[hlay.hidden: hlay.hidden + (nh + 1) * M * H * 2].view(torch.bfloat16).view(nh + 1, M, H)
         hhidden[0].copy_(hidden[skip_from])
-        hhidden[0][:, 0].copy_(last[:, 0])
+        ops.scatter_rows(last[cls_rows].contiguous(), cls_rows, hhidden[0])
         hlo = head.layout
         harr, _ = hlo.layer_structs(head._shadow.data_ptr(), 0, head.flat_nodecay.data_ptr())
-        check(lib().cocodr_stack_fwd(C.byref(hcfg), harr, ptr(mask), B, L, 1, ptr(harena), harena.numel(), stream_ptr()), "stack_fwd")
+        if pk is not None:
+            check(lib().cocodr_stack_fwd_packed(C.byref(hcfg), harr, C.byref(pk.c_struct), 1, ptr(harena), harena.numel(), stream_ptr()), "stack_fwd_packed")
+        else:
+            check(lib().cocodr_stack_fwd(C.byref(hcfg), harr, ptr(mask), B, L, 1, ptr(harena), harena.numel(), stream_ptr()), "stack_fwd")
         head_out = hhidden[nh]
         # ---- lm.cls on the labelled rows of the head output (and of the last backbone layer: "late" MLM)
         # each group of rows is padded to a multiple of 64 with copies of row 0 that carry scale 0 (their dlogits,
@@ -219,7 +236,7 @@ class _CondenserStepFn(torch.autograd.Function):
         ctx.bert, ctx.head = bert, head
         ctx.skip_from, ctx.late_mlm, ctx.n_lab, ctx.n_pad = skip_from, late_mlm, n_lab, n_pad
         ctx.arena, ctx.lay, ctx.harena, ctx.hlay, ctx.hcfg = arena, lay, harena, hlay, hcfg
-        ctx.ids, ctx.mask = ids, mask
+        ctx.ids, ctx.mask, ctx.pk, ctx.cls_rows = ids, mask, pk, cls_rows
         ctx.saved = (rows, xg, a_pre, g_act, t, t_mean, t_rstd, word16, dlogits)
         ctx.set_materialize_grads(False)
         return mlm_loss, cls
@@ -229,7 +246,9 @@ class _CondenserStepFn(torch.autograd.Function):
         bert, head = ctx.bert, ctx.head
         cfg = bert.config
         B, L = ctx.ids.shape
-        M, H, V, NL = B * L, cfg.hidden_size, cfg.vocab_size, cfg.num_hidden_layers
+        pk, cls_rows = ctx.pk, ctx.cls_rows
+        H, V, NL = cfg.hidden_size, cfg.vocab_size, cfg.num_hidden_layers
+        M = pk.T if pk is not None else B * L
         nh, n_lab, skip_from = head.n_head_layers, ctx.n_lab, ctx.skip_from
         rows, xg, a_pre, g_act, t, t_mean, t_rstd, word16, dlogits = ctx.saved
         dev = ctx.ids.device
@@ -261,18 +280,22 @@ class _CondenserStepFn(torch.autograd.Function):
                 ops.scatter_rows(dxg[ctx.n_pad:ctx.n_pad + n_lab], rows, d_last)
         # ---- Condenser head backward (layers nh-1 .. 0), input gradient left at hlay.bwd_dx
         harr, hgarr = hlo.layer_structs(head._shadow.data_ptr(), 0, head.flat_nodecay.data_ptr(), (ghd.data_ptr(), ghn.data_ptr()))
-        check(lib().cocodr_encoder_bwd_range(C.byref(ctx.hcfg), None, harr, None, hgarr, None, ptr(ctx.mask), ptr(d_head_out), B, L,
-                                             ptr(ctx.harena), ctx.harena.numel(), nh, 0, 0, stream_ptr()), "encoder_bwd_range(head)")
+        if pk is not None:
+            check(lib().cocodr_encoder_bwd_packed(C.byref(ctx.hcfg), None, harr, None, hgarr, C.byref(pk.c_struct), ptr(d_head_out),
+                                                  ptr(ctx.harena), ctx.harena.numel(), nh, 0, 0, stream_ptr()), "encoder_bwd_packed(head)")
+        else:
+            check(lib().cocodr_encoder_bwd_range(C.byref(ctx.hcfg), None, harr, None, hgarr, None, ptr(ctx.mask), ptr(d_head_out), B, L,
+                                                 ptr(ctx.harena), ctx.harena.numel(), nh, 0, 0, stream_ptr()), "encoder_bwd_range(head)")
         # in flight only when this is the step's single pass and nothing un-reduced waits in .grad; otherwise the hooks on the
         # backbone AND head flats (adopted in condenser_step) reduce the accumulated gradients
         dp = bert._dp_overlap_ok()
         works = bert._dp_reduce_async([ghd, ghn]) if dp else []  # the head's gradients travel under the whole backbone backward
-        d_hin = ctx.harena[ctx.hlay.bwd_dx: ctx.hlay.bwd_dx + M * H * 2].view(torch.bfloat16).view(B, L, H)
-        d_last.view(B, L, H)[:, 0] += d_hin[:, 0].float()
+        d_hin = ctx.harena[ctx.hlay.bwd_dx: ctx.hlay.bwd_dx + M * H * 2].view(torch.bfloat16).view(M, H)
+        d_last[cls_rows] += d_hin[cls_rows].float()
         if d_cls is not None:
-            d_last.view(B, L, H)[:, 0] += d_cls.float()
+            d_last[cls_rows] += d_cls.float()
         d_skip = d_hin.clone()
-        d_skip[:, 0] = 0
+        d_skip[cls_rows] = 0
         # ---- backbone backward in two ranges; the head's gradient joins at hidden_states[skip_from]
         bgd = torch.empty_like(bert.flat_decay.data)
         bgn = torch.empty_like(bert.flat_nodecay.data)
@@ -280,16 +303,21 @@ class _CondenserStepFn(torch.autograd.Function):
         emb, arr, eg, garr = bert._param_structs((bgd, bgn))
         bcfg = bert._c_config(getattr(ctx.arena, "_cocodr_drop", None))
         d_last16 = d_last.to(torch.bfloat16)
-        dx_view = ctx.arena[ctx.lay.bwd_dx: ctx.lay.bwd_dx + M * H * 2].view(torch.bfloat16).view(B, L, H)
+        dx_view = ctx.arena[ctx.lay.bwd_dx: ctx.lay.bwd_dx + M * H * 2].view(torch.bfloat16).view(M, H)
 
         def bwd_range(hi, lo_, d_in, do_embed):
-            check(lib().cocodr_encoder_bwd_range(C.byref(bcfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ctx.ids), ptr(ctx.mask),
-                                                 ptr(d_in) if d_in is not None else None, B, L, ptr(ctx.arena), ctx.arena.numel(),
-                                                 hi, lo_, int(do_embed), stream_ptr()), "encoder_bwd_range")
+            if pk is not None:
+                check(lib().cocodr_encoder_bwd_packed(C.byref(bcfg), C.byref(emb), arr, C.byref(eg), garr, C.byref(pk.c_struct),
+                                                      ptr(d_in) if d_in is not None else None, ptr(ctx.arena), ctx.arena.numel(),
+                                                      hi, lo_, int(do_embed), stream_ptr()), "encoder_bwd_packed")
+            else:
+                check(lib().cocodr_encoder_bwd_range(C.byref(bcfg), C.byref(emb), arr, C.byref(eg), garr, ptr(ctx.ids), ptr(ctx.mask),
+                                                     ptr(d_in) if d_in is not None else None, B, L, ptr(ctx.arena), ctx.arena.numel(),
+                                                     hi, lo_, int(do_embed), stream_ptr()), "encoder_bwd_range")
 
         if skip_from >= NL or skip_from == 0:  # the head reads the last layer / the embedding output: one range
             if skip_from >= NL:
-                bwd_range(NL, 0, (d_last.view(B, L, H) + d_skip.float()).to(torch.bfloat16).view(M, H), True)
+                bwd_range(NL, 0, (d_last + d_skip.float()).to(torch.bfloat16), True)
             else:
                 bwd_range(NL, 0, d_last16, False)
                 dx_view += d_skip
@@ -310,20 +338,34 @@ class _CondenserStepFn(torch.autograd.Function):
             bert._dp_mark_reduced(bert.flat_decay, bert.flat_nodecay, head.flat_decay, head.flat_nodecay)
         ctx.arena = ctx.harena = None
         ctx.saved = None
-        return bgd, bgn, ghd, ghn, None, None, None, None, None, None, None
+        return bgd, bgn, ghd, ghn, None, None, None, None, None, None, None, None
 
 
-def condenser_step(bert: CocoBertModel, head: CondenserHead, input_ids, attention_mask, labels, skip_from: int, late_mlm: bool):
+def condenser_step(bert: CocoBertModel, head: CondenserHead, input_ids, attention_mask, labels, skip_from: int, late_mlm: bool,
+                   lengths=None):
     """Returns (mlm_loss, cls_fp32): the MLM part of COCO/modeling.py:222-224 and the last-layer [CLS] rows for the
-    contrastive part (:206-210, :226-230)."""
-    ids, mask, L = bert._prep(input_ids, attention_mask)
-    if L != ids.shape[1]:
-        labels = torch.nn.functional.pad(labels, (0, ids.shape[1] - L), value=-100)
+    contrastive part (:206-210, :226-230).  With ``bert.pack_sequences`` (the default) backbone and head run on the packed
+    layout (``lengths``: the B lengths on the host, when the collator has them - no read-back of the mask)."""
     if not (0 <= skip_from <= bert.config.num_hidden_layers):
         raise ValueError(f"skip_from={skip_from} outside [0, {bert.config.num_hidden_layers}]")
     if torch.is_grad_enabled():
         bert._dp_adopt_ddp_wrapper()  # (a torch DistributedDataParallel wrapper around the model: the model reduces, see there)
     if getattr(bert, "_dp_hooks", None) is not None and hasattr(bert, "_dp_unsynced"):
         bert._dp_adopt(head.flat_decay, head.flat_nodecay)  # the head's gradients are averaged with the backbone's, in flight or by hook
+    # (hidden-state dropout in the head layers indexes token rows: a packed and a padded run of one batch draw different - equally
+    #  valid - masks there; the placement tests run padded, include/cocodr.h "Packed batches")
+    pk = bert.pack(input_ids, attention_mask, lengths) if bert.pack_sequences else None
+    if pk is not None:
+        B, L = input_ids.shape
+        lab = labels
+        if pk.L != L:
+            lab = torch.nn.functional.pad(labels, (0, pk.L - L), value=-100)
+        lab_packed = torch.where(pk.mask > 0, lab.reshape(-1)[pk.src], torch.full_like(pk.src, -100))
+        ids32 = input_ids if input_ids.dtype == torch.int32 else input_ids.to(torch.int32)
+        return _CondenserStepFn.apply(bert.flat_decay, bert.flat_nodecay, head.flat_decay, head.flat_nodecay, ids32, None,
+                                      lab_packed.contiguous(), bert, head, int(skip_from), bool(late_mlm), pk)
+    ids, mask, L = bert._prep(input_ids, attention_mask)
+    if L != ids.shape[1]:
+        labels = torch.nn.functional.pad(labels, (0, ids.shape[1] - L), value=-100)
     return _CondenserStepFn.apply(bert.flat_decay, bert.flat_nodecay, head.flat_decay, head.flat_nodecay, ids, mask,
-                                  labels.contiguous(), bert, head, int(skip_from), bool(late_mlm))
+                                  labels.contiguous(), bert, head, int(skip_from), bool(late_mlm), None)

@@ -251,6 +251,12 @@ extern "C" int cocodr_stack_fwd(const cocodr_config* c, const cocodr_layer_param
   return encoder_fwd_impl(c, nullptr, lp, nullptr, mask, B, L, training, arena, arena_bytes, true, stream);
 }
 
+extern "C" int cocodr_stack_fwd_packed(const cocodr_config* c, const cocodr_layer_params* lp, const cocodr_packed_batch* batch,
+                                       int training, void* arena, size_t arena_bytes, cocodr_stream_t stream) {
+  CK_ARG(batch && batch->cls_slot, "stack_fwd_packed: null batch");
+  return encoder_fwd_impl(c, nullptr, lp, nullptr, nullptr, 0, 0, training, arena, arena_bytes, true, stream, 0, -1, batch);
+}
+
 namespace {
 int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, const cocodr_layer_params* lp, const int32_t* ids,
                      const int32_t* mask, int B, int L, int training, void* arena, size_t arena_bytes, bool from_hidden,

@@ -1327,7 +1327,7 @@ class CoCondenserForPretraining(nn.Module):
             from .condenser import condenser_step
             skip_from = int(getattr(self.model_args, "skip_from", 2))
             late_mlm = bool(getattr(self.model_args, "late_mlm", False))
-            mlm_loss, cls = condenser_step(self.lm, self.c_head, ids, mask, labels, skip_from, late_mlm)
+            mlm_loss, cls = condenser_step(self.lm, self.c_head, ids, mask, labels, skip_from, late_mlm, lengths=model_input.get("lengths"))
         else:
             cls = self.lm.encode_cls(ids, mask, packed_index=model_input.get("packed_index"), lengths=model_input.get("lengths"))  # [2b, H] fp32
         W = self._world_size()

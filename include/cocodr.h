@@ -519,6 +519,10 @@ int cocodr_encoder_layout_packed(const cocodr_config* cfg, int T, int B, int tra
 int cocodr_encoder_fwd_packed(const cocodr_config* cfg, const cocodr_embed_params* emb, const cocodr_layer_params* layers_host,
                               const cocodr_packed_batch* batch, int training, void* arena, size_t arena_bytes,
                               cocodr_stream_t stream);
+/* cocodr_stack_fwd on a packed batch: a bare BertLayer stack (the Condenser head, COCO/modeling.py:43-46, 216-220) whose
+ * input the caller has written to hidden slot 0 of the arena ([T, H]); batch->ids / positions are not read */
+int cocodr_stack_fwd_packed(const cocodr_config* cfg, const cocodr_layer_params* layers_host, const cocodr_packed_batch* batch,
+                            int training, void* arena, size_t arena_bytes, cocodr_stream_t stream);
 int cocodr_encoder_bwd_packed(const cocodr_config* cfg, const cocodr_embed_params* emb, const cocodr_layer_params* layers_host,
                               const cocodr_embed_grads* emb_grads, const cocodr_layer_grads* grads_host,
                               const cocodr_packed_batch* batch, const uint16_t* d_in, void* arena, size_t arena_bytes,

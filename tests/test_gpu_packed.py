@@ -215,3 +215,36 @@ def test_merged_single_pass_triplet_step_equals_the_separate_passes():
     loss, _acc, _l = model(t(q[0]), t(q[1]), t(a[0]), t(a[1]), t(b[0]), t(b[1]))
     loss.backward()
     assert model.last_passes == [("qab", 1)] and torch.isfinite(loss) and torch.isfinite(model.bert.flat_decay.grad).all()
+
+
+@pytest.mark.parametrize("skip_from,late", [(1, True), (2, False), (0, True), (3, True)])
+def test_packed_condenser_step_equals_padded_step(skip_from, late):
+    """The full coCondenser step (COCO/modeling.py:192-235: backbone + Condenser head + head / late MLM losses + contrastive) on
+    the packed layout against the same step on the padded layout: same losses, same gradients of backbone and head."""
+    import types
+    cfgd = cfg_small()
+    ids, mask, lens = ragged_batch(8, 64, cfgd["vocab_size"], 21)
+    rng = np.random.Generator(np.random.PCG64(3))
+    pick = (rng.random(ids.shape) < 0.2) & (mask > 0)
+    pick[:, 0] = False
+    pick[0, 1] = True
+    labels = np.where(pick, ids, -100)
+    inp = np.where(pick, 103, ids)
+    res = {}
+    for mode in ("padded", "packed", "packed_host_lengths"):
+        torch.manual_seed(0)
+        bert = CocoBertModel(CocoBertConfig(**cfgd)).to(DEV)
+        with torch.no_grad():
+            bert.flat_decay.mul_(2.0)
+        model = CoCondenserForPretraining(bert, types.SimpleNamespace(n_head_layers=2, skip_from=skip_from, late_mlm=late)).to(DEV).eval()
+        bert.pack_sequences = mode != "padded"
+        batch = {"input_ids": t(inp), "attention_mask": t(mask)}
+        if mode == "packed_host_lengths":
+            batch["lengths"] = torch.from_numpy(lens)
+        loss = model(batch, t(labels))
+        loss.backward()
+        res[mode] = (float(loss.detach()), [p.grad.detach().clone() for p in (bert.flat_decay, bert.flat_nodecay, model.c_head.flat_decay, model.c_head.flat_nodecay)])
+    for mode in ("packed", "packed_host_lengths"):
+        assert abs(res[mode][0] - res["padded"][0]) < 1e-4 * abs(res["padded"][0]), (mode, res[mode][0], res["padded"][0])
+        for g, r in zip(res[mode][1], res["padded"][1]):
+            assert rel_l2(g, r) < 6e-3, (mode, rel_l2(g, r))

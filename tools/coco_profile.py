@@ -18,7 +18,7 @@ if __name__ == "__main__":
         ids, mask = bench.synth_batch(0, 64, 128, cfg.vocab_size, dev)
         print(bench.full_coco_step(cfg, dev, ids, mask, steps=10, warmup=3))
     elif which == "packed":
-        dt, loss, roof, _, _ = bench.contrastive_leg("base", 64, 128, 10, 3, dev, 0, 1, False, 2, False, False, packed=True)
+        dt, loss, roof, _, _, _ = bench.contrastive_leg("base", 64, 128, 10, 3, dev, 0, 1, False, 2, False, False, packed=True)
         print({"ms_per_step": dt / 10 * 1e3, "loss": loss})
     else:
         print(bench.corpus_encode(cfg, dev, seq_len=128))
