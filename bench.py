@@ -329,14 +329,14 @@ def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int =
         model.bert.enable_grad_allreduce(chunks=dp_chunks)
     opt = FlatLamb.for_model(model.bert, lr=5e-6, eps=1e-8)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: max(0.0, 1.0 - s / 1000.0))
-    q, qm = synth_batch(3 * rank, rows, 64, cfg.vocab_size, dev)
-    a, am = synth_batch(3 * rank + 1, rows, 128, cfg.vocab_size, dev)
-    b, bm = synth_batch(3 * rank + 2, rows, 128, cfg.vocab_size, dev)
+    q, qm, ql = synth_batch_lens(3 * rank, rows, 64, cfg.vocab_size, dev)
+    a, am, al = synth_batch_lens(3 * rank + 1, rows, 128, cfg.vocab_size, dev)
+    b, bm, bl = synth_batch_lens(3 * rank + 2, rows, 128, cfg.vocab_size, dev)
     flats = [model.bert.flat_decay, model.bert.flat_nodecay]
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, _acc, _logits = model(q, qm, a, am, b, bm)
+        loss, _acc, _logits = model(q, qm, a, am, b, bm, lengths=(ql, al, bl))  # (lengths: what the CPU-side data function knows)
         loss.backward()
         opt.step(clip=clip_grad_norm_(flats, 1.0))  # norm and coefficient stay on the device
         sched.step()
@@ -359,10 +359,29 @@ def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int =
     dt = (time.perf_counter() - t0) / steps
     out = {"sequences_per_sec": round(3 * rows / dt, 1), "rows_per_sec": round(rows / dt, 1), "ms_per_step": round(dt * 1e3, 3),
            "loss": round(float(loss.detach()), 4),
+           "execution": "BertDotNLL defaults: queries + positives + negatives as ONE packed encoder pass (merge_passes + pack_sequences), "
+                        "dropout on (model.train(), ANCE/drivers/run_ann.py:293)",
            "scope": f"cocodr-large triplet step, {rows} rows (q L64 + pos/neg L128), bf16, clip_grad_norm_(1.0) + LAMB; BASELINE configs[3]"}
-    # the same step with queries, positives and negatives stored back to back as ONE packed encoder pass (side number: same
-    # loss and gradients as the two padded passes without dropout; fewer rows, one backward, no second gradient to add)
-    model.bert.pack_sequences = model.merge_passes = True
+    # roofline of the step's dominant kernel class (bf16 MFMA GEMMs), HIP events around every GEMM launch of three more steps
+    from cocodr_amd import ops
+    ops.prof_begin(1)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    n_launch, gemm_ms, gemm_flops = ops.prof_end()
+    if n_launch and gemm_ms > 0:
+        ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+        H_, N_ = cfg.hidden_size, cfg.num_hidden_layers
+        alg = 3.0 * 24.0 * H_ * H_ * N_ * (rows * 64 + 2 * rows * 128) * 3 / (gemm_ms * 1e-3) / 1e12  # padded tokens of q + pos + neg, 3 steps
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                           "algorithmic_achieved": round(alg, 1), "algorithmic_frac": round(alg / MFMA_BF16_PEAK_TFLOPS, 4),
+                           "launches_per_step": n_launch // 3, "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
+                           "gemm_share_of_step": round(gemm_ms / 3 / (dt * 1e3), 3),
+                           "flops": "achieved / frac: FLOPs the GEMM launches of the step execute (stored rows of the packed pass) / their "
+                                    "summed duration; algorithmic_*: 24 H^2 x 3 per PADDED token of the three encoder inputs over the same time"}
+    # the same step as the reference lays it out: a padded query pass (side stream) next to a padded passage pass
+    model.bert.pack_sequences = model.merge_passes = False
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -371,9 +390,9 @@ def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int =
         step()
     torch.cuda.synchronize()
     mdt = (time.perf_counter() - t0) / steps
-    out["packed_single_pass"] = {"rows_per_sec": round(rows / mdt, 1), "ms_per_step": round(mdt * 1e3, 3),
-                                 "note": "BertDotNLL.merge_passes + pack_sequences: one packed encoder pass for q + pos + neg"}
-    model.bert.pack_sequences = model.merge_passes = False
+    out["padded_two_passes"] = {"rows_per_sec": round(rows / mdt, 1), "ms_per_step": round(mdt * 1e3, 3),
+                                "note": "merge_passes = pack_sequences = False: padded query pass on a side stream + padded passage pass"}
+    model.bert.pack_sequences = model.merge_passes = True
     # the same step with iDRO re-weighting: 50 query clusters, per-group gradients of the last 2 layers
     import types
     n_groups = 50

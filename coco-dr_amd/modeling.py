@@ -1097,7 +1097,10 @@ class BertDotNLL(nn.Module):
         self.config = config
         self.bert = CocoBertModel(config, device=device)
         self.total = 0
-        self.merge_passes = False  # with bert.pack_sequences: queries + positives + negatives as one packed encoder pass
+        # with bert.pack_sequences (both defaults since round 4): queries + positives + negatives go through the encoder as ONE
+        # packed pass - one forward, one backward, one weight-gradient pass over all rows - instead of the reference's three
+        # (ANCE/model/models.py:84-86); same embeddings, loss and gradients.  False: a query pass next to a passage pass
+        self.merge_passes = True
         self.dro_type, self.loss = "erm", None
 
     def add_group_loss(self, args=None, n_groups: int = 0, dro_type: str = "idro", alpha: float = 0.0, eps: float = 0.1,
@@ -1134,7 +1137,7 @@ class BertDotNLL(nn.Module):
     def query_emb(self, input_ids, attention_mask):
         return self.bert.encode_cls(input_ids, attention_mask)
 
-    def _forward_merged(self, query_ids, attention_mask_q, input_ids_a, attention_mask_a, input_ids_b, attention_mask_b):
+    def _forward_merged(self, query_ids, attention_mask_q, input_ids_a, attention_mask_a, input_ids_b, attention_mask_b, lengths=None):
         """Queries, positives and negatives as ONE packed batch (``merge_passes`` with ``bert.pack_sequences``): the packed layout
         stores every sequence at its own length, so the [B, 64] queries and the [2B, 128] passages need not be separate encoder
         passes - one forward, one backward (one weight-gradient pass over all rows, no second full-size gradient to add), GEMMs at
@@ -1142,8 +1145,12 @@ class BertDotNLL(nn.Module):
         Lq, Lp = query_ids.shape[1], input_ids_a.shape[1]
         pad = lambda t: torch.nn.functional.pad(t, (0, Lp - Lq)) if Lp > Lq else t
         ids = torch.cat([pad(query_ids), input_ids_a, input_ids_b])
-        mask = torch.cat([pad(attention_mask_q), attention_mask_a, attention_mask_b])
-        pk = self.bert.pack(ids, mask)
+        if lengths is not None:  # host-known lengths of (queries, positives, negatives): no read-back of the masks
+            import numpy as np
+            lengths, mask = np.concatenate([np.asarray(x).reshape(-1) for x in lengths]), None
+        else:
+            mask = torch.cat([pad(attention_mask_q), attention_mask_a, attention_mask_b])
+        pk = self.bert.pack(ids, mask, lengths)
         if pk is None:
             return None
         calls = lambda: self.bert._dropout_calls if self.bert._next_dropout_peek() else 0
@@ -1156,7 +1163,9 @@ class BertDotNLL(nn.Module):
         return self.query_emb(input_ids, attention_mask)
 
     def forward(self, query_ids, attention_mask_q, input_ids_a=None, attention_mask_a=None, input_ids_b=None,
-                attention_mask_b=None, is_query=True, group_ids=None, weights=None):
+                attention_mask_b=None, is_query=True, group_ids=None, weights=None, lengths=None):
+        """``lengths`` (optional, beyond the reference signature): the host-known lengths ``(len_q, len_a, len_b)`` of the three
+        padded inputs - the merged packed pass is then laid out without reading the masks back from the device."""
         if input_ids_b is None:
             return self.query_emb(query_ids, attention_mask_q) if is_query else self.body_emb(query_ids, attention_mask_q)
         if group_ids is not None and getattr(self, "loss", None) is None:
@@ -1170,7 +1179,7 @@ class BertDotNLL(nn.Module):
             return robust, torch.argmax(logits, dim=1), group_losses, group_counts
         if self.merge_passes and self.bert.pack_sequences and input_ids_a.shape == input_ids_b.shape \
                 and query_ids.shape[1] <= input_ids_a.shape[1] and query_ids.shape[0] == input_ids_a.shape[0]:
-            merged = self._forward_merged(query_ids, attention_mask_q, input_ids_a, attention_mask_a, input_ids_b, attention_mask_b)
+            merged = self._forward_merged(query_ids, attention_mask_q, input_ids_a, attention_mask_a, input_ids_b, attention_mask_b, lengths)
             if merged is not None:
                 q, a, b = merged
                 B = q.shape[0]

@@ -248,6 +248,7 @@ def test_ance_triplet_train_mode_matches_oracle_pass_by_pass():
     for k in (last + "weight", last + "bias"):
         P[k] = (P[k] * 0.2).astype(np.float32)  # logits O(5), as in the triplet goldens
     model = BertDotNLL(CocoBertConfig(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, **cfgd))
+    model.merge_passes = model.bert.pack_sequences = False  # pass by pass on the padded layout: the oracle's mask indices
     model.bert.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
     model.to(DEV).train()
     model.bert.dropout_seed = 99

@@ -168,6 +168,7 @@ def test_packed_ance_step_and_attention_dropout_draw_the_padded_masks():
         model = BertDotNLL(CocoBertConfig(**cfgd)).to(DEV).train()
         model.bert.dropout_seed = 11
         model.bert.pack_sequences = packed
+        model.merge_passes = False  # the reference's pass structure (a query pass and a passage pass), packed or padded
         loss, _acc, logits = model(t(q[0]), t(q[1]), t(a[0]), t(a[1]), t(b[0]), t(b[1]))
         loss.backward()
         res[packed] = (float(loss), logits.detach().clone(), model.bert.flat_decay.grad.detach().clone())
