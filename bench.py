@@ -314,6 +314,91 @@ def eval_search(dev, nq: int = 10000, npass: int = 125000, dim: int = 1024, k: i
     return out
 
 
+def config5_end_to_end(dev, n_pass: int = 1_000_000, nq: int = 10_000, world: int = 8, k: int = 1000, batch: int = 1024, keep: bool = False):
+    """BASELINE configs[4] whole, on ONE GPU (the 8-way configuration walked shard by shard - VERDICT r03 item 8): cocodr-large
+    encodes `n_pass` synthetic passages (L 128) sharded `world` ways by the reference's rule (record i -> shard i % W,
+    ANCE/utils/util.py:390-392) and `nq` queries (L 64), embeddings stay in HBM (ANCE/drivers/run_ann_data_gen.py:157-212); then every
+    shard is searched (k = 1000) and the per-shard lists are merged natively into what ONE IndexFlatIP search over the rank-major
+    merged corpus returns (evaluate/evaluation/evaluate_beir.py:200-224).  ``keep``: also return (Q, P in merged order, D, I) for
+    the parity test (tests/test_gpu_retrieval.py)."""
+    from cocodr_amd import retrieval
+    from cocodr_amd.modeling import BertDotNLL, CocoBertConfig
+    cfg = CocoBertConfig.large()
+    torch.manual_seed(0)
+    model = BertDotNLL(cfg).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(1234)
+
+    def tokens(n, L, mu, sd):  # SURVEY 8(d) synthetic inputs, generated in HBM (the token cache of a corpus this size lives there)
+        lens = torch.clamp(torch.round(torch.randn(n, generator=g, device=dev) * sd + mu), 8, L).to(torch.int64)
+        ids = torch.randint(1000, cfg.vocab_size, (n, L), generator=g, device=dev, dtype=torch.int32)
+        pos = torch.arange(L, device=dev)[None]
+        ids = torch.where(pos < lens[:, None], ids, torch.zeros_like(ids))
+        ids[:, 0] = 101
+        ids.scatter_(1, (lens - 1)[:, None], torch.full((n, 1), 102, dtype=torch.int32, device=dev))
+        return ids, lens.cpu()
+
+    t_all = time.perf_counter()
+    shards, enc_s = [], 0.0
+    for r in range(world):
+        n_r = len(range(r, n_pass, world))
+        ids, lens = tokens(n_r, SEQ_LEN, 76, 30)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        emb, _ = retrieval.encode_corpus(model, ids, None, batch_size=batch, lengths=lens)
+        torch.cuda.synchronize()
+        enc_s += time.perf_counter() - t0
+        shards.append(emb)
+        del ids
+    qids, qlens = tokens(nq, 64, 24, 8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Q, _ = retrieval.encode_corpus(model, qids, None, batch_size=batch, is_query=True, lengths=qlens)
+    torch.cuda.synchronize()
+    q_s = time.perf_counter() - t0
+    del model
+    t0 = time.perf_counter()
+    Ds, Is = [], []
+    for r in range(world):
+        D, I = retrieval.search(Q, shards[r], k)
+        Ds.append(D)
+        Is.append(I.to(torch.int32))
+    offs = torch.tensor([sum(s_.shape[0] for s_ in shards[:w]) for w in range(world)], dtype=torch.int64, device=dev)
+    Dm, Im = retrieval.merge_shard_lists(torch.stack(Ds), torch.stack(Is), offs, k)
+    torch.cuda.synchronize()
+    s_s = time.perf_counter() - t0
+    out = {"passages": n_pass, "queries": nq, "shards": world, "k": k,
+           "encode_passages_per_sec": round(n_pass / enc_s, 1), "encode_s": round(enc_s, 2), "encode_queries_per_sec": round(nq / q_s, 1),
+           "search_dot_products_per_sec": round(nq * n_pass / s_s), "search_ms": round(s_s * 1e3, 2), "wall_s": round(time.perf_counter() - t_all, 2),
+           "workload": f"cocodr-large: {n_pass} passages x L{SEQ_LEN} in {world} shards (i % W) + {nq} queries x L64 encoded (packed batches of "
+                       f"{batch}, host-known lengths), per-shard split-precision search k = {k} + native {world}-way merge; one GPU walks the "
+                       "shards one after the other; BASELINE configs[4]"}
+    if keep:
+        return out, Q, torch.cat(shards), Dm, Im
+    return out
+
+
+def search_cpu_baseline(nq: int = 1000, npass: int = 125000, dim: int = 1024, k: int = 1000):
+    """The reference's search on the host cores (evaluate/evaluation/evaluate_beir.py:220-224 runs faiss IndexFlatIP on the CPU;
+    faiss is not in this image - SURVEY 8c - so the stand-in is what it computes: fp32 Q P^T through the CPU BLAS + top-k), on a
+    bounded slice of one config-5 shard: `nq` of the 10 000 queries x 125 000 passages."""
+    g = torch.Generator().manual_seed(7)
+    Q = torch.randn(nq, dim, generator=g) / dim ** 0.5
+    P = torch.randn(npass, dim, generator=g) / dim ** 0.5
+    threads = _physical_cores()
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.topk(Q[:64] @ P.T, k, dim=1)
+        t0 = time.perf_counter()
+        D, I = torch.topk(Q @ P.T, k, dim=1)
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(old)
+    return {"value": round(nq * npass / dt), "unit": "dot-products/sec", "cores": int(threads), "kind": "port", "cpu": _cpu_model_name(),
+            "sample": f"{nq} queries x {npass} passages x {dim} fp32 (a tenth of one config-5 shard's queries), k = {k}: torch fp32 Q @ P.T on the "
+                      "CPU BLAS + torch.topk - the arithmetic of faiss IndexFlatIP.search, which the reference calls and this image lacks"}
+
+
 def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int = 0, world: int = 1, fence=None, dp_chunks: int = 2):
     """BASELINE config 4 (ANCE/drivers/run_ann.py:293-356): BERT-large triplet step, 32 rows/GPU = queries [32,64] +
     positives / negatives [32,128], backward, clip_grad_norm_(1.0), LAMB (the reference's default optimizer), linear
@@ -764,6 +849,10 @@ def main():
             extras["ance_triplet_step"] = ance_step(dev)
         extras["corpus_encode"] = corpus_encode(cfg, dev, seq_len=args.seq_len)
         extras["eval_search"] = eval_search(dev)
+        if not args.no_cpu_baseline:
+            extras["eval_search"]["cpu_baseline"] = search_cpu_baseline()
+        if args.model == "base":
+            extras["config5_end_to_end"] = config5_end_to_end(dev)
     def fence():
         torch.cuda.synchronize()
         if use_dist:

@@ -38,12 +38,15 @@ def merged_order(n: int, world: int) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------- encode
 @torch.no_grad()
 def encode_corpus(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, batch_size: int = 512,
-                  record_ids: Optional[torch.Tensor] = None, is_query: bool = False, pack: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                  record_ids: Optional[torch.Tensor] = None, is_query: bool = False, pack: bool = True,
+                  lengths=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Eval-mode ``query_emb`` / ``body_emb`` over a token cache (under ``torch.no_grad()``, as run_ann_data_gen.py:183 does), fp32
     [n,H] kept ON DEVICE plus the record ids - the reference copies every batch to the host (``.cpu().numpy()``,
     run_ann_data_gen.py:191-199); here the shard stays in HBM for the search that follows.  ``pack``: store each batch's
     sequences back to back instead of padded (bit-identical embeddings, no work on the padding rows, +18-21 % passages/s;
-    include/cocodr.h "Packed batches"; a batch whose masks are not prefix masks runs padded).  ``pack=False``: always padded."""
+    include/cocodr.h "Packed batches"; a batch whose masks are not prefix masks runs padded).  ``pack=False``: always padded.
+    ``lengths``: the n passage lengths on the host (the token cache stores them in front of every record,
+    ANCE/data/msmarco_data.py:279) - the packed layouts are then built without reading the masks back, batch after batch."""
     n = input_ids.shape[0]
     fn = model.query_emb if is_query else model.body_emb
     outs = []
@@ -54,7 +57,10 @@ def encode_corpus(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, 
     try:
         with torch.no_grad():
             for s in range(0, n, batch_size):
-                outs.append(fn(input_ids[s:s + batch_size], attention_mask[s:s + batch_size]).float())
+                if lengths is not None and bert is not None and bert.pack_sequences:
+                    outs.append(bert.encode_cls(input_ids[s:s + batch_size], None, lengths=lengths[s:s + batch_size]).float())
+                else:
+                    outs.append(fn(input_ids[s:s + batch_size], attention_mask[s:s + batch_size]).float())
     finally:
         if bert is not None:
             bert.pack_sequences = was

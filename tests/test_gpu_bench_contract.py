@@ -92,3 +92,16 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert m["sharded_corpus_encode"]["sequences_per_sec"] > 0
     assert m["sharded_search"]["dot_products_per_sec"] > 0 and m["sharded_search"]["result_rows"] == 2000
     assert m["ance_triplet_step"]["rows_per_sec"] > 0 and m["ance_triplet_step"]["loss"] > 0
+
+
+def test_bench_eight_rank_path_is_configs2_on_one_gpu():
+    """`bench.py --gpus 8` as the driver would launch it on an 8-GPU node, here with the eight ranks sharing the one GPU over gloo:
+    the default becomes BASELINE configs[2] (256 sequences per GPU, global batch 2048), the line carries the 64-per-GPU weak-scaling
+    point and the multi_gpu legs (sharded encode / search / data-parallel ANCE step)."""
+    d = _run("--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline")
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 2048 and d["scaling"] == "weak"
+    assert "configs[2]" in d["config"]["workload"] and d["value"] > 0 and d["loss"] > 0
+    assert d["same_per_gpu_batch_as_n1"]["global_batch"] == 512 and d["same_per_gpu_batch_as_n1"]["sequences_per_sec"] > 0
+    m = d["multi_gpu"]
+    assert m["sharded_corpus_encode"]["sequences_per_sec"] > 0 and m["sharded_search"]["result_rows"] == 2000
+    assert m["ance_triplet_step"]["rows_per_sec"] > 0

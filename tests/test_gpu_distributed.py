@@ -595,14 +595,24 @@ def test_two_rank_condenser_head_is_reduced_after_a_forward_without_backward():
 # ------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[2] at its real per-rank shape: 8 ranks x 256 sequences x 128 tokens = global batch 2048
 # (COCO/README.md:55 NPROC x BATCH_SIZE; COCO/modeling.py:182-190 gather by rank slot, :244-248 the M = 2048 loss).  The eight
-# ranks share the one GPU over gloo; BERT-base width, 2 layers (depth does not change the exchange).
-def _config3_rank(rank, world, seed, n_seq, L):
+# ranks share the one GPU over gloo; BERT-base width, at 2 layers (depth does not change the exchange) and at the full 12 layers of
+# cocodr-base (the configuration itself, on the only hardware there is).
+def _config3_model(layers):
+    from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
+    torch.manual_seed(0)
+    bert = CocoBertModel(_config3_cfg(layers)).to("cuda")
+    if layers > 2:  # raw [CLS] logits are O(H) and saturate the softmax: shrink the last LayerNorm so that they are O(5) and loss and
+        with torch.no_grad():  # gradients are well conditioned through 12 random-init layers (as tests/test_gpu_large_shapes.py does)
+            for k in ("weight", "bias"):
+                bert.hf_view(f"encoder.layer.{layers - 1}.output.LayerNorm.{k}").mul_(float(np.sqrt(5.0 / 768)))
+    return bert, CoCondenserForPretraining(bert)
+
+
+def _config3_rank(rank, world, seed, n_seq, L, layers=2):
     import cocodr_amd  # noqa: F401
     from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
     ids, mask = _config3_batch(seed, rank, n_seq, L)
-    torch.manual_seed(0)
-    bert = CocoBertModel(_config3_cfg()).to("cuda")
-    model = CoCondenserForPretraining(bert)
+    bert, model = _config3_model(layers)
     bert.enable_grad_allreduce(chunks=2)
     loss = model({"input_ids": torch.from_numpy(ids).cuda(), "attention_mask": torch.from_numpy(mask).cuda()}, None)
     loss.backward()
@@ -615,9 +625,9 @@ def _config3_rank(rank, world, seed, n_seq, L):
     return float(loss.detach()), float(gd.double().sum()), float(gn.double().sum()), float(gd.double().abs().sum())
 
 
-def _config3_cfg():
+def _config3_cfg(layers=2):
     from cocodr_amd.modeling import CocoBertConfig
-    return CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=30522, hidden_size=768, num_hidden_layers=2,
+    return CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=30522, hidden_size=768, num_hidden_layers=layers,
                           num_attention_heads=12, intermediate_size=3072, max_position_embeddings=512)
 
 
@@ -633,17 +643,15 @@ def _config3_batch(seed, rank, n_seq, L):
     return ids, mask
 
 
-def test_config3_eight_ranks_at_256_sequences_equal_the_single_process_m2048_step():
+@pytest.mark.parametrize("layers,tol", [(2, 2e-2), (12, 6e-2)])
+def test_config3_eight_ranks_at_256_sequences_equal_the_single_process_m2048_step(layers, tol):
     world, n_seq, L, seed = 8, 256, 128, 1234
-    out = _spawn(_config3_rank, world, "gloo", seed, n_seq, L)
+    out = _spawn(_config3_rank, world, "gloo", seed, n_seq, L, layers)
     import cocodr_amd  # noqa: F401
-    from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertModel
     parts = [_config3_batch(seed, r, n_seq, L) for r in range(world)]  # slot order = global rank (COCO/modeling.py:185)
     ids = np.concatenate([p[0] for p in parts])
     mask = np.concatenate([p[1] for p in parts])
-    torch.manual_seed(0)
-    bert = CocoBertModel(_config3_cfg()).to("cuda")
-    model = CoCondenserForPretraining(bert)
+    bert, model = _config3_model(layers)
     loss = model({"input_ids": torch.from_numpy(ids).cuda(), "attention_mask": torch.from_numpy(mask).cuda()}, None)  # M = 2048
     loss.backward()
     lo = bert.layout
@@ -654,9 +662,10 @@ def test_config3_eight_ranks_at_256_sequences_equal_the_single_process_m2048_ste
     for r in range(world):
         assert abs(out[r][0] - world * full) < 2e-3 * abs(world * full), (r, out[r][0], world * full)
     _, mat, vec, emb = out[0]
-    assert _rel(mat, gd[lo.mat_begin:].cpu().numpy()) < 2e-2, _rel(mat, gd[lo.mat_begin:].cpu().numpy())
-    assert _rel(vec, gn.cpu().numpy()) < 2e-2
-    assert _rel(emb, gd[:lo.mat_begin].cpu().numpy()) < 2e-2
+    # (bf16 tolerance: the M = 2048 batch runs other GEMM pipelines than the 256-sequence ranks - other fp32 summation orders)
+    assert _rel(mat, gd[lo.mat_begin:].cpu().numpy()) < tol, _rel(mat, gd[lo.mat_begin:].cpu().numpy())
+    assert _rel(vec, gn.cpu().numpy()) < tol
+    assert _rel(emb, gd[:lo.mat_begin].cpu().numpy()) < tol
     # the other ranks hold the same averaged gradient (checksums)
     s_gd, s_gn, a_gd = float(np.concatenate([emb.ravel(), mat.ravel()]).astype(np.float64).sum()), float(vec.astype(np.float64).sum()), \
         float(np.abs(np.concatenate([emb.ravel(), mat.ravel()]).astype(np.float64)).sum())

@@ -187,3 +187,41 @@ def test_ance_refresh_cycle_in_miniature(tmp_path):
     loss, acc, _ = model(**kw)
     loss.backward()
     assert torch.isfinite(loss) and float(model.bert.flat_decay.grad.abs().sum()) > 0
+
+
+def test_config5_end_to_end_one_million_passages_eight_shards_ten_thousand_queries():
+    """BASELINE configs[4] at its real size on one GPU (bench.config5_end_to_end): cocodr-large encodes 1 M passages x L128 in 8
+    shards (record i -> shard i % 8) and 10 k queries, per-shard search k = 1000, native 8-way merge.  Checked against fp32
+    `Q @ P.T` + top-k over the whole merged corpus (what IndexFlatIP computes, evaluate/evaluation/evaluate_beir.py:220-224):
+    nDCG@10 of the product's ranking against qrels made of the exact top-10 must be within 1e-3 of the exact ranking's own (1.0,
+    north_star tolerance), the returned scores must be the fp32 scores of the returned positions, lists sorted."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    full = os.environ.get("COCODR_CONFIG5_SMALL") is None
+    n_pass, nq = (1_000_000, 10_000) if full else (100_000, 2_000)
+    out, Q, P, D, I = bench.config5_end_to_end(torch.device(DEV), n_pass=n_pass, nq=nq, keep=True)
+    assert P.shape == (n_pass, 1024) and Q.shape == (nq, 1024) and D.shape == I.shape == (nq, 1000)
+    assert bool((D[:, :-1] >= D[:, 1:]).all()) and int(I.min()) >= 0 and int(I.max()) < n_pass
+    # exact fp32 ranking, in query chunks (the checker: torch's fp32 GEMM + topk, not part of the product)
+    ndcg, top1, overlap, nchunk = 0.0, 0, 0.0, 0
+    disc = 1.0 / torch.log2(torch.arange(2, 12, device=DEV, dtype=torch.float64))
+    for s in range(0, nq, 500):
+        S = Q[s:s + 500] @ P.T
+        Dx, Ix = torch.topk(S, 10, dim=1)
+        got = I[s:s + 500, :10]
+        rel = (got[:, :, None] == Ix[:, None, :]).any(-1).to(torch.float64)      # qrels: the exact top-10, gain 1 each
+        ndcg += float(((rel * disc).sum(1) / disc.sum()).sum())
+        top1 += int((got[:, 0] == Ix[:, 0]).sum())
+        # the returned scores are the fp32 scores of the returned positions
+        ref = torch.gather(S, 1, I[s:s + 500])
+        assert torch.allclose(D[s:s + 500], ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+        k_th = torch.topk(S, 1000, dim=1).values[:, -1:]
+        overlap += float((ref >= k_th - 1e-5 * ref.abs().max()).double().mean())
+        nchunk += 1
+        del S
+    ndcg /= nq
+    assert ndcg >= 1.0 - 1e-3, ndcg
+    assert top1 >= 0.999 * nq and overlap / nchunk >= 0.9999
+    assert out["encode_passages_per_sec"] > 5000 and out["search_dot_products_per_sec"] > 2e10
