@@ -513,6 +513,230 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// L <= 128 (at most four key blocks = one per wave): ONE pass over the (query block, key block) pairs.  The two-phase kernel
+// above forms S and dP - and evaluates the softmax arithmetic: exp2 at quarter rate, the dS product, the bf16 packs - twice, once
+// per layout (28 MFMAs per block pair, 16 exp2 per lane twice); what fills the SIMDs there is that arithmetic, not the MFMAs
+// (profiles/r03_attention_pipelining.md).  Here every wave owns ONE key block (lane = key) and walks the query blocks once:
+//   S, dP (8 MFMAs) -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS (8 MFMAs) -> dS (bf16) into an LDS stage tile [keys][64 queries]
+// and after every two query blocks the waves meet, and dQ^T = K^T dS^T for those 64 queries is 4 MFMAs per block pair with the
+// dS operand read back through the transposing LDS read (wave = (query block of the pair, 32-column half of d)): 20 MFMAs per
+// block pair, the softmax arithmetic once.  dS needs no cross-wave reduction and no atomics: deterministic.
+// LDS: Q, K, dO tiles + the dS stage tile (4 x L x 128 B) + lse / delta rows - what the two-phase kernel takes, so two workgroups
+// share a CU as before; V is not staged (a wave reads the four fragments of its own key block from global memory once).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float acc_colsum16(const f32x16& acc, float mul, int lane, int dt) {  // acc_colsum32 for one 32-column half
+  // The accumulator arrives straight from the LAST MFMA of a dependent chain, and hipcc's hazard recognizer does not look inside
+  // an asm statement: a DPP read there would see registers the matrix pipe has not written back yet (measured: the list
+  // entries read first came out stale).  An ordinary VALU instruction - the scale - takes the MFMA -> VALU wait states instead.
+  float o[16], v[8], w[4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[i] = acc[i] * mul;
+  mul = 1.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) COLSUM_PAIR(v[i], o[i], o[i + 8], "row_ror:8", "0x3", "0xc");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) COLSUM_PAIR(w[i], v[i], v[i + 4], "row_half_mirror", "0x5", "0xa");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    COLSUM_QUAD(w[i], "quad_perm:[1,0,3,2]");
+    COLSUM_QUAD(w[i], "quad_perm:[2,3,0,1]");
+  }
+  const float a = (lane & 1) ? w[1] : w[0], c = (lane & 1) ? w[3] : w[2];
+  const float q = (lane & 2) ? c : a;
+  const float out = q + __shfl_xor(q, 16, 64);
+  return (((lane >> 4) & 1) == dt) ? out * mul : 0.f;  // the lanes that own a column of this half (qk_col)
+}
+__device__ __forceinline__ void store_acc_T16_half(uint16_t* dst, int ld, const f32x16& o, int dt, float mul, int lane) {
+  const int half = lane >> 5;
+#pragma unroll
+  for (int rp = 0; rp < 2; ++rp) {
+    float mine[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mine[g][e] = o[(2 * rp + g) * 4 + e] * mul;
+    const uint2 g0 = pack4(mine[0]), g1 = pack4(mine[1]);
+    const uint2 keep = half ? g1 : g0;
+    const uint2 give = half ? g0 : g1;
+    uint2 got;
+    got.x = __shfl_xor((int)give.x, 32, 64);
+    got.y = __shfl_xor((int)give.y, 32, 64);
+    const int d = dt * 32 + 8 * (2 * rp + half);
+    const uint4 v = half == 0 ? make_uint4(keep.x, keep.y, got.x, got.y) : make_uint4(got.x, got.y, keep.x, keep.y);
+    *reinterpret_cast<uint4*>(dst + (size_t)(lane & 31) * ld + d) = v;
+  }
+}
+
+template <bool QKSUM, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd1_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                           const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ dctx,
+                                                           const float* __restrict__ lse, uint16_t* __restrict__ dqkv, int Lmax,
+                                                           int H, int stagger, float* __restrict__ qk_partial,
+                                                           const cocodr_dropout_mask dm, const AttnPacked pk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ATTN_EXTENT(Lmax, pk)
+  char* Qt = smem;
+  char* Kt = smem + L * 128;
+  char* Dt = smem + 2 * L * 128;
+  char* St = smem + 3 * L * 128;  // dS of the current pair of query blocks: [L keys][64 queries] bf16, tile64 layout
+  float* lse2 = reinterpret_cast<float*>(smem + 4 * L * 128);
+  float* delta = lse2 + L;
+  float qacc = 0.f;
+  const float inv_s = DROP ? 1.0f / dm.scale : 1.0f, out_s = DROP ? dm.scale : 1.0f;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ld = 3 * H;
+  const uint16_t* base = qkv + row0 * ld + h * 64;
+  const uint16_t* obase = ctx + row0 * H + h * 64;
+  const uint16_t* dobase = dctx + row0 * H + h * 64;
+  if (stagger > 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) < 512 && __builtin_amdgcn_s_getreg(6 | (11 << 11)) != 0)
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  const int half = lane >> 5;
+  const int nblk = L / 32;
+  const int kb = wid;               // this wave's key block
+  const bool own = kb < nblk;       // (a short sequence of a packed batch has fewer key blocks than the workgroup has waves)
+  stage_tile_dma(Qt, base, ld, L, lane, wid, 4);
+  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
+  // V fragments and the mask of this wave's own keys straight from global memory (layout of frag_rows)
+  uint4 vraw[4] = {};
+  float my_madd = 0.f;
+  if (own) {
+    const uint16_t* vrow = base + 2 * H + (size_t)(kb * 32 + (lane & 31)) * ld;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vraw[s] = *reinterpret_cast<const uint4*>(vrow + (2 * s + half) * 8);
+    my_madd = mask[row0 + kb * 32 + (lane & 31)] != 0 ? 0.f : kMaskNeg;
+  }
+  constexpr int kMaxIt = 4;  // L <= 128 -> L * 8 / 256 <= 4 chunks per thread
+  const int nit = L * 8 / 256;
+  uint4 dreg[kMaxIt], oreg[kMaxIt];
+#pragma unroll
+  for (int i = 0; i < kMaxIt; ++i)
+    if (i < nit) {
+      const int q = tid + i * 256, row = q >> 3, ch = q & 7;
+      dreg[i] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
+      oreg[i] = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
+    }
+  for (int i = tid; i < L; i += 256) lse2[i] = lse[lse0 + i] * kLog2e;
+#pragma unroll
+  for (int i = 0; i < kMaxIt; ++i)
+    if (i < nit) {
+      const int q = tid + i * 256, row = q >> 3, ch = q & 7;
+      *reinterpret_cast<uint4*>(Dt + tile64_off(row, ch)) = dreg[i];
+      float df[8], of[8];
+      unpack8(dreg[i], df);
+      unpack8(oreg[i], of);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += df[e] * of[e];
+      part += dpp_partner<0xB1>(part);
+      part += dpp_partner<0x4E>(part);
+      part += dpp_partner<0x141>(part);
+      if (ch == 0) delta[row] = DROP ? -part * inv_s : -part;  // negated: it seeds the dP accumulators
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sl2 = kScale * kLog2e;
+  bf16x8 kf[4], vf[4];
+  if (own) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = frag_rows(Kt, kb * 32, s, lane);
+      vf[s] = as_bf16x8(vraw[s]);
+    }
+  }
+  const uint32_t Lh = (uint32_t)dropL >> 1, kshift = (lane & 1) << 4;
+  const uint32_t keypair = DROP ? prob_row_pair(b * heads + h, 4 * half, dropL) + (uint32_t)((kb * 32 + (lane & 31)) >> 1) : 0u;
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+  const int aq = wid & 1, adt = wid >> 1;  // dQ phase: this wave's query block of the pair and its 32-column half of d
+
+  for (int c = 0; 2 * c < nblk; ++c) {
+    if (own) {
+#pragma unroll 1
+      for (int qbl = 0; qbl < 2; ++qbl) {
+        const int qb = 2 * c + qbl;
+        if (qb >= nblk) break;
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {  // dP accumulators start at -delta of their query rows
+          const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
+          dpacc[rg * 4 + 0] = d4.x; dpacc[rg * 4 + 1] = d4.y; dpacc[rg * 4 + 2] = d4.z; dpacc[rg * 4 + 3] = d4.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qt, qb * 32, s, lane), kf[s], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Dt, qb * 32, s, lane), vf[s], dpacc, 0, 0, 0);
+        }
+        float p[16], ds[16];
+        [[maybe_unused]] float sd[DROP ? 16 : 1];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float4 l4 = *reinterpret_cast<const float4*>(lse2 + qb * 32 + 8 * rg + 4 * half);
+          const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+          [[maybe_unused]] float dseed[4] = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (DROP) {
+            const float4 d4 = *reinterpret_cast<const float4*>(delta + qb * 32 + 8 * rg + 4 * half);
+            dseed[0] = d4.x; dseed[1] = d4.y; dseed[2] = d4.z; dseed[3] = d4.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = rg * 4 + e;
+            p[r] = fast_exp2(sacc[r] * sl2 + my_madd - ll[e]);
+            ds[r] = p[r] * dpacc[r];
+            if constexpr (DROP) sd[r] = p[r] * dseed[e];
+          }
+        }
+        if constexpr (DROP)
+          for_keep_klane(keypair + (uint32_t)(qb * 32) * Lh, Lh, kshift, dm, [&](int r, bool keep) {
+            ds[r] = keep ? ds[r] : sd[r];
+            p[r] = keep ? p[r] : 0.f;
+          });
+        // dS of (this key, queries 8 rg + 4 half .. + 3 of block qbl) -> stage tile row = key, 8 bytes at column qbl 32 + 8 rg + 4 half
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float t4[4] = {ds[rg * 4 + 0], ds[rg * 4 + 1], ds[rg * 4 + 2], ds[rg * 4 + 3]};
+          *reinterpret_cast<uint2*>(St + tile64_off(kb * 32 + (lane & 31), qbl * 4 + rg) + 8 * half) = pack4(t4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 pf = pack_acc(p, j), dsf = pack_acc(ds, j);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Dt, qb * 32 + j * 16, dt, lane), pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Qt, qb * 32 + j * 16, dt, lane), dsf, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();  // the pair's dS tile is complete (every key block)
+    if (2 * c + aq < nblk) {  // dQ^T[adt half of d, query block 2 c + aq] = sum over ALL keys
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+      for (int k2 = 0; k2 < nblk; ++k2)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Kt, k2 * 32 + j * 16, adt, lane), frag_cols_tr(St, k2 * 32 + j * 16, aq, lane),
+                                                       dq, 0, 0, 0);
+      if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum16(dq, kScale * out_s, lane, adt);
+      store_acc_T16_half(dqkv + (row0 + (2 * c + aq) * 32) * ld + h * 64, ld, dq, adt, kScale * out_s, lane);
+    }
+    if (2 * (c + 1) < nblk) __syncthreads();  // the next pair overwrites the stage tile
+  }
+  if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
+  if (own) {
+    uint16_t* out0 = dqkv + (row0 + kb * 32) * ld + h * 64;
+    store_acc_T16(out0 + H, ld, dk, kScale * out_s, lane);
+    store_acc_T16(out0 + 2 * H, ld, dv, out_s, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 256 < L <= 512: the four [L,64] tiles no longer fit the LDS together, so the two phases become two kernels that
 // each keep only the pair of tiles they sweep (K,V for dQ; Q,dO for dK/dV, 128 KiB at L = 512) and fetch the fragments
 // of their own 32 rows straight from global memory.
@@ -804,6 +1028,8 @@ int attn_bwd_any(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, 
   if (attr_done.pending()) {
     lds_attr(attn_bwd_kernel<false, false>); lds_attr(attn_bwd_kernel<true, false>);
     lds_attr(attn_bwd_kernel<false, true>); lds_attr(attn_bwd_kernel<true, true>);
+    lds_attr(attn_bwd1_kernel<false, false>); lds_attr(attn_bwd1_kernel<true, false>);
+    lds_attr(attn_bwd1_kernel<false, true>); lds_attr(attn_bwd1_kernel<true, true>);
     lds_attr(attn_bwd_dq_kernel<false, false>); lds_attr(attn_bwd_dq_kernel<true, false>);
     lds_attr(attn_bwd_dq_kernel<false, true>); lds_attr(attn_bwd_dq_kernel<true, true>);
     lds_attr(attn_bwd_dkv_kernel<false>); lds_attr(attn_bwd_dkv_kernel<true>);
@@ -827,6 +1053,16 @@ int attn_bwd_any(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, 
   if (stagger < 0) {
     const char* e = getenv("COCODR_ATTN_STAGGER");
     stagger = e ? atoi(e) : 2;
+  }
+  static const bool two_phase = getenv("COCODR_ATTN_TWO_PHASE") != nullptr;  // A/B switch: the round-1..3 kernel at L <= 128 as well
+  if (L <= 128 && !two_phase) {  // one pass: every wave one key block, dS staged for the dQ product (see attn_bwd1_kernel)
+    const size_t lds1 = (size_t)4 * L * 128 + (size_t)2 * L * 4;
+    auto k1 = dropping ? (qks ? attn_bwd1_kernel<true, true> : attn_bwd1_kernel<false, true>)
+                       : (qks ? attn_bwd1_kernel<true, false> : attn_bwd1_kernel<false, false>);
+    hipLaunchKernelGGL(k1, dim3(heads, B), dim3(256), lds1, st, qkv, mask, ctx, dctx, lse, dqkv, L, H,
+                       2 * lds1 <= 160 * 1024 && heads * B > 512 && !pk.seq_off ? stagger : 0, qk_bias_partial, dm, pk);
+    CK_LAUNCH("attn_bwd(one pass)");
+    return COCODR_OK;
   }
   auto kf = dropping ? (qks ? attn_bwd_kernel<true, true> : attn_bwd_kernel<false, true>)
                      : (qks ? attn_bwd_kernel<true, false> : attn_bwd_kernel<false, false>);
