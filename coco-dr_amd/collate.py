@@ -64,7 +64,10 @@ class CondenserCollator:
                                        self.mask_id, self.mlm_probability, self.seed, self.spans_seen, ptr(ids), ptr(labels), ptr(mask),
                                        stream_ptr()), "mlm_collate")
         self.spans_seen += n
-        return {"input_ids": ids.long(), "labels": labels.long(), "attention_mask": mask.long()}
+        # "lengths": the attended length of every row, known here on the host (truncation window + [CLS] + [SEP], COCO/data.py:131-144) -
+        # a numpy array, so that a trainer's move-to-device of the batch leaves it where it is; with it the model builds its packed
+        # layout without reading the mask back (CocoBertModel.forward(lengths=), CoCondenserForPretraining: batch["lengths"])
+        return {"input_ids": ids.long(), "labels": labels.long(), "attention_mask": mask.long(), "lengths": np.minimum(lens, L - 2) + 2}
 
     def __call__(self, examples: List[Dict[str, List[int]]]):
         return self.collate_spans([e["text"] for e in examples])

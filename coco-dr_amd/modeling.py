@@ -374,12 +374,11 @@ class PackedIndex:
         """``lengths`` (host integers, = attention_mask.sum(1) of prefix masks): no device -> host traffic.  Otherwise the lengths
         are read back from the device mask (a stream synchronisation); None when a mask is not a prefix mask (the reference pads
         at the end, COCO/data.py:135-144; anything else runs padded)."""
+        if lengths is not None and torch.is_tensor(lengths) and lengths.is_cuda:
+            # (a trainer moved the batch to the device: these are no longer host-known - the mask route reads them back, or they do)
+            lengths = None if mask is not None else lengths.cpu()
         if lengths is not None:
-            if torch.is_tensor(lengths):
-                if lengths.is_cuda:
-                    raise ValueError("lengths must live on the host (a CPU tensor, list or numpy array); on the device pass the mask alone")
-                lengths = lengths.numpy()
-            return PackedIndex(ids, lengths)
+            return PackedIndex(ids, lengths.numpy() if torch.is_tensor(lengths) else lengths)
         B, L = ids.shape
         if mask is None:
             import numpy as np

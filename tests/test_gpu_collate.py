@@ -49,5 +49,10 @@ def test_cocondenser_collator_lays_span_pairs_back_to_back():
     assert out["input_ids"].shape == (10, 64)
     att = out["attention_mask"].cpu().numpy()
     assert list(att.sum(1)) == [22, 32] * 5  # rows 2i / 2i+1 are the two spans of document i (COCO/modeling.py:172-177)
+    # the host-known lengths the model packs from (no read-back of the mask): a numpy array, = attention_mask.sum(1)
+    assert isinstance(out["lengths"], np.ndarray) and out["lengths"].tolist() == [22, 32] * 5
+    long_doc = [{"span": [rng.integers(104, 2000, 200).tolist(), rng.integers(104, 2000, 62).tolist()]}]
+    o2 = col(long_doc)
+    assert o2["lengths"].tolist() == o2["attention_mask"].sum(1).cpu().tolist() == [64, 64]  # truncated to max_seq_length - 2 (+ [CLS], [SEP])
     lab = out["labels"].cpu().numpy()
     assert ((lab != -100).sum(1) >= 1).all()

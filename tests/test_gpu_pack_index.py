@@ -57,8 +57,7 @@ def test_pack_index_from_host_lengths(lens, L, dtype):
     dids = torch.from_numpy(ids).to(dtype).to(DEV)
     for lengths in (lens, lens.tolist(), torch.from_numpy(lens), torch.from_numpy(lens).int()):
         check_index(PackedIndex.build(dids, None, lengths), ids, lens, Lp)
-    with pytest.raises(ValueError):
-        PackedIndex.build(dids, None, torch.from_numpy(lens).to(DEV))  # host integers only
+    check_index(PackedIndex.build(dids, None, torch.from_numpy(lens).to(DEV)), ids, lens, Lp)  # (device lengths: read back)
 
 
 @pytest.mark.parametrize("mdtype", [torch.int64, torch.int32, torch.bool, torch.uint8, torch.float32])
