@@ -41,6 +41,7 @@ def model(layers=3, H=256, heads=4, I=512, V=900, **kw):
 
 def step(m, ids, mask, packed, tail):
     m.cls_tail = tail
+    m.pack_sequences = packed  # (packed is the model's default: the padded runs must say so)
     m.zero_grad(set_to_none=True)
     pk = m.pack(ids, mask) if packed else None
     cls = m.encode_cls(ids, mask, packed_index=pk)
@@ -49,10 +50,12 @@ def step(m, ids, mask, packed, tail):
     return cls.detach().clone(), m.flat_decay.grad.clone(), m.flat_nodecay.grad.clone()
 
 
+# (the last two rows: BERT-base and BERT-large WIDTH, two layers - VERDICT r03 item 9)
 @pytest.mark.parametrize("packed", [False, True])
-@pytest.mark.parametrize("B,L,layers", [(8, 64, 3), (64, 128, 2), (5, 96, 1)])
-def test_cls_tail_equals_the_full_last_layer(packed, B, L, layers):
-    m = model(layers=layers)
+@pytest.mark.parametrize("B,L,layers,wide", [(8, 64, 3, None), (64, 128, 2, None), (5, 96, 1, None), (16, 128, 2, (768, 12, 3072)),
+                                             (16, 128, 2, (1024, 16, 4096))])
+def test_cls_tail_equals_the_full_last_layer(packed, B, L, layers, wide):
+    m = model(layers=layers) if wide is None else model(layers=layers, H=wide[0], heads=wide[1], I=wide[2])
     ids, mask = batch(B, L, 900, 3)
     cls_f, gd_f, gn_f = step(m, ids, mask, packed, False)
     cls_t, gd_t, gn_t = step(m, ids, mask, packed, True)
@@ -69,6 +72,7 @@ def test_cls_tail_equals_the_full_last_layer(packed, B, L, layers):
             assert float(a.norm()) == 0.0, name
     with torch.no_grad():  # inference: same rows, lean arena
         m.cls_tail = True
+        m.pack_sequences = packed
         e_t = m.encode_cls(ids, mask, packed_index=m.pack(ids, mask) if packed else None)
         m.cls_tail = False
         e_f = m.encode_cls(ids, mask, packed_index=m.pack(ids, mask) if packed else None)

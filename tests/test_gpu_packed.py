@@ -249,3 +249,36 @@ def test_packed_condenser_step_equals_padded_step(skip_from, late):
         assert abs(res[mode][0] - res["padded"][0]) < 1e-4 * abs(res["padded"][0]), (mode, res[mode][0], res["padded"][0])
         for g, r in zip(res[mode][1], res["padded"][1]):
             assert rel_l2(g, r) < 6e-3, (mode, rel_l2(g, r))
+
+
+@pytest.mark.parametrize("H,heads,I", [(768, 12, 3072), (1024, 16, 4096)])
+def test_packed_step_equals_padded_step_at_full_width(H, heads, I):
+    """Packed against padded at BERT-base / BERT-large WIDTH (two layers, 32 x 128 tokens, MS MARCO-shaped lengths): forward
+    bit-identical at the real tokens, loss within 1e-5, every parameter gradient within 5e-3."""
+    cfgd = cfg_small(hidden_size=H, num_attention_heads=heads, intermediate_size=I, num_hidden_layers=2, vocab_size=3000)
+    ids, mask, lens = ragged_batch(32, 128, 3000, 77)
+    res, cls = {}, {}
+    for packed in (False, True):
+        torch.manual_seed(0)
+        m = CocoBertModel(CocoBertConfig(**cfgd)).to(DEV)
+        with torch.no_grad():
+            s_ln = float(np.sqrt(5.0 / H))  # [CLS] logits O(5): a conditioned InfoNCE (as tests/test_gpu_large_shapes.py)
+            for k in ("weight", "bias"):
+                m.hf_view(f"encoder.layer.1.output.LayerNorm.{k}").mul_(s_ln)
+            m.flat_nodecay.add_(0.02)
+        m.pack_sequences = packed
+        model = CoCondenserForPretraining(m)
+        batch = {"input_ids": t(ids), "attention_mask": t(mask)}
+        if packed:
+            batch["lengths"] = torch.from_numpy(lens)
+        with torch.no_grad():
+            cls[packed] = m.encode_cls(t(ids), t(mask)).clone()
+        loss = model(batch, None)
+        loss.backward()
+        res[packed] = (float(loss.detach()), {k: v.detach().clone() for k, v in m.hf_named_grads()})
+    assert torch.equal(cls[True], cls[False])
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0])
+    for name, ref in res[False][1].items():
+        if name.endswith("key.bias") or float(ref.norm()) == 0:
+            continue
+        assert rel_l2(res[True][1][name], ref) < 5e-3, (name, rel_l2(res[True][1][name], ref))
