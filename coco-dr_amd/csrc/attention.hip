@@ -13,6 +13,7 @@
 //    accumulator layout, and the matching rows of V are fetched with the transposing LDS read
 //    (ds_read_b64_tr_b16), so P never goes through LDS or cross-lane shuffles.
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "prof.h"
 
