@@ -182,14 +182,16 @@ def cpu_baseline_torch(n_seq: int, L: int, warmup: int = 3, steps: int = 10, thr
 
 
 def cpu_baseline():
-    """`value`: a bounded sample of the headline workload (configs[1]: L 128; 8 of its 64 sequences per step) on the host
-    cores.  `config1`: BASELINE.json configs[0] at its exact shape (8 sequences x L 64; BASELINE.md measured the reference's
+    """`value`: a bounded sample of the headline workload at its exact shape (configs[1]: 64 sequences x L 128, a few steps) on
+    the host cores; `eight_sequences`: the same step on 8 sequences (more steps, the round-2/3 number).  `config1`: BASELINE.json configs[0] at its exact shape (8 sequences x L 64; BASELINE.md measured the reference's
     full coCondenser step at 6.4 sequences/s on 8 threads there - this scope has no Condenser head / MLM decoders).
     `port`: the numpy oracle."""
     out = {"kind": "port", "cpu": _cpu_model_name()}
     try:
         thr = _best_thread_count(8, 64)
-        out.update(cpu_baseline_torch(8, SEQ_LEN, threads=thr))
+        # the headline's exact batch (64 sequences x L128) as a bounded sample: 1 warm-up + 2 timed steps (~15-20 s of CPU work)
+        out.update(cpu_baseline_torch(SEQ_PER_GPU, SEQ_LEN, warmup=1, steps=2, threads=thr))
+        out["eight_sequences"] = cpu_baseline_torch(8, SEQ_LEN, threads=thr)
         out["config1"] = cpu_baseline_torch(8, 64, threads=thr)
         out["threads_tried"] = "fastest of 8 / 16 / 32 / 64 / all physical cores on the config-1 shape"
         out["port"] = cpu_baseline_numpy()
@@ -200,7 +202,7 @@ def cpu_baseline():
 
 
 # ---------------------------------------------------------------------------------------------------------- side legs
-def full_coco_step(cfg, dev, ids, mask, lens=None, steps: int = 8, warmup: int = 3):
+def full_coco_step(cfg, dev, ids, mask, lens=None, steps: int = 8, warmup: int = 3, padded_too: bool = True):
     """The reference's whole pre-training step (COCO/modeling.py:192-235 with COCO/README.md:49 settings: 2 Condenser
     head layers, skip_from 6, late MLM): backbone + head + two label-sparse MLM losses + contrastive + AdamW.
     Reported next to the headline metric, never instead of it."""
@@ -237,17 +239,19 @@ def full_coco_step(cfg, dev, ids, mask, lens=None, steps: int = 8, warmup: int =
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    bert.pack_sequences = False  # the same step on the padded layout (all B x L rows)
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    pdt = (time.perf_counter() - t0) / steps
+    pdt = float("nan")
+    if padded_too:
+        bert.pack_sequences = False  # the same step on the padded layout (all B x L rows)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        pdt = (time.perf_counter() - t0) / steps
     return {"sequences_per_sec": round(ids.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss.detach()), 3),
-            "execution": "packed (backbone and Condenser head on the stored rows)", "padded_ms_per_step": round(pdt * 1e3, 3),
+            "execution": "packed (backbone and Condenser head on the stored rows)", "padded_ms_per_step": None if pdt != pdt else round(pdt * 1e3, 3),
             "scope": "backbone + 2 Condenser head layers (skip_from 6) + head & late MLM losses (label-sparse, 15 %) + contrastive + clip_grad_norm_(1.0) + AdamW"}
 
 
@@ -399,7 +403,8 @@ def search_cpu_baseline(nq: int = 1000, npass: int = 125000, dim: int = 1024, k:
                       "CPU BLAS + torch.topk - the arithmetic of faiss IndexFlatIP.search, which the reference calls and this image lacks"}
 
 
-def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int = 0, world: int = 1, fence=None, dp_chunks: int = 2):
+def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int = 0, world: int = 1, fence=None, dp_chunks: int = 2,
+              extras: bool = True):
     """BASELINE config 4 (ANCE/drivers/run_ann.py:293-356): BERT-large triplet step, 32 rows/GPU = queries [32,64] +
     positives / negatives [32,128], backward, clip_grad_norm_(1.0), LAMB (the reference's default optimizer), linear
     schedule.  One training row = 3 sequences.  ``world > 1``: the data-parallel step - every rank its own rows
@@ -465,6 +470,8 @@ def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int =
                            "gemm_share_of_step": round(gemm_ms / 3 / (dt * 1e3), 3),
                            "flops": "achieved / frac: FLOPs the GEMM launches of the step execute (stored rows of the packed pass) / their "
                                     "summed duration; algorithmic_*: 24 H^2 x 3 per PADDED token of the three encoder inputs over the same time"}
+    if not extras:  # (tools/ance_profile.py: the default step alone under the profiler)
+        return out
     # the same step as the reference lays it out: a padded query pass (side stream) next to a padded passage pass
     model.bert.pack_sequences = model.merge_passes = False
     for _ in range(warmup):

@@ -9,5 +9,5 @@ import bench  # noqa: E402
 
 if __name__ == "__main__":
     torch.cuda.set_device(0)
-    out = bench.ance_step(torch.device("cuda:0"), steps=10, warmup=3)
+    out = bench.ance_step(torch.device("cuda:0"), steps=10, warmup=3, extras=False)
     print({k: v for k, v in out.items() if k != "scope"})

@@ -15,8 +15,8 @@ if __name__ == "__main__":
     from cocodr_amd.modeling import CocoBertConfig
     cfg = CocoBertConfig.base(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
     if which == "coco":
-        ids, mask = bench.synth_batch(0, 64, 128, cfg.vocab_size, dev)
-        print(bench.full_coco_step(cfg, dev, ids, mask, steps=10, warmup=3))
+        ids, mask, lens = bench.synth_batch_lens(0, 64, 128, cfg.vocab_size, dev)
+        print(bench.full_coco_step(cfg, dev, ids, mask, lens, steps=10, warmup=3, padded_too=False))
     elif which == "packed":
         dt, loss, roof, _, _, _ = bench.contrastive_leg("base", 64, 128, 10, 3, dev, 0, 1, False, 2, False, False, packed=True)
         print({"ms_per_step": dt / 10 * 1e3, "loss": loss})

@@ -43,6 +43,16 @@ for cfg in "base 64" "large 64" "large 200" "large 256"; do
   fi
  done
 done
+# the other step legs alone under the profiler: full coCondenser step (BERT-base 64 x 128) and the ANCE triplet step (BERT-large, 32 rows)
+if [[ $stages == *k* ]]; then
+  for leg in coco ance; do
+    if [ $leg = coco ]; then cmd="tools/coco_profile.py coco"; else cmd="tools/ance_profile.py"; fi
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/kt_$leg -o kt -- python $root/$cmd > $out/kt_$leg.log 2>&1)
+    db=$(find $out/kt_$leg -name "*.db" | head -1)
+    if [ -n "$db" ]; then python tools/rocpd_stats.py $db > $out/kernel_stats_$leg.md; fi
+    tail -1 $out/kt_$leg.log > $out/kt_bench_$leg.json
+  done
+fi
 # keep the merged-back payload small: drop raw traces
 find $out -name "*.db" -size +20M -delete
 find $out -name "*counter_collection.csv" -size +20M -delete
