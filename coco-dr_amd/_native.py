@@ -29,6 +29,7 @@ class GemmArgs(C.Structure):
         ("drop", DropoutMask),
         ("ab_f16", c_int),
         ("split_ws", c_void_p), ("split_ws_floats", c_size_t),
+        ("row_lse", c_void_p), ("row_scale", c_void_p), ("row_label", c_void_p), ("lse_stats", c_void_p), ("label_logit", c_void_p),
     ]
 
 
@@ -74,7 +75,7 @@ class EncoderBwdLayout(C.Structure):  # mirrors cocodr_encoder_bwd_layout_t
     _fields_ = [(n, c_size_t) for n in ("dy2", "du", "dy1", "dqkv", "ln2_partial", "ln1_partial")] + [("ln_blocks", c_int), ("ln_rows", c_int)]
 
 
-EPI_NONE, EPI_GELU, EPI_ADD, EPI_DGELU = 0, 1, 2, 3
+EPI_NONE, EPI_GELU, EPI_ADD, EPI_DGELU, EPI_LSE, EPI_CE_GRAD = 0, 1, 2, 3, 4, 5
 
 # name -> (restype, argtypes); every symbol include/cocodr.h declares
 SIGNATURES = {
@@ -152,6 +153,8 @@ SIGNATURES = {
     "cocodr_stack_fwd": (c_int, [C.POINTER(Config), C.POINTER(LayerParams), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                                  c_void_p]),
     "cocodr_ce_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "cocodr_decoder_ce_workspace_floats": (c_size_t, [c_int, c_int]),
+    "cocodr_decoder_ce": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_encoder_bwd": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), C.POINTER(EmbedGrads),
                                    C.POINTER(LayerGrads), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                    c_void_p]),

@@ -42,6 +42,12 @@ class CondenserHead(FlatParamsMixin, nn.Module):
     ``cls.predictions.transform.dense.weight`` ..., ``cls.predictions.bias`` (the decoder weight is the backbone's
     word-embedding table)."""
 
+    #: True: decoder GEMM + vocabulary cross entropy in the GEMM epilogue (``cocodr_decoder_ce``: the fp32 logits never reach HBM, at
+    #: the price of a second pass of the GEMM).  Measured at the step's 1216 x 768 x 30 522 problem: 235 us against 173 us for the fp32
+    #: logits + ``cocodr_ce_fwd_bwd`` (profiles/r04_decoder_ce.md) - the recompute costs more than the 300 MB it saves, so the
+    #: default stays the two-kernel form; the fused form halves the step's peak transient memory (149 MB of logits per 1216 rows).
+    fused_ce = False
+
     def __init__(self, config: CocoBertConfig, n_head_layers: int = 2, device=None):
         super().__init__()
         H, V = config.hidden_size, config.vocab_size
@@ -220,19 +226,24 @@ class _CondenserStepFn(torch.autograd.Function):
         g_act, a_pre = ops.gemm(xg.contiguous(), wt, bias=b_t, epi=N.EPI_GELU)
         t, t_mean, t_rstd = ops.ln_fwd(g_act, head.hf_view("cls.predictions.transform.LayerNorm.weight"),
                                        head.hf_view("cls.predictions.transform.LayerNorm.bias"), cfg.layer_norm_eps)
-        word16 = torch.zeros((head.vpad, H), dtype=torch.bfloat16, device=dev)  # tied decoder weight, rows padded to 128
+        # tied decoder weight; rows padded to 256 for the fused GEMM + cross entropy (bias -1e30 there: probability exactly 0)
+        vp = (V + 255) // 256 * 256 if head.fused_ce else head.vpad
+        word16 = torch.zeros((vp, H), dtype=torch.bfloat16, device=dev)
         ops.cast_f32_bf16(bert.hf_view("embeddings.word_embeddings.weight"), word16[:V])
-        dec_bias = torch.full((head.vpad,), _NEG, dtype=torch.float32, device=dev)
+        dec_bias = torch.full((vp,), _NEG, dtype=torch.float32, device=dev)
         dec_bias[:V].copy_(head.hf_view("cls.predictions.bias"))
-        logits = ops.gemm(t, word16, bias=dec_bias, out_f32=True)  # [n2, vpad] fp32
         scale = torch.cat([scale_p, scale_p]) if late_mlm else scale_p
         lab2 = torch.cat([lab_p, lab_p]) if late_mlm else lab_p
-        loss_rows = torch.empty(n2, dtype=torch.float32, device=dev)
-        dlogits = torch.empty((n2, head.vpad), dtype=torch.bfloat16, device=dev)
-        check(lib().cocodr_ce_fwd_bwd(ptr(logits), ptr(lab2), ptr(scale), n2, V, head.vpad, ptr(loss_rows), ptr(dlogits),
-                                      stream_ptr()), "ce_fwd_bwd")
+        if head.fused_ce:  # logits stay on chip: two passes of the decoder GEMM (row statistics, then the gradient)
+            loss_rows, dlogits = ops.decoder_ce(t, word16, dec_bias, lab2, scale)
+        else:
+            logits = ops.gemm(t, word16, bias=dec_bias, out_f32=True)  # [n2, vp] fp32
+            loss_rows = torch.empty(n2, dtype=torch.float32, device=dev)
+            dlogits = torch.empty((n2, vp), dtype=torch.bfloat16, device=dev)
+            check(lib().cocodr_ce_fwd_bwd(ptr(logits), ptr(lab2), ptr(scale), n2, V, vp, ptr(loss_rows), ptr(dlogits),
+                                          stream_ptr()), "ce_fwd_bwd")
+            del logits
         mlm_loss = (loss_rows * scale).sum()  # mean over the head rows + mean over the late rows
-        del logits
         ctx.bert, ctx.head = bert, head
         ctx.skip_from, ctx.late_mlm, ctx.n_lab, ctx.n_pad = skip_from, late_mlm, n_lab, n_pad
         ctx.arena, ctx.lay, ctx.harena, ctx.hlay, ctx.hcfg = arena, lay, harena, hlay, hcfg
@@ -263,7 +274,7 @@ class _CondenserStepFn(torch.autograd.Function):
             dlog = dlogits.mul_(g_mlm.to(dlogits.dtype))  # upstream scale (1.0 in the reference step); no host sync
             # decoder (tied to the word embeddings) and its bias
             # [n2,H] = dlogits . Word: 120 output tiles of 128 rows over K = 30 592: two K slices in one launch fill the CUs
-            dt = ops.gemm(dlog, word16, trans_b=True, split_k=2 if head.vpad % 128 == 0 else 1)
+            dt = ops.gemm(dlog, word16, trans_b=True, split_k=2)
             dword_mlm = ops.gemm(dlog, t, trans_a=True, trans_b=True, out_f32=True)       # [vpad,H] dlogits^T . t
             gv("cls.predictions.bias").copy_(ops.colsum(dlog)[:V])
             # transform: LayerNorm, erf-GELU, dense

@@ -673,6 +673,7 @@ int select_impl(const cocodr_gemm_args& a) {
     else if (tiles256 >= 128) impl = 9;
     else impl = tiles128 >= 512 ? 4 : 2;
   }
+  if (a.epi >= COCODR_EPI_LSE) return 13;  // (validated by cocodr_gemm: only the ping-pong pipeline's epilogue knows these)
   if (impl != 1 && !(k_ok && small)) impl = 1;
   if (impl == 8 && a.N % 192 != 0) impl = 3;  // the 128x192 tile needs N % 192 == 0
   if (impl == 11 && a.N % 256 != 0) impl = 5;  // the 256x256 tile needs N % 256 == 0
@@ -700,7 +701,7 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   CK_ARG(args != nullptr, "gemm: null args");
   cocodr_gemm_args a = *args;
   if (a.batch <= 0) a.batch = 1;
-  CK_ARG(a.A && a.B && a.C, "gemm: null operand");
+  CK_ARG(a.A && a.B && (a.C || a.epi == COCODR_EPI_LSE), "gemm: null operand");
   CK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   CK_ARG(a.N % BN == 0, "gemm: N=%d must be a multiple of 128", a.N);
   CK_ARG(a.K % 8 == 0, "gemm: K=%d must be a multiple of 8", a.K);
@@ -710,7 +711,15 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   CK_ARG(a.lda >= (a.trans_a ? a.M : a.K) && a.ldb >= (a.trans_b ? a.N : a.K) && a.ldc >= a.N, "gemm: leading dim too small");
 #endif
   CK_ARG(!(a.trans_a && !a.trans_b), "gemm: (trans_a=1, trans_b=0) is not used on this path");
-  CK_ARG(a.epi >= COCODR_EPI_NONE && a.epi <= COCODR_EPI_DGELU, "gemm: bad epilogue %d", a.epi);
+  CK_ARG(a.epi >= COCODR_EPI_NONE && a.epi <= COCODR_EPI_CE_GRAD, "gemm: bad epilogue %d", a.epi);
+  if (a.epi >= COCODR_EPI_LSE) {  // the two passes of the fused vocabulary cross entropy: the 256 x 256-tile pipeline's epilogue only
+    CK_ARG(!a.trans_a && !a.trans_b && a.batch == 1 && !a.out_f32 && a.N % 256 == 0 && a.K % 64 == 0 && !a.colsum && !a.colsum_partial &&
+               !a.drop.threshold && !a.ab_f16 && a.row_label,
+           "gemm: EPI_LSE / EPI_CE_GRAD need the plain NT form with N %% 256 == 0, K %% 64 == 0 and row_label");
+    CK_ARG(a.epi != COCODR_EPI_LSE || (a.lse_stats && a.label_logit), "gemm: EPI_LSE needs lse_stats and label_logit");
+    CK_ARG(a.epi != COCODR_EPI_CE_GRAD || (a.row_lse && a.row_scale), "gemm: EPI_CE_GRAD needs row_lse and row_scale");
+    CK_ARG((size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldb * 2 < (1ull << 32), "gemm: operands of the fused cross entropy must stay below 4 GiB");
+  }
   CK_ARG(a.epi != COCODR_EPI_GELU || !a.out_f32, "gemm: EPI_GELU needs a bf16 output");
   CK_ARG((a.epi != COCODR_EPI_ADD && a.epi != COCODR_EPI_DGELU) || (a.R && a.ldr % 8 == 0 && a.ldr >= a.N), "gemm: epilogue needs R");
   CK_ARG((((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.C2 | (uintptr_t)a.R | (uintptr_t)a.bias) & 15) == 0,
