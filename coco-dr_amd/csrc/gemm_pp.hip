@@ -463,7 +463,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
         const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CLD + c8);
         const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CLD + c8 + 4);
         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-        if constexpr (!OUT_F32 && !MULTI) {
+        if constexpr (!OUT_F32 && !MULTI && !TA && !TB && !F16) {  // (the plain forward form only: the other instantiations stay as they were)
           // the fused vocabulary cross entropy (cocodr_decoder_ce).  A row's 256 columns of this tile sit in 32 consecutive lanes
           // (one half-wave: CPRW = 32), so the row statistics are five lane exchanges; the branch is uniform per launch
           if (p.epi >= COCODR_EPI_LSE) {
