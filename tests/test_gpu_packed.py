@@ -289,3 +289,77 @@ def test_packed_step_equals_padded_step_at_full_width(H, heads, I, B):
         # B = 200: different K-summation order in the split-tail tiles = different bf16 roundings of the hidden states; both steps
         # sit 2-3 % from the fp64 oracle's gradients and <= 1.7 % from each other (profiles/r04_split_tail_noise.md)
         assert rel_l2(res[True][1][name], ref) < (5e-3 if B <= 32 else 2.5e-2), (name, rel_l2(res[True][1][name], ref))
+
+
+@pytest.mark.parametrize("B,L,seed", [(2, 32, 0), (6, 50, 1), (10, 100, 2), (14, 128, 3), (4, 200, 4), (2, 512, 5), (26, 64, 6), (8, 33, 7)])
+def test_packed_default_step_equals_padded_step_over_odd_batch_shapes(B, L, seed):
+    """The default (packed) step against the padded one over the shapes a data loader really produces: batch sizes that are not
+    multiples of 8 (last batch of an epoch), lengths that are not multiples of 32, sequences of one token, every sequence full,
+    L up to max_position_embeddings.  Forward bit-identical at the real tokens, loss and gradients equal."""
+    cfgd = cfg_small(num_hidden_layers=2)
+    rng = np.random.Generator(np.random.PCG64(100 + seed))
+    lens = rng.integers(1, L + 1, B)
+    lens[0] = 1
+    lens[-1] = L
+    if seed == 3:
+        lens[:] = L                     # nothing to drop
+    ids, mask, lens = ragged_batch(B, L, cfgd["vocab_size"], seed, lens=lens)
+    res, cls = {}, {}
+    for packed in (False, True):
+        torch.manual_seed(0)
+        m = CocoBertModel(CocoBertConfig(**cfgd)).to(DEV)
+        with torch.no_grad():
+            m.flat_decay.mul_(2.0)
+            m.flat_nodecay.add_(0.02)
+            for k in ("weight", "bias"):
+                m.hf_view(f"encoder.layer.1.output.LayerNorm.{k}").mul_(0.2)   # a conditioned InfoNCE
+        m.pack_sequences = packed
+        model = CoCondenserForPretraining(m)
+        with torch.no_grad():
+            cls[packed] = m.encode_cls(t(ids), t(mask)).clone()
+            hs = m(input_ids=t(ids), attention_mask=t(mask), output_hidden_states=True).hidden_states
+            cls[("hs", packed)] = [h.clone() for h in hs]
+        batch = {"input_ids": t(ids), "attention_mask": t(mask)}
+        if packed and seed % 2 == 0:
+            batch["lengths"] = torch.from_numpy(lens)
+        loss = model(batch, None)
+        loss.backward()
+        res[packed] = (float(loss.detach()), {k: v.detach().clone() for k, v in m.hf_named_grads()})
+    assert torch.equal(cls[True], cls[False])
+    valid = t(mask).bool()
+    for hp, hd in zip(cls[("hs", True)], cls[("hs", False)]):
+        assert hp.shape == hd.shape and torch.equal(hp[valid], hd[valid])
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0]), (res[True][0], res[False][0])
+    for name, ref in res[False][1].items():
+        if name.endswith("key.bias") or float(ref.norm()) == 0:
+            continue
+        assert rel_l2(res[True][1][name], ref) < 6e-3, (name, rel_l2(res[True][1][name], ref))
+
+
+@pytest.mark.parametrize("B,Lq,Lp,seed", [(1, 32, 64, 0), (3, 20, 100, 1), (8, 64, 128, 2), (11, 64, 50, 3), (2, 64, 512, 4)])
+def test_default_triplet_step_equals_the_padded_two_pass_step_over_odd_batch_shapes(B, Lq, Lp, seed):
+    """The ANCE triplet step (ANCE/model/models.py:80-115) as it runs by default - one merged packed pass - against the reference's
+    structure (query pass + passage pass, padded) for batch sizes and lengths a loader really produces, one-token sequences included."""
+    cfgd = cfg_small(num_hidden_layers=2)
+    rng = np.random.Generator(np.random.PCG64(200 + seed))
+    def side(L, s):
+        lens = rng.integers(1, L + 1, B)
+        lens[0] = 1 if s != 1 else L
+        return ragged_batch(B, L, cfgd["vocab_size"], 10 * seed + s, lens=lens)
+    q, a, b = side(Lq, 0), side(Lp, 1), side(Lp, 2)
+    res = {}
+    for mode in ("padded", "default"):
+        torch.manual_seed(0)
+        model = BertDotNLL(CocoBertConfig(**cfgd)).to(DEV).train()
+        with torch.no_grad():
+            model.bert.flat_decay.mul_(2.0)
+        if mode == "padded":
+            model.bert.pack_sequences = model.merge_passes = False
+        else:
+            assert model.bert.pack_sequences and model.merge_passes
+        loss, _acc, logits = model(t(q[0]), t(q[1]), t(a[0]), t(a[1]), t(b[0]), t(b[1]))
+        loss.backward()
+        res[mode] = (float(loss.detach()), logits.detach().clone(), model.bert.flat_decay.grad.detach().clone(), model.bert.flat_nodecay.grad.detach().clone())
+    assert abs(res["default"][0] - res["padded"][0]) < 1e-4 * max(1.0, abs(res["padded"][0]))
+    assert torch.allclose(res["default"][1], res["padded"][1], rtol=1e-4, atol=1e-4)
+    assert rel_l2(res["default"][2], res["padded"][2]) < 6e-3 and rel_l2(res["default"][3], res["padded"][3]) < 6e-3
