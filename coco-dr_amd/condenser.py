@@ -47,6 +47,9 @@ class CondenserHead(FlatParamsMixin, nn.Module):
     #: logits + ``cocodr_ce_fwd_bwd`` (profiles/r04_decoder_ce.md) - the recompute costs more than the 300 MB it saves, so the
     #: default stays the two-kernel form; the fused form halves the step's peak transient memory (149 MB of logits per 1216 rows).
     fused_ce = False
+    #: contraction slices of the decoder's input-gradient GEMM ([n, H] = dlogits . Word over K = 30 720: 30 tiles of 256 rows would
+    #: leave most CUs idle; slices run as the batch items of one launch).  Measured 2 / 4 / 8: profiles/r04_decoder_ce.md
+    decoder_split_k = 8
 
     def __init__(self, config: CocoBertConfig, n_head_layers: int = 2, device=None):
         super().__init__()
@@ -226,9 +229,11 @@ class _CondenserStepFn(torch.autograd.Function):
         g_act, a_pre = ops.gemm(xg.contiguous(), wt, bias=b_t, epi=N.EPI_GELU)
         t, t_mean, t_rstd = ops.ln_fwd(g_act, head.hf_view("cls.predictions.transform.LayerNorm.weight"),
                                        head.hf_view("cls.predictions.transform.LayerNorm.bias"), cfg.layer_norm_eps)
-        # tied decoder weight; rows padded to 256 for the fused GEMM + cross entropy (bias -1e30 there: probability exactly 0)
-        vp = (V + 255) // 256 * 256 if head.fused_ce else head.vpad
-        word16 = torch.zeros((vp, H), dtype=torch.bfloat16, device=dev)
+        # tied decoder weight; rows padded to a multiple of 512 (bias -1e30 there: probability exactly 0, gradient exactly 0): whole
+        # 256-column tiles for the fused GEMM + cross entropy, and a contraction the backward can cut into 8 slices of 64-wide steps
+        vp = (V + 511) // 512 * 512
+        word16 = torch.empty((vp, H), dtype=torch.bfloat16, device=dev)
+        word16[V:].zero_()
         ops.cast_f32_bf16(bert.hf_view("embeddings.word_embeddings.weight"), word16[:V])
         dec_bias = torch.full((vp,), _NEG, dtype=torch.float32, device=dev)
         dec_bias[:V].copy_(head.hf_view("cls.predictions.bias"))
@@ -269,14 +274,28 @@ class _CondenserStepFn(torch.autograd.Function):
         gv = lambda name: hlo.view((ghd, ghn), name)
         d_head_out = torch.zeros((M, H), dtype=torch.bfloat16, device=dev)
         d_last = torch.zeros((M, H), dtype=torch.float32, device=dev)
+        # backbone gradient flats (allocated here: the tied decoder's weight gradient is written straight into the word-table rows)
+        bgd = torch.empty_like(bert.flat_decay.data)
+        bgn = torch.empty_like(bert.flat_nodecay.data)
+        vp = word16.shape[0]
         dword_mlm = None
+        word_rows = 0  # rows of the embedding region the decoder's weight-gradient GEMM has already written (no zeroing there)
         if g_mlm is not None:
-            dlog = dlogits.mul_(g_mlm.to(dlogits.dtype))  # upstream scale (1.0 in the reference step); no host sync
+            # upstream scale (1.0 in the reference step; a device scalar, no host sync): applied to the SMALL operands - t for the
+            # decoder's weight gradient, dt and the bias sums on the way out - instead of a pass over the [n2, vp] dlogits
+            gs = g_mlm.to(torch.float32)
+            dlog = dlogits
             # decoder (tied to the word embeddings) and its bias
-            # [n2,H] = dlogits . Word: 120 output tiles of 128 rows over K = 30 592: two K slices in one launch fill the CUs
-            dt = ops.gemm(dlog, word16, trans_b=True, split_k=2)
-            dword_mlm = ops.gemm(dlog, t, trans_a=True, trans_b=True, out_f32=True)       # [vpad,H] dlogits^T . t
-            gv("cls.predictions.bias").copy_(ops.colsum(dlog)[:V])
+            # [n2,H] = dlogits . Word: 30 output tiles of 256 rows over K = 30 720: eight K slices in one launch fill the CUs
+            dt = ops.gemm(dlog, word16, trans_b=True, split_k=head.decoder_split_k).mul_(gs.to(torch.bfloat16))
+            # [vp,H] = dlogits^T . (g t), written over the word-table rows of the gradient flat (rows >= V of it: exact zeros over the
+            # first position rows, which the embedding backward overwrites / accumulates into like the zeros they replace)
+            if vp * H <= lo.mat_begin:
+                ops.gemm(dlog, t * gs.to(torch.bfloat16), trans_a=True, trans_b=True, out_f32=True, out=bgd[: vp * H].view(vp, H))
+                word_rows = vp
+            else:
+                dword_mlm = ops.gemm(dlog, t * gs.to(torch.bfloat16), trans_a=True, trans_b=True, out_f32=True)
+            gv("cls.predictions.bias").copy_(ops.colsum(dlog)[:V] * gs)
             # transform: LayerNorm, erf-GELU, dense
             dg, dlnw, dlnb = ops.ln_bwd(dt, g_act, head.hf_view("cls.predictions.transform.LayerNorm.weight"), t_mean, t_rstd)
             gv("cls.predictions.transform.LayerNorm.weight").copy_(dlnw)
@@ -308,9 +327,7 @@ class _CondenserStepFn(torch.autograd.Function):
         d_skip = d_hin.clone()
         d_skip[cls_rows] = 0
         # ---- backbone backward in two ranges; the head's gradient joins at hidden_states[skip_from]
-        bgd = torch.empty_like(bert.flat_decay.data)
-        bgn = torch.empty_like(bert.flat_nodecay.data)
-        ops.zero_f32(bgd[:lo.mat_begin])
+        ops.zero_f32(bgd[word_rows * H: lo.mat_begin])
         emb, arr, eg, garr = bert._param_structs((bgd, bgn))
         bcfg = bert._c_config(getattr(ctx.arena, "_cocodr_drop", None))
         d_last16 = d_last.to(torch.bfloat16)
