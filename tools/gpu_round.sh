@@ -53,7 +53,9 @@ if [[ $stages == *k* ]]; then
     tail -1 $out/kt_$leg.log > $out/kt_bench_$leg.json
   done
 fi
-# keep the merged-back payload small: drop raw traces
-find $out -name "*.db" -size +20M -delete
-find $out -name "*counter_collection.csv" -size +20M -delete
+# keep the merged-back payload small (gpurun merges at most 64 MiB back): the summaries are written, drop every raw trace
+find $out -name "*.db" -delete
+find $out -name "*counter_collection.csv" -delete
+find $out -name "*_agent_info.csv" -delete
+du -sh $out
 ls -la $out | head -50
