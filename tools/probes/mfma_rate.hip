@@ -48,9 +48,9 @@ __global__ __launch_bounds__(256) void mfma_pinned_kernel(float* out, int seed) 
   for (int i = 0; i < NACC; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  v4i a[2], b[2];
+  v4i a[4], b[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int x = ZERO ? 0 : 0x3f803f80 + ((threadIdx.x * 2654435761u + i * 40503u + seed) & 0x007f007f);
     a[i] = v4i{x, x ^ 0x00110011, x ^ 0x00230023, x ^ 0x00050005};
     b[i] = v4i{x ^ 0x00070007, x, x ^ 0x00310031, x ^ 0x00130013};
@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void mfma_pinned_kernel(float* out, int seed) 
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
       if constexpr (ACC_V)
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(b[i & 1]), "a"(a[(i >> 1) & 1]));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(b[i & 3]), "a"(a[(i >> 2) & 3]));
       else
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(b[i & 1]), "v"(a[(i >> 1) & 1]));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(b[i & 3]), "v"(a[(i >> 2) & 3]));
     }
   }
   float s = 0.f;
@@ -170,12 +170,17 @@ int main() {
   run16<32, 256, false>("16x16x32: 1 wave/SIMD, 32 acc (128 regs)", out, 256);
   run16<32, 512, false>("16x16x32: 2 waves/SIMD, 32 acc each", out, 256);
   run16<64, 256, true>("16x16x32: 1 wave/SIMD, 64 acc, zero operands", out, 256);
-  run_pinned<15, true, false>("pinned: 1 wave/SIMD, 15 acc in VGPRs, operands in AGPRs", out, 256);
-  run_pinned<15, false, false>("pinned: 1 wave/SIMD, 15 acc in AGPRs, operands in VGPRs", out, 256);
-  run_pinned<16, false, false>("pinned: 1 wave/SIMD, 16 acc in AGPRs, operands in VGPRs", out, 256);
-  run_pinned<12, true, false>("pinned: 1 wave/SIMD, 12 acc in VGPRs, operands in AGPRs", out, 256);
-  run_pinned<12, false, false>("pinned: 1 wave/SIMD, 12 acc in AGPRs, operands in VGPRs", out, 256);
-  run_pinned<8, false, false>("pinned: 1 wave/SIMD, 8 acc in AGPRs, operands in VGPRs", out, 256);
-  run_pinned<15, true, false>("pinned: 15 acc in VGPRs again (warm chip)", out, 256);
+  // (operands: 4 A x 4 B registers as in the compiler-allocated kernels above, so the data toggling per MFMA is the same)
+  run_pinned<16, true, false>("pinned: 16 acc in VGPRs, operands in AGPRs", out, 256);
+  run_pinned<16, false, false>("pinned: 16 acc in AGPRs, operands in VGPRs", out, 256);
+  run_pinned<15, true, false>("pinned: 15 acc in VGPRs, operands in AGPRs", out, 256);
+  run_pinned<15, false, false>("pinned: 15 acc in AGPRs, operands in VGPRs", out, 256);
+  run_pinned<14, false, false>("pinned: 14 acc in AGPRs, operands in VGPRs", out, 256);
+  run_pinned<12, true, false>("pinned: 12 acc in VGPRs, operands in AGPRs", out, 256);
+  run_pinned<12, false, false>("pinned: 12 acc in AGPRs, operands in VGPRs", out, 256);
+  run_pinned<8, false, false>("pinned: 8 acc in AGPRs, operands in VGPRs", out, 256);
+  run_pinned<16, true, false>("pinned: 16 acc in VGPRs again (warm chip)", out, 256);
+  run_pinned<16, false, false>("pinned: 16 acc in AGPRs again (warm chip)", out, 256);
+  run_pinned<16, false, true>("pinned: 16 acc in AGPRs, zero operands", out, 256);
   return 0;
 }
