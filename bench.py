@@ -688,11 +688,16 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
     dt = time.perf_counter() - t0
     roof = None
     # rows and attention extents the timed steps executed (host arithmetic on the lengths the batches carry)
-    def extents_of(i):
+    def extents_of(i):  # rows every sequence of the step's batch is stored on (cocodr_amd.modeling.packed_extents)
+        if not packed:
+            return np.full(seq_per_gpu, seq_len)
+        from cocodr_amd.modeling import packed_extents
         lens_ = pool[(warmup + i) % len(pool)][2].numpy()
-        return (np.maximum(lens_, 1) + 31) // 32 * 32 if packed else np.full(seq_per_gpu, seq_len)
+        host, _, _ = packed_extents(lens_, seq_per_gpu, seq_len)
+        return np.diff(host[seq_per_gpu:].astype(np.int64))
     rows_per_step = float(np.mean([extents_of(i).sum() for i in range(steps)]))
-    attn_flops_per_step = float(np.mean([attention_train_flops(cfg, extents_of(i)) for i in range(steps)]))
+    # (the attention kernels walk an extent in 32-row blocks: their executed FLOPs are those of the extents rounded up to 32)
+    attn_flops_per_step = float(np.mean([attention_train_flops(cfg, (extents_of(i) + 31) // 32 * 32) for i in range(steps)]))
     exec_info = {"rows_per_step": int(round(rows_per_step)), "rows_per_step_padded": seq_per_gpu * seq_len}
     if prof:
         n_launch, gemm_ms, gemm_flops = ops.prof_end()

@@ -53,9 +53,11 @@ __device__ __forceinline__ bf16x8 pack_acc(const float* p, int j) {
 // Same tile, fetched with the LDS DMA (buffer_load ... lds, 1 KiB = 8 rows per wave instruction, no VGPR round trip).
 // The DMA writes lane-linear, so the chunk swizzle is applied to the per-lane SOURCE address (the XOR is an involution).
 // Wave `wid` of `nw` issues pieces wid, wid + nw, ...; completion = s_waitcnt vmcnt(0) + barrier by the caller.
-__device__ __forceinline__ void stage_tile_dma(char* dst, const uint16_t* src, int ld, int L, int lane, int wid, int nw) {
+// Le <= L rows exist (a packed sequence whose extent is not a multiple of 32): the descriptor ends behind row Le - 1, so the rows
+// of the last block that belong to the NEXT sequence (or lie behind the buffer) arrive as zeros through the bounds check.
+__device__ __forceinline__ void stage_tile_dma(char* dst, const uint16_t* src, int ld, int L, int lane, int wid, int nw, int Le) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (uint32_t)(((size_t)(L - 1) * ld + 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (uint32_t)(((size_t)(Le - 1) * ld + 64) * 2), 0x00020000);
   for (int p = wid; p < L / 8; p += nw) {
     const int q = p * 64 + lane;
     const int row = q >> 3, ch = (q & 7) ^ swz64(row);
@@ -66,7 +68,8 @@ __device__ __forceinline__ void stage_tile_dma(char* dst, const uint16_t* src, i
 
 // O^T / dQ^T / dK^T / dV^T accumulator (lane: row index l & 31, 4 consecutive d per register group).  Lanes l and
 // l ^ 32 hold the two 4-wide halves of an 8-column group: they trade halves so that every lane issues 16-B stores.
-__device__ __forceinline__ void store_acc_T16(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane) {
+// rows: how many of the block's 32 rows exist in this sequence (>= 32: all)
+__device__ __forceinline__ void store_acc_T16(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane, int rows) {
   const int half = lane >> 5;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -87,12 +90,12 @@ __device__ __forceinline__ void store_acc_T16(uint16_t* dst, int ld, const f32x1
       got.y = __shfl_xor((int)give.y, 32, 64);
       const int d = dt * 32 + 8 * (2 * rp + half);  // columns d .. d+7: half-0 lane owns d..d+3, half-1 lane d+4..d+7
       const uint4 v = half == 0 ? make_uint4(keep.x, keep.y, got.x, got.y) : make_uint4(got.x, got.y, keep.x, keep.y);
-      *reinterpret_cast<uint4*>(dst + (size_t)(lane & 31) * ld + d) = v;
+      if ((lane & 31) < rows) *reinterpret_cast<uint4*>(dst + (size_t)(lane & 31) * ld + d) = v;
     }
 }
 
 // 8-byte store form (the forward: the 16-byte form costs it a wave of occupancy, 152 vs 94 registers, and measures slower)
-__device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane) {
+__device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 (&o)[2], float mul, int lane, int rows) {
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -101,7 +104,7 @@ __device__ __forceinline__ void store_acc_T(uint16_t* dst, int ld, const f32x16 
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] = o[dt][rg * 4 + e] * mul;
       const int d = dt * 32 + 8 * rg + 4 * (lane >> 5);
-      *reinterpret_cast<uint2*>(dst + (size_t)(lane & 31) * ld + d) = pack4(t);
+      if ((lane & 31) < rows) *reinterpret_cast<uint2*>(dst + (size_t)(lane & 31) * ld + d) = pack4(t);
     }
 }
 
@@ -134,21 +137,25 @@ __device__ __forceinline__ void for_keep_klane(uint32_t pairbase, uint32_t Lh, u
     }
 }
 
-// Packed (variable-length) batches: sequence b occupies rows [seq_off[b], seq_off[b + 1]) of the [T, .] activations, an
-// extent that is a multiple of 32 rows (its tail rows are padding with mask 0); lse is [heads, T].  seq_off == NULL: the
-// padded layout, B sequences of Lmax rows.  drop_L: the padded length the dropout indices are defined on, so a packed
+// Packed (variable-length) batches: sequence b occupies rows [seq_off[b], seq_off[b + 1]) of the [T, .] activations - an extent
+// of Le >= 1 rows, ANY number (rows behind a sequence's tokens inside its extent are padding with mask 0); lse is [heads, T].
+// The kernels walk L = ceil32(Le) rows in 32-row blocks: rows >= Le of the last block (the next sequence's, or behind the
+// buffer) are read as zeros / not read, masked as keys, given a probability of exactly 0 as queries, and never stored.
+// seq_off == NULL: the padded layout, B sequences of Le = L = Lmax rows.  drop_L: the padded length the dropout indices are defined on, so a packed
 // and a padded run of the same batch draw the same masks.
+constexpr float kLseNoRow = 1.0e30f;  // log-sum-exp (in log2 units) of a query row that does not exist: its probabilities are exactly 0
 struct AttnPacked {
   const int32_t* seq_off;
   int T, drop_L;
 };
 #define ATTN_EXTENT(Lmax, pk)                                                                     \
   const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;                                    \
-  int L = (Lmax), dropL = (Lmax);                                                                 \
+  int L = (Lmax), Le = (Lmax), dropL = (Lmax);                                                    \
   size_t row0 = (size_t)b * (Lmax), lse0 = ((size_t)b * heads + h) * (Lmax);                      \
   if ((pk).seq_off) {                                                                             \
     const int o_ = (pk).seq_off[b];                                                               \
-    L = (pk).seq_off[b + 1] - o_;                                                                 \
+    Le = (pk).seq_off[b + 1] - o_;                                                                \
+    L = (Le + 31) & ~31;                                                                          \
     row0 = (size_t)o_;                                                                            \
     lse0 = (size_t)h * (pk).T + o_;                                                               \
     dropL = (pk).drop_L;                                                                          \
@@ -169,20 +176,21 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ld = 3 * H;
   const uint16_t* base = qkv + row0 * ld + h * 64;
-  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
-  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4);
+  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4, Le);
+  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4, Le);
   // additive key mask in units of the raw q.k scores; it seeds the S accumulators, so no add per element later.  -2e5 raw
   // = -3.6e4 in the exponent: exp2 underflows to an exact 0 against any real score, and a row whose keys are ALL masked
   // still gets a finite softmax over its raw scores (what adding finfo.min to every key gives the reference); a seed
   // of -1e30 would leave the fma below with a rounding residue of ~1e22 there.
-  for (int i = tid; i < L; i += 256) madd[i] = mask[row0 + i] != 0 ? 0.f : -2.0e5f;
+  for (int i = tid; i < L; i += 256) madd[i] = (i < Le && mask[row0 + i] != 0) ? 0.f : -2.0e5f;
   const int q0 = blockIdx.z * 128 + wid * 32;
   const int half = lane >> 5;
   bf16x8 qf[4];
   if (q0 < L) {
+    const bool qok = q0 + (lane & 31) < Le;  // (query rows behind the extent: zeros, computed and not stored)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      qf[s] = as_bf16x8(*reinterpret_cast<const uint4*>(base + (size_t)(q0 + (lane & 31)) * ld + (2 * s + half) * 8));
+      qf[s] = as_bf16x8(qok ? *reinterpret_cast<const uint4*>(base + (size_t)(q0 + (lane & 31)) * ld + (2 * s + half) * 8) : make_uint4(0u, 0u, 0u, 0u));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -235,8 +243,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
     }
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-  if (lane < 32) lse[lse0 + q0 + lane] = (m + __log2f(ltot)) * kLn2;
-  store_acc_T(ctx + (row0 + q0) * H + h * 64, H, o, (DROP ? dm.scale : 1.0f) / ltot, lane);
+  if (lane < 32 && q0 + lane < Le) lse[lse0 + q0 + lane] = (m + __log2f(ltot)) * kLn2;
+  store_acc_T(ctx + (row0 + q0) * H + h * 64, H, o, (DROP ? dm.scale : 1.0f) / ltot, lane, Le - q0);
 }
 
 #if defined(COCODR_ABL_TIMELINE)  // tools/attn_timeline.py builds: per-workgroup phase stamps (100 MHz wall clock)
@@ -341,9 +349,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   ATTN_STAMP(0);
   // Q, K, V go HBM -> LDS by DMA; dO and O pass through registers (delta = rowsum(dO * O) needs them there anyway).
   // Every global load of the prologue is in flight before the first one is consumed.
-  stage_tile_dma(Qt, base, ld, L, lane, wid, 4);
-  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
-  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4);
+  stage_tile_dma(Qt, base, ld, L, lane, wid, 4, Le);
+  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4, Le);
+  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4, Le);
   constexpr int kMaxIt = 8;  // L <= 256 -> L * 8 / 256 <= 8 chunks per thread
   const int nit = L * 8 / 256;  // whole waves stay converged (L % 32 == 0)
   uint4 dreg[kMaxIt], oreg[kMaxIt];
@@ -351,12 +359,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   for (int i = 0; i < kMaxIt; ++i)
     if (i < nit) {
       const int q = tid + i * 256, row = q >> 3, ch = q & 7;
-      dreg[i] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
-      oreg[i] = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
+      dreg[i] = oreg[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (row < Le) {
+        dreg[i] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
+        oreg[i] = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
+      }
     }
   for (int i = tid; i < L; i += 256) {
-    madd[i] = mask[row0 + i] != 0 ? 0.f : kMaskNeg;
-    lse2[i] = lse[lse0 + i] * kLog2e;
+    madd[i] = (i < Le && mask[row0 + i] != 0) ? 0.f : kMaskNeg;
+    lse2[i] = i < Le ? lse[lse0 + i] * kLog2e : kLseNoRow;  // (a query row behind the extent: P = exp2(.. - 1e30) = 0, so dS = 0)
   }
 #pragma unroll
   for (int i = 0; i < kMaxIt; ++i)
@@ -434,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     ATTN_STAMP(2);
     // (in front of the store: behind it hipcc interleaves the two and spills 72 SGPRs of lane masks instead of 9)
     if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale * out_s, lane);
-    store_acc_T16(dqkv + (row0 + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane);
+    store_acc_T16(dqkv + (row0 + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane, Le - qb * 32);
   }
   ATTN_STAMP(3);
   if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
@@ -506,8 +517,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     }
     ATTN_STAMP(4);
     uint16_t* out0 = dqkv + (row0 + kb * 32) * ld + h * 64;
-    store_acc_T16(out0 + H, ld, dk, kScale * out_s, lane);
-    store_acc_T16(out0 + 2 * H, ld, dv, out_s, lane);
+    store_acc_T16(out0 + H, ld, dk, kScale * out_s, lane, Le - kb * 32);
+    store_acc_T16(out0 + 2 * H, ld, dv, out_s, lane, Le - kb * 32);
   }
   ATTN_STAMP(5);
 }
@@ -547,7 +558,7 @@ __device__ __forceinline__ float acc_colsum16(const f32x16& acc, float mul, int 
   const float out = q + __shfl_xor(q, 16, 64);
   return (((lane >> 4) & 1) == dt) ? out * mul : 0.f;  // the lanes that own a column of this half (qk_col)
 }
-__device__ __forceinline__ void store_acc_T16_half(uint16_t* dst, int ld, const f32x16& o, int dt, float mul, int lane) {
+__device__ __forceinline__ void store_acc_T16_half(uint16_t* dst, int ld, const f32x16& o, int dt, float mul, int lane, int rows) {
   const int half = lane >> 5;
 #pragma unroll
   for (int rp = 0; rp < 2; ++rp) {
@@ -564,7 +575,7 @@ __device__ __forceinline__ void store_acc_T16_half(uint16_t* dst, int ld, const 
     got.y = __shfl_xor((int)give.y, 32, 64);
     const int d = dt * 32 + 8 * (2 * rp + half);
     const uint4 v = half == 0 ? make_uint4(keep.x, keep.y, got.x, got.y) : make_uint4(got.x, got.y, keep.x, keep.y);
-    *reinterpret_cast<uint4*>(dst + (size_t)(lane & 31) * ld + d) = v;
+    if ((lane & 31) < rows) *reinterpret_cast<uint4*>(dst + (size_t)(lane & 31) * ld + d) = v;
   }
 }
 
@@ -595,16 +606,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1_kernel(const uint16_t* __res
   const int nblk = L / 32;
   const int kb = wid;               // this wave's key block
   const bool own = kb < nblk;       // (a short sequence of a packed batch has fewer key blocks than the workgroup has waves)
-  stage_tile_dma(Qt, base, ld, L, lane, wid, 4);
-  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
+  stage_tile_dma(Qt, base, ld, L, lane, wid, 4, Le);
+  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4, Le);
   // V fragments and the mask of this wave's own keys straight from global memory (layout of frag_rows)
   uint4 vraw[4] = {};
   float my_madd = 0.f;
   if (own) {
+    const bool kok = kb * 32 + (lane & 31) < Le;  // (key rows behind the extent: zero V, masked)
     const uint16_t* vrow = base + 2 * H + (size_t)(kb * 32 + (lane & 31)) * ld;
+    if (kok) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) vraw[s] = *reinterpret_cast<const uint4*>(vrow + (2 * s + half) * 8);
-    my_madd = mask[row0 + kb * 32 + (lane & 31)] != 0 ? 0.f : kMaskNeg;
+      for (int s = 0; s < 4; ++s) vraw[s] = *reinterpret_cast<const uint4*>(vrow + (2 * s + half) * 8);
+    }
+    my_madd = (kok && mask[row0 + kb * 32 + (lane & 31)] != 0) ? 0.f : kMaskNeg;
   }
   constexpr int kMaxIt = 4;  // L <= 128 -> L * 8 / 256 <= 4 chunks per thread
   const int nit = L * 8 / 256;
@@ -613,10 +627,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1_kernel(const uint16_t* __res
   for (int i = 0; i < kMaxIt; ++i)
     if (i < nit) {
       const int q = tid + i * 256, row = q >> 3, ch = q & 7;
-      dreg[i] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
-      oreg[i] = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
+      dreg[i] = oreg[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (row < Le) {
+        dreg[i] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
+        oreg[i] = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
+      }
     }
-  for (int i = tid; i < L; i += 256) lse2[i] = lse[lse0 + i] * kLog2e;
+  for (int i = tid; i < L; i += 256) lse2[i] = i < Le ? lse[lse0 + i] * kLog2e : kLseNoRow;
 #pragma unroll
   for (int i = 0; i < kMaxIt; ++i)
     if (i < nit) {
@@ -725,15 +742,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1_kernel(const uint16_t* __res
           dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Kt, k2 * 32 + j * 16, adt, lane), frag_cols_tr(St, k2 * 32 + j * 16, aq, lane),
                                                        dq, 0, 0, 0);
       if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum16(dq, kScale * out_s, lane, adt);
-      store_acc_T16_half(dqkv + (row0 + (2 * c + aq) * 32) * ld + h * 64, ld, dq, adt, kScale * out_s, lane);
+      store_acc_T16_half(dqkv + (row0 + (2 * c + aq) * 32) * ld + h * 64, ld, dq, adt, kScale * out_s, lane, Le - (2 * c + aq) * 32);
     }
     if (2 * (c + 1) < nblk) __syncthreads();  // the next pair overwrites the stage tile
   }
   if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
   if (own) {
     uint16_t* out0 = dqkv + (row0 + kb * 32) * ld + h * 64;
-    store_acc_T16(out0 + H, ld, dk, kScale * out_s, lane);
-    store_acc_T16(out0 + 2 * H, ld, dv, out_s, lane);
+    store_acc_T16(out0 + H, ld, dk, kScale * out_s, lane, Le - kb * 32);
+    store_acc_T16(out0 + 2 * H, ld, dv, out_s, lane, Le - kb * 32);
   }
 }
 
@@ -742,8 +759,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1_kernel(const uint16_t* __res
 // each keep only the pair of tiles they sweep (K,V for dQ; Q,dO for dK/dV, 128 KiB at L = 512) and fetch the fragments
 // of their own 32 rows straight from global memory.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bf16x8 frag_rows_global(const uint16_t* base, int ld, int r0, int s, int lane) {
-  return as_bf16x8(*reinterpret_cast<const uint4*>(base + (size_t)(r0 + (lane & 31)) * ld + (2 * s + (lane >> 5)) * 8));
+__device__ __forceinline__ bf16x8 frag_rows_global(const uint16_t* base, int ld, int r0, int s, int lane, int Le) {  // rows >= Le: zeros
+  const bool ok = r0 + (lane & 31) < Le;
+  return as_bf16x8(ok ? *reinterpret_cast<const uint4*>(base + (size_t)(r0 + (lane & 31)) * ld + (2 * s + (lane >> 5)) * 8) : make_uint4(0u, 0u, 0u, 0u));
 }
 
 template <bool QKSUM, bool DROP>
@@ -763,9 +781,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
   const uint16_t* base = qkv + row0 * ld + h * 64;
   const uint16_t* obase = ctx + row0 * H + h * 64;
   const uint16_t* dobase = dctx + row0 * H + h * 64;
-  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4);
-  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4);
-  for (int i = tid; i < L; i += 256) madd[i] = mask[row0 + i] != 0 ? 0.f : kMaskNeg;
+  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4, Le);
+  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4, Le);
+  for (int i = tid; i < L; i += 256) madd[i] = (i < Le && mask[row0 + i] != 0) ? 0.f : kMaskNeg;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float sl2 = kScale * kLog2e;
@@ -775,9 +793,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     float dpart = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qf[s] = frag_rows_global(base, ld, qb * 32, s, lane);
-      dof[s] = frag_rows_global(dobase, H, qb * 32, s, lane);
-      const bf16x8 of = frag_rows_global(obase, H, qb * 32, s, lane);
+      qf[s] = frag_rows_global(base, ld, qb * 32, s, lane, Le);
+      dof[s] = frag_rows_global(dobase, H, qb * 32, s, lane, Le);
+      const bf16x8 of = frag_rows_global(obase, H, qb * 32, s, lane, Le);
       float df[8], ofv[8];
       unpack8(__builtin_bit_cast(uint4, dof[s]), df);
       unpack8(__builtin_bit_cast(uint4, of), ofv);
@@ -786,7 +804,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     }
     const float my_ndelta = -(dpart + __shfl_xor(dpart, 32, 64)) * inv_s;  // lanes l and l^32 hold the two halves of row l & 31
     const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, qb * 32 + (lane & 31), dropL) + 2 * half : 0u;
-    const float my_lse = lse[lse0 + qb * 32 + (lane & 31)] * kLog2e;
+    const float my_lse = qb * 32 + (lane & 31) < Le ? lse[lse0 + qb * 32 + (lane & 31)] * kLog2e : kLseNoRow;
     f32x16 dq[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -826,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
       }
     }
     if constexpr (QKSUM && !QK_ABL_NOSUM) qacc += acc_colsum32(dq, kScale * out_s, lane);
-    store_acc_T16(dqkv + (row0 + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane);
+    store_acc_T16(dqkv + (row0 + qb * 32) * ld + h * 64, ld, dq, kScale * out_s, lane, Le - qb * 32);
   }
   if constexpr (QKSUM) qk_bias_store(qk_partial, qacc, b, h, H, tid);
 }
@@ -848,13 +866,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
   const uint16_t* base = qkv + row0 * ld + h * 64;
   const uint16_t* obase = ctx + row0 * H + h * 64;
   const uint16_t* dobase = dctx + row0 * H + h * 64;
-  stage_tile_dma(Qt, base, ld, L, lane, wid, 4);
+  stage_tile_dma(Qt, base, ld, L, lane, wid, 4, Le);
   for (int q0 = 0; q0 < L * 8; q0 += 256 * 4) {  // dO through registers (delta = rowsum(dO * O)), four 16-B chunks per thread a round
     uint4 dreg[4], oreg[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = q0 + tid + i * 256, row = q >> 3, ch = q & 7;
-      if (q < L * 8) {  // L * 8 is a multiple of 256: whole waves are in or out
+      dreg[i] = oreg[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (q < L * 8 && row < Le) {  // L * 8 is a multiple of 256: whole waves are in or out of the first test
         dreg[i] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * H + ch * 8);
         oreg[i] = *reinterpret_cast<const uint4*>(obase + (size_t)row * H + ch * 8);
       }
@@ -876,7 +895,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
       if (ch == 0) delta[row] = DROP ? -part * inv_s : -part;  // negated: it seeds the dP accumulators below
     }
   }
-  for (int i = tid; i < L; i += 256) lse2[i] = lse[lse0 + i] * kLog2e;
+  for (int i = tid; i < L; i += 256) lse2[i] = i < Le ? lse[lse0 + i] * kLog2e : kLseNoRow;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float sl2 = kScale * kLog2e;
@@ -885,10 +904,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      kf[s] = frag_rows_global(base + H, ld, kb * 32, s, lane);
-      vf[s] = frag_rows_global(base + 2 * H, ld, kb * 32, s, lane);
+      kf[s] = frag_rows_global(base + H, ld, kb * 32, s, lane, Le);
+      vf[s] = frag_rows_global(base + 2 * H, ld, kb * 32, s, lane, Le);
     }
-    const float my_madd = mask[row0 + kb * 32 + (lane & 31)] != 0 ? 0.f : kMaskNeg;
+    const float my_madd = (kb * 32 + (lane & 31) < Le && mask[row0 + kb * 32 + (lane & 31)] != 0) ? 0.f : kMaskNeg;
     const uint32_t Lh = (uint32_t)dropL >> 1, kshift = (lane & 1) << 4;
     const uint32_t keypair = DROP ? prob_row_pair(b * heads + h, 4 * half, dropL) + (uint32_t)((kb * 32 + (lane & 31)) >> 1) : 0u;
     f32x16 dk[2], dv[2];
@@ -945,8 +964,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __
       }
     }
     uint16_t* out0 = dqkv + (row0 + kb * 32) * ld + h * 64;
-    store_acc_T16(out0 + H, ld, dk, kScale * out_s, lane);
-    store_acc_T16(out0 + 2 * H, ld, dv, out_s, lane);
+    store_acc_T16(out0 + H, ld, dk, kScale * out_s, lane, Le - kb * 32);
+    store_acc_T16(out0 + 2 * H, ld, dv, out_s, lane, Le - kb * 32);
   }
 }
 
@@ -990,7 +1009,7 @@ int attn_fwd_any(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float*
   return COCODR_OK;
 }
 int check_packed(const int32_t* seq_off, int B, int T, int max_len, int drop_L) {
-  CK_ARG(seq_off != nullptr && B > 0 && T >= 32 * B && T % 32 == 0, "attn(packed): need seq_off, T %% 32 == 0 and T >= 32 B (T=%d, B=%d)", T, B);
+  CK_ARG(seq_off != nullptr && B > 0 && T >= B && T % 32 == 0, "attn(packed): need seq_off, T %% 32 == 0 and T >= B (T=%d, B=%d)", T, B);
   CK_ARG(max_len % 32 == 0 && max_len >= 32 && max_len <= 512 && drop_L >= max_len, "attn(packed): max_len=%d must be a multiple of 32 in [32,512] and <= drop_L=%d", max_len, drop_L);
   return COCODR_OK;
 }

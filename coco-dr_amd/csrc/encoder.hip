@@ -153,7 +153,7 @@ namespace {
 int check_packed_batch(const cocodr_config* c, const cocodr_packed_batch* pk) {
   CK_ARG(pk != nullptr && pk->mask && pk->seq_off, "encoder(packed): null batch");
   TRY(check_cfg(c, 1, 32));
-  CK_ARG(pk->B > 0 && pk->T >= 32 * pk->B && pk->T % 32 == 0, "encoder(packed): T=%d must be a multiple of 32 and >= 32 B (B=%d)", pk->T, pk->B);
+  CK_ARG(pk->B > 0 && pk->T >= pk->B && pk->T % 32 == 0, "encoder(packed): T=%d must be a multiple of 32 and >= B (B=%d)", pk->T, pk->B);
   CK_ARG(pk->max_len >= 32 && pk->max_len % 32 == 0 && pk->max_len <= 512 && pk->max_len <= c->max_pos && pk->drop_L >= pk->max_len,
          "encoder(packed): max_len=%d must be a multiple of 32 in [32, min(512,%d)] and <= drop_L=%d", pk->max_len, c->max_pos, pk->drop_L);
   return COCODR_OK;
@@ -168,7 +168,7 @@ extern "C" int cocodr_encoder_layout(const cocodr_config* c, int B, int L, int t
 }
 extern "C" int cocodr_encoder_layout_packed(const cocodr_config* c, int T, int B, int training, cocodr_encoder_layout_t* out) {
   TRY(check_cfg(c, 1, 32));
-  CK_ARG(out != nullptr && B > 0 && T >= 32 * B && T % 32 == 0, "encoder_layout_packed: T=%d must be a multiple of 32 and >= 32 B (B=%d)", T, B);
+  CK_ARG(out != nullptr && B > 0 && T >= B && T % 32 == 0, "encoder_layout_packed: T=%d must be a multiple of 32 and >= B (B=%d)", T, B);
   return layout_m(c, (size_t)T, B, 32, training, out);
 }
 

@@ -315,23 +315,40 @@ class _EncoderFn(torch.autograd.Function):
 
 
 # =============================================================================== packed (variable-length) batches
-def packed_extents(lengths, B: int, L: int):
-    """Host arithmetic of the packed layout: sequence b gets an extent of ceil32(max(len_b, 1)) rows (a fully masked sequence
-    keeps one masked block).  Returns (int32 [2B + 1] = lengths followed by the B + 1 row offsets, T, longest extent)."""
+#: rows a packed sequence's extent is rounded up to.  1 (default): every sequence is stored on exactly max(length, 1) rows - no
+#: padding rows at all but the <= 31 that make the batch's row count a multiple of 32; 32: the layout of rounds 3-4 (every
+#: extent a multiple of 32: ~16 padding rows per sequence, 17 % of an MS MARCO-shaped batch of 64 x 128)
+PACK_ALIGN = 1
+
+
+def packed_extents(lengths, B: int, L: int, align: Optional[int] = None):
+    """Host arithmetic of the packed layout: sequence b gets an extent of max(len_b, 1) rows rounded up to ``align``
+    (``PACK_ALIGN``; a fully masked sequence keeps one masked row); the rows that make the total a multiple of 32 go to the
+    last sequences that have room below ``ceil32(L)``.  Returns (int32 [2B + 1] = lengths followed by the B + 1 row offsets,
+    T, longest extent rounded up to a multiple of 32)."""
     import numpy as np
+    align = PACK_ALIGN if align is None else int(align)
     lens = np.ascontiguousarray(np.asarray(lengths).reshape(-1), dtype=np.int64)
     if lens.shape[0] != B or (lens < 0).any() or (lens > L).any():
         raise ValueError(f"packed batch: lengths must be {B} integers in [0, {L}]")
-    ext = (np.maximum(lens, 1) + 31) // 32 * 32
+    ext = (np.maximum(lens, 1) + align - 1) // align * align
+    pad = int(-ext.sum() % 32)
+    cap = (L + 31) // 32 * 32
+    b = B - 1
+    while pad > 0:  # (cap - ext sums to a number congruent to pad modulo 32 and >= 0: there is always room)
+        give = min(pad, int(cap - ext[b]))
+        ext[b] += give
+        pad -= give
+        b -= 1
     host = np.zeros(2 * B + 1, np.int32)
     host[:B] = lens
     np.cumsum(ext, out=host[B + 1:])
-    return host, int(host[-1]), int(ext.max())
+    return host, int(host[-1]), int((ext.max() + 31) // 32 * 32)
 
 
 class PackedIndex:
     """Device-side description of a batch stored back to back (include/cocodr.h "Packed batches"): sequence b owns rows
-    [seq_off[b], seq_off[b+1]), an extent of ceil32(length) rows.  ``src`` maps packed row -> row of the padded [B*L] layout.
+    [seq_off[b], seq_off[b+1]): its length (``PACK_ALIGN`` = 1), see ``packed_extents``.  ``src`` maps packed row -> row of the padded [B*L] layout.
 
     Built per batch by ONE native launch (``cocodr_pack_index``) from the padded ids and the B lengths.  The row count T must
     reach the host (it sizes every GEMM of the step):

@@ -480,10 +480,12 @@ int cocodr_encoder_bwd_range(const cocodr_config* cfg, const cocodr_embed_params
  * Packed (variable-length) batches - SURVEY 7 (iii).  The reference pads every sequence of a batch to one length and
  * lets the attention mask hide the padding (COCO/data.py:135-144, ANCE/utils/util.py); on MS MARCO-shaped batches 40 % of
  * the token rows are padding.  Here the B sequences may be stored back to back instead: sequence b owns rows
- * [seq_off[b], seq_off[b+1]) of every [T, .] activation, an extent that is a multiple of 32 rows >= its length (mask [T]
- * is 0 on the at most 31 alignment rows at the end of an extent), seq_off is int32 [B+1] in device memory, T % 32 == 0,
- * max_len = the longest extent.  Every row kernel and GEMM simply sees T rows; the kernels below are the ones that need
- * the sequence structure.  lse is [heads, T] on this layout.  drop_L: the padded length the dropout indices of the
+ * [seq_off[b], seq_off[b+1]) of every [T, .] activation, an extent of ANY number of rows >= max(its length, 1) (mask [T] is 0
+ * on the rows of an extent behind the sequence's tokens; cocodr_amd stores every sequence on exactly its length and spreads the
+ * <= 31 rows that make T a multiple of 32 over the last sequences), seq_off is int32 [B+1] in device memory, T % 32 == 0,
+ * max_len = the longest extent rounded up to a multiple of 32.  Every row kernel and GEMM simply sees T rows; the kernels below
+ * are the ones that need the sequence structure (the attention walks an extent in 32-row blocks: rows of the last block that are
+ * behind the extent - the next sequence's - are read as zeros, masked, and never written).  lse is [heads, T] on this layout.  drop_L: the padded length the dropout indices of the
  * attention probabilities are defined on ((b, h, q, k) -> ((b heads + h) drop_L + q) drop_L + k), so a packed and a padded
  * run of one batch draw the same masks; hidden-state dropout indexes rows, which differ between the layouts.
  * Results at the real tokens equal the padded path's (same arithmetic per token); padding rows hold other values.
@@ -511,8 +513,8 @@ int cocodr_embed_ln_bwd_packed(const uint16_t* dout, const int32_t* ids, const i
  *   cocodr_mask_lengths: mask [B, L] with elem_bytes 1 / 4 / 8 per entry, rows row_stride entries apart -> lens[b] = set
  *     entries of row b, prefix_ok[b] = 1 when they are exactly the first lens[b] (only such batches can be packed).
  *   cocodr_pack_index: ids [B, .] (int32 or int64: elem_bytes 4 / 8; rows row_stride entries apart), lens int32 [B] (<= row
- *     length), seq_off int32 [B+1] = running sum of the extents ceil32(max(len, 1)); writes the int32 [T] arrays of
- *     cocodr_packed_batch (token id or 0 on alignment rows, position, mask, cls_slot) and, when src != NULL, the row of the
+ *     length), seq_off int32 [B+1] = running sum of the extents (each >= max(len, 1)); writes the int32 [T] arrays of
+ *     cocodr_packed_batch (token id or 0 on the rows of an extent behind the tokens, position, mask, cls_slot) and, when src != NULL, the row of the
  *     padded [B, L] layout every packed row came from (int64 [T]; L % 32 == 0 is that layout's row length). */
 int cocodr_mask_lengths(const void* mask, int elem_bytes, int B, int L, long long row_stride, int32_t* lens, int32_t* prefix_ok,
                         cocodr_stream_t stream);

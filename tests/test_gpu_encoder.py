@@ -321,7 +321,10 @@ def test_intermediate_hidden_states_are_differentiable():
         (out.last_hidden_state.float() * t(w[4])).sum().backward()
         res.append(m.flat_decay.grad.clone())
     mb = m.layout.mat_begin  # (the embedding tables accumulate sparse rows with atomics: equal up to summation order)
-    assert torch.equal(res[0][mb:], res[1][mb:]) and torch.allclose(res[0][:mb], res[1][:mb], rtol=1e-4, atol=1e-5)
+    # the tapped forward runs padded, the plain one packed with every sequence on its own length: the weight gradients contract over
+    # the token rows, whose grouping into 16-row MFMA steps differs between the layouts - equal up to fp32 summation order
+    assert float((res[0][mb:] - res[1][mb:]).norm() / res[1][mb:].norm()) < 1e-5
+    assert torch.allclose(res[0][:mb], res[1][:mb], rtol=1e-4, atol=1e-5)
 
 
 def test_condenser_step_after_resize_token_embeddings_matches_oracle():

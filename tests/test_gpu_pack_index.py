@@ -16,7 +16,13 @@ DEV = "cuda"
 def layout_numpy(ids, lens, Lp):
     """The arrays of cocodr_packed_batch, element by element."""
     B, L = ids.shape
-    ext = (np.maximum(lens, 1) + 31) // 32 * 32
+    ext = np.maximum(lens, 1).astype(np.int64)  # every sequence on its own length; T rounded up to 32 on the last sequences with room
+    pad, cap, j = int(-ext.sum() % 32), Lp, B - 1
+    while pad > 0:
+        give = min(pad, int(cap - ext[j]))
+        ext[j] += give
+        pad -= give
+        j -= 1
     off = np.concatenate([[0], np.cumsum(ext)])
     T = int(off[-1])
     out = {k: np.zeros(T, np.int64) for k in ("ids", "positions", "mask", "cls_slot", "src")}
@@ -28,7 +34,7 @@ def layout_numpy(ids, lens, Lp):
             out["ids"][r] = ids[b, p] if p < lens[b] else 0
             out["cls_slot"][r] = b if p == 0 else -1
             out["src"][r] = b * Lp + p
-    return off, T, int(ext.max()), out
+    return off, T, int((ext.max() + 31) // 32 * 32), out
 
 
 def batch(lens, L, seed=0, V=30000):
