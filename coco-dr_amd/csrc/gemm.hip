@@ -662,10 +662,11 @@ int select_impl(const cocodr_gemm_args& a) {
       cocodr_gemm_pp_split_plan(a, total, r, sl);
       if (sl >= 4 && r <= 64) pp_fills = true;
     }
-    // one round of 256 x 256 tiles that fills >= 2/3 of the CUs, forward (NT) form: the ping-pong pipeline beats the 256 x 96 /
-    // 256 x 128 tiles by 8-11 % there (packed BERT-base batches: 5 024-6 304 rows x 2304 x 768 = 180-225 tiles, 28-31 us
-    // against 31-34; profiles/r04_gemm_impl_sweep_base.txt); the dgrad (NN) form at the same tile counts does not gain
-    const bool pp_one_round = !nopp && !a.trans_a && !a.trans_b && batch == 1 && tilespp >= 176 && tilespp <= 256;
+    // one round of 256 x 256 tiles that fills >= 2/3 of the CUs: the ping-pong pipeline beats the 256 x 96 / 256 x 128 tiles by
+    // 8-11 % on the forward (NT) form there (packed BERT-base batches: 5 024-6 304 rows x 2304 x 768 = 180-225 tiles, 28-31 us
+    // against 31-34; profiles/r04_gemm_impl_sweep_base.txt); the dgrad (NN) form is level at BERT-base sizes and 3-9 % ahead
+    // at BERT-large ones (15 040 rows x 1024 x 4096 = 236 tiles: 110 us against 120; profiles/r04_gemm_impl_sweep_unaligned.txt)
+    const bool pp_one_round = !nopp && !a.trans_a && batch == 1 && tilespp >= 176 && tilespp <= 256;
     if (!(k_ok && small)) impl = 1;
     else if (pp_fills || pp_one_round) impl = 13;
     else if (fewer_rounds && !a.trans_a && tiles256 >= 128 && !a.colsum && !a.colsum_partial) impl = 12;
