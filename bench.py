@@ -536,7 +536,7 @@ def corpus_encode(cfg, dev, n: int = 8192, seq_len: int = 128, batch: int = 512,
     return {"sequences_per_sec": round(n / dt, 1), "ms": round(dt * 1e3, 2),
             "packed_sequences_per_sec": round(n / dtp, 1), "packed_equals_padded": bool(torch.equal(emb_p, emb)),
             "workload": f"{n} passages x L{seq_len}, batch {batch}, BertDot_NLL_LN body_emb (last-layer [CLS]), bf16 encoder, eval mode; "
-                        "packed = the same batches stored back to back (32-row alignment), same embeddings"}
+                        "packed = the same batches stored back to back (every sequence on its own length), same embeddings"}
 
 
 def multi_gpu_legs(dev, rank: int, world: int, fence, tmax, shared: bool, dp_chunks: int):
@@ -728,7 +728,7 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
                              "it (24 H^2 per padded token and layer, x3: SURVEY 8d) over the same time - a throughput figure, not a "
                              "utilisation",
                     "batches": "fully dense (every sequence fills L)" if dense else
-                               ("MS MARCO-shaped lengths, stored back to back (32-row alignment): no work on padding rows, same loss and "
+                               ("MS MARCO-shaped lengths, stored back to back (every sequence on its own length): no work on padding rows, same loss and "
                                 "gradients as the padded execution (tests/test_gpu_packed.py)" if packed else
                                 "MS MARCO-shaped lengths, padded to L; every kernel runs over all B x L rows")}
             roof.update(exec_info)
@@ -854,7 +854,7 @@ def main():
                       "note": "same batches, same loss and gradients as the headline step (tests/test_gpu_packed.py); "
                               + ("here every kernel runs over all B x L rows, padding included, as the reference does "
                                  "(CocoBertModel.pack_sequences = False)" if packed else
-                                 "here the sequences are stored back to back with 32-row alignment (no work on padding rows)")})
+                                 "here the sequences are stored back to back, every one on its own length (no work on padding rows)")})
         extras["padded_contrastive_step" if packed else "packed_contrastive_step"] = other
         if args.model == "base":
             extras["full_coco_step"] = full_coco_step(cfg, dev, ids, mask, lens)  # second scope: what the reference's step really runs

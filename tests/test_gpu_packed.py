@@ -1,4 +1,4 @@
-"""Packed (variable-length) batches: sequences stored back to back with 32-row alignment instead of padded to one length
+"""Packed (variable-length) batches: sequences stored back to back, every one on its own length, instead of padded to one length
 (include/cocodr.h "Packed batches", SURVEY 7 iii).  The arithmetic per real token is the padded path's, so the packed path is
 checked against the padded one (tight tolerance) and against the numpy oracle (the usual bf16 tolerances)."""
 import numpy as np
