@@ -63,7 +63,8 @@ class EncoderLayout(C.Structure):
 
 
 class PackedBatch(C.Structure):  # mirrors cocodr_packed_batch
-    _fields_ = [(n, c_void_p) for n in ("ids", "positions", "mask", "seq_off", "cls_slot")] + [(n, c_int) for n in ("B", "T", "max_len", "drop_L")]
+    _fields_ = ([(n, c_void_p) for n in ("ids", "positions", "mask", "seq_off", "cls_slot")] + [(n, c_int) for n in ("B", "T", "max_len", "drop_L")]
+                + [("seq_order", c_void_p)])
 
 
 class LambPlan(C.Structure):  # mirrors cocodr_lamb_plan
@@ -95,8 +96,8 @@ SIGNATURES = {
     "cocodr_embed_ln_fwd_drop": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, C.POINTER(DropoutMask), c_void_p]),
     "cocodr_embed_ln_bwd_drop": (c_int, [c_void_p] * 14 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
     "cocodr_ln_bwd_drop": (c_int, [c_void_p] * 11 + [c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
-    "cocodr_attn_fwd_packed": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_int, c_void_p]),
-    "cocodr_attn_bwd_packed": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_int, c_void_p]),
+    "cocodr_attn_fwd_packed": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_int, c_void_p]),
+    "cocodr_attn_bwd_packed": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_int, c_void_p]),
     "cocodr_embed_ln_fwd_packed": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_float, C.POINTER(DropoutMask), c_void_p]),
     "cocodr_embed_bwd_packed_partial_floats": (c_size_t, [c_int, c_int]),
     "cocodr_embed_ln_bwd_packed": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_void_p]),

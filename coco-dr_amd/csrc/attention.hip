@@ -144,12 +144,15 @@ __device__ __forceinline__ void for_keep_klane(uint32_t pairbase, uint32_t Lh, u
 // seq_off == NULL: the padded layout, B sequences of Le = L = Lmax rows.  drop_L: the padded length the dropout indices are defined on, so a packed
 // and a padded run of the same batch draw the same masks.
 constexpr float kLseNoRow = 1.0e30f;  // log-sum-exp (in log2 units) of a query row that does not exist: its probabilities are exactly 0
+// order (optional): the sequence the y-th workgroup row takes - the host passes the sequences longest first, so that the
+// workgroups of the last, partial round over the CUs are the cheap ones (a workgroup costs ~ its number of 32-row blocks squared).
 struct AttnPacked {
   const int32_t* seq_off;
   int T, drop_L;
+  const int32_t* order;
 };
 #define ATTN_EXTENT(Lmax, pk)                                                                     \
-  const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;                                    \
+  const int h = blockIdx.x, b = (pk).order ? (pk).order[blockIdx.y] : (int)blockIdx.y, heads = gridDim.x; \
   int L = (Lmax), Le = (Lmax), dropL = (Lmax);                                                    \
   size_t row0 = (size_t)b * (Lmax), lse0 = ((size_t)b * heads + h) * (Lmax);                      \
   if ((pk).seq_off) {                                                                             \
@@ -1017,13 +1020,13 @@ int check_packed(const int32_t* seq_off, int B, int T, int max_len, int drop_L) 
 
 extern "C" int cocodr_attn_fwd_drop(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
                                     const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
-  return attn_fwd_any(qkv, mask, ctx, lse, B, L, heads, drop, AttnPacked{nullptr, 0, 0}, stream);
+  return attn_fwd_any(qkv, mask, ctx, lse, B, L, heads, drop, AttnPacked{nullptr, 0, 0, nullptr}, stream);
 }
-extern "C" int cocodr_attn_fwd_packed(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, const int32_t* seq_off, int B,
-                                      int T, int max_len, int heads, const cocodr_dropout_mask* drop, int drop_L,
-                                      cocodr_stream_t stream) {
+extern "C" int cocodr_attn_fwd_packed(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, const int32_t* seq_off,
+                                      const int32_t* seq_order, int B, int T, int max_len, int heads, const cocodr_dropout_mask* drop,
+                                      int drop_L, cocodr_stream_t stream) {
   if (int rc = check_packed(seq_off, B, T, max_len, drop_L)) return rc;
-  return attn_fwd_any(qkv, mask, ctx, lse, B, max_len, heads, drop, AttnPacked{seq_off, T, drop_L}, stream);
+  return attn_fwd_any(qkv, mask, ctx, lse, B, max_len, heads, drop, AttnPacked{seq_off, T, drop_L, seq_order}, stream);
 }
 extern "C" int cocodr_attn_fwd(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, int B, int L, int heads,
                                cocodr_stream_t stream) {
@@ -1096,13 +1099,14 @@ int attn_bwd_any(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, 
 extern "C" int cocodr_attn_bwd_drop(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
                                     const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,
                                     const cocodr_dropout_mask* drop, cocodr_stream_t stream) {
-  return attn_bwd_any(qkv, mask, ctx, dctx, lse, dqkv, qk_bias_partial, B, L, heads, drop, AttnPacked{nullptr, 0, 0}, stream);
+  return attn_bwd_any(qkv, mask, ctx, dctx, lse, dqkv, qk_bias_partial, B, L, heads, drop, AttnPacked{nullptr, 0, 0, nullptr}, stream);
 }
 extern "C" int cocodr_attn_bwd_packed(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
-                                      const float* lse, uint16_t* dqkv, float* qk_bias_partial, const int32_t* seq_off, int B, int T,
-                                      int max_len, int heads, const cocodr_dropout_mask* drop, int drop_L, cocodr_stream_t stream) {
+                                      const float* lse, uint16_t* dqkv, float* qk_bias_partial, const int32_t* seq_off,
+                                      const int32_t* seq_order, int B, int T, int max_len, int heads, const cocodr_dropout_mask* drop,
+                                      int drop_L, cocodr_stream_t stream) {
   if (int rc = check_packed(seq_off, B, T, max_len, drop_L)) return rc;
-  return attn_bwd_any(qkv, mask, ctx, dctx, lse, dqkv, qk_bias_partial, B, max_len, heads, drop, AttnPacked{seq_off, T, drop_L}, stream);
+  return attn_bwd_any(qkv, mask, ctx, dctx, lse, dqkv, qk_bias_partial, B, max_len, heads, drop, AttnPacked{seq_off, T, drop_L, seq_order}, stream);
 }
 extern "C" int cocodr_attn_bwd(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx,
                                const float* lse, uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads,

@@ -324,7 +324,7 @@ int encoder_fwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
     cocodr_gemm_args g = gemm_base(x_in, w.wqkv, qkv, M, 3 * H, H, H, H, 3 * H, 0, 0);
     g.bias = w.bqkv;
     TRY(cocodr_gemm(&g, stream));
-    if (pk) TRY(cocodr_attn_fwd_packed(qkv, mask, ctx, lse, pk->seq_off, B, M, pk->max_len, c->heads, &ld.probs, pk->drop_L, stream));
+    if (pk) TRY(cocodr_attn_fwd_packed(qkv, mask, ctx, lse, pk->seq_off, pk->seq_order, B, M, pk->max_len, c->heads, &ld.probs, pk->drop_L, stream));
     else TRY(cocodr_attn_fwd_drop(qkv, mask, ctx, lse, B, L, c->heads, &ld.probs, stream));
     if (c->cls_tail && l == NL - 1) {
       // [CLS] tail (cocodr_config.cls_tail): everything behind the attention on the B first rows of the sequences only.  The
@@ -550,7 +550,7 @@ int encoder_bwd_impl(const cocodr_config* c, const cocodr_embed_params* emb, con
       TRY(cocodr_gemm(&tw, stream));
     }
     // the query / key bias gradients are column sums of dQ | dK: the attention backward leaves four partial rows per sequence
-    if (pk) TRY(cocodr_attn_bwd_packed(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, pk->seq_off, B, M, pk->max_len, c->heads,
+    if (pk) TRY(cocodr_attn_bwd_packed(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, pk->seq_off, pk->seq_order, B, M, pk->max_len, c->heads,
                                        &ld.probs, pk->drop_L, stream));
     else TRY(cocodr_attn_bwd_drop(qkv, mask, ctx, dctx, lse, dqkv, bqk_slots + li * bqk_slot, B, L, c->heads, &ld.probs, stream));
     if (!defer) TRY(cocodr_reduce_partials(bqk_slots + li * bqk_slot, gr.bqkv, nullptr, nullptr, 4 * B, 1, 2 * H, 1, 0, hst));

@@ -371,8 +371,12 @@ class PackedIndex:
         dev = ids.device
         self.B, self.L = B, Lp
         self.lengths = host[:B]
-        staged = torch.from_numpy(host).pin_memory().to(dev, non_blocking=True)
-        self.seq_off = staged[B:]
+        # attention launches hand the sequences to workgroups longest first (the partial last round over the CUs gets the cheap ones)
+        import numpy as np
+        order = np.argsort(-np.diff(host[B:].astype(np.int64)), kind="stable").astype(np.int32)
+        staged = torch.from_numpy(np.concatenate([host, order])).pin_memory().to(dev, non_blocking=True)
+        self.seq_off = staged[B:2 * B + 1]
+        self.seq_order = staged[2 * B + 1:]
         buf = torch.empty(4 * self.T, dtype=torch.int32, device=dev)
         self.ids, self.positions, self.mask, self.cls_slot = buf[:self.T], buf[self.T:2 * self.T], buf[2 * self.T:3 * self.T], buf[3 * self.T:]
         self.src = torch.empty(self.T, dtype=torch.int64, device=dev)
@@ -380,7 +384,7 @@ class PackedIndex:
                                       ptr(self.positions), ptr(self.mask), ptr(self.cls_slot), ptr(self.src), stream_ptr()), "pack_index")
         self._keep = (staged, buf)
         self.c_struct = N.PackedBatch(self.ids.data_ptr(), self.positions.data_ptr(), self.mask.data_ptr(), self.seq_off.data_ptr(),
-                                      self.cls_slot.data_ptr(), B, self.T, self.max_len, Lp)
+                                      self.cls_slot.data_ptr(), B, self.T, self.max_len, Lp, self.seq_order.data_ptr())
 
     @property
     def cls_rows(self) -> torch.Tensor:

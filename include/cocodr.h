@@ -490,11 +490,15 @@ int cocodr_encoder_bwd_range(const cocodr_config* cfg, const cocodr_embed_params
  * run of one batch draw the same masks; hidden-state dropout indexes rows, which differ between the layouts.
  * Results at the real tokens equal the padded path's (same arithmetic per token); padding rows hold other values.
  * ------------------------------------------------------------------------------------------ */
-int cocodr_attn_fwd_packed(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, const int32_t* seq_off, int B,
-                           int T, int max_len, int heads, const cocodr_dropout_mask* drop, int drop_L, cocodr_stream_t stream);
+/* seq_order (optional, int32 [B] on the device, a permutation of 0..B-1): the order in which the attention launches hand the
+ * sequences to workgroups - longest first, so that the last, partial round over the CUs holds the cheap ones.  NULL: 0..B-1.
+ * Results do not depend on it. */
+int cocodr_attn_fwd_packed(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx, float* lse, const int32_t* seq_off,
+                           const int32_t* seq_order, int B, int T, int max_len, int heads, const cocodr_dropout_mask* drop, int drop_L,
+                           cocodr_stream_t stream);
 int cocodr_attn_bwd_packed(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx, const float* lse,
-                           uint16_t* dqkv, float* qk_bias_partial, const int32_t* seq_off, int B, int T, int max_len, int heads,
-                           const cocodr_dropout_mask* drop, int drop_L, cocodr_stream_t stream);
+                           uint16_t* dqkv, float* qk_bias_partial, const int32_t* seq_off, const int32_t* seq_order, int B, int T,
+                           int max_len, int heads, const cocodr_dropout_mask* drop, int drop_L, cocodr_stream_t stream);
 /* positions: int32 [T], the position id of every row (0.. within its sequence) */
 int cocodr_embed_ln_fwd_packed(const int32_t* ids, const int32_t* positions, const float* word, const float* pos,
                                const float* type0, const float* gamma, const float* beta, uint16_t* out, float* mean,
@@ -536,6 +540,7 @@ typedef struct {
   const int32_t* seq_off;
   const int32_t* cls_slot;
   int B, T, max_len, drop_L;
+  const int32_t* seq_order; /* optional (NULL: 0..B-1): see cocodr_attn_fwd_packed */
 } cocodr_packed_batch;
 int cocodr_encoder_layout_packed(const cocodr_config* cfg, int T, int B, int training, cocodr_encoder_layout_t* out);
 int cocodr_encoder_fwd_packed(const cocodr_config* cfg, const cocodr_embed_params* emb, const cocodr_layer_params* layers_host,

@@ -73,7 +73,7 @@ def test_packed_attention_matches_per_sequence_padded_attention(L, heads):
     dctx = dctx_pad[pk.src].contiguous()
     ctx = torch.empty((pk.T, H), dtype=torch.bfloat16, device=DEV)
     lse = torch.empty((heads, pk.T), dtype=torch.float32, device=DEV)
-    check(lib().cocodr_attn_fwd_packed(ptr(qkv), ptr(pk.mask), ptr(ctx), ptr(lse), ptr(pk.seq_off), B, pk.T, pk.max_len, heads, None, L,
+    check(lib().cocodr_attn_fwd_packed(ptr(qkv), ptr(pk.mask), ptr(ctx), ptr(lse), ptr(pk.seq_off), ptr(pk.seq_order), B, pk.T, pk.max_len, heads, None, L,
                                        stream_ptr()), "attn_fwd_packed")
     rctx, rlse = ops.attn_fwd(qkv_pad, t(mask).int(), B, L, heads)
     real = pk.mask.bool()
@@ -82,7 +82,7 @@ def test_packed_attention_matches_per_sequence_padded_attention(L, heads):
     assert torch.allclose(lse[:, real], rl[:, real], atol=1e-6, rtol=1e-6)
     dqkv = torch.empty_like(qkv)
     part = torch.empty((4 * B, 2 * H), dtype=torch.float32, device=DEV)
-    check(lib().cocodr_attn_bwd_packed(ptr(qkv), ptr(pk.mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(part), ptr(pk.seq_off), B, pk.T,
+    check(lib().cocodr_attn_bwd_packed(ptr(qkv), ptr(pk.mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(part), ptr(pk.seq_off), None if L == 128 else ptr(pk.seq_order), B, pk.T,
                                        pk.max_len, heads, None, L, stream_ptr()), "attn_bwd_packed")
     # the padded reference needs zero upstream gradient on its padding rows (the packed layout does not have them)
     dpad = torch.zeros_like(dctx_pad)
