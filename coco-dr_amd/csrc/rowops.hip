@@ -784,7 +784,7 @@ extern "C" int cocodr_zero_f32(float* dst, size_t n, cocodr_stream_t stream) {
   CK_ARG(((uintptr_t)dst & 15) == 0, "zero_f32: pointer must be 16-byte aligned");
   if (n == 0) return COCODR_OK;
   const size_t n4 = n / 4;
-  const int grid = (int)std::min((size_t)2048, n4 / 256 + 1);
+  const int grid = (int)std::min((size_t)0x7fffffff, n4 / 256 + 1);
   hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(dst), n4, dst + 4 * n4, (int)(n - 4 * n4));
   CK_LAUNCH("zero_f32");
   return COCODR_OK;
@@ -985,19 +985,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // ---- gradient norm / clip coefficient (torch.nn.utils.clip_grad_norm_, ANCE/drivers/run_ann.py:347-352), no host sync
 constexpr int GN_BLOCKS = 1024;
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
-  __shared__ float red[4];
+template <int THREADS, bool NT>
+__global__ __launch_bounds__(THREADS) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+  __shared__ float red[THREADS / 64];
   float acc = 0.f;
   const size_t n4 = n / 4;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+  const size_t chunk = (n4 + gridDim.x - 1) / gridDim.x;  // a contiguous run per block (a grid stride put its iterations MBs apart)
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n4 ? lo + chunk : n4;
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  for (size_t i = lo + threadIdx.x; i < hi; i += THREADS) {
+    const f4v v = NT ? __builtin_nontemporal_load(reinterpret_cast<const f4v*>(x) + i) : reinterpret_cast<const f4v*>(x)[i];
     acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = x[n4 * 4 + threadIdx.x]; acc += t * t; }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) s += red[w];
+    partial[blockIdx.x] = s;
+  }
 }
 __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int np, float max_norm, float* __restrict__ out) {
   __shared__ float red[4];
@@ -1030,10 +1039,11 @@ __global__ __launch_bounds__(256) void lamb_moments_kernel(const float* __restri
   const int len4 = chunk_len[blockIdx.x] / 4;
   float sw = 0.f, su = 0.f;
   for (int i = threadIdx.x; i < len4; i += 256) {
-    const float4 pv = reinterpret_cast<const float4*>(p)[base + i];
-    const float4 gv = reinterpret_cast<const float4*>(g)[base + i];
-    float4 mv = reinterpret_cast<float4*>(m)[base + i];
-    float4 vv = reinterpret_cast<float4*>(v)[base + i];
+    typedef float f4v __attribute__((ext_vector_type(4)));  // (42 B / parameter over the two passes that nothing re-reads soon)
+    const f4v pv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p) + base + i);
+    const f4v gv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(g) + base + i);
+    const f4v mv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m) + base + i);
+    const f4v vv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v) + base + i);
     const float pa[4] = {pv.x, pv.y, pv.z, pv.w};
     const float ga[4] = {gv.x * grad_scale, gv.y * grad_scale, gv.z * grad_scale, gv.w * grad_scale};
     float ma[4] = {mv.x, mv.y, mv.z, mv.w};
@@ -1046,8 +1056,8 @@ __global__ __launch_bounds__(256) void lamb_moments_kernel(const float* __restri
       sw += pa[e] * pa[e];
       su += u * u;
     }
-    reinterpret_cast<float4*>(m)[base + i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
-    reinterpret_cast<float4*>(v)[base + i] = make_float4(va[0], va[1], va[2], va[3]);
+    { f4v t = {ma[0], ma[1], ma[2], ma[3]}; __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(m) + base + i); }
+    { f4v t = {va[0], va[1], va[2], va[3]}; __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(v) + base + i); }
   }
   sw = wave_sum(sw);
   su = wave_sum(su);
@@ -1081,15 +1091,16 @@ __global__ __launch_bounds__(256) void lamb_apply_kernel(float* __restrict__ p, 
   const int len4 = chunk_len[blockIdx.x] / 4;
   const float step = lr * trust[chunk_seg[blockIdx.x]];
   for (int i = threadIdx.x; i < len4; i += 256) {
-    float4 pv = reinterpret_cast<float4*>(p)[base + i];
-    const float4 mv = reinterpret_cast<const float4*>(m)[base + i];
-    const float4 vv = reinterpret_cast<const float4*>(v)[base + i];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v pv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p) + base + i);
+    const f4v mv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m) + base + i);
+    const f4v vv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v) + base + i);
     float pa[4] = {pv.x, pv.y, pv.z, pv.w};
     const float ma[4] = {mv.x, mv.y, mv.z, mv.w};
     const float va[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) pa[e] -= step * lamb_u(pa[e], ma[e], va[e], eps, wd);
-    reinterpret_cast<float4*>(p)[base + i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    { f4v t = {pa[0], pa[1], pa[2], pa[3]}; __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p) + base + i); }
     const size_t el = (base + i) * 4;
     if (shadow && el >= shadow_begin) *reinterpret_cast<uint2*>(shadow + (el - shadow_begin)) = pack4(pa);
   }
@@ -1102,7 +1113,8 @@ extern "C" int cocodr_grad_norm_clip(const float* const* grads, const size_t* nu
   hipStream_t st = (hipStream_t)stream;
   for (int t = 0; t < count; ++t) {
     CK_ARG(grads[t] && (((uintptr_t)grads[t]) & 15) == 0, "grad_norm_clip: tensor %d must be a 16-byte aligned device pointer", t);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(GN_BLOCKS), dim3(256), 0, st, grads[t], numels[t], partial + (size_t)t * GN_BLOCKS);
+    // 1024 threads per block and non-temporal loads: 73 us against 82 for 256-thread blocks on 110 M gradients (tools/optim_time.py)
+    hipLaunchKernelGGL((sumsq_kernel<1024, true>), dim3(GN_BLOCKS), dim3(1024), 0, st, grads[t], numels[t], partial + (size_t)t * GN_BLOCKS);
     CK_LAUNCH("grad_norm_clip(sumsq)");
   }
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, partial, count * GN_BLOCKS, max_norm, out);
@@ -1147,7 +1159,10 @@ extern "C" int cocodr_adamw_step(float* p, const float* g, float* m, float* v, u
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2 = sqrtf(1.0f - powf(beta2, (float)step));
   const size_t n4 = n / 4;
-  const int grid = (int)std::min((size_t)4096, (n4 + 255) / 256);
+  // one block per 256 float4 (no grid stride): 4096 grid-striding blocks streamed 5.36 TB/s, this 6.5 (110 M parameters: 615 -> 505 us;
+  // tools/adamw_time.py) - a block's successive iterations were 4 MB apart
+  static const size_t grid_cap = getenv("COCODR_ADAMW_GRID") ? (size_t)atoll(getenv("COCODR_ADAMW_GRID")) : (size_t)0x7fffffff;  // (A/B knob)
+  const int grid = (int)std::min(grid_cap, (n4 + 255) / 256);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, shadow_begin, n4, lr, beta1,
                      beta2, eps, weight_decay, bc1, bc2, grad_scale, grad_scale_dev);
   CK_LAUNCH("adamw_step");
