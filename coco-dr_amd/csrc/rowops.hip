@@ -765,7 +765,7 @@ extern "C" int cocodr_cast_f32_bf16(const float* src, uint16_t* dst, size_t n, c
   CK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "cast: pointers must be 16-byte aligned");
   if (n == 0) return COCODR_OK;
   const size_t n8 = n / 8;
-  const int grid = (int)std::min((size_t)2048, (n8 + 255) / 256 + 1);
+  const int grid = (int)std::min((size_t)0x7fffffff, (n8 + 255) / 256 + 1);  // (full grid: see cocodr_adamw_step)
   hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, n8, n);
   CK_LAUNCH("cast_f32_bf16");
   return COCODR_OK;
@@ -859,7 +859,7 @@ extern "C" int cocodr_mul_bf16(const uint16_t* a, const uint16_t* b, uint16_t* o
   CK_ARG(n % 4 == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 7) == 0), "mul_bf16: n %% 4 == 0 and 8-byte aligned pointers");
   if (n == 0) return COCODR_OK;
   const size_t n4 = n / 4;
-  hipLaunchKernelGGL(mul_bf16_kernel, dim3((int)std::min((size_t)2048, n4 / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(mul_bf16_kernel, dim3((int)std::min((size_t)0x7fffffff, n4 / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const uint2*>(a), reinterpret_cast<const uint2*>(b), reinterpret_cast<uint2*>(out), n4);
   CK_LAUNCH("mul_bf16");
   return COCODR_OK;
