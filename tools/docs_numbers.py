@@ -1,0 +1,67 @@
+"""Regenerate DESIGN.md section 11.1 and the README's last-run sentence from profiles/<tag>_bench_line.json.
+    python tools/docs_numbers.py <tag> <commit> <old tag in README>"""
+import json
+import os
+import sys
+
+tag, commit, old_tag = sys.argv[1], sys.argv[2], sys.argv[3]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = json.loads(open(os.path.join(root, "profiles", f"{tag}_bench_line.json")).read())
+tests = [l for l in open(os.path.join(root, "profiles", f"{tag}_pytest_gpu.txt")) if " passed" in l][-1].strip()
+ns = d["north_star_large_step"]
+p = os.path.join(root, "DESIGN.md")
+s = open(p).read()
+i, j = s.index("### 11.1 Numbers of the round"), s.index("### 11.2 What bounds the steps now")
+pc = d["padded_contrastive_step"]
+rows = [("**headline: cocodr-base 64 x 128, packed, layout built in the step**", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["algorithmic_frac"],
+         d["executed_whole_step_frac"], d["algorithmic_whole_step_frac"], d["rows_per_step"]),
+        ("the same step padded (`pack_sequences = False`)", pc["sequences_per_sec"], pc["ms_per_step"], pc["roofline"]["frac"], pc["roofline"]["algorithmic_frac"],
+         pc["executed_whole_step_frac"], pc["algorithmic_whole_step_frac"], pc["rows_per_step"])]
+for n in (64, 200, 256):
+    for suf, lab in (("", "packed"), ("_padded", "padded")):
+        v = ns[f"{n}_sequences{suf}"]
+        rows.append((f"cocodr-large {n} x 128, {lab}", v["sequences_per_sec"], v["ms_per_step"], v["roofline"]["frac"], v["roofline"]["algorithmic_frac"],
+                     v["executed_whole_step_frac"], v["algorithmic_whole_step_frac"], v["rows_per_step"]))
+tab = "| leg | sequences/s | ms / step | GEMM class frac (algorithmic) | whole step executed (algorithmic) | rows / step |\n|---|---:|---:|---:|---:|---:|\n"
+for r in rows:
+    val = f"**{r[1]:.0f}**" if r[0].startswith("**") else f"{r[1]:.0f}"
+    tab += f"| {r[0]} | {val} | {r[2]} | {r[3]} ({r[4]}) | {r[5]} ({r[6]}) | {r[7]} |\n"
+a, c, es, fc, tr = d["ance_triplet_step"], d["config5_end_to_end"], d["eval_search"], d["full_coco_step"], d["roofline"]
+big = ns["256_sequences_padded"]["roofline"]
+text = f"""### 11.1 Numbers of the round
+
+Last GPU run of the round (`profiles/{tag}_bench_line.json`, commit {commit}, one box; `profiles/{tag}_pytest_gpu.txt`: {tests};
+kernel stats of all eight contrastive legs + the coCondenser and ANCE legs in `profiles/r04_kernel_stats_*.md`, HBM-traffic PMC passes in
+`profiles/gemm_pmc_*.json` at the same commit; `tools/gpu_round.sh` + `tools/collect_round.py` + `tools/docs_numbers.py`).  `frac` = EXECUTED FLOPs of the
+GEMM class / its launch time; boxes differ by ±3 %.  Packed legs: every sequence on its own length, attention workgroups longest sequence first.
+
+{tab}
+The run before the alignment rows were dropped (`profiles/r04g_bench_line.json`, commit 7a2a9bf, another box): headline 10 764 sequences/s at 5 654 rows
+per step, BERT-large packed 3 850 / 4 868 / 5 076, coCondenser 7 699, ANCE 1 691 rows/s, corpus encode 46 630 passages/s, 1 M passages in 60.4 s.
+
+Other legs: full coCondenser step {fc['sequences_per_sec']:.0f} sequences/s ({fc['ms_per_step']} ms packed; {fc['padded_ms_per_step']} ms padded); ANCE triplet step
+{a['rows_per_sec']:.0f} rows/s ({a['ms_per_step']} ms, GEMM class {a['roofline']['frac']} executed; two padded passes {a['padded_two_passes']['rows_per_sec']:.0f} rows/s); corpus encode
+{d['corpus_encode']['sequences_per_sec']:.0f} passages/s (BERT-base, batch 512); search {es['dot_products_per_sec'] / 1e9:.0f} G dot-products/s on the config-5 shard (CPU baseline: {es['cpu_baseline']['value'] / 1e9:.2f} G/s on
+{es['cpu_baseline']['cores']} host cores, torch fp32 GEMM + topk); configs[4] end to end on one GPU: 1 M passages encoded by cocodr-large in {c['encode_s']} s
+({c['encode_passages_per_sec']:.0f} passages/s), 10 k x 1 M search over 8 shards + native merge {c['search_ms']} ms ({c['search_dot_products_per_sec'] / 1e9:.0f} G dot-products/s).
+CPU baseline of the headline step (HF BertModel fp32 on {d['cpu_baseline']['cores']} host threads): {d['cpu_baseline']['value']} sequences/s.
+HBM-side traffic of the GEMM class (PMC): {tr['traffic'] / 1e6:.0f} MB per launch x {tr['launches_per_step']} launches = {tr['traffic_per_step_bytes'] / 1e9:.1f} GB per step = {tr['traffic_gbps'] / 1e3:.2f} TB/s while the class runs
+(headline); {big['traffic_per_step_bytes'] / 1e9:.0f} GB per step = {big['traffic_gbps'] / 1e3:.2f} TB/s at 256 padded BERT-large sequences.
+
+"""
+open(p, "w").write(s[:i] + text + s[j:])
+
+p = os.path.join(root, "README.md")
+s = open(p).read()
+old = s[s.index(f"Last run\n(`profiles/{old_tag}_bench_line.json`"):s.index("The north-star target\n(>= 0.50")]
+v = lambda k: ns[k]  # noqa: E731
+ntests = tests.split(" passed")[0].split()[-1]
+new = (f"Last run\n(`profiles/{tag}_bench_line.json`, `profiles/{tag}_pytest_gpu.txt`: {ntests} GPU tests): **{d['value']:.0f} sequences/s ({d['ms_per_step']:.2f} ms; GEMM class {d['roofline']['frac']:.3f}\n"
+       f"executed / {d['roofline']['algorithmic_frac']:.3f} algorithmic)** on the headline step against {pc['sequences_per_sec']:.0f} padded (GEMM class {pc['roofline']['frac']:.3f}); BERT-large {v('64_sequences')['sequences_per_sec']:.0f} / {v('200_sequences')['sequences_per_sec']:.0f} / {v('256_sequences')['sequences_per_sec']:.0f}\n"
+       f"sequences/s at 64 / 200 / 256 sequences packed (GEMM class {v('64_sequences')['roofline']['frac']:.2f} / {v('200_sequences')['roofline']['frac']:.2f} / {v('256_sequences')['roofline']['frac']:.2f} executed) and {v('64_sequences_padded')['sequences_per_sec']:.0f} / {v('200_sequences_padded')['sequences_per_sec']:.0f} / {v('256_sequences_padded')['sequences_per_sec']:.0f} padded ({v('64_sequences_padded')['roofline']['frac']:.2f} / {v('200_sequences_padded')['roofline']['frac']:.2f} /\n"
+       f"{v('256_sequences_padded')['roofline']['frac']:.2f}; whole step {v('64_sequences_padded')['executed_whole_step_frac']:.2f} / {v('200_sequences_padded')['executed_whole_step_frac']:.2f} / {v('256_sequences_padded')['executed_whole_step_frac']:.3f}); full coCondenser step {fc['sequences_per_sec']:.0f} sequences/s ({fc['ms_per_step']:.2f} ms), ANCE {a['rows_per_sec']:.0f} rows/s, corpus encode {d['corpus_encode']['sequences_per_sec']:.0f}\n"
+       f"passages/s, search {es['dot_products_per_sec'] / 1e9:.0f} G dot-products/s, 1 M-passage encode + 8-shard search end to end in {c['wall_s']:.0f} s on one GPU.  Also built and measured\n"
+       "late in the round: the fused decoder GEMM + cross entropy (`cocodr_decoder_ce`, parity-green, slower than the two-kernel form at this\n"
+       "size: off by default), a row-split dispatch and side-stream weight gradients (`profiles/r04_gemm_dispatch_probes.md`, not adopted).  ")
+open(p, "w").write(s.replace(old, new))
+print("docs updated from", tag)
