@@ -336,6 +336,7 @@ def packed_extents(lengths, B: int, L: int, align: Optional[int] = None):
     cap = (L + 31) // 32 * 32
     b = B - 1
     while pad > 0:  # (cap - ext sums to a number congruent to pad modulo 32 and >= 0: there is always room)
+        assert b >= 0, "packed_extents: no room for the rows that make T a multiple of 32"
         give = min(pad, int(cap - ext[b]))
         ext[b] += give
         pad -= give
