@@ -358,3 +358,43 @@ def test_default_triplet_step_equals_the_padded_two_pass_step_over_odd_batch_sha
     assert abs(res["default"][0] - res["padded"][0]) < 1e-4 * max(1.0, abs(res["padded"][0]))
     assert torch.allclose(res["default"][1], res["padded"][1], rtol=1e-4, atol=1e-4)
     assert rel_l2(res["default"][2], res["padded"][2]) < 6e-3 and rel_l2(res["default"][3], res["padded"][3]) < 6e-3
+
+
+@pytest.mark.parametrize("L,heads", [(128, 2), (256, 2), (384, 1)])
+def test_packed_attention_of_a_sequence_does_not_depend_on_its_neighbours(L, heads):
+    """Sequences are stored on exactly their lengths, so the last 32-row block of one sequence overlaps the first rows of the next:
+    the kernels must neither use those rows nor write them.  Changing every OTHER sequence's q / k / v / dctx rows (to huge values
+    and NaN-free garbage) leaves a sequence's context, log-sum-exp and gradients bit-identical - forward, one-pass backward
+    (L <= 128), two-phase backward (L <= 256) and the two-kernel backward (L > 256)."""
+    B, H = 5, heads * 64
+    rng = np.random.Generator(np.random.PCG64(L))
+    lens = np.array([L, 1, 33, L - 5, 17])
+    ids, mask, lens = ragged_batch(B, L, 100, L, lens=lens)
+    pk = PackedIndex.build(t(mask).int(), t(mask).int())
+    off = pk.seq_off.cpu().numpy()
+    g = torch.Generator().manual_seed(L)
+    qkv = torch.randn(pk.T, 3 * H, generator=g).to(torch.bfloat16).to(DEV)
+    dctx = torch.randn(pk.T, H, generator=g).to(torch.bfloat16).to(DEV)
+
+    def run(qkv_, dctx_):
+        ctx = torch.full((pk.T, H), 7.0, dtype=torch.bfloat16, device=DEV)
+        lse = torch.full((heads, pk.T), 7.0, dtype=torch.float32, device=DEV)
+        check(lib().cocodr_attn_fwd_packed(ptr(qkv_), ptr(pk.mask), ptr(ctx), ptr(lse), ptr(pk.seq_off), ptr(pk.seq_order), B, pk.T, pk.max_len, heads,
+                                           None, L, stream_ptr()), "attn_fwd_packed")
+        dqkv = torch.full_like(qkv_, 7.0)
+        part = torch.empty((4 * B, 2 * H), dtype=torch.float32, device=DEV)
+        check(lib().cocodr_attn_bwd_packed(ptr(qkv_), ptr(pk.mask), ptr(ctx), ptr(dctx_), ptr(lse), ptr(dqkv), ptr(part), ptr(pk.seq_off),
+                                           ptr(pk.seq_order), B, pk.T, pk.max_len, heads, None, L, stream_ptr()), "attn_bwd_packed")
+        return ctx, lse, dqkv
+
+    ctx0, lse0, dq0 = run(qkv, dctx)
+    assert not (ctx0 == 7.0).all(dim=1).any() and not (dq0 == 7.0).all(dim=1).any()   # every stored row was written
+    for b in range(B):
+        q2, d2 = qkv.clone(), dctx.clone()
+        other = torch.ones(pk.T, dtype=torch.bool, device=DEV)
+        other[off[b]:off[b + 1]] = False
+        q2[other] = (torch.randn(int(other.sum()), 3 * H, generator=g) * 300.0).to(torch.bfloat16).to(DEV)
+        d2[other] = (torch.randn(int(other.sum()), H, generator=g) * 300.0).to(torch.bfloat16).to(DEV)
+        ctx1, lse1, dq1 = run(q2, d2)
+        rows = slice(int(off[b]), int(off[b + 1]))
+        assert torch.equal(ctx1[rows], ctx0[rows]) and torch.equal(lse1[:, rows], lse0[:, rows]) and torch.equal(dq1[rows], dq0[rows]), b
