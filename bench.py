@@ -12,18 +12,23 @@ activations with fp32 accumulation, in-batch negatives): encoder forward -> last
 (all-gather over ranks) -> span-pair InfoNCE -> encoder backward -> gradient all-reduce -> clip + AdamW + linear
 warm-up schedule.  Inputs are resident in HBM before the timed region.  Weak scaling: 64 sequences per GPU.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events bracketing every launch of the
-dominant kernel class (the bf16 MFMA GEMM, coco-dr_amd/csrc/gemm.hip) inside the timed region.  At N = 1 the line also
-carries `north_star_large_step` (the BERT-large seq-128 contrastive step the north star names, with its own roofline
-block), `eval_search` (BASELINE.json's second metric at the real config-5 shard, with its fp32-MFMA roofline) and
-`cpu_baseline` (the same step on the host cores: torch-CPU HuggingFace BertModel + restated loss + AdamW, and the
-numpy oracle as a second number).
+The LAST line rank 0 writes to stdout is the contract object, compact (< 4 KB): metric / value / unit / n_gpus / steps / warmup /
+ms_per_step / dtype / data / config, `roofline` (numbers only; measured live with HIP events bracketing every launch of the
+dominant kernel class - the bf16 MFMA GEMM, coco-dr_amd/csrc/gemm.hip + gemm_pp.hip - inside the timed region), ONE
+`cpu_baseline` block (the same step on the host cores: torch-CPU HuggingFace BertModel + restated loss + AdamW) and `summary`
+(one number per side leg).  Every side leg in full - `north_star_large_step` (the BERT-large seq-128 step the north star names),
+`host_lengths_contrastive_step`, `padded_contrastive_step`, `full_coco_step`, `ance_triplet_step`, `corpus_encode`, `eval_search`
+(BASELINE.json's second metric at the real config-5 shard), `config5_end_to_end`, `multi_gpu`, the other CPU baselines - goes to
+`bench_legs.json` next to this file (and to gpurun_out/ when that directory exists) and, one leg per line prefixed `[leg]`, to stderr.
 """
 import argparse
 import json
 import os
 import sys
 import time
+import warnings
+
+warnings.filterwarnings("ignore")  # (nothing but the contract line may look like output; warnings are not results)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -189,8 +194,8 @@ def cpu_baseline():
     out = {"kind": "port", "cpu": _cpu_model_name()}
     try:
         thr = _best_thread_count(8, 64)
-        # the headline's exact batch (64 sequences x L128) as a bounded sample: 1 warm-up + 2 timed steps (~15-20 s of CPU work)
-        out.update(cpu_baseline_torch(SEQ_PER_GPU, SEQ_LEN, warmup=1, steps=2, threads=thr))
+        # the headline's exact batch (64 sequences x L128) as a bounded sample: 1 warm-up + 5 timed steps (~25 s of CPU work)
+        out.update(cpu_baseline_torch(SEQ_PER_GPU, SEQ_LEN, warmup=1, steps=5, threads=thr))
         out["eight_sequences"] = cpu_baseline_torch(8, SEQ_LEN, threads=thr)
         out["config1"] = cpu_baseline_torch(8, 64, threads=thr)
         out["threads_tried"] = "fastest of 8 / 16 / 32 / 64 / all physical cores on the config-1 shape"
@@ -404,7 +409,7 @@ def search_cpu_baseline(nq: int = 1000, npass: int = 125000, dim: int = 1024, k:
 
 
 def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int = 0, world: int = 1, fence=None, dp_chunks: int = 2,
-              extras: bool = True):
+              extras: bool = True, host_lengths: bool = False):
     """BASELINE config 4 (ANCE/drivers/run_ann.py:293-356): BERT-large triplet step, 32 rows/GPU = queries [32,64] +
     positives / negatives [32,128], backward, clip_grad_norm_(1.0), LAMB (the reference's default optimizer), linear
     schedule.  One training row = 3 sequences.  ``world > 1``: the data-parallel step - every rank its own rows
@@ -426,7 +431,8 @@ def ance_step(dev, rows: int = 32, steps: int = 10, warmup: int = 3, rank: int =
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, _acc, _logits = model(q, qm, a, am, b, bm, lengths=(ql, al, bl))  # (lengths: what the CPU-side data function knows)
+        # the reference's 6 tensors (ANCE/data/msmarco_data.py:381-382 after .to(device)); host_lengths: + what the CPU-side data function knows
+        loss, _acc, _logits = model(q, qm, a, am, b, bm, lengths=(ql, al, bl) if host_lengths else None)
         loss.backward()
         opt.step(clip=clip_grad_norm_(flats, 1.0))  # norm and coefficient stay on the device
         sched.step()
@@ -559,15 +565,16 @@ def multi_gpu_legs(dev, rank: int, world: int, fence, tmax, shared: bool, dp_chu
     enc = BertDotNLL(cfg).to(dev).eval()
     n_local, batch = (1024, 256) if shared else (8192, 512)
     ids, mask = synth_batch(100 + rank, n_local, SEQ_LEN, cfg.vocab_size, dev)
-    retrieval.encode_corpus(enc, ids[:batch], mask[:batch], batch_size=batch, pack=False)
+    retrieval.encode_corpus(enc, ids[:batch], mask[:batch], batch_size=batch)
     fence()
     t0 = time.perf_counter()
-    emb, _ = retrieval.encode_corpus(enc, ids, mask, batch_size=batch, pack=False)
+    emb, _ = retrieval.encode_corpus(enc, ids, mask, batch_size=batch)
     fence()
     dt = tmax(time.perf_counter() - t0)
     out["sharded_corpus_encode"] = {"sequences_per_sec": round(n_local * world / dt, 1), "ms": round(dt * 1e3, 2),
                                     "workload": f"cocodr-large body_emb, {n_local} passages x L{SEQ_LEN} per rank (record i -> rank i % W), batch {batch}, "
-                                                "padded batches, embeddings kept in HBM; BASELINE configs[4] encode half"}
+                                                "packed execution of the padded batches (layout planned on the device from the masks), embeddings "
+                                                "kept in HBM; BASELINE configs[4] encode half"}
     del enc, ids, mask, emb
     torch.cuda.empty_cache()
     # ---- sharded search
@@ -618,7 +625,7 @@ def _traffic_for(model_name: str, seq_per_gpu: int, seq_len: int, packed: bool =
 
 
 def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int, warmup: int, dev, rank: int, world: int, use_dist: bool,
-                    dp_chunks: int, roofline: bool, dense: bool = False, packed: bool = False):
+                    dp_chunks: int, roofline: bool, dense: bool = False, packed: bool = False, host_lengths: bool = False):
     """Build the model, run `warmup` untimed + exactly `steps` timed contrastive steps between two fences; returns
     (seconds over the timed steps on this rank, final loss, roofline dict or None, cfg, one batch, what the steps executed)."""
     import torch.distributed as dist
@@ -636,15 +643,19 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / max(1, int(0.1 * total))))
     # a small pool of different synthetic batches, resident in HBM before the timed region, visited round-robin (one
     # repeated batch is memorised within a few steps and the loss saturates at 0).  A batch is what the reference's collator
-    # hands the model - padded ids + attention mask (COCO/data.py:150-154) - plus the B lengths on the host, which a collator
-    # that pads on the CPU knows; NOTHING of the packed layout is prebuilt: every timed step builds its own from these inside
-    # model(batch) (one pinned copy of 2B+1 integers + one native launch, coco-dr_amd/modeling.py PackedIndex)
+    # hands the model - padded ids + attention mask (COCO/data.py:150-154), nothing else (``host_lengths``: plus the B lengths
+    # on the host, which a collator that pads on the CPU knows - a boundary extension, measured as a side leg); NOTHING of the
+    # packed layout is prebuilt: every timed step builds its own inside model(batch) (coco-dr_amd/modeling.py PackedIndex:
+    # planned on the device from the mask, 16 bytes read back; with host lengths one pinned copy of 3B+1 integers)
     pool = [synth_batch_lens(rank + 10007 * i, seq_per_gpu, seq_len, cfg.vocab_size, dev, dense) for i in range(8)]
     bert.pack_sequences = bool(packed)  # (True is the model's default)
 
     def fresh_batch(i):  # a new dict per step: nothing a previous step attached can survive
         ids_, mask_, lens_ = pool[i % len(pool)]
-        return {"input_ids": ids_, "attention_mask": mask_, "lengths": lens_}
+        b_ = {"input_ids": ids_, "attention_mask": mask_}
+        if host_lengths:
+            b_["lengths"] = lens_
+        return b_
 
     step_no = [0]
     flats = [bert.flat_decay, bert.flat_nodecay]
@@ -755,6 +766,57 @@ def whole_step_fracs(n_seq: int, steps: int, dt: float, cfg, seq_len: int, exec_
     return d
 
 
+def compact_roofline(roof: dict) -> dict:
+    """The contract line's roofline block: numbers plus a short kernel name; the prose of the full block stays in bench_legs.json."""
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_per_step_bytes", "traffic_gbps", "algorithmic_achieved",
+            "algorithmic_frac", "launches_per_step", "avg_launch_us", "gemm_share_of_step", "rows_per_step", "rows_per_step_padded")
+    out = {k: roof[k] for k in keep if k in roof}
+    out["kernel"] = "bf16 MFMA GEMM class (gemm.hip + gemm_pp.hip), all launches of the step"
+    return out
+
+
+def leg_summary(extras: dict) -> dict:
+    """One number per side leg for the contract line."""
+    s = {}
+    g = lambda d, *ks: (g(d.get(ks[0], {}), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None  # noqa: E731
+    ns = extras.get("north_star_large_step", {})
+    s["large_256_padded_gemm_frac"] = g(ns, "256_sequences_padded", "roofline", "frac")
+    s["large_256_padded_step_frac"] = g(ns, "256_sequences_padded", "executed_whole_step_frac")
+    s["large_256_padded_seq_per_sec"] = g(ns, "256_sequences_padded", "sequences_per_sec")
+    s["large_256_packed_seq_per_sec"] = g(ns, "256_sequences", "sequences_per_sec")
+    s["host_lengths_seq_per_sec"] = g(extras, "host_lengths_contrastive_step", "sequences_per_sec")
+    s["reference_batch_seq_per_sec"] = g(extras, "reference_batch_contrastive_step", "sequences_per_sec")
+    s["padded_seq_per_sec"] = g(extras, "padded_contrastive_step", "sequences_per_sec")
+    s["padded_gemm_frac"] = g(extras, "padded_contrastive_step", "roofline", "frac")
+    s["full_coco_seq_per_sec"] = g(extras, "full_coco_step", "sequences_per_sec")
+    s["ance_rows_per_sec"] = g(extras, "ance_triplet_step", "rows_per_sec")
+    s["ance_gemm_frac"] = g(extras, "ance_triplet_step", "roofline", "frac")
+    s["corpus_encode_packed_seq_per_sec"] = g(extras, "corpus_encode", "packed_sequences_per_sec")
+    s["search_dot_products_per_sec"] = g(extras, "eval_search", "dot_products_per_sec")
+    s["search_cpu_dot_products_per_sec"] = g(extras, "eval_search", "cpu_baseline", "value")
+    s["config5_search_dot_products_per_sec"] = g(extras, "config5_end_to_end", "search_dot_products_per_sec")
+    s["config5_encode_passages_per_sec"] = g(extras, "config5_end_to_end", "encode_passages_per_sec")
+    s["same_per_gpu_batch_seq_per_sec"] = g(extras, "same_per_gpu_batch_as_n1", "sequences_per_sec")
+    s["sharded_search_dot_products_per_sec"] = g(extras, "multi_gpu", "sharded_search", "dot_products_per_sec")
+    s["sharded_encode_seq_per_sec"] = g(extras, "multi_gpu", "sharded_corpus_encode", "sequences_per_sec")
+    s["dp_ance_rows_per_sec"] = g(extras, "multi_gpu", "ance_triplet_step", "rows_per_sec")
+    return {k: v for k, v in s.items() if v is not None}
+
+
+def write_legs(legs: dict) -> None:
+    """bench_legs.json next to this file (+ gpurun_out/ when it exists), and one `[leg] name {json}` line per leg on stderr."""
+    text = json.dumps(legs, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_legs.json"), "w") as f:
+                    f.write(text + "\n")
+            except OSError:
+                pass
+    for k, v in legs.items():
+        print(f"[leg] {k} {json.dumps(v)}", file=sys.stderr)
+
+
 def _self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run."""
     import socket
@@ -783,6 +845,9 @@ def main():
     ap.add_argument("--padded", action="store_true",
                     help="headline on the padded execution (every GEMM over all B x L rows, as the reference computes); default: packed "
                          "execution of the same padded batches - identical loss and gradients, no work on padding rows")
+    ap.add_argument("--host-lengths", action="store_true",
+                    help="batches carry the B sequence lengths on the host next to ids + mask (a boundary extension: nothing is read back); "
+                         "default: the reference's batch unchanged, {input_ids, attention_mask}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true", help="skip the extra legs (north-star large step, full coCondenser step, search, encode, ANCE)")
@@ -821,8 +886,10 @@ def main():
 
     solo = not use_dist
     packed = not args.padded
+    host_lengths = bool(args.host_lengths)
     dt, final_loss, roof, cfg, (ids, mask, lens), xinfo = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, rank,
-                                                            world, use_dist, args.dp_chunks, not args.no_roofline, args.dense, packed=packed)
+                                                            world, use_dist, args.dp_chunks, not args.no_roofline, args.dense, packed=packed,
+                                                            host_lengths=host_lengths)
     extras = {}
     if solo and not args.no_full_step and rank == 0:
         # the north-star target shape (BASELINE.json north_star: ">= 50 % MFMA roofline on BERT-large seq128 contrastive step
@@ -834,7 +901,7 @@ def main():
         for n_seq, k_steps in ((64, 10), (200, 6), (256, 5)):
             for pk_ in (True, False):
                 ldt, lloss, lroof, lcfg, _, linfo = contrastive_leg("large", n_seq, SEQ_LEN, k_steps, 3, dev, 0, 1, False, args.dp_chunks,
-                                                                    not args.no_roofline, args.dense, packed=pk_)
+                                                                    not args.no_roofline, args.dense, packed=pk_, host_lengths=host_lengths)
                 v = n_seq * k_steps / ldt
                 entry = {"sequences_per_sec": round(v, 1), "ms_per_step": round(ldt / k_steps * 1e3, 3), "steps": k_steps, "loss": round(lloss, 4)}
                 entry.update(whole_step_fracs(n_seq, k_steps, ldt, lcfg, SEQ_LEN, linfo))
@@ -842,10 +909,21 @@ def main():
                 large[f"{n_seq}_sequences" + ("" if pk_ else "_padded")] = entry
         large["workload"] = "cocodr-large (BERT-large, 24 x 1024) contrastive step, seq_len 128, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW, 1 GPU"
         extras["north_star_large_step"] = large
+        if packed:
+            # the same headline step with the batch in the OTHER boundary form: host-known lengths next to ids + mask (a collator that
+            # pads on the CPU has them; nothing is read back) when the headline takes the reference's batch unchanged, and vice versa
+            hdt, hloss, _, _, _, _ = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
+                                                     args.dp_chunks, False, args.dense, packed=True, host_lengths=not host_lengths)
+            hv = args.seq_per_gpu * args.steps / hdt
+            extras["reference_batch_contrastive_step" if host_lengths else "host_lengths_contrastive_step"] = {
+                "sequences_per_sec": round(hv, 1), "ms_per_step": round(hdt / args.steps * 1e3, 3), "loss": round(hloss, 4),
+                "headline_vs_this": round((args.seq_per_gpu * args.steps / dt) / hv, 4),
+                "batch": "{input_ids, attention_mask} only (COCO/data.py:150-154): layout planned on the device, 16 bytes read back" if host_lengths
+                         else "{input_ids, attention_mask, lengths}: the B lengths on the host, nothing read back"}
         # the same headline step in the other execution: padded (every GEMM over all B x L rows, executed FLOPs = the dense count: the
         # line that is comparable kernel for kernel with rounds 1-2) when the headline is packed, and the other way round
         odt, oloss, oroof, _, _, oinfo = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
-                                                         args.dp_chunks, not args.no_roofline, args.dense, packed=not packed)
+                                                         args.dp_chunks, not args.no_roofline, args.dense, packed=not packed, host_lengths=host_lengths)
         ov = args.seq_per_gpu * args.steps / odt
         other = {"sequences_per_sec": round(ov, 1), "ms_per_step": round(odt / args.steps * 1e3, 3), "loss": round(oloss, 4),
                  "headline_vs_this": round((args.seq_per_gpu * args.steps / dt) / ov, 3)}
@@ -857,8 +935,8 @@ def main():
                                  "here the sequences are stored back to back, every one on its own length (no work on padding rows)")})
         extras["padded_contrastive_step" if packed else "packed_contrastive_step"] = other
         if args.model == "base":
-            extras["full_coco_step"] = full_coco_step(cfg, dev, ids, mask, lens)  # second scope: what the reference's step really runs
-            extras["ance_triplet_step"] = ance_step(dev)
+            extras["full_coco_step"] = full_coco_step(cfg, dev, ids, mask, lens if host_lengths else None)  # second scope: what the reference's step really runs
+            extras["ance_triplet_step"] = ance_step(dev, host_lengths=host_lengths)
         extras["corpus_encode"] = corpus_encode(cfg, dev, seq_len=args.seq_len)
         extras["eval_search"] = eval_search(dev)
         if not args.no_cpu_baseline:
@@ -882,7 +960,7 @@ def main():
     if world > 1 and not args.no_full_step:
         if config3:  # the weak-scaling point that keeps N = 1's per-GPU batch (the headline of this line is configs[2]'s 256 per GPU)
             wdt, wloss, _, _, _, _ = contrastive_leg(args.model, SEQ_PER_GPU, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
-                                                  args.dp_chunks, False, args.dense, packed=packed)
+                                                  args.dp_chunks, False, args.dense, packed=packed, host_lengths=host_lengths)
             wdt = tmax(wdt)
             extras["same_per_gpu_batch_as_n1"] = {"sequences_per_sec": round(SEQ_PER_GPU * world * args.steps / wdt, 2),
                                                   "ms_per_step": round(wdt / args.steps * 1e3, 3), "global_batch": SEQ_PER_GPU * world,
@@ -897,34 +975,50 @@ def main():
         par = f"dp{world}"
         if world > 1:
             par += " + RCCL all_gather negatives" if backend == "nccl" else f" over gloo ({world} ranks sharing {n_dev} GPU(s): code-path check, not a scaling number)"
+        which = ("BASELINE configs[1]" if args.model == "base" and world == 1 else
+                 "BASELINE configs[2] (8 GPUs, RCCL all_gather negatives, global batch 2048)" if config3 else
+                 "BASELINE configs[1]'s batch per GPU, negatives all-gathered as in configs[2]" if args.model == "base" else
+                 "north_star BERT-large target shape")
+        boundary = ("{input_ids, attention_mask, lengths}: B lengths on the host" if host_lengths else
+                    "{input_ids, attention_mask} as the reference's collator emits them (COCO/data.py:150-154)")
+        config = {"workload": f"cocodr-{args.model} contrastive step (COCO in-batch negatives), seq_len={args.seq_len}, {args.seq_per_gpu} sequences/GPU "
+                              f"padded to seq_len (MS MARCO-shaped lengths), bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW; {which}",
+                  "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len, "execution": "packed" if packed else "padded",
+                  "batch": boundary, "parallelism": par}
         out = {
             "metric": "contrastive-step sequences/sec", "value": round(value, 2), "unit": "sequences/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"cocodr-{args.model} contrastive step (COCO in-batch negatives), seq_len={args.seq_len}, "
-                                   f"{args.seq_per_gpu} sequences/GPU padded to seq_len at the boundary (MS MARCO-shaped lengths), "
-                                   + ("executed packed (sequences stored back to back inside the encoder: no work on padding rows, "
-                                      "loss and gradients identical to the padded execution); " if packed else "executed padded (all B x L rows); ")
-                                   + "bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW; "
-                                   + ("BASELINE configs[1]" if args.model == "base" and world == 1 else
-                                      "BASELINE configs[2] (8 GPUs, RCCL all_gather negatives, global batch 2048)" if config3 else
-                                      "BASELINE configs[1]'s batch on every GPU, negatives all-gathered as in configs[2] (whose 2048 global batch at 8 GPUs is 256 per GPU, the default at --gpus 8)" if args.model == "base" else "north_star BERT-large target shape"),
-                       "global_batch": args.seq_per_gpu * world, "seq_len": args.seq_len,
-                       "batches": "8 pre-generated synthetic batches per rank (padded ids + attention mask in HBM, the B lengths on the "
-                                  "host as a collator that pads on the CPU has them), visited round-robin; every timed step gets a fresh "
-                                  "batch dict" + (" and builds its packed layout inside the step (one pinned copy of 2B+1 integers + "
-                                                  "one native launch; nothing prebuilt or hoisted)" if packed else ""),
-                       "execution": "packed" if packed else "padded",
-                       "parallelism": par},
-            "loss": round(final_loss, 4),
+            "config": config, "loss": round(final_loss, 4),
         }
-        out.update(whole_step_fracs(args.seq_per_gpu * world, args.steps, dt, cfg, args.seq_len, xinfo, world))
+        fracs = whole_step_fracs(args.seq_per_gpu * world, args.steps, dt, cfg, args.seq_len, xinfo, world)
+        out.update(fracs)
         if roof is not None:
-            out["roofline"] = roof
-        out.update(extras)
+            out["roofline"] = compact_roofline(roof)
+        cpu = None
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+            cpu = cpu_baseline()
+            out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "cpu") if k in cpu}
+        out["summary"] = leg_summary(extras)
+        out["legs_file"] = "bench_legs.json"
+        # ---- every leg in full: side file + stderr, never the contract line
+        legs = {"headline": {**out, "roofline": roof, "cpu_baseline": cpu,
+                             "config_notes": {
+                                 "execution": "packed: sequences stored back to back inside the encoder, no work on padding rows, loss and gradients "
+                                              "identical to the padded execution (tests/test_gpu_packed.py)" if packed else "padded: all B x L rows",
+                                 "batches": "8 pre-generated synthetic batches per rank (padded ids + attention mask in HBM" +
+                                            (", the B lengths on the host" if host_lengths else "") + "), visited round-robin; every timed step "
+                                            "gets a fresh batch dict" + (" and builds its packed layout inside the step (nothing prebuilt or hoisted)"
+                                                                         if packed else "")}}}
+        legs.update(extras)
+        write_legs(legs)
+        line = json.dumps(out, separators=(",", ":"))
+        if len(line) >= 4096:  # the driver's parser gave up on a 20 KB line in round 4: never again
+            for k in ("summary", "legs_file", "loss"):
+                out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+        sys.stderr.flush()
+        print(line, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -102,6 +102,7 @@ SIGNATURES = {
     "cocodr_embed_bwd_packed_partial_floats": (c_size_t, [c_int, c_int]),
     "cocodr_embed_ln_bwd_packed": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_int, c_int, C.POINTER(DropoutMask), c_void_p]),
     "cocodr_mask_lengths": (c_int, [c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
+    "cocodr_pack_plan": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cocodr_pack_index": (c_int, [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "cocodr_ln_fwd_slots": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "cocodr_encoder_layout_packed": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),

@@ -915,7 +915,108 @@ __global__ __launch_bounds__(128) void pack_index_kernel(const void* __restrict_
     if (src) src[r0 + p] = (long long)b * L + p;
   }
 }
+// The host arithmetic of the packed layout (cocodr_amd.modeling.packed_extents) on the device, ONE workgroup: extents =
+// max(len, 1), the rows that make T a multiple of 32 handed to the last sequences with room below cap, running offsets, the
+// longest-first order (stable, = numpy argsort(-ext, kind="stable")) and {T, max extent rounded up to 32, all masks prefix masks}.
+// plan = lens [B] | seq_off [B + 1] | seq_order [B]
+constexpr int PLAN_THREADS = 1024, PLAN_MAX_B = 4096;
+__global__ __launch_bounds__(PLAN_THREADS) void pack_plan_kernel(const int32_t* __restrict__ lens, const int32_t* __restrict__ ok, int B, int cap,
+                                                                 int32_t* __restrict__ plan, int32_t* __restrict__ result) {
+  __shared__ int ext[PLAN_MAX_B];
+  __shared__ int wsum[PLAN_THREADS / 64], wmax[PLAN_THREADS / 64], wok[PLAN_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (B + PLAN_THREADS - 1) / PLAN_THREADS, b0 = tid * per, b1 = min(B, b0 + per);
+  int s = 0, good = 1;
+  for (int b = b0; b < b1; ++b) {
+    const int n = lens[b], e = max(n, 1);
+    ext[b] = e;
+    plan[b] = n;
+    s += e;
+    good &= (ok[b] != 0 && n <= cap) ? 1 : 0;
+  }
+  // inclusive scan of the per-thread sums: lanes, then waves
+  int incl = s;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  good = __all(good) ? 1 : 0;
+  if (lane == 63) wsum[wave] = incl;
+  if (lane == 0) wok[wave] = good;
+  __syncthreads();
+  int base = 0, total = 0, all_ok = 1;
+  for (int w = 0; w < PLAN_THREADS / 64; ++w) {
+    if (w < wave) base += wsum[w];
+    total += wsum[w];
+    all_ok &= wok[w];
+  }
+  // the <= 31 rows that make T a multiple of 32 go to the last sequences with room (one thread: a handful of iterations)
+  const int pad = (32 - (total & 31)) & 31;
+  __syncthreads();
+  if (tid == 0) {
+    int left = pad;
+    for (int b = B - 1; b >= 0 && left > 0; --b) {
+      const int give = min(left, max(cap - ext[b], 0));
+      ext[b] += give;
+      left -= give;
+    }
+    wsum[0] = left;  // (0 unless a length exceeds cap: reported through `result`)
+  }
+  __syncthreads();
+  const int left = wsum[0];
+  __syncthreads();
+  // offsets with the adjusted extents (the adjustment touched the tail only, but a rescan is as cheap as patching it)
+  s = 0;
+  int mx = 0;
+  for (int b = b0; b < b1; ++b) { s += ext[b]; mx = max(mx, ext[b]); }
+  incl = s;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+  if (lane == 63) wsum[wave] = incl;
+  if (lane == 0) wmax[wave] = mx;
+  __syncthreads();
+  base = 0;
+  mx = 0;
+  for (int w = 0; w < PLAN_THREADS / 64; ++w) {
+    if (w < wave) base += wsum[w];
+    mx = max(mx, wmax[w]);
+  }
+  int run = base + incl - s;  // exclusive prefix of this thread's first sequence
+  for (int b = b0; b < b1; ++b) {
+    plan[B + b] = run;
+    run += ext[b];
+  }
+  if (tid == 0) plan[2 * B] = total + pad - left;
+  // longest first, ties in batch order: the rank of b counts the longer extents and the equal ones in front of it
+  for (int b = tid; b < B; b += PLAN_THREADS) {
+    const int e = ext[b];
+    int rank = 0;
+    for (int j = 0; j < B; ++j) {
+      const int ej = ext[j];
+      rank += (ej > e || (ej == e && j < b)) ? 1 : 0;
+    }
+    plan[2 * B + 1 + rank] = b;
+  }
+  if (tid == 0) {
+    result[0] = total + pad - left;
+    result[1] = (mx + 31) / 32 * 32;
+    result[2] = (all_ok && left == 0) ? 1 : 0;
+    result[3] = B;
+  }
+}
 }  // namespace
+
+extern "C" int cocodr_pack_plan(const int32_t* lens, const int32_t* prefix_ok, int B, int cap, int32_t* plan, int32_t* result,
+                                cocodr_stream_t stream) {
+  CK_ARG(lens && prefix_ok && plan && result, "pack_plan: null pointer");
+  CK_ARG(B > 0 && B <= PLAN_MAX_B && cap > 0 && cap % 32 == 0, "pack_plan: bad arguments (B <= 4096, cap a multiple of 32)");
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, (hipStream_t)stream, lens, prefix_ok, B, cap, plan, result);
+  CK_LAUNCH("pack_plan");
+  return COCODR_OK;
+}
 
 extern "C" int cocodr_mask_lengths(const void* mask, int elem_bytes, int B, int L, long long row_stride, int32_t* lens, int32_t* prefix_ok,
                                    cocodr_stream_t stream) {

@@ -356,18 +356,13 @@ class PackedIndex:
       * ``lengths`` known on the host - the reference's collators pad on the CPU (COCO/data.py:135-144,
         ANCE/data/msmarco_data.py:381-382), ``collate.CoCondenserCollator`` emits them - : extents and offsets are a numpy
         cumsum, one small pinned host -> device copy, nothing waits for the device queue;
-      * only the device mask: ``cocodr_mask_lengths`` + a device -> host copy of 2 B integers, which waits for everything
-        queued on the stream before it (the cost of not knowing the lengths; results are the same)."""
+      * only the device mask (the reference's batch unchanged): the whole layout is planned on the device (``from_mask``:
+        ``cocodr_mask_lengths`` -> ``cocodr_pack_plan`` -> ``cocodr_pack_index`` queued back to back) and 16 bytes - T, the
+        longest extent, "all prefix masks" - come back through a pinned buffer; the host waits for the stream to reach the
+        plan kernel (unavoidable: the mask may have been produced by the work queued just before) and nothing else."""
 
     def __init__(self, ids: torch.Tensor, lens_host, L: Optional[int] = None):
-        if ids.dim() != 2 or ids.dtype not in (torch.int32, torch.int64):
-            raise ValueError("PackedIndex: ids must be an int32 / int64 [B, L] tensor")
-        if not ids.is_cuda:
-            raise RuntimeError("PackedIndex describes a batch in HBM: move the ids with .to('cuda') (there is no CPU fallback)")
-        if ids.stride(1) != 1:
-            ids = ids.contiguous()
-        B, L_in = ids.shape
-        Lp = (L_in + 31) // 32 * 32 if L is None else int(L)
+        ids, B, L_in, Lp = self._check_ids(ids, L)
         host, self.T, self.max_len = packed_extents(lens_host, B, L_in)
         dev = ids.device
         self.B, self.L = B, Lp
@@ -376,31 +371,98 @@ class PackedIndex:
         import numpy as np
         order = np.argsort(-np.diff(host[B:].astype(np.int64)), kind="stable").astype(np.int32)
         staged = torch.from_numpy(np.concatenate([host, order])).pin_memory().to(dev, non_blocking=True)
+        self._finish(ids, staged, self.T)
+
+    @staticmethod
+    def _check_ids(ids: torch.Tensor, L: Optional[int]):
+        if ids.dim() != 2 or ids.dtype not in (torch.int32, torch.int64):
+            raise ValueError("PackedIndex: ids must be an int32 / int64 [B, L] tensor")
+        if not ids.is_cuda:
+            raise RuntimeError("PackedIndex describes a batch in HBM: move the ids with .to('cuda') (there is no CPU fallback)")
+        if ids.stride(1) != 1:
+            ids = ids.contiguous()
+        B, L_in = ids.shape
+        return ids, B, L_in, ((L_in + 31) // 32 * 32 if L is None else int(L))
+
+    def _finish(self, ids: torch.Tensor, staged: torch.Tensor, rows: int, launch: bool = True):
+        """``staged`` = lens [B] | seq_off [B + 1] | seq_order [B] on the device; ``rows`` = the row count the [T] arrays are
+        allocated for (T, or its upper bound B x L when T is still on its way to the host)."""
+        B, Lp, dev = self.B, self.L, ids.device
         self.seq_off = staged[B:2 * B + 1]
         self.seq_order = staged[2 * B + 1:]
-        buf = torch.empty(4 * self.T, dtype=torch.int32, device=dev)
-        self.ids, self.positions, self.mask, self.cls_slot = buf[:self.T], buf[self.T:2 * self.T], buf[2 * self.T:3 * self.T], buf[3 * self.T:]
-        self.src = torch.empty(self.T, dtype=torch.int64, device=dev)
-        check(lib().cocodr_pack_index(ptr(ids), ids.element_size(), ids.stride(0), ptr(staged), ptr(self.seq_off), B, Lp, ptr(self.ids),
-                                      ptr(self.positions), ptr(self.mask), ptr(self.cls_slot), ptr(self.src), stream_ptr()), "pack_index")
+        buf = torch.empty(4 * rows, dtype=torch.int32, device=dev)
+        self._rows_buf = (buf, torch.empty(rows, dtype=torch.int64, device=dev), rows)
         self._keep = (staged, buf)
+        if launch:
+            self._launch_index(ids, staged)
+            self._bind(self.T)
+
+    def _launch_index(self, ids: torch.Tensor, staged: torch.Tensor):
+        buf, src, rows = self._rows_buf
+        check(lib().cocodr_pack_index(ptr(ids), ids.element_size(), ids.stride(0), ptr(staged), ptr(self.seq_off), self.B, self.L, ptr(buf),
+                                      ptr(buf[rows:]), ptr(buf[2 * rows:]), ptr(buf[3 * rows:]), ptr(src), stream_ptr()), "pack_index")
+
+    def _bind(self, T: int):
+        buf, src, rows = self._rows_buf
+        self.ids, self.positions, self.mask, self.cls_slot = buf[:T], buf[rows:rows + T], buf[2 * rows:2 * rows + T], buf[3 * rows:3 * rows + T]
+        self.src = src[:T]
         self.c_struct = N.PackedBatch(self.ids.data_ptr(), self.positions.data_ptr(), self.mask.data_ptr(), self.seq_off.data_ptr(),
-                                      self.cls_slot.data_ptr(), B, self.T, self.max_len, Lp, self.seq_order.data_ptr())
+                                      self.cls_slot.data_ptr(), self.B, T, self.max_len, self.L, self.seq_order.data_ptr())
 
     @property
     def cls_rows(self) -> torch.Tensor:
         return self.seq_off[:-1].to(torch.int64)
 
+    #: sequences per batch up to which the layout of a mask-only batch is planned on the device (cocodr_pack_plan: one workgroup)
+    PLAN_MAX_B = 4096
+
+    @classmethod
+    def from_mask(cls, ids: torch.Tensor, mask: torch.Tensor) -> Optional["PackedIndex"]:
+        """The reference's batch unchanged - padded ids + attention mask in HBM, no lengths on the host (COCO/data.py:150-154,
+        ANCE/data/msmarco_data.py:381-382): lengths, extents, offsets, order AND the row arrays are all built on the device
+        (``cocodr_mask_lengths`` -> ``cocodr_pack_plan`` -> ``cocodr_pack_index``, queued back to back); the host reads back 16
+        bytes - {T, longest extent, prefix masks?} - through a pinned buffer behind an event recorded in front of the last
+        launch, because T sizes every GEMM of the step.  The wait ends when the stream reaches the plan kernel (it cannot end
+        earlier: the mask may be the result of work queued just before), and everything that does not depend on T has been
+        prepared by then.  None: some mask is not a prefix mask (the caller runs padded)."""
+        ids, B, L_in, Lp = cls._check_ids(ids, None)
+        dev = ids.device
+        self = cls.__new__(cls)
+        self.B, self.L, self.lengths = B, Lp, None
+        scratch = torch.empty(2 * B + 4, dtype=torch.int32, device=dev)  # lens | prefix_ok | result
+        staged = torch.empty(3 * B + 1, dtype=torch.int32, device=dev)
+        check(lib().cocodr_mask_lengths(ptr(mask), mask.element_size(), B, L_in, mask.stride(0), ptr(scratch), ptr(scratch[B:]), stream_ptr()),
+              "mask_lengths")
+        check(lib().cocodr_pack_plan(ptr(scratch), ptr(scratch[B:]), B, Lp, ptr(staged), ptr(scratch[2 * B:]), stream_ptr()), "pack_plan")
+        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host.copy_(scratch[2 * B:], non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        self._finish(ids, staged, B * Lp, launch=False)
+        self._launch_index(ids, staged)  # (takes lens / offsets from the plan: queued before the host knows T)
+        ready.synchronize()
+        T, max_len, ok, _ = (int(v) for v in host.tolist())
+        if not ok:
+            return None
+        self.T, self.max_len = T, max_len
+        self._keep = self._keep + (scratch,)
+        self._bind(T)
+        return self
+
     @staticmethod
     def build(ids: torch.Tensor, mask: Optional[torch.Tensor] = None, lengths=None) -> Optional["PackedIndex"]:
-        """``lengths`` (host integers, = attention_mask.sum(1) of prefix masks): no device -> host traffic.  Otherwise the lengths
-        are read back from the device mask (a stream synchronisation); None when a mask is not a prefix mask (the reference pads
-        at the end, COCO/data.py:135-144; anything else runs padded)."""
+        """``lengths`` (host integers, = attention_mask.sum(1) of prefix masks): no device -> host traffic.  Otherwise the layout
+        is planned on the device from the mask and 16 bytes come back (``from_mask``); None when a mask is not a prefix mask
+        (the reference pads at the end, COCO/data.py:135-144; anything else runs padded)."""
         if lengths is not None and torch.is_tensor(lengths) and lengths.is_cuda:
-            # (a trainer moved the batch to the device: these are no longer host-known - the mask route reads them back, or they do)
+            # (a trainer moved the batch to the device: these are no longer host-known - the mask route plans on the device, or they do)
             lengths = None if mask is not None else lengths.cpu()
         if lengths is not None:
-            return PackedIndex(ids, lengths.numpy() if torch.is_tensor(lengths) else lengths)
+            lengths = lengths.numpy() if torch.is_tensor(lengths) else lengths
+            pk = PackedIndex(ids, lengths)
+            if mask is not None and PackedIndex.check_lengths:
+                pk.assert_lengths_match(mask)
+            return pk
         B, L = ids.shape
         if mask is None:
             import numpy as np
@@ -411,12 +473,34 @@ class PackedIndex:
             mask = mask.view(torch.uint8)
         if mask.element_size() not in (1, 4, 8) or mask.is_floating_point() or mask.stride(1) != 1:
             mask = mask.to(torch.int32).contiguous()
+        if B <= PackedIndex.PLAN_MAX_B and PACK_ALIGN == 1:
+            return PackedIndex.from_mask(ids, mask)
         out = torch.empty(2 * B, dtype=torch.int32, device=ids.device)
         check(lib().cocodr_mask_lengths(ptr(mask), mask.element_size(), B, L, mask.stride(0), ptr(out), ptr(out[B:]), stream_ptr()), "mask_lengths")
         host = out.cpu().numpy()
         if not host[B:].all():
             return None
         return PackedIndex(ids, host[:B])
+
+    #: debug switch: with host ``lengths`` AND a mask, compare them on the device (one launch + a read-back per call)
+    check_lengths = False
+
+    def assert_lengths_match(self, mask: torch.Tensor) -> None:
+        """Host-passed ``lengths`` are trusted over the mask (no read-back on the fast path); this check - ``PackedIndex.check_lengths
+        = True``, or call it directly - raises when they are not the mask's prefix lengths (lengths counted without [CLS] / [SEP], a
+        mask with holes: the packed run would silently attend a different token set than the reference's padded run)."""
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        if mask.element_size() not in (1, 4, 8) or mask.is_floating_point() or mask.stride(1) != 1:
+            mask = mask.to(torch.int32).contiguous()
+        B, L = mask.shape
+        out = torch.empty(2 * B, dtype=torch.int32, device=mask.device)
+        check(lib().cocodr_mask_lengths(ptr(mask), mask.element_size(), B, L, mask.stride(0), ptr(out), ptr(out[B:]), stream_ptr()), "mask_lengths")
+        host = out.cpu().numpy()
+        import numpy as np
+        if not host[B:].all() or not np.array_equal(host[:B], np.asarray(self.lengths).reshape(-1)):
+            raise ValueError("PackedIndex: `lengths` are not the prefix lengths of `attention_mask` (lengths must equal "
+                             "attention_mask.sum(1) and every mask must be 1 .. 1 0 .. 0)")
 
     def unpack(self, x: torch.Tensor) -> torch.Tensor:
         """[T, H] -> padded [B, L, H]; rows past a sequence's extent are zeros (the padded path leaves masked garbage there)."""
@@ -1059,12 +1143,15 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
             pk = self.pack(input_ids, attention_mask, lengths)  # None: not prefix masks -> padded
         ids = mask = None
         if pk is None:
+            if attention_mask is None and lengths is not None:  # padded run of a batch described by its lengths alone
+                lens_dev = torch.as_tensor(lengths, dtype=torch.int64).reshape(-1).to(input_ids.device)
+                attention_mask = (torch.arange(L, device=input_ids.device)[None] < lens_dev[:, None]).to(torch.int32)
             ids, mask, L = self._prep(input_ids, attention_mask)
         cls_only = bool(cls_only and not output_hidden_states and self.cls_tail)
         if pk is not None:
-            last, cls = _PackedEncoderFn.apply(self.flat_decay, self.flat_nodecay, self, pk, torch.is_grad_enabled(), cls_only)
+            last, cls = _PackedEncoderFn.apply(*self._flat_leaves(), self, pk, torch.is_grad_enabled(), cls_only)
         else:
-            outs = _EncoderFn.apply(self.flat_decay, self.flat_nodecay, ids, mask, self, torch.is_grad_enabled(), want_taps, cls_only)
+            outs = _EncoderFn.apply(*self._flat_leaves(), ids, mask, self, torch.is_grad_enabled(), want_taps, cls_only)
             last, cls, taps = outs[0], outs[1], outs[2:]
         if last is None:  # [CLS] tail
             out = EncoderOutput(None, None, cls)
@@ -1085,6 +1172,29 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         out = EncoderOutput(last[:, :L], hs, cls)
         self._last_hidden_states = None
         return out if return_dict else (out.last_hidden_state, None)
+
+    def _flat_leaves(self):
+        """The two tensors a forward attaches its autograd node to: the flat parameters - or, inside ``side_stream_aliases()``, views
+        of them that were created on the caller's main stream."""
+        return getattr(self, "_flat_alias", None) or (self.flat_decay, self.flat_nodecay)
+
+    def side_stream_aliases(self):
+        """Context for an encoder pass that runs on a SIDE stream next to another pass (``BertDotNLL``'s two-pass step): autograd
+        replays a pass's backward on its forward stream, and a gradient that arrives at a leaf's AccumulateGrad node from another
+        stream than the leaf's makes torch warn and synchronise there.  Entered on the MAIN stream, this hands the pass views of the
+        flats whose ViewBackward nodes belong to the main stream: the engine joins the side stream in front of them (the join the
+        step needs anyway) and AccumulateGrad only ever sees main-stream producers."""
+        import contextlib
+        model = self
+
+        @contextlib.contextmanager
+        def ctx():
+            model._flat_alias = (model.flat_decay.view(-1), model.flat_nodecay.view(-1)) if torch.is_grad_enabled() else None
+            try:
+                yield
+            finally:
+                model._flat_alias = None
+        return ctx()
 
     def encode_cls(self, input_ids, attention_mask=None, packed_index=None, lengths=None) -> torch.Tensor:
         """fp32 last-layer [CLS] rows [B,H] with autograd (what every reference wrapper consumes)."""
@@ -1225,7 +1335,7 @@ class BertDotNLL(nn.Module):
         # where the reference runs three passes (models.py:84-86), positives and negatives share one here when shapes allow
         calls = lambda: self.bert._dropout_calls if self.bert._next_dropout_peek() else 0
         self.last_passes = []
-        with torch.cuda.stream(side):
+        with self.bert.side_stream_aliases(), torch.cuda.stream(side):
             q = self.query_emb(query_ids, attention_mask_q)
         self.last_passes.append(("q", calls()))
         B = q.shape[0]

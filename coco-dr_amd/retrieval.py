@@ -46,21 +46,29 @@ def encode_corpus(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, 
     sequences back to back instead of padded (bit-identical embeddings, no work on the padding rows, +18-21 % passages/s;
     include/cocodr.h "Packed batches"; a batch whose masks are not prefix masks runs padded).  ``pack=False``: always padded.
     ``lengths``: the n passage lengths on the host (the token cache stores them in front of every record,
-    ANCE/data/msmarco_data.py:279) - the packed layouts are then built without reading the masks back, batch after batch."""
+    ANCE/data/msmarco_data.py:279) - the packed layouts are then built without reading anything back, batch after batch;
+    ``attention_mask`` may then be None (it is rebuilt from the lengths where a padded run needs it).  Batches with
+    ``lengths`` go through ``model.bert.encode_cls`` (the embedding of ``BertDotNLL`` - raw last-layer [CLS] - for both
+    queries and passages); a wrapper whose ``query_emb`` / ``body_emb`` do more than that must pass masks instead."""
     n = input_ids.shape[0]
     fn = model.query_emb if is_query else model.body_emb
     outs = []
     bert = getattr(model, "bert", None)
     was = getattr(bert, "pack_sequences", False)
+    if lengths is None and attention_mask is None:
+        raise ValueError("encode_corpus: give attention_mask or lengths")
+    if lengths is not None and bert is None:
+        raise ValueError("encode_corpus(lengths=): the model has no .bert encoder to hand the lengths to; pass attention_mask")
     if bert is not None:
-        bert.pack_sequences = bool(pack) or was
+        bert.pack_sequences = bool(pack)
     try:
         with torch.no_grad():
             for s in range(0, n, batch_size):
-                if lengths is not None and bert is not None and bert.pack_sequences:
-                    outs.append(bert.encode_cls(input_ids[s:s + batch_size], None, lengths=lengths[s:s + batch_size]).float())
+                m = None if attention_mask is None else attention_mask[s:s + batch_size]
+                if lengths is not None:  # (packed: laid out from the lengths; padded: the mask - given or rebuilt from them)
+                    outs.append(bert.encode_cls(input_ids[s:s + batch_size], m, lengths=lengths[s:s + batch_size]).float())
                 else:
-                    outs.append(fn(input_ids[s:s + batch_size], attention_mask[s:s + batch_size]).float())
+                    outs.append(fn(input_ids[s:s + batch_size], m).float())
     finally:
         if bert is not None:
             bert.pack_sequences = was

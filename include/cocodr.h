@@ -525,6 +525,16 @@ int cocodr_mask_lengths(const void* mask, int elem_bytes, int B, int L, long lon
 int cocodr_pack_index(const void* ids, int elem_bytes, long long row_stride, const int32_t* lens, const int32_t* seq_off, int B,
                       int L, int32_t* out_ids, int32_t* positions, int32_t* mask, int32_t* cls_slot, long long* src,
                       cocodr_stream_t stream);
+/* The host arithmetic of the layout on the device, for callers that hand over the reference's batch unchanged
+ * ({input_ids, attention_mask}, COCO/data.py:150-154; ANCE/data/msmarco_data.py:381-382) and do not know the lengths:
+ *   cocodr_pack_plan: lens / prefix_ok int32 [B] (cocodr_mask_lengths' outputs), cap = the padded row length rounded up to 32 ->
+ *     plan int32 [3B + 1] = lens [B] | seq_off [B + 1] | seq_order [B] (extent = max(len, 1); the <= 31 rows that make T a
+ *     multiple of 32 go to the last sequences with room below cap; order = longest extent first, ties in batch order) and
+ *     result int32 [4] = {T, longest extent rounded up to 32, 1 when every mask is a prefix mask, B}.  One workgroup, B <= 4096.
+ * A host then reads `result` back (16 bytes, the only thing the launches behind it need from the device: T sizes the GEMMs)
+ * while cocodr_pack_index (which takes lens / seq_off from `plan`) is already queued. */
+int cocodr_pack_plan(const int32_t* lens, const int32_t* prefix_ok, int B, int cap, int32_t* plan, int32_t* result,
+                     cocodr_stream_t stream);
 /* cocodr_ln_fwd whose fp32 [CLS] copies are named row by row: cls_slot int32 [M], -1 or the row of cls_out a row goes to */
 int cocodr_ln_fwd_slots(const uint16_t* y, const float* gamma, const float* beta, uint16_t* out, float* mean, float* rstd,
                         float* cls_out, int cls_stride, const int32_t* cls_slot, int M, int H, float eps,

@@ -83,6 +83,56 @@ def test_pack_index_from_the_device_mask(mdtype):
     check_index(PackedIndex.build(torch.from_numpy(full).to(DEV), None), full, np.full(3, 64), 64)
 
 
+@pytest.mark.parametrize("B,L", [(1, 32), (2, 33), (64, 128), (257, 64), (1500, 96), (4096, 32), (4100, 32)])
+def test_device_planned_layout_equals_the_host_arithmetic(B, L):
+    """cocodr_pack_plan (extents, offsets, longest-first order, T, longest extent) against packed_extents + numpy's stable argsort,
+    bit for bit, on MS MARCO-shaped and degenerate lengths; B > 4096 takes the read-back route with the same result."""
+    rng = np.random.Generator(np.random.PCG64(B * 1000 + L))
+    for kind in ("marco", "all_full", "all_empty", "ties"):
+        lens = {"marco": np.clip(np.rint(rng.normal(0.6 * L, 0.25 * L, B)), 0, L), "all_full": np.full(B, L), "all_empty": np.zeros(B),
+                "ties": rng.integers(1, 4, B) * (L // 4)}[kind].astype(np.int64)
+        ids, mask, lens = batch(lens, L, seed=B)
+        dids, dmask = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+        dev, host = PackedIndex.build(dids, dmask), PackedIndex.build(dids, None, lens)
+        assert (dev.T, dev.max_len, dev.B, dev.L) == (host.T, host.max_len, host.B, host.L), kind
+        assert torch.equal(dev.seq_off, host.seq_off) and torch.equal(dev.seq_order, host.seq_order), kind
+        for k in ("ids", "positions", "mask", "cls_slot", "src"):
+            assert torch.equal(getattr(dev, k), getattr(host, k)), (kind, k)
+        assert dev.T % 32 == 0 and sorted(dev.seq_order.cpu().tolist()) == list(range(B))
+
+
+def test_host_lengths_that_contradict_the_mask_are_caught_by_the_debug_check():
+    ids, mask, lens = batch([10, 20, 5], 32)
+    d = lambda a: torch.from_numpy(a).to(DEV)  # noqa: E731
+    PackedIndex.check_lengths = True
+    try:
+        assert PackedIndex.build(d(ids), d(mask), lens) is not None
+        with pytest.raises(ValueError):
+            PackedIndex.build(d(ids), d(mask), lens - 1)          # (lengths counted without [SEP])
+        hole = mask.copy()
+        hole[1, 3] = 0
+        with pytest.raises(ValueError):
+            PackedIndex.build(d(ids), d(hole), lens)
+    finally:
+        PackedIndex.check_lengths = False
+    assert PackedIndex.build(d(ids), d(mask), lens - 1) is not None  # the fast path trusts the host
+
+
+def test_padded_run_of_a_batch_given_by_lengths_alone_masks_the_padding():
+    """pack_sequences = False with attention_mask = None and host lengths: the padded mask is built from the lengths."""
+    cfg = CocoBertConfig(vocab_size=900, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
+    torch.manual_seed(0)
+    bert = CocoBertModel(cfg).to(DEV).eval()
+    ids, mask, lens = batch([40, 64, 3, 17], 64, seed=2, V=900)
+    with torch.no_grad():
+        bert.pack_sequences = False
+        a = bert.encode_cls(torch.from_numpy(ids).to(DEV), None, lengths=lens)
+        b = bert.encode_cls(torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV))
+        bert.pack_sequences = True
+        c = bert.encode_cls(torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV))
+    assert torch.equal(a, b) and torch.equal(b, c)
+
+
 def test_masks_with_holes_or_leading_padding_are_not_packed():
     ids, mask, _ = batch([10, 20], 32)
     hole, lead = mask.copy(), mask.copy()
