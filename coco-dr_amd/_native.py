@@ -29,7 +29,6 @@ class GemmArgs(C.Structure):
         ("drop", DropoutMask),
         ("ab_f16", c_int),
         ("split_ws", c_void_p), ("split_ws_floats", c_size_t),
-        ("row_lse", c_void_p), ("row_scale", c_void_p), ("row_label", c_void_p), ("lse_stats", c_void_p), ("label_logit", c_void_p),
     ]
 
 
@@ -72,11 +71,15 @@ class LambPlan(C.Structure):  # mirrors cocodr_lamb_plan
                 ("nchunk", c_int), ("nseg", c_int)]
 
 
+class LambFusedPlan(C.Structure):  # mirrors cocodr_lamb_fused_plan
+    _fields_ = [("seg_start", c_void_p), ("seg_len", c_void_p), ("seg_index", c_void_p), ("nfused", c_int)]
+
+
 class EncoderBwdLayout(C.Structure):  # mirrors cocodr_encoder_bwd_layout_t
     _fields_ = [(n, c_size_t) for n in ("dy2", "du", "dy1", "dqkv", "ln2_partial", "ln1_partial")] + [("ln_blocks", c_int), ("ln_rows", c_int)]
 
 
-EPI_NONE, EPI_GELU, EPI_ADD, EPI_DGELU, EPI_LSE, EPI_CE_GRAD = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GELU, EPI_ADD, EPI_DGELU = 0, 1, 2, 3
 
 # name -> (restype, argtypes); every symbol include/cocodr.h declares
 SIGNATURES = {
@@ -134,6 +137,11 @@ SIGNATURES = {
     "cocodr_grad_norm_clip": (c_int, [C.POINTER(c_void_p), C.POINTER(c_size_t), c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "cocodr_lamb_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, C.POINTER(LambPlan), c_float,
                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cocodr_lamb_fused_capacity": (c_size_t, []),
+    "cocodr_lamb_fused_workspace_floats": (c_size_t, [c_int]),
+    "cocodr_lamb_fused_error_index": (c_size_t, [c_int]),
+    "cocodr_lamb_step_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, C.POINTER(LambFusedPlan), c_float,
+                                       c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_scatter_cls_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cocodr_cls_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "cocodr_simce_workspace_floats": (c_size_t, [c_int]),
@@ -155,8 +163,6 @@ SIGNATURES = {
     "cocodr_stack_fwd": (c_int, [C.POINTER(Config), C.POINTER(LayerParams), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                                  c_void_p]),
     "cocodr_ce_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "cocodr_decoder_ce_workspace_floats": (c_size_t, [c_int, c_int]),
-    "cocodr_decoder_ce": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_encoder_bwd": (c_int, [C.POINTER(Config), C.POINTER(EmbedParams), C.POINTER(LayerParams), C.POINTER(EmbedGrads),
                                    C.POINTER(LayerGrads), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                    c_void_p]),

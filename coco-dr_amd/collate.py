@@ -27,10 +27,14 @@ class CondenserCollator:
     """``CondenserCollator`` (COCO/data.py:24-156) for BERT vocabularies.  ``__call__(examples)`` takes the reference's
     ``[{'text': [token ids]}, ...]`` and returns ``{"input_ids", "labels", "attention_mask"}`` (int64 CUDA tensors
     ``[n, max_seq_length]``).  ``seed`` + a running span counter drive the counter-based generator, so a run is
-    reproducible and independent of the batch composition."""
+    reproducible and independent of the batch composition.  ``emit_lengths=True`` adds ``"lengths"``: the attended length of every
+    row as a CPU int64 tensor (a boundary extension the reference's batch does not have - ``split_tensor_dict``-style code that
+    calls ``.split`` on every value, COCO/trainer.py:137-140, still works on it and cuts it consistently; the model then lays its packed
+    batch out without reading anything back).  Default off: the model plans the layout on the device from the mask at < 2 % cost."""
 
     def __init__(self, subword_flags: np.ndarray, cls_id: int = 101, sep_id: int = 102, pad_id: int = 0, mask_id: int = 103,
-                 mlm_probability: float = 0.15, max_seq_length: int = 512, seed: int = 0, device="cuda"):
+                 mlm_probability: float = 0.15, max_seq_length: int = 512, seed: int = 0, device="cuda", emit_lengths: bool = False):
+        self.emit_lengths = bool(emit_lengths)
         self.device = torch.device(device)
         self.flags = torch.from_numpy(np.ascontiguousarray(subword_flags, dtype=np.uint8)).to(self.device)
         self.vocab = int(self.flags.numel())
@@ -64,10 +68,10 @@ class CondenserCollator:
                                        self.mask_id, self.mlm_probability, self.seed, self.spans_seen, ptr(ids), ptr(labels), ptr(mask),
                                        stream_ptr()), "mlm_collate")
         self.spans_seen += n
-        # "lengths": the attended length of every row, known here on the host (truncation window + [CLS] + [SEP], COCO/data.py:131-144) -
-        # a numpy array, so that a trainer's move-to-device of the batch leaves it where it is; with it the model builds its packed
-        # layout without reading the mask back (CocoBertModel.forward(lengths=), CoCondenserForPretraining: batch["lengths"])
-        return {"input_ids": ids.long(), "labels": labels.long(), "attention_mask": mask.long(), "lengths": np.minimum(lens, L - 2) + 2}
+        out = {"input_ids": ids.long(), "labels": labels.long(), "attention_mask": mask.long()}  # the reference's batch (COCO/data.py:150-154)
+        if self.emit_lengths:  # truncation window + [CLS] + [SEP] (COCO/data.py:131-144), known here on the host
+            out["lengths"] = torch.from_numpy(np.minimum(lens, L - 2) + 2).to(torch.int64)
+        return out
 
     def __call__(self, examples: List[Dict[str, List[int]]]):
         return self.collate_spans([e["text"] for e in examples])

@@ -42,11 +42,8 @@ class CondenserHead(FlatParamsMixin, nn.Module):
     ``cls.predictions.transform.dense.weight`` ..., ``cls.predictions.bias`` (the decoder weight is the backbone's
     word-embedding table)."""
 
-    #: True: decoder GEMM + vocabulary cross entropy in the GEMM epilogue (``cocodr_decoder_ce``: the fp32 logits never reach HBM, at
-    #: the price of a second pass of the GEMM).  Measured at the step's 1216 x 768 x 30 522 problem: 235 us against 173 us for the fp32
-    #: logits + ``cocodr_ce_fwd_bwd`` (profiles/r04_decoder_ce.md) - the recompute costs more than the 300 MB it saves, so the
-    #: default stays the two-kernel form; the fused form halves the step's peak transient memory (149 MB of logits per 1216 rows).
-    fused_ce = False
+    #: (a fused decoder GEMM + cross entropy was built in round 4 and measured slower than logits + ``cocodr_ce_fwd_bwd`` - 235 against
+    #: 173 us, profiles/r04_decoder_ce.md; the code is archived in tools/experiments/decoder_ce_removed.hip.txt)
     #: contraction slices of the decoder's input-gradient GEMM ([n, H] = dlogits . Word over K = 30 720: 30 tiles of 256 rows would
     #: leave most CUs idle; slices run as the batch items of one launch).  Measured 2 / 4 / 8: profiles/r04_decoder_ce.md
     decoder_split_k = 8
@@ -230,7 +227,7 @@ class _CondenserStepFn(torch.autograd.Function):
         t, t_mean, t_rstd = ops.ln_fwd(g_act, head.hf_view("cls.predictions.transform.LayerNorm.weight"),
                                        head.hf_view("cls.predictions.transform.LayerNorm.bias"), cfg.layer_norm_eps)
         # tied decoder weight; rows padded to a multiple of 512 (bias -1e30 there: probability exactly 0, gradient exactly 0): whole
-        # 256-column tiles for the fused GEMM + cross entropy, and a contraction the backward can cut into 8 slices of 64-wide steps
+        # 256-column tiles for the logits GEMM, and a contraction the backward can cut into 8 slices of 64-wide steps
         vp = (V + 511) // 512 * 512
         word16 = torch.empty((vp, H), dtype=torch.bfloat16, device=dev)
         word16[V:].zero_()
@@ -239,15 +236,12 @@ class _CondenserStepFn(torch.autograd.Function):
         dec_bias[:V].copy_(head.hf_view("cls.predictions.bias"))
         scale = torch.cat([scale_p, scale_p]) if late_mlm else scale_p
         lab2 = torch.cat([lab_p, lab_p]) if late_mlm else lab_p
-        if head.fused_ce:  # logits stay on chip: two passes of the decoder GEMM (row statistics, then the gradient)
-            loss_rows, dlogits = ops.decoder_ce(t, word16, dec_bias, lab2, scale)
-        else:
-            logits = ops.gemm(t, word16, bias=dec_bias, out_f32=True)  # [n2, vp] fp32
-            loss_rows = torch.empty(n2, dtype=torch.float32, device=dev)
-            dlogits = torch.empty((n2, vp), dtype=torch.bfloat16, device=dev)
-            check(lib().cocodr_ce_fwd_bwd(ptr(logits), ptr(lab2), ptr(scale), n2, V, vp, ptr(loss_rows), ptr(dlogits),
-                                          stream_ptr()), "ce_fwd_bwd")
-            del logits
+        logits = ops.gemm(t, word16, bias=dec_bias, out_f32=True)  # [n2, vp] fp32
+        loss_rows = torch.empty(n2, dtype=torch.float32, device=dev)
+        dlogits = torch.empty((n2, vp), dtype=torch.bfloat16, device=dev)
+        check(lib().cocodr_ce_fwd_bwd(ptr(logits), ptr(lab2), ptr(scale), n2, V, vp, ptr(loss_rows), ptr(dlogits),
+                                      stream_ptr()), "ce_fwd_bwd")
+        del logits
         mlm_loss = (loss_rows * scale).sum()  # mean over the head rows + mean over the late rows
         ctx.bert, ctx.head = bert, head
         ctx.skip_from, ctx.late_mlm, ctx.n_lab, ctx.n_pad = skip_from, late_mlm, n_lab, n_pad

@@ -618,6 +618,15 @@ extern "C" int cocodr_gemm_set_impl(int impl) {
 }
 
 namespace {
+// the window in which cutting the last partial round of 256 x 256 tiles into contraction slices was measured to win (see select_impl):
+// r <= 64 tiles in s >= 4 slices at K >= 2048.  An automatically selected launch is cut ONLY there (a plan with fewer slices or a
+// longer tail exists - cocodr_gemm_pp_split_plan is general, the parity tests force it - but loses to whole tiles)
+bool split_tail_wins(const cocodr_gemm_args& a) {
+  if (a.split_ws == nullptr || a.batch > 1 || a.K < 2048) return false;
+  int total, r, sl;
+  cocodr_gemm_pp_split_plan(a, total, r, sl);
+  return sl >= 4 && r <= 64;
+}
 // which pipeline a call runs on (see g_gemm_impl); shape-only, so callers can ask before they launch
 int select_impl(const cocodr_gemm_args& a) {
   // the direct-to-LDS pipeline needs whole 64-wide K-steps for every operand whose contraction index is the
@@ -657,11 +666,7 @@ int select_impl(const cocodr_gemm_args& a) {
     // against 163 for the 256 x 128 tiles and 180 for whole 256 x 256 tiles; the same shape at K = 1024: 64 against 55) - and
     // loses wherever the tail is long (368 tiles: 200 against 180) because two slices of a tile cost a ramp, a 256 KB fp32
     // partial tile each way and the finishing pass.  So: exactly that window.
-    if (!nopp && !pp_fills && tilespp > 256 && a.split_ws != nullptr && batch == 1 && a.K >= 2048) {
-      int total, r, sl;
-      cocodr_gemm_pp_split_plan(a, total, r, sl);
-      if (sl >= 4 && r <= 64) pp_fills = true;
-    }
+    if (!nopp && !pp_fills && tilespp > 256 && split_tail_wins(a)) pp_fills = true;
     // one round of 256 x 256 tiles that fills >= 2/3 of the CUs: the ping-pong pipeline beats the 256 x 96 / 256 x 128 tiles by
     // 8-11 % on the forward (NT) form there (packed BERT-base batches: 5 024-6 304 rows x 2304 x 768 = 180-225 tiles, 28-31 us
     // against 31-34; profiles/r04_gemm_impl_sweep_base.txt); the dgrad (NN) form is level at BERT-base sizes and 3-9 % ahead
@@ -674,7 +679,6 @@ int select_impl(const cocodr_gemm_args& a) {
     else if (tiles256 >= 128) impl = 9;
     else impl = tiles128 >= 512 ? 4 : 2;
   }
-  if (a.epi >= COCODR_EPI_LSE) return 13;  // (validated by cocodr_gemm: only the ping-pong pipeline's epilogue knows these)
   if (impl != 1 && !(k_ok && small)) impl = 1;
   if (impl == 8 && a.N % 192 != 0) impl = 3;  // the 128x192 tile needs N % 192 == 0
   if (impl == 11 && a.N % 256 != 0) impl = 5;  // the 256x256 tile needs N % 256 == 0
@@ -702,7 +706,7 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   CK_ARG(args != nullptr, "gemm: null args");
   cocodr_gemm_args a = *args;
   if (a.batch <= 0) a.batch = 1;
-  CK_ARG(a.A && a.B && (a.C || a.epi == COCODR_EPI_LSE), "gemm: null operand");
+  CK_ARG(a.A && a.B && a.C, "gemm: null operand");
   CK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   CK_ARG(a.N % BN == 0, "gemm: N=%d must be a multiple of 128", a.N);
   CK_ARG(a.K % 8 == 0, "gemm: K=%d must be a multiple of 8", a.K);
@@ -712,15 +716,7 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   CK_ARG(a.lda >= (a.trans_a ? a.M : a.K) && a.ldb >= (a.trans_b ? a.N : a.K) && a.ldc >= a.N, "gemm: leading dim too small");
 #endif
   CK_ARG(!(a.trans_a && !a.trans_b), "gemm: (trans_a=1, trans_b=0) is not used on this path");
-  CK_ARG(a.epi >= COCODR_EPI_NONE && a.epi <= COCODR_EPI_CE_GRAD, "gemm: bad epilogue %d", a.epi);
-  if (a.epi >= COCODR_EPI_LSE) {  // the two passes of the fused vocabulary cross entropy: the 256 x 256-tile pipeline's epilogue only
-    CK_ARG(!a.trans_a && !a.trans_b && a.batch == 1 && !a.out_f32 && a.N % 256 == 0 && a.K % 64 == 0 && !a.colsum && !a.colsum_partial &&
-               !a.drop.threshold && !a.ab_f16 && a.row_label,
-           "gemm: EPI_LSE / EPI_CE_GRAD need the plain NT form with N %% 256 == 0, K %% 64 == 0 and row_label");
-    CK_ARG(a.epi != COCODR_EPI_LSE || (a.lse_stats && a.label_logit), "gemm: EPI_LSE needs lse_stats and label_logit");
-    CK_ARG(a.epi != COCODR_EPI_CE_GRAD || (a.row_lse && a.row_scale), "gemm: EPI_CE_GRAD needs row_lse and row_scale");
-    CK_ARG((size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldb * 2 < (1ull << 32), "gemm: operands of the fused cross entropy must stay below 4 GiB");
-  }
+  CK_ARG(a.epi >= COCODR_EPI_NONE && a.epi <= COCODR_EPI_DGELU, "gemm: bad epilogue %d", a.epi);
   CK_ARG(a.epi != COCODR_EPI_GELU || !a.out_f32, "gemm: EPI_GELU needs a bf16 output");
   CK_ARG((a.epi != COCODR_EPI_ADD && a.epi != COCODR_EPI_DGELU) || (a.R && a.ldr % 8 == 0 && a.ldr >= a.N), "gemm: epilogue needs R");
   CK_ARG((((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.C2 | (uintptr_t)a.R | (uintptr_t)a.bias) & 15) == 0,
@@ -749,7 +745,8 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   const int cs_rows = colsum_rows(impl, a.M);  // the kernels with 128-column tiles reduce in their epilogue
   CK_ARG(!cs_part || cs_out || cs_rows > 0, "gemm: deferred column sums (colsum == NULL) are not available on this pipeline; ask cocodr_gemm_colsum_rows first");
   if (cs_rows == 0) a.colsum_partial = nullptr;
-  if (impl == 13 && cocodr_gemm_pp_launch_split(a, st)) { /* whole rounds + a cut last round */ }
+  // (a pipeline forced through cocodr_gemm_set_impl takes any cut the plan allows - tests, sweeps; the automatic selection only the measured window)
+  if (impl == 13 && (gemm_impl_override() != 0 || split_tail_wins(a)) && cocodr_gemm_pp_launch_split(a, st)) { /* whole rounds + a cut last round */ }
   else if (impl >= 13) cocodr_gemm_pp_launch(a, impl == 18 ? 105 : 2, st);
   else if (impl == 12) launch_glds_any<256, 64, 2, 1, 4, 3>(a, st);
   else if (impl == 11) launch_glds_any<256, 32, 2, 4>(a, st);

@@ -463,44 +463,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
         const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CLD + c8);
         const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CLD + c8 + 4);
         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-        if constexpr (!OUT_F32 && !MULTI && !TA && !TB && !F16) {  // (the plain forward form only: the other instantiations stay as they were)
-          // the fused vocabulary cross entropy (cocodr_decoder_ce).  A row's 256 columns of this tile sit in 32 consecutive lanes
-          // (one half-wave: CPRW = 32), so the row statistics are five lane exchanges; the branch is uniform per launch
-          if (p.epi >= COCODR_EPI_LSE) {
-            constexpr float kL2e = 1.4426950408889634f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += bias8[j];
-            const int lab = p.row_label[gm] - gn;  // this chunk holds the label's column iff 0 <= lab < 8
-            if (p.epi == COCODR_EPI_LSE) {
-              float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
-#pragma unroll
-              for (int o = 1; o < 32; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-              float sum = 0.f;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) sum += __builtin_amdgcn_exp2f((v[j] - m) * kL2e);
-#pragma unroll
-              for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
-              if ((tid & 31) == 0) {
-                float* st2 = p.lse_stats + ((size_t)gm * ntn + tn_) * 2;
-                st2[0] = m;
-                st2[1] = sum;
-              }
-              if (lab >= 0 && lab < 8) {
-                float lv = v[0];
-#pragma unroll
-                for (int j = 1; j < 8; ++j) lv = lab == j ? v[j] : lv;
-                p.label_logit[gm] = lv;
-              }
-            } else {  // COCODR_EPI_CE_GRAD
-              const float lse2 = p.row_lse[gm] * kL2e, sc = p.row_scale[gm];
-              float g[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) g[j] = sc * (__builtin_amdgcn_exp2f(v[j] * kL2e - lse2) - (lab == j ? 1.f : 0.f));
-              *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + (size_t)gm * p.ldc + gn) = pack8(g);
-            }
-            continue;
-          }
-        }
         epilogue_store8<OUT_F32, true, true>(p, z, bias, R_, gm, gn, v, rcur[i], bias8);
         if (do_colsum) {
 #pragma unroll

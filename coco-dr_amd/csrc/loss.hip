@@ -320,48 +320,6 @@ extern "C" int cocodr_ce_fwd_bwd(const float* logits, const int32_t* labels, con
   return COCODR_OK;
 }
 
-// ---- fused decoder GEMM + vocabulary cross entropy (include/cocodr.h cocodr_decoder_ce)
-namespace {
-// one thread per row: the per-tile (max, sum exp) pairs of pass 1 -> lse, loss
-__global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ stats, const float* __restrict__ label_logit, int n, int nt,
-                                                         float* __restrict__ lse_out, float* __restrict__ loss_rows) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float* st = stats + (size_t)i * nt * 2;
-  float m = -INFINITY;
-  for (int t = 0; t < nt; ++t) m = fmaxf(m, st[2 * t]);
-  float s = 0.f;
-  for (int t = 0; t < nt; ++t) s += st[2 * t + 1] * __expf(st[2 * t] - m);
-  const float lse = m + __logf(s);
-  lse_out[i] = lse;
-  loss_rows[i] = lse - label_logit[i];
-}
-}  // namespace
-
-extern "C" size_t cocodr_decoder_ce_workspace_floats(int n, int vpad) {
-  if (n <= 0 || vpad <= 0) return 0;
-  return (size_t)n * (vpad / 256) * 2 + 2 * (size_t)n + 8;
-}
-
-extern "C" int cocodr_decoder_ce(const uint16_t* t, const uint16_t* W, const float* bias, const int32_t* labels, const float* row_scale,
-                                 int n, int H, int vpad, float* loss_rows, uint16_t* dlogits, float* workspace, cocodr_stream_t stream) {
-  CK_ARG(t && W && bias && labels && row_scale && loss_rows && dlogits && workspace, "decoder_ce: null pointer");
-  CK_ARG(n > 0 && H > 0 && H % 64 == 0 && vpad > 0 && vpad % 256 == 0, "decoder_ce: bad shape n=%d H=%d vpad=%d (H %% 64 == 0, vpad %% 256 == 0)", n, H, vpad);
-  const int nt = vpad / 256;
-  float* stats = workspace;
-  float* lab_logit = workspace + (size_t)n * nt * 2;
-  float* lse = lab_logit + (((size_t)n + 3) & ~(size_t)3);
-  cocodr_gemm_args g = {};
-  g.A = t; g.B = W; g.bias = bias;
-  g.M = n; g.N = vpad; g.K = H; g.lda = H; g.ldb = H; g.ldc = vpad; g.batch = 1;
-  g.epi = COCODR_EPI_LSE; g.row_label = labels; g.lse_stats = stats; g.label_logit = lab_logit;
-  int rc = cocodr_gemm(&g, stream);
-  if (rc != COCODR_OK) return rc;
-  hipLaunchKernelGGL(ce_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, lab_logit, n, nt, lse, loss_rows);
-  CK_LAUNCH("decoder_ce(combine)");
-  g.epi = COCODR_EPI_CE_GRAD; g.C = dlogits; g.row_lse = lse; g.row_scale = row_scale; g.lse_stats = nullptr; g.label_logit = nullptr;
-  return cocodr_gemm(&g, stream);
-}
 
 extern "C" size_t cocodr_simce_workspace_floats(int M) { return (size_t)M * M + (size_t)M; }
 

@@ -1173,6 +1173,7 @@ __global__ __launch_bounds__(256) void lamb_moments_kernel(const float* __restri
 __global__ __launch_bounds__(64) void lamb_trust_kernel(const float* __restrict__ chunk_sums, const int* __restrict__ seg_chunk_begin,
                                                         float* __restrict__ trust, float* __restrict__ stats) {
   const int s = blockIdx.x, lane = threadIdx.x;
+  if (seg_chunk_begin[s] == seg_chunk_begin[s + 1]) return;  // a tensor the one-pass kernel owns (cocodr_lamb_step_fused): no chunks here
   float sw = 0.f, su = 0.f;
   for (int c = seg_chunk_begin[s] + lane; c < seg_chunk_begin[s + 1]; c += 64) { sw += chunk_sums[2 * c]; su += chunk_sums[2 * c + 1]; }
   sw = wave_sum(sw);
@@ -1206,7 +1207,207 @@ __global__ __launch_bounds__(256) void lamb_apply_kernel(float* __restrict__ p, 
     if (shadow && el >= shadow_begin) *reinterpret_cast<uint2*>(shadow + (el - shadow_begin)) = pack4(pa);
   }
 }
+
+// ---- LAMB in ONE pass over a tensor (round 5).  The two-pass form above moves 42 B / parameter because the trust ratio of a tensor
+// needs ||u|| of the WHOLE tensor before any element can be updated, so p, m, v are read a second time.  A weight matrix of the
+// encoder (<= 4 M elements) fits the chip's register files: here a persistent grid of G co-resident workgroups spreads every tensor
+// over all of them, pass 1 (m, v, u; p and u stay in registers) leaves one partial (sum w^2, sum u^2) per workgroup and an arrival
+// count, and once all G have arrived every workgroup adds the G partials in the same fixed order (deterministic, the same ratio
+// everywhere) and applies the step from its registers: 30 B / parameter (AdamW's traffic).  The arrival of tensor k is waited for
+// only after pass 1 of tensor k + 1 has been issued (two register sets), so nobody ever spins on a 20 us tensor.
+// Inter-workgroup visibility: partials are published with an agent-scope release in front of the relaxed arrival add, readers take
+// ONE agent-scope acquire behind their relaxed poll (MI355X_MICROARCH.md "Workgroup dispatch ... visibility").  The spin is bounded:
+// a grid that is not co-resident (it is sized from the occupancy query, minus one block per CU of margin) raises *err and the
+// step finishes with whatever arrived - wrong numbers and a loud flag instead of a hung queue.
+constexpr int LF_THREADS = 256, LF_V = 4, LF_PER_CU = 4;  // float4 per thread and tensor: capacity = G * 256 * 16 floats (G = 4 per CU)
+typedef float lf4 __attribute__((ext_vector_type(4)));
+struct LambFusedArgs {
+  float* p; const float* g; float* m; float* v; uint16_t* shadow; size_t shadow_begin;
+  const long long* seg_start; const int* seg_len; const int* seg_index; int nfused;
+  float beta1, beta2, eps, wd, grad_scale, lr; const float* grad_scale_dev;
+  float* part; int* counter; int* err; float* trust; float* stats;
+};
+__global__ __launch_bounds__(LF_THREADS, LF_PER_CU) void lamb_fused_kernel(const LambFusedArgs a) {
+  __shared__ float red[2][LF_THREADS / 64];
+  const int tid = threadIdx.x, bid = blockIdx.x, G = gridDim.x;
+  const float gs = a.grad_scale * (a.grad_scale_dev ? *a.grad_scale_dev : 1.0f);
+  auto block_sum2 = [&](float& x, float& y) {  // both sums over the workgroup, the same value in every thread
+    x = wave_sum(x);
+    y = wave_sum(y);
+    __syncthreads();  // (red is reused)
+    if ((tid & 63) == 0) { red[0][tid >> 6] = x; red[1][tid >> 6] = y; }
+    __syncthreads();
+    x = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    y = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  };
+  // A tensor is addressed through buffer descriptors that END with it: a lane whose float4 lies behind the tensor loads zeros
+  // (u = 0: no contribution to either norm) and its stores are dropped by the bounds check - no branches in the element loops, and
+  // 32-bit offsets.  aux 2 = non-temporal (streamed once).
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+  auto rsrc = [&](const void* base, size_t elem0, int n_elem, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + elem0 * bytes), 0, (uint32_t)((size_t)n_elem * bytes), 0x00020000);
+  };
+  const uint32_t off0 = (uint32_t)(bid * LF_THREADS + tid) * 16u, offj = (uint32_t)G * LF_THREADS * 16u;  // byte offset of float4 j: off0 + j offj
+  // pass 1 of tensor k: m, v updated in memory; P = the weights, U = the update direction, in registers
+  auto pass1 = [&](int k, lf4 (&P)[LF_V], lf4 (&U)[LF_V]) {
+    const size_t e0 = (size_t)a.seg_start[k];
+    const int n = a.seg_len[k];
+    const __amdgpu_buffer_rsrc_t rp = rsrc(a.p, e0, n, 4), rg = rsrc(a.g, e0, n, 4), rm = rsrc(a.m, e0, n, 4), rv = rsrc(a.v, e0, n, 4);
+    float sw = 0.f, su = 0.f;
+#pragma unroll
+    for (int j0 = 0; j0 < LF_V; j0 += 2) {  // two float4 quadruples in flight per thread: 8 x 16 B loads, then the arithmetic
+      lf4 gv[2], mv[2], vv[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const uint32_t o = off0 + (uint32_t)(j0 + jj) * offj;
+        P[j0 + jj] = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(rp, o, 0, 2));
+        gv[jj] = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(rg, o, 0, 2));
+        mv[jj] = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(rm, o, 0, 2));
+        vv[jj] = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(rv, o, 0, 2));
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = j0 + jj;
+        const uint32_t o = off0 + (uint32_t)j * offj;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ge = gv[jj][e] * gs;
+          mv[jj][e] = a.beta1 * mv[jj][e] + (1.0f - a.beta1) * ge;
+          vv[jj][e] = a.beta2 * vv[jj][e] + (1.0f - a.beta2) * ge * ge;
+          const float u = lamb_u(P[j][e], mv[jj][e], vv[jj][e], a.eps, a.wd);
+          U[j][e] = u;
+          sw += P[j][e] * P[j][e];
+          su += u * u;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, mv[jj]), rm, o, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, vv[jj]), rv, o, 0, 2);
+      }
+    }
+    block_sum2(sw, su);
+    if (tid == 0) {
+      float* mine = a.part + ((size_t)k * G + bid) * 2;
+      mine[0] = sw;
+      mine[1] = su;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (hipcc may drop the wait behind buffer_wbl2: restate it where it cannot)
+      __hip_atomic_fetch_add(a.counter + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  // wait for all G partials of tensor k, form the trust ratio, apply the step from the registers
+  auto apply = [&](int k, lf4 (&P)[LF_V], const lf4 (&U)[LF_V]) {
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(a.counter + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 25)) { *a.err = 1; break; }  // ~10 s: the grid is not co-resident
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    float sw = 0.f, su = 0.f;
+    for (int w = tid; w < G; w += LF_THREADS) {  // fixed order: thread t adds partials t, t + 256, ...; then the block tree
+      sw += a.part[((size_t)k * G + w) * 2];
+      su += a.part[((size_t)k * G + w) * 2 + 1];
+    }
+    block_sum2(sw, su);
+    const float wn = fminf(sqrtf(sw), 10.0f), un = sqrtf(su);
+    const float tr = (wn == 0.f || un == 0.f) ? 1.0f : wn / un;
+    if (bid == 0 && tid == 0) {
+      const int s = a.seg_index[k];
+      a.trust[s] = tr;
+      if (a.stats) { a.stats[2 * s] = wn; a.stats[2 * s + 1] = un; }
+    }
+    const float step = a.lr * tr;
+    const size_t e0 = (size_t)a.seg_start[k];
+    const int n = a.seg_len[k];
+    const __amdgpu_buffer_rsrc_t rp = rsrc(a.p, e0, n, 4);
+    const bool shadowed = a.shadow != nullptr && e0 >= a.shadow_begin;  // (workgroup-uniform)
+    const __amdgpu_buffer_rsrc_t rs = rsrc(a.shadow, shadowed ? e0 - a.shadow_begin : 0, shadowed ? n : 0, 2);
+#pragma unroll
+    for (int j = 0; j < LF_V; ++j) {
+      const uint32_t o = off0 + (uint32_t)j * offj;
+      float pa[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pa[e] = P[j][e] - step * U[j][e];
+      const lf4 t = {pa[0], pa[1], pa[2], pa[3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, t), rp, o, 0, 2);
+      const uint2 h = pack4(pa);
+      const u2v hv = {h.x, h.y};
+      __builtin_amdgcn_raw_buffer_store_b64(hv, rs, o >> 1, 0, 0);  // (num_records 0 when the tensor has no shadow: dropped)
+    }
+  };
+  lf4 P0[LF_V], U0[LF_V], P1[LF_V], U1[LF_V];
+  int k = 0;
+#pragma unroll 1
+  for (; k + 1 < a.nfused; k += 2) {
+    pass1(k, P0, U0);
+    if (k > 0) apply(k - 1, P1, U1);
+    pass1(k + 1, P1, U1);
+    apply(k, P0, U0);
+  }
+  if (k < a.nfused) {  // odd count: one more tensor in set 0
+    pass1(k, P0, U0);
+    if (k > 0) apply(k - 1, P1, U1);
+    apply(k, P0, U0);
+  } else if (k > 0) {
+    apply(k - 1, P1, U1);
+  }
+}
+// workgroups of the persistent grid: what is certainly co-resident per the occupancy query, at most LF_PER_CU per CU; 0 = the kernel
+// cannot run here
+int lamb_fused_grid() {
+  static int grid = -1;
+  if (grid < 0) {
+    int dev = 0, n_cu = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, lamb_fused_kernel, LF_THREADS, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      grid = 0;
+    } else {
+      // (the query is one block per CU high only where it answers 7 or 8 for 256-thread blocks - MI355X_MICROARCH.md "Residency")
+      const int safe = occ >= 7 ? occ - 1 : occ;
+      const int per_cu = safe < LF_PER_CU ? safe : LF_PER_CU;
+      grid = per_cu > 0 && n_cu > 0 ? per_cu * n_cu : 0;
+    }
+  }
+  return grid;
+}
 }  // namespace
+
+extern "C" size_t cocodr_lamb_fused_capacity(void) { return (size_t)lamb_fused_grid() * LF_THREADS * LF_V * 4; }
+extern "C" size_t cocodr_lamb_fused_workspace_floats(int nfused) {
+  return nfused > 0 ? (size_t)nfused * lamb_fused_grid() * 2 + (size_t)nfused + 4 : 0;
+}
+extern "C" size_t cocodr_lamb_fused_error_index(int nfused) { return (size_t)nfused * lamb_fused_grid() * 2 + (size_t)nfused; }
+extern "C" int cocodr_lamb_step_fused(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin,
+                                      const cocodr_lamb_fused_plan* plan, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                      float grad_scale, const float* grad_scale_dev, float* workspace, float* trust, float* stats,
+                                      cocodr_stream_t stream) {
+  CK_ARG(p && g && m && v && plan && workspace && trust, "lamb_step_fused: null pointer");
+  CK_ARG(plan->seg_start && plan->seg_len && plan->seg_index && plan->nfused > 0, "lamb_step_fused: incomplete plan");
+  CK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)workspace) & 15) == 0 && (((uintptr_t)shadow) & 7) == 0 &&
+             shadow_begin % 4 == 0, "lamb_step_fused: pointers must be 16-byte aligned");
+  CK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "lamb_step_fused: bad hyper-parameters");
+  const int G = lamb_fused_grid();
+  CK_ARG(G > 0, "lamb_step_fused: no co-resident grid on this device (cocodr_lamb_fused_capacity() == 0): use cocodr_lamb_step");
+  hipStream_t st = (hipStream_t)stream;
+  LambFusedArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.shadow = shadow; a.shadow_begin = shadow_begin;
+  a.seg_start = plan->seg_start; a.seg_len = plan->seg_len; a.seg_index = plan->seg_index; a.nfused = plan->nfused;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.grad_scale = grad_scale; a.lr = lr; a.grad_scale_dev = grad_scale_dev;
+  a.part = workspace;
+  a.counter = reinterpret_cast<int*>(workspace + (size_t)plan->nfused * G * 2);
+  a.err = a.counter + plan->nfused;
+  a.trust = trust; a.stats = stats;
+  if (hipMemsetAsync(a.counter, 0, ((size_t)plan->nfused + 1) * sizeof(int), st) != hipSuccess) {
+    cocodr_set_error("lamb_step_fused: hipMemsetAsync failed");
+    return COCODR_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(lamb_fused_kernel, dim3(G), dim3(LF_THREADS), 0, st, a);
+  CK_LAUNCH("lamb_step_fused");
+  return COCODR_OK;
+}
 
 extern "C" int cocodr_grad_norm_clip(const float* const* grads, const size_t* numels, int count, float max_norm, float* partial,
                                      float* out, cocodr_stream_t stream) {

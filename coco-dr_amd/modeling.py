@@ -347,6 +347,10 @@ def packed_extents(lengths, B: int, L: int, align: Optional[int] = None):
     return host, int(host[-1]), int((ext.max() + 31) // 32 * 32)
 
 
+class NotPrefixMask(ValueError):
+    """A batch whose layout was planned on the device turned out not to be packable (some attention mask is not 1 .. 1 0 .. 0)."""
+
+
 class PackedIndex:
     """Device-side description of a batch stored back to back (include/cocodr.h "Packed batches"): sequence b owns rows
     [seq_off[b], seq_off[b+1]): its length (``PACK_ALIGN`` = 1), see ``packed_extents``.  ``src`` maps packed row -> row of the padded [B*L] layout.
@@ -417,14 +421,17 @@ class PackedIndex:
     PLAN_MAX_B = 4096
 
     @classmethod
-    def from_mask(cls, ids: torch.Tensor, mask: torch.Tensor) -> Optional["PackedIndex"]:
+    def from_mask(cls, ids: torch.Tensor, mask: torch.Tensor, lazy: bool = False) -> Optional["PackedIndex"]:
         """The reference's batch unchanged - padded ids + attention mask in HBM, no lengths on the host (COCO/data.py:150-154,
         ANCE/data/msmarco_data.py:381-382): lengths, extents, offsets, order AND the row arrays are all built on the device
         (``cocodr_mask_lengths`` -> ``cocodr_pack_plan`` -> ``cocodr_pack_index``, queued back to back); the host reads back 16
         bytes - {T, longest extent, prefix masks?} - through a pinned buffer behind an event recorded in front of the last
         launch, because T sizes every GEMM of the step.  The wait ends when the stream reaches the plan kernel (it cannot end
-        earlier: the mask may be the result of work queued just before), and everything that does not depend on T has been
-        prepared by then.  None: some mask is not a prefix mask (the caller runs padded)."""
+        earlier: the mask may be the result of work queued just before).  ``lazy``: return at once and wait at the first use of
+        ``T`` / the [T] arrays / ``c_struct`` - the encoder forward prepares everything that does not depend on T (weight structs,
+        the arena at its padded bound, the autograd node) first, so ~20 us of host work separate the wait from the first launch;
+        a batch that turns out not to be packable then raises ``NotPrefixMask`` at that use (``CocoBertModel.forward`` falls back to
+        the padded execution).  Not lazy: None when some mask is not a prefix mask."""
         ids, B, L_in, Lp = cls._check_ids(ids, None)
         dev = ids.device
         self = cls.__new__(cls)
@@ -440,17 +447,39 @@ class PackedIndex:
         ready.record()
         self._finish(ids, staged, B * Lp, launch=False)
         self._launch_index(ids, staged)  # (takes lens / offsets from the plan: queued before the host knows T)
+        self._keep = self._keep + (scratch,)
+        self._pending = (ready, host)
+        if lazy:  # T, max_len, the [T] arrays and c_struct resolve at first use (the encoder prepares everything else first)
+            return self
+        return self if self.resolve() else None
+
+    #: attributes that exist once T has reached the host
+    _LAZY = frozenset(("T", "max_len", "ids", "positions", "mask", "cls_slot", "src", "c_struct"))
+
+    def resolve(self) -> bool:
+        """Wait (if still pending) for the 16 bytes of a device-planned layout; False: the masks are not prefix masks."""
+        pend = self.__dict__.get("_pending")
+        if pend is None:
+            return self.__dict__.get("_ok", True)
+        ready, host = pend
         ready.synchronize()
         T, max_len, ok, _ = (int(v) for v in host.tolist())
-        if not ok:
-            return None
-        self.T, self.max_len = T, max_len
-        self._keep = self._keep + (scratch,)
-        self._bind(T)
-        return self
+        self._pending, self._ok = None, bool(ok)
+        if ok:
+            self.T, self.max_len = T, max_len
+            self._bind(T)
+        return self._ok
+
+    def __getattr__(self, name):  # (only reached when the attribute is not set yet)
+        if name in PackedIndex._LAZY:
+            if self.__dict__.get("_pending") is not None and self.resolve():
+                return self.__dict__[name]
+            if self.__dict__.get("_ok") is False:
+                raise NotPrefixMask("the batch cannot be packed: an attention mask is not a prefix mask (1 .. 1 0 .. 0)")
+        raise AttributeError(name)
 
     @staticmethod
-    def build(ids: torch.Tensor, mask: Optional[torch.Tensor] = None, lengths=None) -> Optional["PackedIndex"]:
+    def build(ids: torch.Tensor, mask: Optional[torch.Tensor] = None, lengths=None, lazy: bool = False) -> Optional["PackedIndex"]:
         """``lengths`` (host integers, = attention_mask.sum(1) of prefix masks): no device -> host traffic.  Otherwise the layout
         is planned on the device from the mask and 16 bytes come back (``from_mask``); None when a mask is not a prefix mask
         (the reference pads at the end, COCO/data.py:135-144; anything else runs padded)."""
@@ -474,7 +503,7 @@ class PackedIndex:
         if mask.element_size() not in (1, 4, 8) or mask.is_floating_point() or mask.stride(1) != 1:
             mask = mask.to(torch.int32).contiguous()
         if B <= PackedIndex.PLAN_MAX_B and PACK_ALIGN == 1:
-            return PackedIndex.from_mask(ids, mask)
+            return PackedIndex.from_mask(ids, mask, lazy)
         out = torch.empty(2 * B, dtype=torch.int32, device=ids.device)
         check(lib().cocodr_mask_lengths(ptr(mask), mask.element_size(), B, L, mask.stride(0), ptr(out), ptr(out[B:]), stream_ptr()), "mask_lengths")
         host = out.cpu().numpy()
@@ -818,23 +847,33 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
     def _run_forward_packed(self, pk: "PackedIndex", training: bool, cls_tail: bool = False):
         if not self.flat_decay.is_cuda:
             raise RuntimeError("CocoBertModel runs on an MI355X only: move it with .to('cuda') (there is no CPU fallback)")
+        # Everything that does not depend on the row count T comes first: a layout planned on the device (PackedIndex.from_mask,
+        # the reference's batch without host lengths) is still on its way to the host, and the wait for it should be followed by
+        # as little host work as possible (the GPU is idle from the moment it has produced T until the first launch below)
         self._refresh_shadow()
-        if training:
-            self._dp_note_forward()
-        lay = N.EncoderLayout()
-        arena_drop = self._next_dropout(training)
-        tail = bool(cls_tail and arena_drop is None and (not training or pk.B % 8 == 0))
-        cfg = self._c_config(arena_drop, tail)
-        check(lib().cocodr_encoder_layout_packed(C.byref(cfg), pk.T, pk.B, int(training), C.byref(lay)), "encoder_layout_packed")
+        emb, arr, _, _ = self._param_structs()
+        c = self.config  # (what _next_dropout will decide; it also advances the call counter, so it runs after the wait)
+        drops = bool(training and self.training and (c.hidden_dropout_prob > 0 or c.attention_probs_dropout_prob > 0))
+        tail = bool(cls_tail and not drops and (not training or pk.B % 8 == 0))
         # T changes with every batch; the arena is allocated at the size of the PADDED batch (B x L rows, the upper bound of T) so
         # that the caching allocator hands back the same block step after step instead of growing / splitting a 10-20 GB block
         # whenever a batch is a little longer than any before it (a hipMalloc of that size inside a step costs tens of ms)
         cap = N.EncoderLayout()
-        check(lib().cocodr_encoder_layout_packed(C.byref(cfg), pk.B * pk.L, pk.B, int(training), C.byref(cap)), "encoder_layout_packed")
-        arena = torch.empty(max(cap.total_bytes, lay.total_bytes), dtype=torch.uint8, device=pk.ids.device)
+        check(lib().cocodr_encoder_layout_packed(C.byref(self._c_config(None, tail)), pk.B * pk.L, pk.B, int(training), C.byref(cap)), "encoder_layout_packed")
+        arena = torch.empty(cap.total_bytes, dtype=torch.uint8, device=self.flat_decay.device)
+        if not pk.resolve():  # <- the only wait of a step without host lengths
+            raise NotPrefixMask("the batch cannot be packed: an attention mask is not a prefix mask (1 .. 1 0 .. 0)")
+        if training:
+            self._dp_note_forward()
+        arena_drop = self._next_dropout(training)
+        assert (arena_drop is not None) == drops
+        cfg = self._c_config(arena_drop, tail)
+        lay = N.EncoderLayout()
+        check(lib().cocodr_encoder_layout_packed(C.byref(cfg), pk.T, pk.B, int(training), C.byref(lay)), "encoder_layout_packed")
+        if lay.total_bytes > cap.total_bytes:
+            arena = torch.empty(lay.total_bytes, dtype=torch.uint8, device=self.flat_decay.device)
         arena._cocodr_drop = arena_drop
         arena._cocodr_tail = tail
-        emb, arr, _, _ = self._param_structs()
         check(lib().cocodr_encoder_fwd_packed(C.byref(cfg), C.byref(emb), arr, C.byref(pk.c_struct), int(training), ptr(arena),
                                               arena.numel(), stream_ptr()), "encoder_fwd_packed")
         return arena, lay
@@ -920,11 +959,28 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         ``no_sync()`` is rebound to this model's, so gradient-accumulation loops written against DDP
         (ANCE/drivers/run_ann.py:318-341) keep their meaning.  tests/test_gpu_distributed.py::test_reference_ddp_wrap_line_*."""
         from torch.nn.parallel import DistributedDataParallel as DDP
-        ddp = getattr(DDP, "_active_ddp_module", None)
+        if not hasattr(DDP, "_active_ddp_module"):  # (a private attribute of torch's wrapper: say so when a torch release drops it)
+            if not getattr(CocoBertModel, "_warned_ddp_api", False) and torch.distributed.is_available() and torch.distributed.is_initialized():
+                CocoBertModel._warned_ddp_api = True
+                import warnings
+                warnings.warn("cocodr_amd: this torch has no DistributedDataParallel._active_ddp_module - a model wrapped in DDP cannot "
+                              "detect its wrapper and its flat gradients would NOT be reduced; call model.enable_grad_allreduce() instead")
+            return
+        ddp = DDP._active_ddp_module
         if ddp is None:
             return
         adopted = ddp.__dict__.get("_cocodr_adopted")
         if adopted is None:
+            # the wrapper's reducer is about to be made passive: that is only right when everything it wraps is a view of adopted
+            # flat storage.  An ordinary nn.Parameter in the wrapped module (a projection head, DRO weights) would silently never be
+            # reduced - refuse instead (ADVICE r04)
+            from .flatparams import ViewParameter
+            plain = [n for n, q in ddp.module.named_parameters() if q.requires_grad and not isinstance(q, ViewParameter)]
+            if plain:
+                raise RuntimeError("DistributedDataParallel wraps ordinary parameters next to the cocodr_amd encoder (" + ", ".join(plain[:4]) +
+                                   (", ..." if len(plain) > 4 else "") + "): the encoder reduces its own flat gradients and keeps torch's "
+                                   "reducer passive, so these would never be averaged.  Wrap them in their own DDP module, or reduce the "
+                                   "encoder with model.enable_grad_allreduce() and leave it out of the wrapper")
             adopted = ddp.__dict__["_cocodr_adopted"] = {"models": [], "in_no_sync": False}
             import contextlib
 
@@ -950,7 +1006,7 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
                 raise RuntimeError("CocoBertModel: enable_grad_allreduce() was set up on a different process group than the "
                                    "DistributedDataParallel wrapper around this model")
         ddp.require_backward_grad_sync = False  # the wrapper's reducer has nothing to reduce: keep it passive
-        if not adopted["in_no_sync"]:
+        if not adopted["in_no_sync"] and not getattr(self, "_dp_user_no_sync", 0):  # (a no_sync() the user opened on the model itself stands)
             self._dp_enabled = not in_no_sync
 
     def _dp_note_forward(self) -> None:
@@ -981,9 +1037,11 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         def ctx():
             was = getattr(self, "_dp_enabled", False)
             self._dp_enabled = False
+            self._dp_user_no_sync = getattr(self, "_dp_user_no_sync", 0) + 1
             try:
                 yield
             finally:
+                self._dp_user_no_sync -= 1
                 self._dp_enabled = was
         return ctx()
 
@@ -1099,7 +1157,7 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
             mask = torch.nn.functional.pad(mask, (0, Lp - L))
         return ids.contiguous(), mask.contiguous(), L
 
-    def pack(self, input_ids, attention_mask=None, lengths=None) -> Optional["PackedIndex"]:
+    def pack(self, input_ids, attention_mask=None, lengths=None, lazy: bool = False) -> Optional["PackedIndex"]:
         """The packed-layout description of a batch (or None when its masks are not prefix masks), for callers that reuse a
         batch: ``forward`` builds it per call when ``pack_sequences`` is set (one native launch; see ``PackedIndex`` for what
         knowing the ``lengths`` on the host saves)."""
@@ -1107,7 +1165,7 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
             raise ValueError(f"input_ids must be [B, L], got {tuple(input_ids.shape)}")
         if input_ids.dtype not in (torch.int32, torch.int64):
             input_ids = input_ids.to(torch.int32)
-        return PackedIndex.build(input_ids, attention_mask, lengths)
+        return PackedIndex.build(input_ids, attention_mask, lengths, lazy)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None,
                 output_hidden_states: bool = False, return_dict: bool = True, packed_index: Optional["PackedIndex"] = None,
@@ -1140,17 +1198,19 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         elif pk is None and self.pack_sequences:
             if not self.flat_decay.is_cuda:
                 raise RuntimeError("CocoBertModel runs on an MI355X only: move it with .to('cuda') (there is no CPU fallback)")
-            pk = self.pack(input_ids, attention_mask, lengths)  # None: not prefix masks -> padded
+            pk = self.pack(input_ids, attention_mask, lengths, lazy=True)  # None: not prefix masks -> padded
+        cls_only = bool(cls_only and not output_hidden_states and self.cls_tail)
+        if pk is not None:
+            try:
+                last, cls = _PackedEncoderFn.apply(*self._flat_leaves(), self, pk, torch.is_grad_enabled(), cls_only)
+            except NotPrefixMask:  # (a device-planned layout, resolved inside the forward: some mask has holes - run padded)
+                pk = None
         ids = mask = None
         if pk is None:
             if attention_mask is None and lengths is not None:  # padded run of a batch described by its lengths alone
                 lens_dev = torch.as_tensor(lengths, dtype=torch.int64).reshape(-1).to(input_ids.device)
                 attention_mask = (torch.arange(L, device=input_ids.device)[None] < lens_dev[:, None]).to(torch.int32)
             ids, mask, L = self._prep(input_ids, attention_mask)
-        cls_only = bool(cls_only and not output_hidden_states and self.cls_tail)
-        if pk is not None:
-            last, cls = _PackedEncoderFn.apply(*self._flat_leaves(), self, pk, torch.is_grad_enabled(), cls_only)
-        else:
             outs = _EncoderFn.apply(*self._flat_leaves(), ids, mask, self, torch.is_grad_enabled(), want_taps, cls_only)
             last, cls, taps = outs[0], outs[1], outs[2:]
         if last is None:  # [CLS] tail

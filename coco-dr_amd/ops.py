@@ -323,24 +323,6 @@ def scatter_cls_grad(dE: torch.Tensor, L: int, out: Optional[torch.Tensor] = Non
 
 
 # ----------------------------------------------------------------------------------------------- losses
-def decoder_ce(t: torch.Tensor, word16: torch.Tensor, bias: torch.Tensor, labels: torch.Tensor, row_scale: torch.Tensor):
-    """Fused decoder GEMM + vocabulary cross entropy (``cocodr_decoder_ce``): t bf16 [n, H], word16 bf16 [vpad, H] (vpad % 256 == 0),
-    bias fp32 [vpad] (<= -1e30 on padding columns), labels int32 [n], row_scale fp32 [n] ->
-    (loss_rows fp32 [n], dlogits bf16 [n, vpad] = row_scale * (softmax - onehot)).  The logits are never written."""
-    n, H = t.shape
-    vpad = word16.shape[0]
-    _req(t, BF16, "decoder_ce t", 2), _req(word16, BF16, "decoder_ce word16", 2), _req(bias, F32, "decoder_ce bias", 1)
-    _req(labels, I32, "decoder_ce labels", 1), _req(row_scale, F32, "decoder_ce row_scale", 1)
-    if bias.numel() != vpad or labels.numel() != n or row_scale.numel() != n or word16.shape[1] != H:
-        raise ValueError("decoder_ce: shape mismatch")
-    loss_rows = torch.empty(n, dtype=torch.float32, device=t.device)
-    dlogits = torch.empty((n, vpad), dtype=torch.bfloat16, device=t.device)
-    ws = torch.empty(int(lib().cocodr_decoder_ce_workspace_floats(n, vpad)), dtype=torch.float32, device=t.device)
-    check(lib().cocodr_decoder_ce(ptr(t), ptr(word16), ptr(bias), ptr(labels), ptr(row_scale), n, H, vpad,
-                                  ptr(loss_rows), ptr(dlogits), ptr(ws), stream_ptr()), "decoder_ce")
-    return loss_rows, dlogits
-
-
 def simce_fwd_bwd(E: torch.Tensor, world: int = 1, row0: int = 0, m_local: Optional[int] = None):
     """Returns (loss scalar tensor, loss_rows [M], dE_local [m_local, H]) - COCO/modeling.py:244-248."""
     _req(E, F32, "E", 2)

@@ -35,21 +35,38 @@ def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float) -> torc
     return out
 
 
-def lamb_plan(offsets: Sequence[int], numel: int, chunk: int = 4096) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+def lamb_plan(offsets: Sequence[int], numel: int, chunk: int = 4096, skip: Sequence[int] = ()) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
     """Chunk table for ``cocodr_lamb_step``: tensor s covers ``[offsets[s], offsets[s+1])`` (the last one runs to
     ``numel``; alignment padding between tensors rides with the tensor in front of it - it holds zeros and receives
-    zero gradients, so it changes no norm).  Returns (chunk_start i64, chunk_len i32, chunk_seg i32, seg_chunk_begin i32)."""
+    zero gradients, so it changes no norm).  Tensors listed in ``skip`` get no chunks (the one-pass kernel updates them,
+    ``lamb_fused_plan``).  Returns (chunk_start i64, chunk_len i32, chunk_seg i32, seg_chunk_begin i32)."""
     offs = list(offsets) + [numel]
     if offs[0] != 0 or any(b <= a for a, b in zip(offs, offs[1:])) or any(o % 4 for o in offs):
         raise ValueError("lamb_plan: offsets must start at 0, increase strictly and be multiples of 4")
+    skip = set(skip)
     start, length, seg, seg_begin = [], [], [], [0]
     for s, (a, b) in enumerate(zip(offs, offs[1:])):
-        for c in range(a, b, chunk):
-            start.append(c)
-            length.append(min(chunk, b - c))
-            seg.append(s)
+        if s not in skip:
+            for c in range(a, b, chunk):
+                start.append(c)
+                length.append(min(chunk, b - c))
+                seg.append(s)
         seg_begin.append(len(start))
     return (np.asarray(start, np.int64), np.asarray(length, np.int32), np.asarray(seg, np.int32), np.asarray(seg_begin, np.int32))
+
+
+#: tensors below this size stay on the two-pass kernels: the one-pass kernel pays one chip-wide rendezvous per tensor
+LAMB_FUSED_MIN = 1 << 18
+
+
+def lamb_fused_plan(offsets: Sequence[int], numel: int, capacity: int, min_len: int = LAMB_FUSED_MIN):
+    """The tensors of a flat parameter that ``cocodr_lamb_step_fused`` updates in one pass: at least ``min_len`` elements and at
+    most ``capacity`` (what the persistent grid keeps in registers: ``cocodr_lamb_fused_capacity()``).  Returns (indices into
+    ``offsets``, seg_start i64, seg_len i32, seg_index i32) - empty arrays when nothing qualifies."""
+    offs = list(offsets) + [numel]
+    idx = [s for s, (a, b) in enumerate(zip(offs, offs[1:])) if min_len <= b - a <= capacity]
+    return (idx, np.asarray([offs[s] for s in idx], np.int64), np.asarray([offs[s + 1] - offs[s] for s in idx], np.int32),
+            np.asarray(idx, np.int32))
 
 
 def _shadow_owners(model) -> dict:
@@ -151,16 +168,45 @@ class FlatLamb(torch.optim.Optimizer):
         opt._owners = _shadow_owners(model)
         return opt
 
+    #: False: every tensor through the two-pass kernels (A/B switch; the tests run both)
+    one_pass = True
+
     def _plan(self, p, offs):
-        key = id(p)
+        """(two-pass plan or None, one-pass plan or None, keep-alive, workspace, stats, one-pass workspace): the weight matrices
+        (>= 2^18 elements, <= what the persistent grid holds in registers) go through ``cocodr_lamb_step_fused`` - 30 instead of
+        42 B / parameter -, everything else (vectors, the embedding tables) through ``cocodr_lamb_step``."""
+        key = (id(p), bool(self.one_pass))
         if key not in self._plans:
-            arrs = lamb_plan(offs, p.numel())
-            dev = [torch.from_numpy(a).to(p.device) for a in arrs]
-            plan = N.LambPlan(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), len(arrs[0]), len(offs))
+            fused_idx, fplan, fws = [], None, None
+            keep = []
+            if self.one_pass:
+                cap = int(lib().cocodr_lamb_fused_capacity())
+                fused_idx, f_start, f_len, f_seg = lamb_fused_plan(offs, p.numel(), cap) if cap > 0 else ([], None, None, None)
+                if fused_idx:
+                    fdev = [torch.from_numpy(a).to(p.device) for a in (f_start, f_len, f_seg)]
+                    keep += fdev
+                    fplan = N.LambFusedPlan(fdev[0].data_ptr(), fdev[1].data_ptr(), fdev[2].data_ptr(), len(fused_idx))
+                    fws = torch.zeros(int(lib().cocodr_lamb_fused_workspace_floats(len(fused_idx))), dtype=torch.float32, device=p.device)
+            arrs = lamb_plan(offs, p.numel(), skip=fused_idx)
+            plan = None
+            if len(arrs[0]):
+                dev = [torch.from_numpy(a).to(p.device) for a in arrs]
+                keep += dev
+                plan = N.LambPlan(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), len(arrs[0]), len(offs))
             ws = torch.empty(2 * len(arrs[0]) + len(offs), dtype=torch.float32, device=p.device)
             stats = torch.empty((len(offs), 2), dtype=torch.float32, device=p.device)
-            self._plans[key] = (plan, dev, ws, stats)
+            self._plans[key] = (plan, fplan, keep, ws, stats, fws, 2 * len(arrs[0]))
         return self._plans[key]
+
+    def one_pass_error(self) -> bool:
+        """True if a workgroup of the one-pass kernel ever gave up waiting for the others (a device that cannot hold its grid:
+        the numbers of that step are wrong).  Reads the flags back: a debugging / test call, not part of a step."""
+        bad = False
+        for (plan, fplan, _keep, _ws, _stats, fws, _t0) in self._plans.values():
+            if fplan is not None:
+                i = int(lib().cocodr_lamb_fused_error_index(fplan.nfused))
+                bad |= bool(fws[i:i + 1].view(torch.int32).item())
+        return bad
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, clip: torch.Tensor = None):
@@ -184,16 +230,22 @@ class FlatLamb(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
-                plan, _keep, ws, stats = self._plan(p, offs)
+                plan, fplan, _keep, ws, stats, fws, trust0 = self._plan(p, offs)
                 shadow, begin = None, 0
                 m = self._owners.get(id(p))
                 if m is not None:
                     shadow, begin = m._shadow_target()
-                check(lib().cocodr_lamb_step(ptr(p), ptr(p.grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(shadow), begin,
-                                             p.numel(), C.byref(plan), float(group["lr"]), b1, b2, group["eps"],
-                                             group["weight_decay"], grad_scale, None if clip is None else clip.data_ptr() + 4,
-                                             ptr(ws), ptr(stats), stream_ptr()), "lamb_step")
+                gsd = None if clip is None else clip.data_ptr() + 4
+                if plan is not None:
+                    check(lib().cocodr_lamb_step(ptr(p), ptr(p.grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(shadow), begin,
+                                                 p.numel(), C.byref(plan), float(group["lr"]), b1, b2, group["eps"],
+                                                 group["weight_decay"], grad_scale, gsd, ptr(ws), ptr(stats), stream_ptr()), "lamb_step")
+                if fplan is not None:
+                    check(lib().cocodr_lamb_step_fused(ptr(p), ptr(p.grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(shadow), begin,
+                                                       C.byref(fplan), float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                                                       grad_scale, gsd, ptr(fws), ptr(ws[trust0:]), ptr(stats), stream_ptr()),
+                          "lamb_step_fused")
                 st["weight_norm"], st["adam_norm"] = stats[:, 0], stats[:, 1]
-                st["trust_ratio"] = ws[2 * plan.nchunk:]
+                st["trust_ratio"] = ws[trust0:]
                 _after_native_update(p, m, shadow is not None)
         return loss

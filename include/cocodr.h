@@ -84,10 +84,7 @@ enum {
   COCODR_EPI_NONE = 0,      /* C = acc (+bias)                                  */
   COCODR_EPI_GELU = 1,      /* u = acc+bias: C = gelu(u), C2 = gelu'(u)         */
   COCODR_EPI_ADD = 2,       /* C = acc (+bias) + R                              */
-  COCODR_EPI_DGELU = 3,     /* C = acc * R          (R = the C2 of EPI_GELU)    */
-  /* the two passes of the fused vocabulary cross entropy (cocodr_decoder_ce; 256 x 256-tile pipeline, NT form, batch 1): */
-  COCODR_EPI_LSE = 4,       /* no C: per row and 256-column tile (max, sum exp(u - max)) of u = acc + bias -> lse_stats, u[label] -> label_logit */
-  COCODR_EPI_CE_GRAD = 5    /* C (bf16) = row_scale * (exp(u - row_lse) - [column == row_label]) */
+  COCODR_EPI_DGELU = 3      /* C = acc * R          (R = the C2 of EPI_GELU)    */
 };
 typedef struct {
   const uint16_t* A;
@@ -116,13 +113,6 @@ typedef struct {
    * counts (packed batches) on that pipeline.  cocodr_gemm_split_workspace_floats() floats serve any call; NULL: whole tiles. */
   float* split_ws;
   size_t split_ws_floats;
-  /* EPI_LSE / EPI_CE_GRAD: per-row operands (length M).  EPI_LSE writes lse_stats fp32 [M][N / 256][2] and label_logit fp32 [M];
-   * EPI_CE_GRAD reads row_lse, row_scale (fp32) and row_label (int32; a column index, or -1 for none) */
-  const float* row_lse;
-  const float* row_scale;
-  const int32_t* row_label;
-  float* lse_stats;
-  float* label_logit;
 } cocodr_gemm_args;
 size_t cocodr_gemm_split_workspace_floats(void);
 size_t cocodr_gemm_colsum_partial_floats(int M, int N);
@@ -278,6 +268,28 @@ int cocodr_lamb_step(float* p, const float* g, float* m, float* v, uint16_t* sha
                      const cocodr_lamb_plan* plan, float lr, float beta1, float beta2, float eps, float weight_decay,
                      float grad_scale, const float* grad_scale_dev, float* workspace, float* stats,
                      cocodr_stream_t stream);
+/* The same update in ONE pass (30 instead of 42 B / parameter) for the tensors of a flat parameter that fit the chip's register
+ * files - the encoder's weight matrices: a persistent grid of co-resident workgroups spreads each tensor over all of them, keeps w
+ * and u in registers between the norm and the update, and exchanges per-workgroup partial norms through `workspace` (added in a
+ * fixed order: deterministic; same arithmetic per element as cocodr_lamb_step).  plan: tensor k = elements [seg_start[k],
+ * seg_start[k] + seg_len[k]) (multiples of 4, seg_len[k] <= cocodr_lamb_fused_capacity(), which is 0 where the kernel cannot run),
+ * seg_index[k] = its row in trust / stats (the tensor numbering of the cocodr_lamb_plan the rest of the flat goes through: give
+ * those tensors NO chunks there).  workspace: cocodr_lamb_fused_workspace_floats(nfused) floats; the int at float index
+ * cocodr_lamb_fused_error_index(nfused) is set to 1 if a workgroup gave up waiting for the others (never, unless the device
+ * cannot hold the grid; the numbers of that step are then wrong).  trust fp32 [>= max seg_index + 1]. */
+typedef struct {
+  const long long* seg_start;
+  const int* seg_len;
+  const int* seg_index;
+  int nfused;
+} cocodr_lamb_fused_plan;
+size_t cocodr_lamb_fused_capacity(void);
+size_t cocodr_lamb_fused_workspace_floats(int nfused);
+size_t cocodr_lamb_fused_error_index(int nfused);
+int cocodr_lamb_step_fused(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin,
+                           const cocodr_lamb_fused_plan* plan, float lr, float beta1, float beta2, float eps, float weight_decay,
+                           float grad_scale, const float* grad_scale_dev, float* workspace, float* trust, float* stats,
+                           cocodr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses
@@ -310,16 +322,6 @@ int cocodr_allgather_rows(const float* local_rows, float* gathered, int rows, in
  * dlogits bf16 [n, ld] = row_scale_i * (softmax_i - onehot_i), zero in the padding columns. */
 int cocodr_ce_fwd_bwd(const float* logits, const int32_t* labels, const float* row_scale, int n, int V, int ld,
                       float* loss_rows, uint16_t* dlogits, cocodr_stream_t stream);
-/* The same loss and gradient FUSED with the decoder GEMM (COCO/modeling.py:87-93: lm.cls's decoder tied to the word table, then
- * CrossEntropyLoss): the fp32 [n, V] logits never reach HBM.  Pass 1: logits tile by tile on the 256 x 256-tile GEMM pipeline, the
- * epilogue keeps per row and tile (max, sum exp) and the label's logit; a small kernel combines the tiles into lse and
- * loss_rows[i] = lse_i - logit_i[label_i]; pass 2 recomputes the tiles and writes dlogits bf16 [n, vpad] = row_scale_i *
- * (softmax_i - onehot_i) (what the two backward GEMMs of the decoder read).  t bf16 [n, H] (the MLM transform's output rows),
- * W bf16 [vpad, H], bias fp32 [vpad] with <= -1e30 on the padding columns >= V (their probabilities are exactly 0),
- * vpad % 256 == 0, H % 64 == 0; workspace: cocodr_decoder_ce_workspace_floats(n, vpad) floats. */
-size_t cocodr_decoder_ce_workspace_floats(int n, int vpad);
-int cocodr_decoder_ce(const uint16_t* t, const uint16_t* W, const float* bias, const int32_t* labels, const float* row_scale, int n,
-                      int H, int vpad, float* loss_rows, uint16_t* dlogits, float* workspace, cocodr_stream_t stream);
 
 /* out [G,G] = A A^T for a short, very wide fp32 matrix A [G, D] (row stride lda), G <= 64: iDRO's gram of the per-group
  * gradients (ANCE/model/dro_loss.py:236-238 `all_grads @ all_grads.T`, D = the parameters of BertLayers 9-11).  One pass

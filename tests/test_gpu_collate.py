@@ -49,10 +49,15 @@ def test_cocondenser_collator_lays_span_pairs_back_to_back():
     assert out["input_ids"].shape == (10, 64)
     att = out["attention_mask"].cpu().numpy()
     assert list(att.sum(1)) == [22, 32] * 5  # rows 2i / 2i+1 are the two spans of document i (COCO/modeling.py:172-177)
-    # the host-known lengths the model packs from (no read-back of the mask): a numpy array, = attention_mask.sum(1)
-    assert isinstance(out["lengths"], np.ndarray) and out["lengths"].tolist() == [22, 32] * 5
+    assert set(out) == {"input_ids", "labels", "attention_mask"}  # the reference's batch, nothing else (COCO/data.py:150-154)
+    # opt-in: the host-known lengths a model can pack from without reading anything back - a CPU tensor (= attention_mask.sum(1)),
+    # so code that calls .split() on every value of the batch (COCO/trainer.py:137-140) cuts it with the rest
+    col_l = CoCondenserCollator(flags, max_seq_length=64, seed=4, emit_lengths=True)
+    out_l = col_l(docs)
+    assert torch.is_tensor(out_l["lengths"]) and not out_l["lengths"].is_cuda and out_l["lengths"].tolist() == [22, 32] * 5
+    assert torch.equal(out_l["input_ids"], out["input_ids"]) and [t.shape[0] for t in out_l["lengths"].split(4)] == [4, 4, 2]
     long_doc = [{"span": [rng.integers(104, 2000, 200).tolist(), rng.integers(104, 2000, 62).tolist()]}]
-    o2 = col(long_doc)
+    o2 = col_l(long_doc)
     assert o2["lengths"].tolist() == o2["attention_mask"].sum(1).cpu().tolist() == [64, 64]  # truncated to max_seq_length - 2 (+ [CLS], [SEP])
     lab = out["labels"].cpu().numpy()
     assert ((lab != -100).sum(1) >= 1).all()

@@ -348,6 +348,66 @@ def test_flat_lamb_on_the_model_matches_the_oracle_per_tensor():
     assert torch.equal(m._shadow, m.flat_decay.data[lo.mat_begin:].to(torch.bfloat16))
 
 
+def test_one_pass_lamb_equals_the_two_pass_kernels_and_the_oracle_on_matrix_sized_tensors():
+    """cocodr_lamb_step_fused (the weight matrices in ONE pass: w and u stay in registers between the norm and the update) against the
+    two-pass kernels on the same flat - BERT-large's matrix shapes, a tensor with a ragged tail, small tensors and an over-sized one
+    that stay on the two-pass path - and against the fp64 oracle; three steps with clipping and weight decay; the rendezvous never
+    timed out."""
+    import oracle as O
+    from cocodr_amd.optim import FlatLamb, LAMB_FUSED_MIN, clip_grad_norm_
+    from cocodr_amd._native import lib
+    cap = int(lib().cocodr_lamb_fused_capacity())
+    assert cap >= 4096 * 1024, cap  # BERT-large's FFN matrices fit
+    sizes = [1024, 3072 * 1024, 1024 * 1024, 64, 4096 * 1024, 4096 * 1024 - 12, LAMB_FUSED_MIN, LAMB_FUSED_MIN - 64, cap + 4, 300 * 1024 + 20]
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o = (o + n + 63) // 64 * 64
+    g = torch.Generator().manual_seed(4)
+    p0 = torch.randn(o, generator=g) * 0.05
+    for i, n in enumerate(sizes):  # padding between tensors holds zeros
+        p0[offs[i] + n: (offs + [o])[i + 1]] = 0
+    p0[offs[3]: offs[3] + 64] = 0  # a tensor of zeros: trust ratio 1
+    runs = {}
+    for one_pass in (True, False):
+        p = torch.nn.Parameter(p0.clone().to(DEV))
+        opt = FlatLamb([p], [offs], lr=2e-3, eps=1e-6, weight_decay=0.01)
+        opt.one_pass = one_pass
+        gg = torch.Generator().manual_seed(5)
+        grads = []
+        for step in range(3):
+            gr = torch.randn(o, generator=gg) * (1e-3 if step else 2e-5)
+            for i, n in enumerate(sizes):
+                gr[offs[i] + n: (offs + [o])[i + 1]] = 0
+            grads.append(gr)
+            p.grad = gr.to(DEV)
+            opt.step(clip=clip_grad_norm_([p], 1.0))
+        assert not opt.one_pass_error()
+        runs[one_pass] = (p.data.clone(), opt.state[p]["trust_ratio"].clone(), opt.state[p]["weight_norm"].clone(), opt.state[p]["adam_norm"].clone(),
+                          opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
+    # which tensors took the one-pass kernel
+    plan, fplan = opt._plan(p, offs)[:2]
+    p1 = torch.nn.Parameter(p0.clone().to(DEV))
+    o1 = FlatLamb([p1], [offs], lr=2e-3, eps=1e-6)
+    assert o1._plan(p1, offs)[1].nfused == 6  # the four matrices, the 2^18 tensor and the 300 K one
+    a, b = runs[True], runs[False]
+    assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])                    # m, v: the same arithmetic per element
+    for k in (1, 2, 3):
+        torch.testing.assert_close(a[k], b[k], rtol=2e-6, atol=0)               # norms: another summation order
+    torch.testing.assert_close(a[0], b[0], rtol=1e-6, atol=1e-9)
+    # oracle (fp64), tensor by tensor
+    P = [p0[offs[i]: offs[i] + n].double().numpy().copy() for i, n in enumerate(sizes)]
+    M = [np.zeros_like(x) for x in P]
+    V = [np.zeros_like(x) for x in P]
+    for step in range(3):
+        G = [grads[step][offs[i]: offs[i] + n].double().numpy() for i, n in enumerate(sizes)]
+        _, coef = O.clip_grad_norm(G, 1.0)
+        trust = O.lamb_step(P, [x * coef for x in G], M, V, lr=2e-3, eps=1e-6, weight_decay=0.01)
+    np.testing.assert_allclose(a[1].cpu().numpy(), np.asarray(trust), rtol=2e-4)
+    for i, n in enumerate(sizes):
+        np.testing.assert_allclose(a[0][offs[i]: offs[i] + n].cpu().numpy(), P[i], rtol=3e-4, atol=1e-7, err_msg=str(i))
+
+
 @pytest.mark.parametrize("layers,M,H,I", [(6, 2048, 768, 3072), (2, 1024, 256, 512), (3, 4096, 1024, 4096), (12, 1024, 768, 3072)])
 def test_gemm_multi_weight_gradients_in_one_launch(layers, M, H, I):
     """cocodr_gemm_multi: the four weight-gradient problems of a layer range (different shapes, one contraction length) as one

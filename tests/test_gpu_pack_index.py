@@ -143,6 +143,32 @@ def test_masks_with_holes_or_leading_padding_are_not_packed():
     assert PackedIndex.build(d(ids), d(mask)) is not None
 
 
+def test_forward_with_a_holey_mask_falls_back_to_the_padded_execution():
+    """The default forward plans the packed layout on the device and learns only INSIDE the encoder call that a mask is not a prefix
+    mask (PackedIndex.from_mask(lazy=True)): it must then run padded - same embeddings and gradients as pack_sequences = False - and
+    draw exactly one dropout call / count one forward."""
+    cfg = CocoBertConfig(vocab_size=900, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
+    torch.manual_seed(0)
+    bert = CocoBertModel(cfg).to(DEV)
+    ids, mask, lens = batch([40, 64, 3, 17, 9, 33, 64, 20], 64, seed=2, V=900)
+    mask[1, 5] = 0  # a hole
+    dids, dmask = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    out = {}
+    for packed in (True, False):
+        bert.pack_sequences = packed
+        bert.flat_decay.grad = bert.flat_nodecay.grad = None
+        calls0 = bert._dropout_calls
+        e = bert.encode_cls(dids, dmask)
+        e.square().sum().backward()
+        out[packed] = (e.detach().clone(), bert.flat_decay.grad.clone(), bert._dropout_calls - calls0)
+    bert.pack_sequences = True
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1]) and out[True][2] == out[False][2]
+    lazy = PackedIndex.build(dids, dmask, lazy=True)
+    assert lazy is not None and lazy.resolve() is False
+    with pytest.raises(ValueError):
+        lazy.T
+
+
 def test_unpack_is_the_inverse_of_the_row_map_and_differentiable():
     ids, mask, lens = batch([40, 96, 3], 96, seed=1)
     pk = PackedIndex.build(torch.from_numpy(ids).to(DEV), None, lens)

@@ -1,4 +1,4 @@
-"""A/B switches of the full coCondenser step (BERT-base, 64 x 128, packed): decoder split-K, fused CE.  ms per step."""
+"""A/B switches of the full coCondenser step (BERT-base, 64 x 128, packed): decoder split-K.  ms per step."""
 import os
 import sys
 
@@ -20,6 +20,3 @@ if __name__ == "__main__":
             r = bench.full_coco_step(cfg, dev, ids, mask, lens, steps=20, warmup=5, padded_too=False)
             print(f"split_k {sk}: {r['ms_per_step']:.3f} ms  loss {r['loss']:.3f}", flush=True)
     CondenserHead.decoder_split_k = 8
-    CondenserHead.fused_ce = True
-    r = bench.full_coco_step(cfg, dev, ids, mask, lens, steps=20, warmup=5, padded_too=False)
-    print(f"fused_ce: {r['ms_per_step']:.3f} ms  loss {r['loss']:.3f}", flush=True)
