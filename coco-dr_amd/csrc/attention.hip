@@ -164,41 +164,12 @@ struct AttnPacked {
     dropL = (pk).drop_L;                                                                          \
   }
 
-// three waves per SIMD (168 registers): at the default bound hipcc parks the O accumulators in AGPRs and pays an
-// accvgpr read + write per element for every online-softmax rescale
+// One wave's 32 query rows q0 .. q0 + 31 of one (sequence, head) against the K / V tiles in LDS: online softmax over the L / 32 key
+// blocks, O^T accumulated in registers, result rows and log-sum-exp stored (rows behind the extent Le are computed and not stored).
 template <bool DROP>
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
-                                                       uint16_t* __restrict__ ctx, float* __restrict__ lse, int Lmax, int H,
-                                                       const cocodr_dropout_mask dm, const AttnPacked pk) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  ATTN_EXTENT(Lmax, pk)
-  if ((int)blockIdx.z * 128 >= L) return;  // (packed batches: a sequence shorter than the longest has fewer query blocks)
-  char* Kt = smem;
-  char* Vt = smem + L * 128;
-  float* madd = reinterpret_cast<float*>(smem + 2 * L * 128);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int ld = 3 * H;
-  const uint16_t* base = qkv + row0 * ld + h * 64;
-  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4, Le);
-  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4, Le);
-  // additive key mask in units of the raw q.k scores; it seeds the S accumulators, so no add per element later.  -2e5 raw
-  // = -3.6e4 in the exponent: exp2 underflows to an exact 0 against any real score, and a row whose keys are ALL masked
-  // still gets a finite softmax over its raw scores (what adding finfo.min to every key gives the reference); a seed
-  // of -1e30 would leave the fma below with a rounding residue of ~1e22 there.
-  for (int i = tid; i < L; i += 256) madd[i] = (i < Le && mask[row0 + i] != 0) ? 0.f : -2.0e5f;
-  const int q0 = blockIdx.z * 128 + wid * 32;
+__device__ __forceinline__ void attn_fwd_rows(const char* Kt, const char* Vt, const float* madd, const bf16x8 (&qf)[4], int L, int Le, int q0,
+                                              int lane, int bh, int dropL, const cocodr_dropout_mask& dm, uint16_t* out, int H, float* lse_out) {
   const int half = lane >> 5;
-  bf16x8 qf[4];
-  if (q0 < L) {
-    const bool qok = q0 + (lane & 31) < Le;  // (query rows behind the extent: zeros, computed and not stored)
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      qf[s] = as_bf16x8(qok ? *reinterpret_cast<const uint4*>(base + (size_t)(q0 + (lane & 31)) * ld + (2 * s + half) * 8) : make_uint4(0u, 0u, 0u, 0u));
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (q0 >= L) return;
-
   f32x16 o[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -206,8 +177,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = kMaskNeg, lsum = 0.f;
   const float sl2 = kScale * kLog2e;
-  const uint32_t rowpair = DROP ? prob_row_pair(b * heads + h, q0 + (lane & 31), dropL) + 2 * half : 0u;
-
+  const uint32_t rowpair = DROP ? prob_row_pair(bh, q0 + (lane & 31), dropL) + 2 * half : 0u;
   for (int kb = 0; kb < L / 32; ++kb) {
     f32x16 sacc;
 #pragma unroll
@@ -246,8 +216,47 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
     }
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-  if (lane < 32 && q0 + lane < Le) lse[lse0 + q0 + lane] = (m + __log2f(ltot)) * kLn2;
-  store_acc_T(ctx + (row0 + q0) * H + h * 64, H, o, (DROP ? dm.scale : 1.0f) / ltot, lane, Le - q0);
+  if (lane < 32 && q0 + lane < Le) lse_out[lane] = (m + __log2f(ltot)) * kLn2;
+  store_acc_T(out, H, o, (DROP ? dm.scale : 1.0f) / ltot, lane, Le - q0);
+}
+
+
+// three waves per SIMD (168 registers): at the default bound hipcc parks the O accumulators in AGPRs and pays an
+// accvgpr read + write per element for every online-softmax rescale
+template <bool DROP>
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                       uint16_t* __restrict__ ctx, float* __restrict__ lse, int Lmax, int H,
+                                                       const cocodr_dropout_mask dm, const AttnPacked pk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ATTN_EXTENT(Lmax, pk)
+  if ((int)blockIdx.z * 128 >= L) return;  // (packed batches: a sequence shorter than the longest has fewer query blocks)
+  char* Kt = smem;
+  char* Vt = smem + L * 128;
+  float* madd = reinterpret_cast<float*>(smem + 2 * L * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ld = 3 * H;
+  const uint16_t* base = qkv + row0 * ld + h * 64;
+  stage_tile_dma(Kt, base + H, ld, L, lane, wid, 4, Le);
+  stage_tile_dma(Vt, base + 2 * H, ld, L, lane, wid, 4, Le);
+  // additive key mask in units of the raw q.k scores; it seeds the S accumulators, so no add per element later.  -2e5 raw
+  // = -3.6e4 in the exponent: exp2 underflows to an exact 0 against any real score, and a row whose keys are ALL masked
+  // still gets a finite softmax over its raw scores (what adding finfo.min to every key gives the reference); a seed
+  // of -1e30 would leave the fma below with a rounding residue of ~1e22 there.
+  for (int i = tid; i < L; i += 256) madd[i] = (i < Le && mask[row0 + i] != 0) ? 0.f : -2.0e5f;
+  const int q0 = blockIdx.z * 128 + wid * 32;
+  const int half = lane >> 5;
+  bf16x8 qf[4];
+  if (q0 < L) {
+    const bool qok = q0 + (lane & 31) < Le;  // (query rows behind the extent: zeros, computed and not stored)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[s] = as_bf16x8(qok ? *reinterpret_cast<const uint4*>(base + (size_t)(q0 + (lane & 31)) * ld + (2 * s + half) * 8) : make_uint4(0u, 0u, 0u, 0u));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (q0 >= L) return;
+
+  attn_fwd_rows<DROP>(Kt, Vt, madd, qf, L, Le, q0, lane, b * heads + h, dropL, dm, ctx + (row0 + q0) * H + h * 64, H, lse + lse0 + q0);
 }
 
 #if defined(COCODR_ABL_TIMELINE)  // tools/attn_timeline.py builds: per-workgroup phase stamps (100 MHz wall clock)

@@ -1215,8 +1215,8 @@ __global__ __launch_bounds__(256) void lamb_apply_kernel(float* __restrict__ p, 
 // count, and once all G have arrived every workgroup adds the G partials in the same fixed order (deterministic, the same ratio
 // everywhere) and applies the step from its registers: 30 B / parameter (AdamW's traffic).  The arrival of tensor k is waited for
 // only after pass 1 of tensor k + 1 has been issued (two register sets), so nobody ever spins on a 20 us tensor.
-// Inter-workgroup visibility: partials are published with an agent-scope release in front of the relaxed arrival add, readers take
-// ONE agent-scope acquire behind their relaxed poll (MI355X_MICROARCH.md "Workgroup dispatch ... visibility").  The spin is bounded:
+// Inter-workgroup visibility: a partial is one 8-byte write-through (sc1) granule, drained before the relaxed arrival add; readers
+// poll relaxed and read the granules with sc1 loads - no fences (MI355X_MICROARCH.md "Workgroup dispatch ... visibility").  The spin is bounded:
 // a grid that is not co-resident (it is sized from the occupancy query, minus one block per CU of margin) raises *err and the
 // step finishes with whatever arrived - wrong numbers and a loud flag instead of a hung queue.
 constexpr int LF_THREADS = 256, LF_V = 4, LF_PER_CU = 4;  // float4 per thread and tensor: capacity = G * 256 * 16 floats (G = 4 per CU)
@@ -1286,11 +1286,12 @@ __global__ __launch_bounds__(LF_THREADS, LF_PER_CU) void lamb_fused_kernel(const
     }
     block_sum2(sw, su);
     if (tid == 0) {
-      float* mine = a.part + ((size_t)k * G + bid) * 2;
-      mine[0] = sw;
-      mine[1] = su;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (hipcc may drop the wait behind buffer_wbl2: restate it where it cannot)
+      // publish: ONE 8-byte write-through (sc1) store of (sum w^2, sum u^2), drained, then the arrival add.  No release fence: a
+      // fence would write back the XCD's whole L2 - tens of MB of freshly streamed m / v / p lines - once per workgroup and tensor
+      // (measured: the step 6.5x slower than the two-pass kernels)
+      unsigned long long pair = ((unsigned long long)__float_as_uint(su) << 32) | __float_as_uint(sw);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.part) + (size_t)k * G + bid, pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(a.counter + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
@@ -1302,13 +1303,15 @@ __global__ __launch_bounds__(LF_THREADS, LF_PER_CU) void lamb_fused_kernel(const
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1 << 25)) { *a.err = 1; break; }  // ~10 s: the grid is not co-resident
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     float sw = 0.f, su = 0.f;
     for (int w = tid; w < G; w += LF_THREADS) {  // fixed order: thread t adds partials t, t + 256, ...; then the block tree
-      sw += a.part[((size_t)k * G + w) * 2];
-      su += a.part[((size_t)k * G + w) * 2 + 1];
+      // (sc1 loads of sc1-stored granules: served past this CU's L1, no acquire fence - MI355X_MICROARCH.md "Valid forms")
+      const unsigned long long pair = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.part) + (size_t)k * G + w, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+      sw += __uint_as_float((uint32_t)pair);
+      su += __uint_as_float((uint32_t)(pair >> 32));
     }
     block_sum2(sw, su);
     const float wn = fminf(sqrtf(sw), 10.0f), un = sqrtf(su);

@@ -5,6 +5,7 @@ device.  The pass over ``flat_decay`` also refreshes the bf16 weight shadow the 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Iterable, List, Sequence, Tuple
 
 import numpy as np
@@ -168,8 +169,8 @@ class FlatLamb(torch.optim.Optimizer):
         opt._owners = _shadow_owners(model)
         return opt
 
-    #: False: every tensor through the two-pass kernels (A/B switch; the tests run both)
-    one_pass = True
+    #: False: every tensor through the two-pass kernels (A/B switch - also COCODR_LAMB_TWO_PASS=1; the tests run both)
+    one_pass = os.environ.get("COCODR_LAMB_TWO_PASS") is None
 
     def _plan(self, p, offs):
         """(two-pass plan or None, one-pass plan or None, keep-alive, workspace, stats, one-pass workspace): the weight matrices

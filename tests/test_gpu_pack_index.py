@@ -150,6 +150,7 @@ def test_forward_with_a_holey_mask_falls_back_to_the_padded_execution():
     cfg = CocoBertConfig(vocab_size=900, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
     torch.manual_seed(0)
     bert = CocoBertModel(cfg).to(DEV)
+    bert.dropout_seed = 7
     ids, mask, lens = batch([40, 64, 3, 17, 9, 33, 64, 20], 64, seed=2, V=900)
     mask[1, 5] = 0  # a hole
     dids, dmask = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
@@ -157,7 +158,7 @@ def test_forward_with_a_holey_mask_falls_back_to_the_padded_execution():
     for packed in (True, False):
         bert.pack_sequences = packed
         bert.flat_decay.grad = bert.flat_nodecay.grad = None
-        calls0 = bert._dropout_calls
+        bert._dropout_calls = calls0 = 0  # (train() mode drops: both runs draw the masks of call 1)
         e = bert.encode_cls(dids, dmask)
         e.square().sum().backward()
         out[packed] = (e.detach().clone(), bert.flat_decay.grad.clone(), bert._dropout_calls - calls0)
