@@ -1211,107 +1211,110 @@ __global__ __launch_bounds__(256) void lamb_apply_kernel(float* __restrict__ p, 
 // ---- LAMB in ONE pass over a tensor (round 5).  The two-pass form above moves 42 B / parameter because the trust ratio of a tensor
 // needs ||u|| of the WHOLE tensor before any element can be updated, so p, m, v are read a second time.  A weight matrix of the
 // encoder (<= 4 M elements) fits the chip's register files: here a persistent grid of G co-resident workgroups spreads every tensor
-// over all of them, pass 1 (m, v, u; p and u stay in registers) leaves one partial (sum w^2, sum u^2) per workgroup and an arrival
-// count, and once all G have arrived every workgroup adds the G partials in the same fixed order (deterministic, the same ratio
-// everywhere) and applies the step from its registers: 30 B / parameter (AdamW's traffic).  The arrival of tensor k is waited for
-// only after pass 1 of tensor k + 1 has been issued (two register sets), so nobody ever spins on a 20 us tensor.
-// Inter-workgroup visibility: a partial is one 8-byte write-through (sc1) granule, drained before the relaxed arrival add; readers
-// poll relaxed and read the granules with sc1 loads - no fences (MI355X_MICROARCH.md "Workgroup dispatch ... visibility").  The spin is bounded:
-// a grid that is not co-resident (it is sized from the occupancy query, minus one block per CU of margin) raises *err and the
-// step finishes with whatever arrived - wrong numbers and a loud flag instead of a hung queue.
-constexpr int LF_THREADS = 256, LF_V = 4, LF_PER_CU = 4;  // float4 per thread and tensor: capacity = G * 256 * 16 floats (G = 4 per CU)
+// over all of them; pass 1 (m, v, u; w and u stay on chip - registers, then LDS) leaves ONE 16-byte granule (sum w^2, sum u^2, each next to the
+// launch's epoch tag) per workgroup, and one tensor later every workgroup reads the G granules, adds them in the same fixed order
+// (deterministic, the same ratio everywhere) and applies the step from its registers: 30 B / parameter (AdamW's traffic).
+// The element stream is software-pipelined across tensor boundaries (the loads of the next float4 quadruple are in flight while the
+// current one is worked on), and nobody waits for anybody in the common case: a granule is read a whole tensor after it was written.
+// Inter-workgroup visibility without fences: granules are written with ONE write-through (sc1) 16-byte store and read with sc1
+// loads; each 8-byte half carries its own tag, so a torn read is recognised and repeated (MI355X_MICROARCH.md "Workgroup dispatch
+// ... visibility": data-tagged granules).  A release fence here would write back the XCD's whole L2 - tens of MB of freshly
+// streamed m / v lines - per workgroup and tensor (measured: 6.5x slower than the two-pass kernels).  The spin is bounded: a grid
+// that is not co-resident (it is sized from the occupancy query) raises *err and the step finishes with whatever arrived - wrong
+// numbers and a loud flag instead of a hung queue.
+constexpr int LF_THREADS = 1024, LF_V = 4, LF_PER_CU = 1;  // ONE 1024-thread workgroup per CU (G = #CUs: a gather reads G granules - with 256-thread
+                                                            // workgroups, 4 per CU, the G^2 granule reads were half of the tensors' own traffic); capacity G * 1024 * 16 floats
 typedef float lf4 __attribute__((ext_vector_type(4)));
+typedef uint32_t lu4 __attribute__((ext_vector_type(4)));
+typedef uint32_t lu2 __attribute__((ext_vector_type(2)));
 struct LambFusedArgs {
   float* p; const float* g; float* m; float* v; uint16_t* shadow; size_t shadow_begin;
   const long long* seg_start; const int* seg_len; const int* seg_index; int nfused;
   float beta1, beta2, eps, wd, grad_scale, lr; const float* grad_scale_dev;
-  float* part; int* counter; int* err; float* trust; float* stats;
+  float* part; uint32_t epoch; int* err; float* trust; float* stats;
 };
-__global__ __launch_bounds__(LF_THREADS, LF_PER_CU) void lamb_fused_kernel(const LambFusedArgs a) {
+__global__ __launch_bounds__(LF_THREADS, LF_PER_CU * LF_THREADS / 256) void lamb_fused_kernel(const LambFusedArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
   __shared__ float red[2][LF_THREADS / 64];
+  __shared__ lf4 keep[LF_V][2][LF_THREADS];  // w and u of the PREVIOUS tensor (128 KB: thread-private slots, no barriers), see below
   const int tid = threadIdx.x, bid = blockIdx.x, G = gridDim.x;
   const float gs = a.grad_scale * (a.grad_scale_dev ? *a.grad_scale_dev : 1.0f);
-  auto block_sum2 = [&](float& x, float& y) {  // both sums over the workgroup, the same value in every thread
+  auto block_sum2 = [&](float& x, float& y) {  // both sums over the workgroup, the same value in every thread (fixed order)
     x = wave_sum(x);
     y = wave_sum(y);
     __syncthreads();  // (red is reused)
     if ((tid & 63) == 0) { red[0][tid >> 6] = x; red[1][tid >> 6] = y; }
     __syncthreads();
-    x = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    y = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    x = y = 0.f;
+#pragma unroll
+    for (int w = 0; w < LF_THREADS / 64; ++w) { x += red[0][w]; y += red[1][w]; }
   };
   // A tensor is addressed through buffer descriptors that END with it: a lane whose float4 lies behind the tensor loads zeros
-  // (u = 0: no contribution to either norm) and its stores are dropped by the bounds check - no branches in the element loops, and
-  // 32-bit offsets.  aux 2 = non-temporal (streamed once).
-  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-  typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-  auto rsrc = [&](const void* base, size_t elem0, int n_elem, int bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + elem0 * bytes), 0, (uint32_t)((size_t)n_elem * bytes), 0x00020000);
+  // (u = 0: no contribution to either norm) and its stores are dropped by the bounds check - no branches in the element stream, and
+  // 32-bit offsets.  aux 2 = non-temporal (streamed once), aux 16 = sc1 (write-through / past the L1).
+  auto uni64 = [](unsigned long long x) {  // (tell hipcc the value is wave-uniform: a descriptor it believes divergent puts every
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;  //  buffer instruction into a readfirstlane waterfall loop)
+  };
+  auto rsrc = [&](const void* base, size_t elem0, size_t n_elem, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + elem0 * bytes), 0, (uint32_t)(n_elem * bytes), 0x00020000);
   };
   const uint32_t off0 = (uint32_t)(bid * LF_THREADS + tid) * 16u, offj = (uint32_t)G * LF_THREADS * 16u;  // byte offset of float4 j: off0 + j offj
-  // pass 1 of tensor k: m, v updated in memory; P = the weights, U = the update direction, in registers
-  auto pass1 = [&](int k, lf4 (&P)[LF_V], lf4 (&U)[LF_V]) {
-    const size_t e0 = (size_t)a.seg_start[k];
-    const int n = a.seg_len[k];
-    const __amdgpu_buffer_rsrc_t rp = rsrc(a.p, e0, n, 4), rg = rsrc(a.g, e0, n, 4), rm = rsrc(a.m, e0, n, 4), rv = rsrc(a.v, e0, n, 4);
-    float sw = 0.f, su = 0.f;
+  const __amdgpu_buffer_rsrc_t rgran = rsrc(a.part, 0, (size_t)a.nfused * G * 4, 4);
+  struct Quad { lf4 p, g, m, v; };
+  struct Desc { __amdgpu_buffer_rsrc_t p, g, m, v; };
+  auto desc = [&](int k) {
+    const size_t e0 = (size_t)uni64((unsigned long long)a.seg_start[k]);
+    const size_t n = (size_t)uni64((unsigned long long)a.seg_len[k]);
+    return Desc{rsrc(a.p, e0, n, 4), rsrc(a.g, e0, n, 4), rsrc(a.m, e0, n, 4), rsrc(a.v, e0, n, 4)};
+  };
+  auto load = [&](const Desc& d, int j) {
+    const uint32_t o = off0 + (uint32_t)j * offj;
+    Quad q;
+    q.p = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(d.p, o, 0, 2));
+    q.g = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(d.g, o, 0, 2));
+    q.m = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(d.m, o, 0, 2));
+    q.v = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(d.v, o, 0, 2));
+    return q;
+  };
+  // one float4 of pass 1: m, v updated in memory; P = the weights, U = the update direction stay in registers
+  auto work = [&](const Desc& d, int j, Quad q, lf4& P, lf4& U, float& sw, float& su) {
+    const uint32_t o = off0 + (uint32_t)j * offj;
 #pragma unroll
-    for (int j0 = 0; j0 < LF_V; j0 += 2) {  // two float4 quadruples in flight per thread: 8 x 16 B loads, then the arithmetic
-      lf4 gv[2], mv[2], vv[2];
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const uint32_t o = off0 + (uint32_t)(j0 + jj) * offj;
-        P[j0 + jj] = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(rp, o, 0, 2));
-        gv[jj] = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(rg, o, 0, 2));
-        mv[jj] = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(rm, o, 0, 2));
-        vv[jj] = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(rv, o, 0, 2));
-      }
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = j0 + jj;
-        const uint32_t o = off0 + (uint32_t)j * offj;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float ge = gv[jj][e] * gs;
-          mv[jj][e] = a.beta1 * mv[jj][e] + (1.0f - a.beta1) * ge;
-          vv[jj][e] = a.beta2 * vv[jj][e] + (1.0f - a.beta2) * ge * ge;
-          const float u = lamb_u(P[j][e], mv[jj][e], vv[jj][e], a.eps, a.wd);
-          U[j][e] = u;
-          sw += P[j][e] * P[j][e];
-          su += u * u;
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, mv[jj]), rm, o, 0, 2);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, vv[jj]), rv, o, 0, 2);
-      }
+    for (int e = 0; e < 4; ++e) {
+      const float ge = q.g[e] * gs;
+      q.m[e] = a.beta1 * q.m[e] + (1.0f - a.beta1) * ge;
+      q.v[e] = a.beta2 * q.v[e] + (1.0f - a.beta2) * ge * ge;
+      const float u = lamb_u(q.p[e], q.m[e], q.v[e], a.eps, a.wd);
+      U[e] = u;
+      sw += q.p[e] * q.p[e];
+      su += u * u;
     }
+    P = q.p;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lu4, q.m), d.m, o, 0, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lu4, q.v), d.v, o, 0, 2);
+  };
+  auto publish = [&](int k, float sw, float su) {
     block_sum2(sw, su);
     if (tid == 0) {
-      // publish: ONE 8-byte write-through (sc1) store of (sum w^2, sum u^2), drained, then the arrival add.  No release fence: a
-      // fence would write back the XCD's whole L2 - tens of MB of freshly streamed m / v / p lines - once per workgroup and tensor
-      // (measured: the step 6.5x slower than the two-pass kernels)
-      unsigned long long pair = ((unsigned long long)__float_as_uint(su) << 32) | __float_as_uint(sw);
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.part) + (size_t)k * G + bid, pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(a.counter + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const lu4 gr = {__float_as_uint(sw), a.epoch, __float_as_uint(su), a.epoch};
+      __builtin_amdgcn_raw_buffer_store_b128(gr, rgran, (uint32_t)(((size_t)k * G + bid) * 16), 0, 16);
     }
   };
-  // wait for all G partials of tensor k, form the trust ratio, apply the step from the registers
-  auto apply = [&](int k, lf4 (&P)[LF_V], const lf4 (&U)[LF_V]) {
-    if (tid == 0) {
-      int spins = 0;
-      while (__hip_atomic_load(a.counter + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 25)) { *a.err = 1; break; }  // ~10 s: the grid is not co-resident
-      }
-    }
-    __syncthreads();
+  // the trust ratio of tensor k from the G granules (fixed order: thread t adds granules t, t + 1024, ...; then the block sum)
+  auto gather = [&](int k) {
     float sw = 0.f, su = 0.f;
-    for (int w = tid; w < G; w += LF_THREADS) {  // fixed order: thread t adds partials t, t + 256, ...; then the block tree
-      // (sc1 loads of sc1-stored granules: served past this CU's L1, no acquire fence - MI355X_MICROARCH.md "Valid forms")
-      const unsigned long long pair = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.part) + (size_t)k * G + w, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-      sw += __uint_as_float((uint32_t)pair);
-      su += __uint_as_float((uint32_t)(pair >> 32));
+    for (int w = tid; w < G; w += LF_THREADS) {
+      const uint32_t o = (uint32_t)(((size_t)k * G + w) * 16);
+      lu4 gr = __builtin_amdgcn_raw_buffer_load_b128(rgran, o, 0, 16);
+      int spins = 0;
+      while (gr[1] != a.epoch || gr[3] != a.epoch) {  // not there yet (or torn): rare - it was written a whole tensor ago
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 24)) { *a.err = 1; break; }  // seconds: the grid is not co-resident
+        gr = __builtin_amdgcn_raw_buffer_load_b128(rgran, o, 0, 16);
+      }
+      sw += __uint_as_float(gr[0]);
+      su += __uint_as_float(gr[2]);
     }
     block_sum2(sw, su);
     const float wn = fminf(sqrtf(sw), 10.0f), un = sqrtf(su);
@@ -1321,41 +1324,60 @@ __global__ __launch_bounds__(LF_THREADS, LF_PER_CU) void lamb_fused_kernel(const
       a.trust[s] = tr;
       if (a.stats) { a.stats[2 * s] = wn; a.stats[2 * s + 1] = un; }
     }
+    return tr;
+  };
+  auto apply = [&](int k, float tr) {  // w, u of tensor k come back from this thread's LDS slots
     const float step = a.lr * tr;
-    const size_t e0 = (size_t)a.seg_start[k];
-    const int n = a.seg_len[k];
+    const size_t e0 = (size_t)uni64((unsigned long long)a.seg_start[k]);
+    const size_t n = (size_t)uni64((unsigned long long)a.seg_len[k]);
     const __amdgpu_buffer_rsrc_t rp = rsrc(a.p, e0, n, 4);
     const bool shadowed = a.shadow != nullptr && e0 >= a.shadow_begin;  // (workgroup-uniform)
     const __amdgpu_buffer_rsrc_t rs = rsrc(a.shadow, shadowed ? e0 - a.shadow_begin : 0, shadowed ? n : 0, 2);
 #pragma unroll
     for (int j = 0; j < LF_V; ++j) {
       const uint32_t o = off0 + (uint32_t)j * offj;
+      const lf4 P = keep[j][0][tid], U = keep[j][1][tid];
       float pa[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pa[e] = P[j][e] - step * U[j][e];
+      for (int e = 0; e < 4; ++e) pa[e] = P[e] - step * U[e];
       const lf4 t = {pa[0], pa[1], pa[2], pa[3]};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, t), rp, o, 0, 2);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lu4, t), rp, o, 0, 2);
       const uint2 h = pack4(pa);
-      const u2v hv = {h.x, h.y};
+      const lu2 hv = {h.x, h.y};
       __builtin_amdgcn_raw_buffer_store_b64(hv, rs, o >> 1, 0, 0);  // (num_records 0 when the tensor has no shadow: dropped)
     }
   };
-  lf4 P0[LF_V], U0[LF_V], P1[LF_V], U1[LF_V];
-  int k = 0;
+  // The stream: tensor k's quadruples with TWO requests ahead of the one being worked on (across the tensor boundary too: the
+  // tail of a tensor - its granule, the previous tensor's ratio and update - runs with the next tensor's first two quadruples in
+  // flight).  The current tensor's w, u are in registers; behind its tail they move to this thread's LDS slots, where the update
+  // of the previous tensor has just been read from.
+  auto unit = [&](int u) {  // request quadruple u of the flattened (tensor, j) sequence; past the end: a repeat of the last (not used)
+    const int total = a.nfused * LF_V;
+    const int uu = u < total ? u : total - 1;
+    const int k_ = uu / LF_V;
+    return load(desc(k_), uu - k_ * LF_V);
+  };
+  Quad q0 = unit(0), q1 = unit(1);
 #pragma unroll 1
-  for (; k + 1 < a.nfused; k += 2) {
-    pass1(k, P0, U0);
-    if (k > 0) apply(k - 1, P1, U1);
-    pass1(k + 1, P1, U1);
-    apply(k, P0, U0);
+  for (int k = 0; k < a.nfused; ++k) {
+    lf4 P[LF_V], U[LF_V];
+    float sw = 0.f, su = 0.f;
+    const Desc d = desc(k);
+#pragma unroll
+    for (int j = 0; j < LF_V; ++j) {
+      const Quad q2 = unit(k * LF_V + j + 2);
+      work(d, j, q0, P[j], U[j], sw, su);
+      q0 = q1;
+      q1 = q2;
+      __builtin_amdgcn_sched_barrier(0);  // (keep exactly two quadruples of requests ahead)
+    }
+    publish(k, sw, su);
+    if (k > 0) apply(k - 1, gather(k - 1));
+#pragma unroll
+    for (int j = 0; j < LF_V; ++j) { keep[j][0][tid] = P[j]; keep[j][1][tid] = U[j]; }
   }
-  if (k < a.nfused) {  // odd count: one more tensor in set 0
-    pass1(k, P0, U0);
-    if (k > 0) apply(k - 1, P1, U1);
-    apply(k, P0, U0);
-  } else if (k > 0) {
-    apply(k - 1, P1, U1);
-  }
+  apply(a.nfused - 1, gather(a.nfused - 1));
+#endif
 }
 // workgroups of the persistent grid: what is certainly co-resident per the occupancy query, at most LF_PER_CU per CU; 0 = the kernel
 // cannot run here
@@ -1380,9 +1402,9 @@ int lamb_fused_grid() {
 
 extern "C" size_t cocodr_lamb_fused_capacity(void) { return (size_t)lamb_fused_grid() * LF_THREADS * LF_V * 4; }
 extern "C" size_t cocodr_lamb_fused_workspace_floats(int nfused) {
-  return nfused > 0 ? (size_t)nfused * lamb_fused_grid() * 2 + (size_t)nfused + 4 : 0;
+  return nfused > 0 ? (size_t)nfused * lamb_fused_grid() * 4 + 4 : 0;
 }
-extern "C" size_t cocodr_lamb_fused_error_index(int nfused) { return (size_t)nfused * lamb_fused_grid() * 2 + (size_t)nfused; }
+extern "C" size_t cocodr_lamb_fused_error_index(int nfused) { return (size_t)nfused * lamb_fused_grid() * 4; }
 extern "C" int cocodr_lamb_step_fused(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin,
                                       const cocodr_lamb_fused_plan* plan, float lr, float beta1, float beta2, float eps, float weight_decay,
                                       float grad_scale, const float* grad_scale_dev, float* workspace, float* trust, float* stats,
@@ -1394,20 +1416,20 @@ extern "C" int cocodr_lamb_step_fused(float* p, const float* g, float* m, float*
   CK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "lamb_step_fused: bad hyper-parameters");
   const int G = lamb_fused_grid();
   CK_ARG(G > 0, "lamb_step_fused: no co-resident grid on this device (cocodr_lamb_fused_capacity() == 0): use cocodr_lamb_step");
-  hipStream_t st = (hipStream_t)stream;
+  CK_ARG((size_t)plan->nfused * G * 16 < (1ull << 32), "lamb_step_fused: too many tensors for one call");
+  // the tag of this call's granules: any value the previous calls on this workspace did not use (the workspace starts zeroed)
+  static std::atomic<uint32_t> epoch_counter{0};
+  uint32_t epoch = ++epoch_counter;
+  if (epoch == 0) epoch = ++epoch_counter;
   LambFusedArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.shadow = shadow; a.shadow_begin = shadow_begin;
   a.seg_start = plan->seg_start; a.seg_len = plan->seg_len; a.seg_index = plan->seg_index; a.nfused = plan->nfused;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.grad_scale = grad_scale; a.lr = lr; a.grad_scale_dev = grad_scale_dev;
   a.part = workspace;
-  a.counter = reinterpret_cast<int*>(workspace + (size_t)plan->nfused * G * 2);
-  a.err = a.counter + plan->nfused;
+  a.epoch = epoch;
+  a.err = reinterpret_cast<int*>(workspace + (size_t)plan->nfused * G * 4);
   a.trust = trust; a.stats = stats;
-  if (hipMemsetAsync(a.counter, 0, ((size_t)plan->nfused + 1) * sizeof(int), st) != hipSuccess) {
-    cocodr_set_error("lamb_step_fused: hipMemsetAsync failed");
-    return COCODR_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(lamb_fused_kernel, dim3(G), dim3(LF_THREADS), 0, st, a);
+  hipLaunchKernelGGL(lamb_fused_kernel, dim3(G), dim3(LF_THREADS), 0, (hipStream_t)stream, a);
   CK_LAUNCH("lamb_step_fused");
   return COCODR_OK;
 }

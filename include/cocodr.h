@@ -274,7 +274,8 @@ int cocodr_lamb_step(float* p, const float* g, float* m, float* v, uint16_t* sha
  * fixed order: deterministic; same arithmetic per element as cocodr_lamb_step).  plan: tensor k = elements [seg_start[k],
  * seg_start[k] + seg_len[k]) (multiples of 4, seg_len[k] <= cocodr_lamb_fused_capacity(), which is 0 where the kernel cannot run),
  * seg_index[k] = its row in trust / stats (the tensor numbering of the cocodr_lamb_plan the rest of the flat goes through: give
- * those tensors NO chunks there).  workspace: cocodr_lamb_fused_workspace_floats(nfused) floats; the int at float index
+ * those tensors NO chunks there).  workspace: cocodr_lamb_fused_workspace_floats(nfused) floats, ZEROED once by the caller and then
+ * left to this function (it holds the tagged partial-norm granules of the previous calls); the int at float index
  * cocodr_lamb_fused_error_index(nfused) is set to 1 if a workgroup gave up waiting for the others (never, unless the device
  * cannot hold the grid; the numbers of that step are then wrong).  trust fp32 [>= max seg_index + 1]. */
 typedef struct {
