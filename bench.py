@@ -912,8 +912,10 @@ def main():
         if packed:
             # the same headline step with the batch in the OTHER boundary form: host-known lengths next to ids + mask (a collator that
             # pads on the CPU has them; nothing is read back) when the headline takes the reference's batch unchanged, and vice versa
+            # (with the same roofline sampling as the headline leg - its event pairs cost ~1.5 % of the timed region - so that the
+            # two numbers differ by the boundary form alone)
             hdt, hloss, _, _, _, _ = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
-                                                     args.dp_chunks, False, args.dense, packed=True, host_lengths=not host_lengths)
+                                                     args.dp_chunks, not args.no_roofline, args.dense, packed=True, host_lengths=not host_lengths)
             hv = args.seq_per_gpu * args.steps / hdt
             extras["reference_batch_contrastive_step" if host_lengths else "host_lengths_contrastive_step"] = {
                 "sequences_per_sec": round(hv, 1), "ms_per_step": round(hdt / args.steps * 1e3, 3), "loss": round(hloss, 4),

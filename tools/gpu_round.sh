@@ -5,7 +5,7 @@
 # The PMC stage writes gemm_pmc_<model>_<seq>x128[_packed].json; copy them to profiles/ (bench.py's roofline.traffic reads profiles/gemm_pmc_*.json
 # and reports the commit recorded inside).
 set -u
-tag=${1:-r04}; commit=${2:-unknown}; stages=${3:-tbkp}
+tag=${1:-r05}; commit=${2:-unknown}; stages=${3:-tbkp}
 export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/$tag
@@ -18,6 +18,7 @@ fi
 if [[ $stages == *b* ]]; then
   timeout 1500 python bench.py > $out/bench.json 2> $out/bench.err
   echo "bench exit $?"; tail -c 600 $out/bench.json
+  cp bench_legs.json $out/bench_legs.json   # every side leg in full (the later profiler runs of bench.py overwrite the file)
 fi
 prof_args="--steps 10 --warmup 3 --no-cpu-baseline --no-full-step"
 # every leg in both executions: packed (bench.py's default: no work on padding rows) and padded (--padded: all B x L rows)
