@@ -163,7 +163,8 @@ def test_forward_with_a_holey_mask_falls_back_to_the_padded_execution():
         e.square().sum().backward()
         out[packed] = (e.detach().clone(), bert.flat_decay.grad.clone(), bert._dropout_calls - calls0)
     bert.pack_sequences = True
-    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1]) and out[True][2] == out[False][2]
+    assert torch.equal(out[True][0], out[False][0]) and out[True][2] == out[False][2]
+    assert float((out[True][1] - out[False][1]).norm() / out[False][1].norm()) < 1e-6  # (word rows: fp32 atomics, free order)
     lazy = PackedIndex.build(dids, dmask, lazy=True)
     assert lazy is not None and lazy.resolve() is False
     with pytest.raises(ValueError):
