@@ -405,9 +405,10 @@ __global__ void scale_exp_kernel(const uint32_t* __restrict__ maxbits, int* __re
     exps[which] = e;
   }
 }
-// Xc [rows_pad, 3 Hp] half: Q rows as [xl | xh | xh], P rows as [xh | xl | xh] (is_p), zero padding in rows and columns
+// Xc [rows_pad, parts Hp] half, zero padding in rows and columns.  parts = 3: Q rows as [xl | xh | xh], P rows as [xh | xl | xh]
+// (is_p).  parts = 1 (mode 2, opt-in): the high halves alone - scores of IEEE-half operands with fp32 accumulation.
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ X, _Float16* __restrict__ Xc, int rows, int rows_pad, int H,
-                                                        int Hp, const int* __restrict__ exps, int is_p) {
+                                                        int Hp, const int* __restrict__ exps, int is_p, int parts) {
   const float scale = ldexpf(1.0f, exps[is_p]);
   const size_t total = (size_t)rows_pad * Hp;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -418,13 +419,17 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
       hi = (_Float16)x;
       lo = (_Float16)(x - (float)hi);
     }
-    _Float16* row = Xc + (size_t)r * 3 * Hp;
-    if (is_p) { row[c] = hi; row[Hp + c] = lo; row[2 * Hp + c] = hi; }
+    _Float16* row = Xc + (size_t)r * parts * Hp;
+    if (parts == 1) { row[c] = hi; }
+    else if (is_p) { row[c] = hi; row[Hp + c] = lo; row[2 * Hp + c] = hi; }
     else { row[c] = lo; row[Hp + c] = hi; row[2 * Hp + c] = hi; }
   }
 }
 
-int g_score_mode = -1;  // 0 = auto (split precision when the workspace allows), 1 = exact fp32 MFMA always
+// 0 = auto (split precision - fp32-accurate scores on the 16-bit pipe - when the workspace allows), 1 = exact fp32 MFMA always,
+// 2 = half-precision scores (opt-in: ONE product of the operands rounded to IEEE half, fp32 accumulation - what a faiss fp16 flat
+//     index computes; a third of mode 0's matrix work, score error ~1e-5 of |q||p| instead of ~1e-7)
+int g_score_mode = -1;
 int score_mode() {
   if (g_score_mode < 0) {
     const char* e = getenv("COCODR_SCORE_EXACT");
@@ -432,13 +437,15 @@ int score_mode() {
   }
   return g_score_mode;
 }
+int score_parts() { return score_mode() == 2 ? 1 : 3; }
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct SplitPlan {
-  int Hp, np_pad, QC;
+  int Hp, np_pad, QC, parts;
   size_t off_q, off_p, off_misc, off_slab, total;
 };
 SplitPlan split_plan(int Nq, int Np, int H) {
   SplitPlan s;
+  s.parts = score_parts();
   s.Hp = (H + 63) / 64 * 64;
   s.np_pad = (Np + 255) / 256 * 256;
   long long qc = (1ll << 28) / s.np_pad;  // two slabs of <= 1 GiB
@@ -446,8 +453,8 @@ SplitPlan split_plan(int Nq, int Np, int H) {
   qc = (qc / 128) * 128;
   s.QC = (int)std::min<long long>(qc, ((long long)Nq + 127) / 128 * 128);
   size_t o = 0;
-  s.off_q = o; o = align256(o + (size_t)Nq * 3 * s.Hp * 2);
-  s.off_p = o; o = align256(o + (size_t)s.np_pad * 3 * s.Hp * 2);
+  s.off_q = o; o = align256(o + (size_t)Nq * s.parts * s.Hp * 2);
+  s.off_p = o; o = align256(o + (size_t)s.np_pad * s.parts * s.Hp * 2);
   s.off_misc = o; o = align256(o + 64);
   s.off_slab = o; o = align256(o + 2 * (size_t)s.QC * s.np_pad * 4);
   s.total = o;
@@ -492,11 +499,11 @@ size_t exact_bytes(int Nq, int Np) {
 extern "C" size_t cocodr_score_topk_workspace_bytes_dim(int Nq, int Np, int H, int k) {
   (void)k;
   if (Nq <= 0 || Np <= 0 || H <= 0) return 0;
-  return score_mode() == 1 ? exact_bytes(Nq, Np) : std::max(exact_bytes(Nq, Np), split_plan(Nq, Np, H).total);
+  return score_mode() == 1 ? exact_bytes(Nq, Np) : std::max(exact_bytes(Nq, Np), split_plan(Nq, Np, H).total);  // (mode 2 needs less than mode 0)
 }
 extern "C" size_t cocodr_score_topk_workspace_bytes(int Nq, int Np, int k) { return cocodr_score_topk_workspace_bytes_dim(Nq, Np, 1024, k); }
 extern "C" int cocodr_score_set_mode(int mode) {
-  CK_ARG(mode == 0 || mode == 1, "score_set_mode: 0 = auto (split precision), 1 = exact fp32 MFMA");
+  CK_ARG(mode >= 0 && mode <= 2, "score_set_mode: 0 = auto (split precision), 1 = exact fp32 MFMA, 2 = half-precision scores");
   g_score_mode = mode;
   return COCODR_OK;
 }
@@ -515,7 +522,7 @@ extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np,
   CK_ARG(((uintptr_t)workspace & 255) == 0, "score_topk: workspace must be 256-byte aligned");
   // split precision (16-bit matrix pipe) when the workspace has room for the half operands; exact fp32 MFMA otherwise
   const SplitPlan sp = split_plan(Nq, Np, H);
-  const bool split = score_mode() == 0 && workspace_bytes >= sp.total;
+  const bool split = score_mode() != 1 && workspace_bytes >= sp.total;
   char* wsb = reinterpret_cast<char*>(workspace);
   _Float16* Qc = reinterpret_cast<_Float16*>(wsb + sp.off_q);
   _Float16* Pc = reinterpret_cast<_Float16*>(wsb + sp.off_p);
@@ -526,8 +533,8 @@ extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np,
     hipLaunchKernelGGL(maxabs_kernel, dim3(1024), dim3(256), 0, st, Q, (size_t)Nq * H, maxbits);
     hipLaunchKernelGGL(maxabs_kernel, dim3(2048), dim3(256), 0, st, P, (size_t)Np * H, maxbits + 1);
     hipLaunchKernelGGL(scale_exp_kernel, dim3(1), dim3(64), 0, st, maxbits, exps);
-    hipLaunchKernelGGL(split_f16_kernel, dim3(2048), dim3(256), 0, st, Q, Qc, Nq, Nq, H, sp.Hp, exps, 0);
-    hipLaunchKernelGGL(split_f16_kernel, dim3(4096), dim3(256), 0, st, P, Pc, Np, sp.np_pad, H, sp.Hp, exps, 1);
+    hipLaunchKernelGGL(split_f16_kernel, dim3(2048), dim3(256), 0, st, Q, Qc, Nq, Nq, H, sp.Hp, exps, 0, sp.parts);
+    hipLaunchKernelGGL(split_f16_kernel, dim3(4096), dim3(256), 0, st, P, Pc, Np, sp.np_pad, H, sp.Hp, exps, 1, sp.parts);
     CK_LAUNCH("score_split");
   }
   const int QC = split ? sp.QC : query_chunk(Nq, Np);
@@ -551,15 +558,15 @@ extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np,
     if (split) {
       ProfScope prof(PROF_SCORE, st, 2.0 * nq * (double)Np * H);  // algorithmic FLOPs of the scores, whatever pipe produces them
       // the GEMM addresses an operand with 32-bit byte offsets: passages go in column blocks of < 4 GiB of half operands
-      int pblk = (int)std::min<long long>(sp.np_pad, ((1ll << 32) / ((long long)3 * sp.Hp * 2) - 1) / 256 * 256);
+      int pblk = (int)std::min<long long>(sp.np_pad, ((1ll << 32) / ((long long)sp.parts * sp.Hp * 2) - 1) / 256 * 256);
       if (const char* e = getenv("COCODR_SCORE_PBLK")) pblk = std::max(256, std::min(pblk, atoi(e) / 256 * 256));  // test hook: small column blocks
       for (int p0 = 0; p0 < sp.np_pad; p0 += pblk) {
         cocodr_gemm_args g = {};
-        g.A = reinterpret_cast<const uint16_t*>(Qc + (size_t)q0 * 3 * sp.Hp);
-        g.B = reinterpret_cast<const uint16_t*>(Pc + (size_t)p0 * 3 * sp.Hp);
+        g.A = reinterpret_cast<const uint16_t*>(Qc + (size_t)q0 * sp.parts * sp.Hp);
+        g.B = reinterpret_cast<const uint16_t*>(Pc + (size_t)p0 * sp.parts * sp.Hp);
         g.C = S + p0;
-        g.M = nq; g.N = std::min(pblk, sp.np_pad - p0); g.K = 3 * sp.Hp;
-        g.lda = g.ldb = 3 * sp.Hp; g.ldc = (int)ld;
+        g.M = nq; g.N = std::min(pblk, sp.np_pad - p0); g.K = sp.parts * sp.Hp;
+        g.lda = g.ldb = sp.parts * sp.Hp; g.ldc = (int)ld;
         g.out_f32 = 1; g.batch = 1; g.ab_f16 = 1;
         const int rc = cocodr_gemm(&g, stream);
         if (rc != COCODR_OK) return rc;

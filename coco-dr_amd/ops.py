@@ -389,7 +389,8 @@ def topk_merge(D: torch.Tensor, I: torch.Tensor, shard_offset: torch.Tensor, k_o
 
 
 def score_set_mode(mode: int) -> None:
-    """0 = split-precision scores on the 16-bit matrix pipe (default), 1 = exact fp32 MFMA scores (include/cocodr.h)."""
+    """0 = split-precision scores on the 16-bit matrix pipe (default: fp32-accurate), 1 = exact fp32 MFMA scores, 2 = half-precision
+    scores (opt-in: one product of the operands rounded to IEEE half, a third of mode 0's matrix work; include/cocodr.h)."""
     check(lib().cocodr_score_set_mode(int(mode)), "score_set_mode")
 
 

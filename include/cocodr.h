@@ -336,7 +336,7 @@ int cocodr_gram_f32(const float* A, long long lda, int G, long long D, float* ou
  *  ANCE/utils/eval_mrr.py:81-90).  Q [Nq,H] fp32, P [Np,H] fp32; D [Nq,k] fp32 descending,
  * I [Nq,k] int64 positions into P (+ id_offset), ties -> lower position first, (-inf,-1) padding.
  * ------------------------------------------------------------------------------------------ */
-/* Two score pipelines, same selection:
+/* Three score pipelines, same selection:
  *  - split precision (default): Q and P are scaled by a power of two and split into two IEEE halves each (x = xh + xl to 22
  *    bits); ql.ph + qh.pl + qh.ph run as ONE half-precision MFMA GEMM of depth 3H with fp32 accumulation (small terms
  *    first).  Every partial product is exact in fp32; the result is closer to the real q.p than a sequential fp32 dot
@@ -344,6 +344,11 @@ int cocodr_gram_f32(const float* A, long long lda, int G, long long D, float* ou
  *    bit-identical scores, and integer-valued inputs below 2^11 stay exact.  3/16 of the fp32 matrix pipe's time per score.
  *  - exact fp32 MFMA (cocodr_score_set_mode(1) or COCODR_SCORE_EXACT=1, and whenever the workspace is too small for the
  *    half operands): scores bit-identical to an fmaf chain over the contraction index.
+ *  - half-precision scores (cocodr_score_set_mode(2), opt-in, never selected automatically): ONE product of the operands rounded
+ *    to IEEE half (11 significant bits, after the same power-of-two scaling) with fp32 accumulation - the arithmetic of a faiss
+ *    fp16 flat index; a third of the default pipeline's matrix work.  Score error ~1e-5 of |q||p| on embedding-shaped data
+ *    (worst case 1e-3): rankings differ from the fp32 ones only between near-ties; nDCG@10 / recall@1000 within 1e-3 of the exact
+ *    search on the config-5 workload (tests/test_gpu_retrieval.py).  Identical passages still score bit-identically.
  * Embeddings with non-finite components get NaN scores on the split path (ranked last).
  * workspace_bytes_dim: for embeddings of width H; workspace_bytes: the same for H = 1024 (enough for any H <= 1024).
  * The workspace must be 256-byte aligned. */
