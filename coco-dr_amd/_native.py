@@ -72,7 +72,8 @@ class LambPlan(C.Structure):  # mirrors cocodr_lamb_plan
 
 
 class LambFusedPlan(C.Structure):  # mirrors cocodr_lamb_fused_plan
-    _fields_ = [("seg_start", c_void_p), ("seg_len", c_void_p), ("seg_index", c_void_p), ("nfused", c_int)]
+    _fields_ = [("seg_start", c_void_p), ("seg_len", c_void_p), ("seg_index", c_void_p), ("wg_begin", c_void_p), ("wg_count", c_void_p),
+                ("round_first", c_void_p), ("nfused", c_int), ("nrounds", c_int)]
 
 
 class EncoderBwdLayout(C.Structure):  # mirrors cocodr_encoder_bwd_layout_t
@@ -138,6 +139,8 @@ SIGNATURES = {
     "cocodr_lamb_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, C.POINTER(LambPlan), c_float,
                                  c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_lamb_fused_capacity": (c_size_t, []),
+    "cocodr_lamb_fused_workgroups": (c_int, []),
+    "cocodr_lamb_fused_workgroup_elements": (c_size_t, []),
     "cocodr_lamb_fused_workspace_floats": (c_size_t, [c_int]),
     "cocodr_lamb_fused_error_index": (c_size_t, [c_int]),
     "cocodr_lamb_step_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, C.POINTER(LambFusedPlan), c_float,

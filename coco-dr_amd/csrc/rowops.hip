@@ -1229,14 +1229,15 @@ typedef uint32_t lu4 __attribute__((ext_vector_type(4)));
 typedef uint32_t lu2 __attribute__((ext_vector_type(2)));
 struct LambFusedArgs {
   float* p; const float* g; float* m; float* v; uint16_t* shadow; size_t shadow_begin;
-  const long long* seg_start; const int* seg_len; const int* seg_index; int nfused;
+  const long long* seg_start; const int* seg_len; const int* seg_index; const int* wg_begin; const int* wg_count; const int* round_first;
+  int nfused, nrounds;
   float beta1, beta2, eps, wd, grad_scale, lr; const float* grad_scale_dev;
   float* part; uint32_t epoch; int* err; float* trust; float* stats;
 };
 __global__ __launch_bounds__(LF_THREADS, LF_PER_CU * LF_THREADS / 256) void lamb_fused_kernel(const LambFusedArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ float red[2][LF_THREADS / 64];
-  __shared__ lf4 keep[LF_V][2][LF_THREADS];  // w and u of the PREVIOUS tensor (128 KB: thread-private slots, no barriers), see below
+  __shared__ lf4 keep[LF_V][2][LF_THREADS];  // w and u of the PREVIOUS round (128 KB: thread-private slots, no barriers), see below
   const int tid = threadIdx.x, bid = blockIdx.x, G = gridDim.x;
   const float gs = a.grad_scale * (a.grad_scale_dev ? *a.grad_scale_dev : 1.0f);
   auto block_sum2 = [&](float& x, float& y) {  // both sums over the workgroup, the same value in every thread (fixed order)
@@ -1252,24 +1253,43 @@ __global__ __launch_bounds__(LF_THREADS, LF_PER_CU * LF_THREADS / 256) void lamb
   // A tensor is addressed through buffer descriptors that END with it: a lane whose float4 lies behind the tensor loads zeros
   // (u = 0: no contribution to either norm) and its stores are dropped by the bounds check - no branches in the element stream, and
   // 32-bit offsets.  aux 2 = non-temporal (streamed once), aux 16 = sc1 (write-through / past the L1).
-  auto uni64 = [](unsigned long long x) {  // (tell hipcc the value is wave-uniform: a descriptor it believes divergent puts every
+  auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };  // (tell hipcc the value is wave-uniform: a descriptor it believes
+  auto uni64 = [](unsigned long long x) {                               //  divergent puts every buffer instruction into a waterfall loop)
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-    return ((unsigned long long)hi << 32) | lo;  //  buffer instruction into a readfirstlane waterfall loop)
+    return ((unsigned long long)hi << 32) | lo;
   };
   auto rsrc = [&](const void* base, size_t elem0, size_t n_elem, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + elem0 * bytes), 0, (uint32_t)(n_elem * bytes), 0x00020000);
   };
-  const uint32_t off0 = (uint32_t)(bid * LF_THREADS + tid) * 16u, offj = (uint32_t)G * LF_THREADS * 16u;  // byte offset of float4 j: off0 + j offj
   const __amdgpu_buffer_rsrc_t rgran = rsrc(a.part, 0, (size_t)a.nfused * G * 4, 4);
+  // A ROUND holds one or more tensors, each spread over its own range of workgroups (the host sizes the ranges by tensor length:
+  // BERT's 1 M-element Wq / Wk / Wv / Wo share a round, a 4 M-element FFN matrix has one to itself), so the per-round tail - granule,
+  // gather, two workgroup sums - is paid once per ~4 M elements and a gather reads only the granules of the workgroup's own tensor.
+  // This workgroup's tensor of round r: entry e (-1: none, the workgroup idles through the round), first element, length, its index
+  // among the tensor's workgroups and their number.
+  struct Slot { int e; size_t e0, n; int local, cnt; };
+  auto slot = [&](int r) {
+    Slot s{-1, 0, 0, 0, 1};
+    for (int e = uni(a.round_first[r]); e < uni(a.round_first[r + 1]); ++e) {
+      const int b0 = uni(a.wg_begin[e]), c = uni(a.wg_count[e]);
+      if (bid >= b0 && bid < b0 + c) {
+        s.e = e;
+        s.e0 = (size_t)uni64((unsigned long long)a.seg_start[e]);
+        s.n = (size_t)uni64((unsigned long long)a.seg_len[e]);
+        s.local = bid - b0;
+        s.cnt = c;
+      }
+    }
+    return s;
+  };
   struct Quad { lf4 p, g, m, v; };
-  struct Desc { __amdgpu_buffer_rsrc_t p, g, m, v; };
-  auto desc = [&](int k) {
-    const size_t e0 = (size_t)uni64((unsigned long long)a.seg_start[k]);
-    const size_t n = (size_t)uni64((unsigned long long)a.seg_len[k]);
-    return Desc{rsrc(a.p, e0, n, 4), rsrc(a.g, e0, n, 4), rsrc(a.m, e0, n, 4), rsrc(a.v, e0, n, 4)};
+  struct Desc { __amdgpu_buffer_rsrc_t p, g, m, v; uint32_t off0, offj; };  // byte offset of this thread's float4 j: off0 + j offj
+  auto desc = [&](const Slot& s) {
+    return Desc{rsrc(a.p, s.e0, s.n, 4), rsrc(a.g, s.e0, s.n, 4), rsrc(a.m, s.e0, s.n, 4), rsrc(a.v, s.e0, s.n, 4),
+                (uint32_t)(s.local * LF_THREADS + tid) * 16u, (uint32_t)s.cnt * LF_THREADS * 16u};
   };
   auto load = [&](const Desc& d, int j) {
-    const uint32_t o = off0 + (uint32_t)j * offj;
+    const uint32_t o = d.off0 + (uint32_t)j * d.offj;
     Quad q;
     q.p = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(d.p, o, 0, 2));
     q.g = __builtin_bit_cast(lf4, __builtin_amdgcn_raw_buffer_load_b128(d.g, o, 0, 2));
@@ -1279,7 +1299,7 @@ __global__ __launch_bounds__(LF_THREADS, LF_PER_CU * LF_THREADS / 256) void lamb
   };
   // one float4 of pass 1: m, v updated in memory; P = the weights, U = the update direction stay in registers
   auto work = [&](const Desc& d, int j, Quad q, lf4& P, lf4& U, float& sw, float& su) {
-    const uint32_t o = off0 + (uint32_t)j * offj;
+    const uint32_t o = d.off0 + (uint32_t)j * d.offj;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float ge = q.g[e] * gs;
@@ -1294,21 +1314,21 @@ __global__ __launch_bounds__(LF_THREADS, LF_PER_CU * LF_THREADS / 256) void lamb
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lu4, q.m), d.m, o, 0, 2);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lu4, q.v), d.v, o, 0, 2);
   };
-  auto publish = [&](int k, float sw, float su) {
+  auto publish = [&](const Slot& s, float sw, float su) {
     block_sum2(sw, su);
-    if (tid == 0) {
+    if (tid == 0 && s.e >= 0) {
       const lu4 gr = {__float_as_uint(sw), a.epoch, __float_as_uint(su), a.epoch};
-      __builtin_amdgcn_raw_buffer_store_b128(gr, rgran, (uint32_t)(((size_t)k * G + bid) * 16), 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(gr, rgran, (uint32_t)(((size_t)s.e * G + s.local) * 16), 0, 16);
     }
   };
-  // the trust ratio of tensor k from the G granules (fixed order: thread t adds granules t, t + 1024, ...; then the block sum)
-  auto gather = [&](int k) {
+  // the trust ratio of this workgroup's tensor from its granules (fixed order: thread t adds granules t, t + 1024, ...; then the block sum)
+  auto gather = [&](const Slot& s) {
     float sw = 0.f, su = 0.f;
-    for (int w = tid; w < G; w += LF_THREADS) {
-      const uint32_t o = (uint32_t)(((size_t)k * G + w) * 16);
+    for (int w = tid; w < s.cnt && s.e >= 0; w += LF_THREADS) {
+      const uint32_t o = (uint32_t)(((size_t)s.e * G + w) * 16);
       lu4 gr = __builtin_amdgcn_raw_buffer_load_b128(rgran, o, 0, 16);
       int spins = 0;
-      while (gr[1] != a.epoch || gr[3] != a.epoch) {  // not there yet (or torn): rare - it was written a whole tensor ago
+      while (gr[1] != a.epoch || gr[3] != a.epoch) {  // not there yet (or torn): rare - it was written a whole round ago
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1 << 24)) { *a.err = 1; break; }  // seconds: the grid is not co-resident
         gr = __builtin_amdgcn_raw_buffer_load_b128(rgran, o, 0, 16);
@@ -1319,20 +1339,19 @@ __global__ __launch_bounds__(LF_THREADS, LF_PER_CU * LF_THREADS / 256) void lamb
     block_sum2(sw, su);
     const float wn = fminf(sqrtf(sw), 10.0f), un = sqrtf(su);
     const float tr = (wn == 0.f || un == 0.f) ? 1.0f : wn / un;
-    if (bid == 0 && tid == 0) {
-      const int s = a.seg_index[k];
-      a.trust[s] = tr;
-      if (a.stats) { a.stats[2 * s] = wn; a.stats[2 * s + 1] = un; }
+    if (s.e >= 0 && s.local == 0 && tid == 0) {
+      const int si = a.seg_index[s.e];
+      a.trust[si] = tr;
+      if (a.stats) { a.stats[2 * si] = wn; a.stats[2 * si + 1] = un; }
     }
     return tr;
   };
-  auto apply = [&](int k, float tr) {  // w, u of tensor k come back from this thread's LDS slots
+  auto apply = [&](const Slot& s, float tr) {  // w, u of the slot's tensor come back from this thread's LDS slots
     const float step = a.lr * tr;
-    const size_t e0 = (size_t)uni64((unsigned long long)a.seg_start[k]);
-    const size_t n = (size_t)uni64((unsigned long long)a.seg_len[k]);
-    const __amdgpu_buffer_rsrc_t rp = rsrc(a.p, e0, n, 4);
-    const bool shadowed = a.shadow != nullptr && e0 >= a.shadow_begin;  // (workgroup-uniform)
-    const __amdgpu_buffer_rsrc_t rs = rsrc(a.shadow, shadowed ? e0 - a.shadow_begin : 0, shadowed ? n : 0, 2);
+    const __amdgpu_buffer_rsrc_t rp = rsrc(a.p, s.e0, s.n, 4);
+    const bool shadowed = a.shadow != nullptr && s.e0 >= a.shadow_begin;  // (workgroup-uniform)
+    const __amdgpu_buffer_rsrc_t rs = rsrc(a.shadow, shadowed ? s.e0 - a.shadow_begin : 0, shadowed ? s.n : 0, 2);
+    const uint32_t off0 = (uint32_t)(s.local * LF_THREADS + tid) * 16u, offj = (uint32_t)s.cnt * LF_THREADS * 16u;
 #pragma unroll
     for (int j = 0; j < LF_V; ++j) {
       const uint32_t o = off0 + (uint32_t)j * offj;
@@ -1347,36 +1366,39 @@ __global__ __launch_bounds__(LF_THREADS, LF_PER_CU * LF_THREADS / 256) void lamb
       __builtin_amdgcn_raw_buffer_store_b64(hv, rs, o >> 1, 0, 0);  // (num_records 0 when the tensor has no shadow: dropped)
     }
   };
-  // The stream: tensor k's quadruples with TWO requests ahead of the one being worked on (across the tensor boundary too: the
-  // tail of a tensor - its granule, the previous tensor's ratio and update - runs with the next tensor's first two quadruples in
-  // flight).  The current tensor's w, u are in registers; behind its tail they move to this thread's LDS slots, where the update
-  // of the previous tensor has just been read from.
-  auto unit = [&](int u) {  // request quadruple u of the flattened (tensor, j) sequence; past the end: a repeat of the last (not used)
-    const int total = a.nfused * LF_V;
+  // The stream: a round's quadruples with TWO requests ahead of the one being worked on (across the round boundary too: the tail of
+  // a round - its granule, the previous round's ratio and update - runs with the next round's first two quadruples in flight).  The
+  // current round's w, u are in registers; behind its tail they move to this thread's LDS slots, where the update of the previous
+  // round has just been read from.
+  auto unit = [&](int u) {  // request quadruple u of the flattened (round, j) sequence; past the end: a repeat of the last (not used)
+    const int total = a.nrounds * LF_V;
     const int uu = u < total ? u : total - 1;
-    const int k_ = uu / LF_V;
-    return load(desc(k_), uu - k_ * LF_V);
+    const int r_ = uu / LF_V;
+    return load(desc(slot(r_)), uu - r_ * LF_V);
   };
   Quad q0 = unit(0), q1 = unit(1);
+  Slot prev{-1, 0, 0, 0, 1};
 #pragma unroll 1
-  for (int k = 0; k < a.nfused; ++k) {
+  for (int r = 0; r < a.nrounds; ++r) {
     lf4 P[LF_V], U[LF_V];
     float sw = 0.f, su = 0.f;
-    const Desc d = desc(k);
+    const Slot cur = slot(r);
+    const Desc d = desc(cur);
 #pragma unroll
     for (int j = 0; j < LF_V; ++j) {
-      const Quad q2 = unit(k * LF_V + j + 2);
+      const Quad q2 = unit(r * LF_V + j + 2);
       work(d, j, q0, P[j], U[j], sw, su);
       q0 = q1;
       q1 = q2;
       __builtin_amdgcn_sched_barrier(0);  // (keep exactly two quadruples of requests ahead)
     }
-    publish(k, sw, su);
-    if (k > 0) apply(k - 1, gather(k - 1));
+    publish(cur, sw, su);
+    if (r > 0) apply(prev, gather(prev));
 #pragma unroll
     for (int j = 0; j < LF_V; ++j) { keep[j][0][tid] = P[j]; keep[j][1][tid] = U[j]; }
+    prev = cur;
   }
-  apply(a.nfused - 1, gather(a.nfused - 1));
+  apply(prev, gather(prev));
 #endif
 }
 // workgroups of the persistent grid: what is certainly co-resident per the occupancy query, at most LF_PER_CU per CU; 0 = the kernel
@@ -1401,6 +1423,8 @@ int lamb_fused_grid() {
 }  // namespace
 
 extern "C" size_t cocodr_lamb_fused_capacity(void) { return (size_t)lamb_fused_grid() * LF_THREADS * LF_V * 4; }
+extern "C" int cocodr_lamb_fused_workgroups(void) { return lamb_fused_grid(); }
+extern "C" size_t cocodr_lamb_fused_workgroup_elements(void) { return (size_t)LF_THREADS * LF_V * 4; }
 extern "C" size_t cocodr_lamb_fused_workspace_floats(int nfused) {
   return nfused > 0 ? (size_t)nfused * lamb_fused_grid() * 4 + 4 : 0;
 }
@@ -1410,7 +1434,8 @@ extern "C" int cocodr_lamb_step_fused(float* p, const float* g, float* m, float*
                                       float grad_scale, const float* grad_scale_dev, float* workspace, float* trust, float* stats,
                                       cocodr_stream_t stream) {
   CK_ARG(p && g && m && v && plan && workspace && trust, "lamb_step_fused: null pointer");
-  CK_ARG(plan->seg_start && plan->seg_len && plan->seg_index && plan->nfused > 0, "lamb_step_fused: incomplete plan");
+  CK_ARG(plan->seg_start && plan->seg_len && plan->seg_index && plan->wg_begin && plan->wg_count && plan->round_first && plan->nfused > 0 &&
+             plan->nrounds > 0 && plan->nrounds <= plan->nfused, "lamb_step_fused: incomplete plan");
   CK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)workspace) & 15) == 0 && (((uintptr_t)shadow) & 7) == 0 &&
              shadow_begin % 4 == 0, "lamb_step_fused: pointers must be 16-byte aligned");
   CK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "lamb_step_fused: bad hyper-parameters");
@@ -1424,6 +1449,7 @@ extern "C" int cocodr_lamb_step_fused(float* p, const float* g, float* m, float*
   LambFusedArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.shadow = shadow; a.shadow_begin = shadow_begin;
   a.seg_start = plan->seg_start; a.seg_len = plan->seg_len; a.seg_index = plan->seg_index; a.nfused = plan->nfused;
+  a.wg_begin = plan->wg_begin; a.wg_count = plan->wg_count; a.round_first = plan->round_first; a.nrounds = plan->nrounds;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.grad_scale = grad_scale; a.lr = lr; a.grad_scale_dev = grad_scale_dev;
   a.part = workspace;
   a.epoch = epoch;

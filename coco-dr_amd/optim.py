@@ -60,14 +60,39 @@ def lamb_plan(offsets: Sequence[int], numel: int, chunk: int = 4096, skip: Seque
 LAMB_FUSED_MIN = 1 << 18
 
 
-def lamb_fused_plan(offsets: Sequence[int], numel: int, capacity: int, min_len: int = LAMB_FUSED_MIN):
+def lamb_fused_plan(offsets: Sequence[int], numel: int, capacity: int, min_len: int = LAMB_FUSED_MIN, workgroups: int = 0,
+                    wg_elements: int = 16384):
     """The tensors of a flat parameter that ``cocodr_lamb_step_fused`` updates in one pass: at least ``min_len`` elements and at
-    most ``capacity`` (what the persistent grid keeps in registers: ``cocodr_lamb_fused_capacity()``).  Returns (indices into
-    ``offsets``, seg_start i64, seg_len i32, seg_index i32) - empty arrays when nothing qualifies."""
+    most ``capacity`` (what the persistent grid keeps on chip: ``cocodr_lamb_fused_capacity()`` = ``workgroups`` x ``wg_elements``),
+    packed in order into ROUNDS of at most ``workgroups`` workgroups: a tensor needs ceil(len / wg_elements) of them, a round's spare
+    workgroups are handed out in proportion (every CU streams), so BERT's 1 M-element Wq / Wk / Wv / Wo share one round and a 4 M-element
+    FFN matrix has its own.  Returns (indices into ``offsets``, seg_start i64, seg_len i32, seg_index i32, wg_begin i32, wg_count i32,
+    round_first i32 [rounds + 1]) - empty arrays when nothing qualifies."""
     offs = list(offsets) + [numel]
-    idx = [s for s, (a, b) in enumerate(zip(offs, offs[1:])) if min_len <= b - a <= capacity]
-    return (idx, np.asarray([offs[s] for s in idx], np.int64), np.asarray([offs[s + 1] - offs[s] for s in idx], np.int32),
-            np.asarray(idx, np.int32))
+    G = int(workgroups) if workgroups else max(1, capacity // wg_elements)
+    idx = [s for s, (a, b) in enumerate(zip(offs, offs[1:])) if min_len <= b - a <= capacity] if capacity > 0 else []
+    lens = [offs[s + 1] - offs[s] for s in idx]
+    need = [-(-n // wg_elements) for n in lens]
+    rounds, cur, used = [], [], 0
+    for k, nd in enumerate(need):
+        if cur and used + nd > G:
+            rounds.append(cur)
+            cur, used = [], 0
+        cur.append(k)
+        used += nd
+    if cur:
+        rounds.append(cur)
+    wg_begin, wg_count, round_first = [0] * len(idx), [0] * len(idx), [0]
+    for members in rounds:
+        total = sum(need[k] for k in members)
+        spare, b0 = G - total, 0
+        for i, k in enumerate(members):  # spare workgroups in proportion to the need (the last member takes the rounding remainder)
+            extra = spare * need[k] // total if i + 1 < len(members) else G - b0 - need[k]
+            wg_begin[k], wg_count[k] = b0, need[k] + extra
+            b0 += wg_count[k]
+        round_first.append(round_first[-1] + len(members))
+    return (idx, np.asarray([offs[s] for s in idx], np.int64), np.asarray(lens, np.int32), np.asarray(idx, np.int32),
+            np.asarray(wg_begin, np.int32), np.asarray(wg_count, np.int32), np.asarray(round_first, np.int32))
 
 
 def _shadow_owners(model) -> dict:
@@ -182,11 +207,12 @@ class FlatLamb(torch.optim.Optimizer):
             keep = []
             if self.one_pass:
                 cap = int(lib().cocodr_lamb_fused_capacity())
-                fused_idx, f_start, f_len, f_seg = lamb_fused_plan(offs, p.numel(), cap) if cap > 0 else ([], None, None, None)
+                fused_idx, *arrs_f = lamb_fused_plan(offs, p.numel(), cap, workgroups=int(lib().cocodr_lamb_fused_workgroups()),
+                                                     wg_elements=int(lib().cocodr_lamb_fused_workgroup_elements())) if cap > 0 else ([],)
                 if fused_idx:
-                    fdev = [torch.from_numpy(a).to(p.device) for a in (f_start, f_len, f_seg)]
+                    fdev = [torch.from_numpy(a).to(p.device) for a in arrs_f]
                     keep += fdev
-                    fplan = N.LambFusedPlan(fdev[0].data_ptr(), fdev[1].data_ptr(), fdev[2].data_ptr(), len(fused_idx))
+                    fplan = N.LambFusedPlan(*(t.data_ptr() for t in fdev), len(fused_idx), len(arrs_f[-1]) - 1)
                     fws = torch.zeros(int(lib().cocodr_lamb_fused_workspace_floats(len(fused_idx))), dtype=torch.float32, device=p.device)
             arrs = lamb_plan(offs, p.numel(), skip=fused_idx)
             plan = None

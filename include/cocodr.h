@@ -271,20 +271,28 @@ int cocodr_lamb_step(float* p, const float* g, float* m, float* v, uint16_t* sha
 /* The same update in ONE pass (30 instead of 42 B / parameter) for the tensors of a flat parameter that fit the chip's register
  * files - the encoder's weight matrices: a persistent grid of co-resident workgroups spreads each tensor over all of them, keeps w
  * and u in registers between the norm and the update, and exchanges per-workgroup partial norms through `workspace` (added in a
- * fixed order: deterministic; same arithmetic per element as cocodr_lamb_step).  plan: tensor k = elements [seg_start[k],
- * seg_start[k] + seg_len[k]) (multiples of 4, seg_len[k] <= cocodr_lamb_fused_capacity(), which is 0 where the kernel cannot run),
- * seg_index[k] = its row in trust / stats (the tensor numbering of the cocodr_lamb_plan the rest of the flat goes through: give
- * those tensors NO chunks there).  workspace: cocodr_lamb_fused_workspace_floats(nfused) floats, ZEROED once by the caller and then
- * left to this function (it holds the tagged partial-norm granules of the previous calls); the int at float index
- * cocodr_lamb_fused_error_index(nfused) is set to 1 if a workgroup gave up waiting for the others (never, unless the device
- * cannot hold the grid; the numbers of that step are then wrong).  trust fp32 [>= max seg_index + 1]. */
+ * fixed order: deterministic; same arithmetic per element as cocodr_lamb_step).  plan: entry k = one tensor = elements [seg_start[k],
+ * seg_start[k] + seg_len[k]) (multiples of 4), seg_index[k] = its row in trust / stats (the tensor numbering of the cocodr_lamb_plan
+ * the rest of the flat goes through: give those tensors NO chunks there).  The kernel runs in ROUNDS: round r holds the entries
+ * round_first[r] .. round_first[r + 1] - 1, and entry k is worked on by the workgroups wg_begin[k] .. wg_begin[k] + wg_count[k] - 1 of
+ * the G = cocodr_lamb_fused_workgroups() (disjoint ranges inside [0, G) within a round; seg_len[k] <= wg_count[k] *
+ * cocodr_lamb_fused_workgroup_elements()): several small tensors share a round, a tensor of cocodr_lamb_fused_capacity() elements
+ * (= G x that; 0 where the kernel cannot run) has one to itself.  workspace: cocodr_lamb_fused_workspace_floats(nfused) floats, ZEROED
+ * once by the caller and then left to this function (it holds the tagged partial-norm granules of the previous calls); the int at
+ * float index cocodr_lamb_fused_error_index(nfused) is set to 1 if a workgroup gave up waiting for the others (never, unless the
+ * device cannot hold the grid; the numbers of that step are then wrong).  trust fp32 [>= max seg_index + 1]. */
 typedef struct {
   const long long* seg_start;
   const int* seg_len;
   const int* seg_index;
-  int nfused;
+  const int* wg_begin;
+  const int* wg_count;
+  const int* round_first; /* [nrounds + 1] */
+  int nfused, nrounds;
 } cocodr_lamb_fused_plan;
 size_t cocodr_lamb_fused_capacity(void);
+int cocodr_lamb_fused_workgroups(void);
+size_t cocodr_lamb_fused_workgroup_elements(void);
 size_t cocodr_lamb_fused_workspace_floats(int nfused);
 size_t cocodr_lamb_fused_error_index(int nfused);
 int cocodr_lamb_step_fused(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t shadow_begin,

@@ -408,6 +408,43 @@ def test_one_pass_lamb_equals_the_two_pass_kernels_and_the_oracle_on_matrix_size
         np.testing.assert_allclose(a[0][offs[i]: offs[i] + n].cpu().numpy(), P[i], rtol=3e-4, atol=1e-7, err_msg=str(i))
 
 
+def test_one_pass_lamb_on_a_bert_base_width_model_equals_the_two_pass_step():
+    """FlatLamb.for_model at BERT-base width (one layer): the six weight matrices (Wq, Wk, Wv are tensors of their own) AND the position table (393 K elements, in
+    front of the bf16 shadow's range: the one-pass kernel must not write a shadow for it) take the one-pass kernel, the word table
+    (too large here? no: 1000 x 768 - it is fused as well), vectors and the token-type table the two-pass kernels; parameters, optimizer
+    state and the bf16 shadow after three clipped steps equal the all-two-pass run."""
+    import copy
+    from cocodr_amd.modeling import CocoBertConfig, CocoBertModel
+    from cocodr_amd.optim import FlatLamb, clip_grad_norm_
+    cfg = CocoBertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=1000, hidden_size=768, num_hidden_layers=1,
+                         num_attention_heads=12, intermediate_size=3072, max_position_embeddings=512)
+    torch.manual_seed(0)
+    models = [CocoBertModel(cfg).to(DEV)]
+    models.append(copy.deepcopy(models[0]))
+    outs = []
+    for m, one_pass in zip(models, (True, False)):
+        opt = FlatLamb.for_model(m, lr=1e-3, eps=1e-6, weight_decay=0.01)
+        opt.one_pass = one_pass
+        gen = torch.Generator().manual_seed(3)
+        for step in range(3):
+            for p in (m.flat_decay, m.flat_nodecay):
+                p.grad = (torch.randn(p.shape, generator=gen) * (0.3 if step == 0 else 0.01)).to(DEV)
+            opt.step(clip=clip_grad_norm_([m.flat_decay, m.flat_nodecay], 1.0))
+        assert not opt.one_pass_error()
+        nf = [pl[1].nfused if pl[1] is not None else 0 for pl in opt._plans.values()]
+        outs.append((m.flat_decay.data.clone(), m.flat_nodecay.data.clone(), m._shadow.clone(), opt.state[m.flat_decay]["exp_avg"].clone(),
+                     opt.state[m.flat_decay]["trust_ratio"].clone(), sorted(nf)))
+    assert outs[0][5] == [0, 8] and outs[1][5] == [0, 0]  # word + position tables, Wq, Wk, Wv, Wo, W1, W2 in one pass; the vector flat never
+    a, b = outs
+    assert torch.equal(a[3], b[3])                                     # m: the same arithmetic per element
+    torch.testing.assert_close(a[4], b[4], rtol=2e-6, atol=0)          # trust ratios: another summation order
+    torch.testing.assert_close(a[0], b[0], rtol=1e-6, atol=1e-9)
+    assert torch.equal(a[1], b[1])                                     # vectors: two-pass both times
+    lo = models[0].layout
+    assert torch.equal(a[2], a[0][lo.mat_begin:].to(torch.bfloat16))   # the shadow follows the one-pass update, over its own range only
+    assert float((a[2].float() - b[2].float()).abs().max()) <= 2.0 ** -7 * float(b[2].float().abs().max())
+
+
 @pytest.mark.parametrize("layers,M,H,I", [(6, 2048, 768, 3072), (2, 1024, 256, 512), (3, 4096, 1024, 4096), (12, 1024, 768, 3072)])
 def test_gemm_multi_weight_gradients_in_one_launch(layers, M, H, I):
     """cocodr_gemm_multi: the four weight-gradient problems of a layer range (different shapes, one contraction length) as one

@@ -21,7 +21,10 @@ def test_lamb_plans_partition_the_flat_between_the_one_pass_and_the_two_pass_ker
         offs.append(o)
         o = (o + n + 63) // 64 * 64
     cap = 4 * 1024 * 1024
-    idx, f_start, f_len, f_seg = lamb_fused_plan(offs, o, cap)
+    idx, f_start, f_len, f_seg, wg_begin, wg_count, round_first = lamb_fused_plan(offs, o, cap, workgroups=256, wg_elements=16384)
+    # rounds: 3 M + 1 M fill the 256 workgroups exactly (192 + 64); the 2^18 tensor gets a round - and all its workgroups - to itself
+    assert round_first.tolist() == [0, 2, 3] and wg_begin.tolist() == [0, 192, 0] and wg_count.tolist() == [192, 64, 256]
+    assert all(int(c) * 16384 >= int(n) for c, n in zip(wg_count, f_len))
     assert idx == [1, 3, 4] and f_seg.tolist() == idx                       # >= 2^18 and <= capacity; the 5 M tensor is too large
     assert f_start.tolist() == [offs[i] for i in idx] and all(int(n) % 4 == 0 for n in f_len)
     assert f_len.tolist() == [(offs + [o])[i + 1] - offs[i] for i in idx]   # alignment padding rides with the tensor in front of it
@@ -37,7 +40,7 @@ def test_lamb_plans_partition_the_flat_between_the_one_pass_and_the_two_pass_ker
         mine = seg[seg_begin[s]:seg_begin[s + 1]]
         assert (len(mine) == 0) == (s in idx) and (mine == s).all()
     # nothing qualifies: empty one-pass plan, the chunk plan covers everything
-    idx0, *_ = lamb_fused_plan(offs, o, capacity=1024)
+    idx0, *_ = lamb_fused_plan(offs, o, capacity=1024, workgroups=1, wg_elements=1024)
     assert idx0 == [] and sum(lamb_plan(offs, o)[1]) == o
     # capacity 0 (no co-resident grid on the device) never selects anything
     assert lamb_fused_plan(offs, o, 0)[0] == []
