@@ -1429,11 +1429,16 @@ class _SimCEFn(torch.autograd.Function):
         ctx.save_for_backward(dE)
         ctx.row0, ctx.m_local, ctx.M = row0, m_local, E_all.shape[0]
         ctx.mark_non_differentiable(rows)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the per-row losses' missing gradient: one fill kernel per step)
         return loss[0], rows
 
     @staticmethod
     def backward(ctx, g, _rows):
         (dE,) = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None
+        if ctx.row0 == 0 and ctx.m_local == ctx.M:  # one rank: the local rows are all rows (no zero-filled [M, H] + slice copy)
+            return dE * g, None, None, None
         full = dE.new_zeros((ctx.M, dE.shape[1]))
         full[ctx.row0:ctx.row0 + ctx.m_local] = dE * g
         return full, None, None, None

@@ -35,7 +35,7 @@ def test_simce_matches_reference_goldens(golden_loss):
         assert abs(float(loss) - float(g[f"rows_{M}"].mean())) < 2e-5
 
 
-@pytest.mark.parametrize("M,H,W", [(6, 128, 1), (64, 768, 1), (256, 768, 4), (2048, 768, 8)])
+@pytest.mark.parametrize("M,H,W", [(6, 128, 1), (64, 768, 1), (64, 1024, 2), (60, 768, 2), (32, 100, 4), (256, 768, 4), (2048, 768, 8)])
 def test_simce_local_rows_vs_oracle(M, H, W):
     rng = np.random.Generator(np.random.PCG64(M))
     E = (rng.standard_normal((M, H)) * (6.0 / np.sqrt(H))).astype(np.float32)
