@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "gemm_tile.h"
+#include "score_filter.h"
 
 namespace cocodr_gemm_pp {
 using namespace cocodr_gemm_v2;
@@ -154,9 +155,11 @@ struct MultiArgs {
   float* split_ws;
 };
 constexpr int SPLIT_TILE = BM * 256;  // floats of one partial tile
-template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false>
+// FILTER (the search, score_filter.h): the epilogue keeps the scores >= a per-row threshold instead of storing the tile
+template <int NB, int TA, int TB, bool OUT_F32, int VAR = 5, bool F16 = false, bool MULTI = false, bool FILTER = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std::conditional<MULTI, MultiArgs, cocodr_gemm_args>::type pa,
-                                                              const int flags) {
+                                                              const int flags,
+                                                              const typename std::conditional<FILTER, cocodr_score_filter, int>::type flt) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using S = Shape<NB>;
   static_assert(VAR == 0 || VAR == 5, "VAR 0: four thin phases per K-tile, VAR 5: two fat ones");
@@ -210,6 +213,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   else if (flat) grouped_tile(tile, ntm, ntn, 8, tm_, tn_);
   else { tm_ = tile / ntn; tn_ = tile % ntn; }
   const int m0 = tm_ * BM, n0 = tn_ * BN;
+  if constexpr (FILTER) {
+    if (flt.m_dev != nullptr && m0 >= *flt.m_dev - flt.m_base) return;  // workgroup-uniform, in front of every barrier
+  }
   const uint16_t* A = p.A + (size_t)z * p.strideA;
   const uint16_t* B = p.B + (size_t)z * p.strideB;
   const uint32_t a_bytes = (uint32_t)((size_t)(TA ? p.K : p.M) * p.lda * 2);
@@ -406,6 +412,77 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
     }
   }
 
+  if constexpr (FILTER) {
+    if (flt.mode == 0) {
+      // ---- filter epilogue: the same two 128-row passes through LDS; a thread scans 8 chunks of 8 consecutive columns per pass
+      // into a 64-bit hit mask (branch-free), then walks ITS hits - a wave runs as many trips as its busiest lane has hits (a
+      // handful at ~1.6 % density), not one branch per accumulator register.  A hit takes its slot in the (row, column tile)
+      // block from an LDS counter of the row.
+      static_assert(NB == 2, "filter epilogue: 256-column tiles");
+      constexpr int CLD = S::CT_LD, CPRW = BN / 8, NCH = 128 * CPRW / NTHREADS;
+      static_assert(NCH == 8, "one byte of the hit mask per chunk");
+      float* ct = reinterpret_cast<float*>(smem);
+      float* thr_s = ct + 128 * CLD;
+      int* rowcnt = reinterpret_cast<int*>(thr_s + 128);
+      const int tn_g = flt.tile0 + tn_;
+      __syncthreads();
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        const int gm_t = m0 + h * 128 + tid;  // (tid < 128)
+        if (tid < 128) {
+          thr_s[tid] = gm_t < p.M ? flt.thr[(size_t)gm_t * flt.thr_stride] : __builtin_inff();
+          rowcnt[tid] = 0;
+        }
+        if (wr == h) {
+#pragma unroll
+          for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) {
+                const int row = ai * 32 + (lane & 31);
+                const int col = wc * 32 * NB + b * 32 + 8 * rg + 4 * (lane >> 5);
+                *reinterpret_cast<float4*>(ct + row * CLD + col) =
+                    make_float4(acc[ai][b][rg * 4 + 0], acc[ai][b][rg * 4 + 1], acc[ai][b][rg * 4 + 2], acc[ai][b][rg * 4 + 3]);
+              }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        unsigned long long hits = 0;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = tid + i * NTHREADS;
+          const int row = c / CPRW, c8 = (c % CPRW) << 3;
+          const float t = thr_s[row];
+          const float4 c0 = *reinterpret_cast<const float4*>(ct + row * CLD + c8);
+          const float4 c1 = *reinterpret_cast<const float4*>(ct + row * CLD + c8 + 4);
+          const int left = flt.n_valid - (flt.col0 + n0 + c8);  // columns of this chunk that exist
+          unsigned m8 = (c0.x >= t ? 1u : 0u) | (c0.y >= t ? 2u : 0u) | (c0.z >= t ? 4u : 0u) | (c0.w >= t ? 8u : 0u) |
+                        (c1.x >= t ? 16u : 0u) | (c1.y >= t ? 32u : 0u) | (c1.z >= t ? 64u : 0u) | (c1.w >= t ? 128u : 0u);
+          if (left < 8) m8 &= left <= 0 ? 0u : ((1u << left) - 1u);
+          hits |= (unsigned long long)m8 << (8 * i);
+        }
+        while (hits != 0) {
+          const int bit = __builtin_ctzll(hits);
+          hits &= hits - 1;
+          const int c = tid + (bit >> 3) * NTHREADS;
+          const int row = c / CPRW, cl = ((c % CPRW) << 3) + (bit & 7);
+          const float v = ct[row * CLD + cl];
+          const int pos = atomicAdd(&rowcnt[row], 1);
+          if (pos + 1 < flt.capt)
+            flt.cand[((size_t)(m0 + h * 128 + row) * flt.ntn_total + tn_g) * flt.capt + 1 + pos] =
+                make_uint2(__float_as_uint(v), (uint32_t)(flt.col0 + n0 + cl));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 128 && gm_t < p.M) flt.cand[((size_t)gm_t * flt.ntn_total + tn_g) * flt.capt] = make_uint2((uint32_t)rowcnt[tid], 0u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      return;
+    }
+  }
+
   // ---- epilogue (gemm.hip's, for this geometry): two 128-row passes of the fp32 tile through LDS, row-major 16-B stores
   const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
   const uint16_t* __restrict__ R_ = p.R ? p.R + (size_t)z * p.strideR : nullptr;
@@ -515,9 +592,9 @@ void launch_form(const cocodr_gemm_args& a, hipStream_t st) {
     attr_done.done();
   }
   if (a.out_f32)
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, true, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat, 0);
   else
-    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat);
+    hipLaunchKernelGGL((gemm_pp_kernel<NB, TA, TB, false, VAR, F16>), grid, dim3(NTHREADS), S::LDS_BYTES, st, a, flat, 0);
 }
 
 }  // namespace cocodr_gemm_pp
@@ -656,7 +733,7 @@ void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, si
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done.done();
   }
-  hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
+  hipLaunchKernelGGL(kern, dim3(split ? total - r + r * s : total), dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1, 0);
   if (split) hipLaunchKernelGGL(gemm_pp_split_finish, dim3(r, SPLIT_TILE / 4 / 256), dim3(256), 0, st, ma, r);
 }
 
@@ -697,10 +774,10 @@ static void launch_split(const cocodr_gemm_args& a, int total, int r, int s, hip
   }
   const dim3 grid(total - r + r * s);
   if (a.out_f32) {
-    hipLaunchKernelGGL((gemm_pp_kernel<2, TA, TB, true, 0, false, true>), grid, dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
+    hipLaunchKernelGGL((gemm_pp_kernel<2, TA, TB, true, 0, false, true>), grid, dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1, 0);
     hipLaunchKernelGGL((gemm_pp_split_finish_epi<true, TA>), dim3(r, 8), dim3(256), 0, st, ma);
   } else {
-    hipLaunchKernelGGL((gemm_pp_kernel<2, TA, TB, false, 0, false, true>), grid, dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1);
+    hipLaunchKernelGGL((gemm_pp_kernel<2, TA, TB, false, 0, false, true>), grid, dim3(NTHREADS), Shape<2>::LDS_BYTES, st, ma, 1, 0);
     hipLaunchKernelGGL((gemm_pp_split_finish_epi<false, TA>), dim3(r, 8), dim3(256), 0, st, ma);
   }
 }
@@ -722,6 +799,18 @@ static void launch_any(const cocodr_gemm_args& a, hipStream_t st) {
   if (!a.trans_a && !a.trans_b) launch_form<2, 0, 0, VAR>(a, st);
   else if (!a.trans_a && a.trans_b) launch_form<2, 0, 1, VAR>(a, st);
   else launch_form<2, 1, 1, VAR>(a, st);
+}
+void cocodr_gemm_pp_launch_filter(const cocodr_gemm_args& a, const cocodr_score_filter& f, hipStream_t st) {
+  using namespace cocodr_gemm_pp;
+  using S = Shape<2>;
+  auto kern = gemm_pp_kernel<2, 0, 0, true, 5, true, false, true>;
+  static cocodr_lds_once attr_done;
+  if (attr_done.pending()) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done.done();
+  }
+  const int ntm = (a.M + BM - 1) / BM, ntn = a.N / S::BN;
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, 1), dim3(NTHREADS), S::LDS_BYTES, st, a, 0, f);
 }
 void cocodr_gemm_pp_launch(const cocodr_gemm_args& a, int nb, hipStream_t st) {
   if (nb == 104) cocodr_gemm_pp::launch_form<2, 0, 0, 5, true>(a, st);

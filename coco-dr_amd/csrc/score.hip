@@ -10,6 +10,7 @@
 // workspace holds TWO such slabs: the selection of chunk c runs on a side stream while the score GEMM of chunk c + 1
 // runs on the caller's stream - the GEMM is bound by the fp32 matrix pipe and leaves the memory system and the LDS
 // atomics the selection lives on almost idle, so the selection (17 % of the search when serialised) hides under it.
+#include <math.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -17,6 +18,7 @@
 
 #include "common.h"
 #include "prof.h"
+#include "score_filter.h"
 
 namespace {
 
@@ -135,9 +137,11 @@ struct SelState {
 
 // One radix pass over the elements `scan` enumerates: histogram digit(v) of the values val(key, idx, v) accepts whose
 // high bits match the prefix, pick the smallest digit whose cumulative count reaches st.need.
-template <typename Scan, typename Val>
+// THREADS: the workgroup's size; REP: histogram replicas (hist holds REP * NBIN words)
+template <int THREADS = TOPK_THREADS, int REP = NREP, typename Scan, typename Val>
 __device__ __forceinline__ void radix_pass(Scan scan, Val val, int shift, int bits, uint32_t himask, SelState& st, uint32_t* hist,
                                            int* sh) {
+  constexpr int TOPK_THREADS = THREADS, NREP = REP;  // (shadow the file-level defaults inside this function)
   const int tid = threadIdx.x;
   const int nb = 1 << bits;
   for (int i = tid; i < NREP * NBIN; i += TOPK_THREADS) hist[i] = 0;
@@ -213,17 +217,22 @@ __device__ __forceinline__ void radix_pass(Scan scan, Val val, int shift, int bi
 // identical on both paths.
 // unscale (or NULL): two ints, the binary exponents the split-precision path scaled Q and P by - D is multiplied by
 // 2^-(unscale[0] + unscale[1]) on the way out (exact; ordering and ties are those of the scaled scores)
+// row_map / n_dev (or NULL): slab row b holds the scores of output row row_map[b + n_base], and only while b + n_base < *n_dev
+// (the exhaustive pass over the rows the filtered search hands back; the count exists on the device alone)
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ S, long long lds_s, int np, int k,
                                                             long long id_offset, float* __restrict__ D, long long* __restrict__ I,
-                                                            const int* __restrict__ unscale) {
+                                                            const int* __restrict__ unscale, const int* __restrict__ row_map = nullptr,
+                                                            const int* __restrict__ n_dev = nullptr, int n_base = 0) {
   __shared__ uint32_t hist[NREP * NBIN];
   __shared__ unsigned long long buf[KMAX];   // (key << 32) | idx : ascending = score desc, idx asc
   __shared__ unsigned long long cand[NCAND];
   __shared__ int sh[8 + TOPK_THREADS / 64];  // [0..2] radix-pass result, [3], [4] list counters, [8..] wave totals of its prefix sum
   const int tid = threadIdx.x;
+  if (n_dev != nullptr && (int)blockIdx.x + n_base >= *n_dev) return;  // workgroup-uniform
+  const size_t orow = row_map ? (size_t)row_map[blockIdx.x + n_base] : (size_t)blockIdx.x;
   const float* row = S + (size_t)blockIdx.x * lds_s;
-  float* Drow = D + (size_t)blockIdx.x * k;
-  long long* Irow = I + (size_t)blockIdx.x * k;
+  float* Drow = D + orow * k;
+  long long* Irow = I + orow * k;
   const int kk = min(k, np);
   int kpad = 1;
   while (kpad < kk) kpad <<= 1;
@@ -375,6 +384,159 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------ filtered search: selection from the GEMM's candidate blocks
+// (score_filter.h).  One workgroup per query row: the row's hits of all column tiles are gathered into LDS as (key << 32) | column,
+// sorted (bitonic, ascending = score descending, position ascending on ties - the order of topk_kernel) and the first k leave.
+// A row whose blocks hold fewer than k hits (threshold too high), more than FCAP, or an overflowed block is not answered here:
+// its index goes to fb_rows[atomicAdd(fb_count)] and the exhaustive pass (plain scores + topk_kernel) answers it.
+// LDS: the list + ONE histogram (8 KiB) - 39 KiB for the 3 968-entry build, so four rows are in flight per CU: the kernel is a chain
+// of short barrier-separated steps (three radix passes, 55 bitonic stages over 1 024 winners), bound by their latency, not by work.
+constexpr int FCAP = 8192, FCAP_SMALL = 3968;  // candidates of a row the selection can hold (the plan picks the build)
+constexpr int FSEL_THREADS = 256;
+template <int LCAP>
+__global__ __launch_bounds__(FSEL_THREADS) void filter_select_kernel(const uint2* __restrict__ cand, int ntn, int capt, int k,
+                                                                     long long id_offset, float* __restrict__ D, long long* __restrict__ I,
+                                                                     const int* __restrict__ unscale, int* __restrict__ fb_count,
+                                                                     int* __restrict__ fb_rows) {
+  __shared__ uint32_t hist[NBIN];
+  __shared__ unsigned long long list[LCAP];   // (key << 32) | column : ascending = score descending, position ascending
+  __shared__ int sh[8 + FSEL_THREADS / 64];   // [0..2] radix-pass result, [3] winners taken, [5] hits, [6] overflow, [7] gather cursor
+  const int tid = threadIdx.x, row = blockIdx.x;
+  const uint2* blocks = cand + (size_t)row * ntn * capt;
+  if (tid == 0) { sh[3] = 0; sh[5] = 0; sh[6] = 0; sh[7] = 0; }
+  __syncthreads();
+  {
+    int total = 0, over = 0;
+    for (int t = tid; t < ntn; t += FSEL_THREADS) {
+      const int c = (int)blocks[(size_t)t * capt].x;
+      total += c;
+      over |= c > capt - 1;
+    }
+    if (total) atomicAdd(&sh[5], total);
+    if (over) sh[6] = 1;
+  }
+  __syncthreads();
+  const int n = sh[5];
+  if (sh[6] != 0 || n < k || n > LCAP) {  // workgroup-uniform: not answerable from the candidates
+    if (tid == 0) fb_rows[atomicAdd(fb_count, 1)] = row;
+    return;
+  }
+  for (int t = tid; t < ntn; t += FSEL_THREADS) {
+    const uint2* b = blocks + (size_t)t * capt;
+    const int c = (int)b[0].x;
+    if (c > 0) {
+      const int at = atomicAdd(&sh[7], c);
+      for (int i = 0; i < c; ++i) {
+        const uint2 e = b[1 + i];
+        list[at + i] = ((unsigned long long)desc_key(__uint_as_float(e.x)) << 32) | e.y;
+      }
+    }
+  }
+  __syncthreads();
+  auto scan = [&](auto body) {
+    for (int c = tid; c < n; c += FSEL_THREADS) {
+      const unsigned long long e = list[c];
+      body((uint32_t)(e >> 32), (uint32_t)e);
+    }
+  };
+  uint32_t thr = 0xffffffffu, ithr = 0xffffffffu;
+  if (k < n) {  // the exact cut of topk_kernel, on the list
+    auto by_key = [](uint32_t key, uint32_t, uint32_t& v) { v = key; return true; };
+    SelState st{0u, k, 0};
+    radix_pass<FSEL_THREADS, 1>(scan, by_key, 21, 11, 0x00000000u, st, hist, sh);
+    radix_pass<FSEL_THREADS, 1>(scan, by_key, 10, 11, 0xffe00000u, st, hist, sh);
+    radix_pass<FSEL_THREADS, 1>(scan, by_key, 0, 10, 0xfffffc00u, st, hist, sh);
+    thr = st.prefix;
+    if (st.count_eq > st.need) {  // exact score ties straddle the cut: keep the lowest positions
+      SelState si{0u, st.need, 0};
+      const uint32_t t = thr;
+      auto by_idx = [t](uint32_t key, uint32_t idx, uint32_t& v) { v = idx; return key == t; };
+      radix_pass<FSEL_THREADS, 1>(scan, by_idx, 21, 11, 0x00000000u, si, hist, sh);
+      radix_pass<FSEL_THREADS, 1>(scan, by_idx, 10, 11, 0xffe00000u, si, hist, sh);
+      radix_pass<FSEL_THREADS, 1>(scan, by_idx, 0, 10, 0xfffffc00u, si, hist, sh);
+      ithr = si.prefix;
+    }
+  }
+  int kpad = 1;
+  while (kpad < k) kpad <<= 1;
+  // the k winners move to the front of the list: every thread holds its entries in registers across the barrier, so no slot is
+  // overwritten before it was read
+  constexpr int PER = (LCAP + FSEL_THREADS - 1) / FSEL_THREADS;
+  unsigned long long mine[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = tid + i * FSEL_THREADS;
+    mine[i] = c < n ? list[c] : ~0ull;  // (n <= LCAP)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const uint32_t key = (uint32_t)(mine[i] >> 32), idx = (uint32_t)mine[i];
+    if (tid + i * FSEL_THREADS < n && (key < thr || (key == thr && idx <= ithr))) list[atomicAdd(&sh[3], 1)] = mine[i];
+  }
+  __syncthreads();
+  for (int i = k + tid; i < kpad; i += FSEL_THREADS) list[i] = ~0ull;  // (kpad <= KMAX <= LCAP)
+  __syncthreads();
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (kpad >> 1); t += FSEL_THREADS) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const unsigned long long a = list[lo], b = list[hi];
+        if ((a > b) == up) { list[lo] = b; list[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  const float out_mul = unscale ? ldexpf(1.0f, -(unscale[0] + unscale[1])) : 1.0f;
+  float* Drow = D + (size_t)row * k;
+  long long* Irow = I + (size_t)row * k;
+  for (int i = tid; i < k; i += FSEL_THREADS) {
+    const unsigned long long e = list[i];
+    Drow[i] = key_to_float((uint32_t)(e >> 32)) * out_mul;
+    Irow[i] = (long long)(uint32_t)e + id_offset;
+  }
+}
+
+// thr[row] = the j-th best of the row's n scores (the filter's threshold): three radix passes over the row, no list, no sort
+__global__ __launch_bounds__(TOPK_THREADS) void row_rank_kernel(const float* __restrict__ S, long long lds_s, int n, int j,
+                                                                float* __restrict__ thr) {
+  __shared__ uint32_t hist[NREP * NBIN];
+  __shared__ int sh[8 + TOPK_THREADS / 64];
+  const int tid = threadIdx.x;
+  const float* row = S + (size_t)blockIdx.x * lds_s;
+  auto scan = [&](auto body) {  // (rows start 16-byte aligned, n % 4 == 0)
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+    for (int i = tid; i < (n >> 2); i += TOPK_THREADS) {
+      const float4 v = r4[i];
+      body(desc_key(v.x), 0u); body(desc_key(v.y), 0u); body(desc_key(v.z), 0u); body(desc_key(v.w), 0u);
+    }
+  };
+  auto by_key = [](uint32_t key, uint32_t, uint32_t& v) { v = key; return true; };
+  SelState st{0u, j, 0};
+  radix_pass(scan, by_key, 21, 11, 0x00000000u, st, hist, sh);
+  radix_pass(scan, by_key, 10, 11, 0xffe00000u, st, hist, sh);
+  radix_pass(scan, by_key, 0, 10, 0xfffffc00u, st, hist, sh);
+  if (tid == 0) thr[blockIdx.x] = key_to_float(st.prefix);
+}
+
+// rows i * stride of X (row_halfs 16-bit elements each, a multiple of 8) -> row i of Y: the strided passage sample the
+// thresholds come from.  idx != NULL: row idx[i + i_base] instead, for i + i_base < *n_dev (the fallback rows' operand copy).
+__global__ __launch_bounds__(256) void copy_rows_kernel(const _Float16* __restrict__ X, _Float16* __restrict__ Y, int row_halfs,
+                                                        long long stride, const int* __restrict__ idx, const int* __restrict__ n_dev,
+                                                        int i_base) {
+  const int i = blockIdx.x;
+  long long src = (long long)i * stride;
+  if (idx != nullptr) {
+    if (i + i_base >= *n_dev) return;
+    src = idx[i + i_base];
+  }
+  const uint4* x = reinterpret_cast<const uint4*>(X + (size_t)src * row_halfs);
+  uint4* y = reinterpret_cast<uint4*>(Y + (size_t)i * row_halfs);
+  for (int c = threadIdx.x; c < row_halfs / 8; c += 256) y[c] = x[c];
+}
+
 // ------------------------------------------------------------------ split-precision scores on the 16-bit matrix pipe
 // x 2^s = xh + xl + r with xh, xl IEEE half (11 significant bits each) and |r| <= 2^-22 |x|: the three partial products
 // ql.ph + qh.pl + qh.ph, every one exact in fp32 and accumulated in fp32 by v_mfma_f32_32x32x16_f16 in that order (small
@@ -384,9 +546,14 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
 // xl out of the half subnormals for every element that matters; it is exact and undone exactly.
 __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ X, size_t n, uint32_t* __restrict__ out) {
   uint32_t m = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const uint32_t b = __float_as_uint(X[i]) & 0x7fffffffu;
+  auto one = [&](float x) {
+    const uint32_t b = __float_as_uint(x) & 0x7fffffffu;
     if (b < 0x7f800000u) m = max(m, b);  // finite magnitudes only (bit patterns of non-negative floats order like the floats)
+  };
+  const float4* X4 = reinterpret_cast<const float4*>(X);  // (16-byte aligned, n % 4 == 0: checked by the caller)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)gridDim.x * 256) {
+    const float4 v = X4[i];
+    one(v.x); one(v.y); one(v.z); one(v.w);
   }
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
@@ -409,20 +576,26 @@ __global__ void scale_exp_kernel(const uint32_t* __restrict__ maxbits, int* __re
 // (is_p).  parts = 1 (mode 2, opt-in): the high halves alone - scores of IEEE-half operands with fp32 accumulation.
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ X, _Float16* __restrict__ Xc, int rows, int rows_pad, int H,
                                                         int Hp, const int* __restrict__ exps, int is_p, int parts) {
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
   const float scale = ldexpf(1.0f, exps[is_p]);
-  const size_t total = (size_t)rows_pad * Hp;
+  const int q = Hp / 4;  // four columns per thread (H % 4 == 0: a group of four is all data or all padding)
+  const size_t total = (size_t)rows_pad * q;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int r = (int)(i / Hp), c = (int)(i - (size_t)r * Hp);
-    _Float16 hi = (_Float16)0.f, lo = (_Float16)0.f;
+    const int r = (int)(i / q), c = (int)(i - (size_t)r * q) * 4;
+    half4 hi = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f}, lo = hi;
     if (r < rows && c < H) {
-      const float x = X[(size_t)r * H + c] * scale;
-      hi = (_Float16)x;
-      lo = (_Float16)(x - (float)hi);
+      const float4 x4 = *reinterpret_cast<const float4*>(X + (size_t)r * H + c);
+      const float x[4] = {x4.x * scale, x4.y * scale, x4.z * scale, x4.w * scale};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)x[e];
+        lo[e] = (_Float16)(x[e] - (float)hi[e]);
+      }
     }
-    _Float16* row = Xc + (size_t)r * parts * Hp;
-    if (parts == 1) { row[c] = hi; }
-    else if (is_p) { row[c] = hi; row[Hp + c] = lo; row[2 * Hp + c] = hi; }
-    else { row[c] = lo; row[Hp + c] = hi; row[2 * Hp + c] = hi; }
+    _Float16* row = Xc + (size_t)r * parts * Hp + c;
+    if (parts == 1) { *reinterpret_cast<half4*>(row) = hi; }
+    else if (is_p) { *reinterpret_cast<half4*>(row) = hi; *reinterpret_cast<half4*>(row + Hp) = lo; *reinterpret_cast<half4*>(row + 2 * Hp) = hi; }
+    else { *reinterpret_cast<half4*>(row) = lo; *reinterpret_cast<half4*>(row + Hp) = hi; *reinterpret_cast<half4*>(row + 2 * Hp) = hi; }
   }
 }
 
@@ -461,6 +634,66 @@ SplitPlan split_plan(int Nq, int Np, int H) {
   return s;
 }
 
+// The filtered search (score_filter.h): thresholds from a strided sample of ns passages, candidate blocks instead of a score slab.
+// Everything it needs beyond the legacy layout sits behind sp.total; the slab area is reused, one after the other, for the sample's
+// scores, the candidate blocks and the exhaustive pass over the rows handed back.
+struct FilterPlan {
+  bool on = false;
+  int ns = 0, j = 0, capt = 0, ntn = 0, QF = 0, FBR = 0, lcap = 0;
+  long long stride = 1;
+  size_t off_ps = 0, off_qfb = 0, off_dt = 0, off_fb = 0, area = 0, total = 0;
+};
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+FilterPlan filter_plan(int Nq, int Np, int k, const SplitPlan& sp) {
+  FilterPlan f;
+  f.total = sp.total;
+  if (score_mode() == 1 || env_int("COCODR_SCORE_NOFILTER", 0) != 0) return f;
+  const int min_np = env_int("COCODR_SCORE_FILTER_MIN_NP", 32768);  // (test hook: small searches through this path)
+  if (Np < min_np || k > KMAX || (long long)k * 16 > Np) return f;
+  // sample: every stride-th passage, ~Np / 32 of them (the sample's product is that fraction of extra matrix work)
+  int ns = (Np / 32 + 255) / 256 * 256;
+  ns = std::max(std::min(ns, 32768), std::min(4096, Np / 256 * 256));
+  if (ns < 256) return f;
+  f.ns = ns;
+  f.stride = Np / ns;
+  const double rho = (double)Np / ns;
+  // the sample holds ~mu of the row's k best; its j-th best, j a few deviations past mu, is with near certainty BELOW the k-th best
+  // of the row (the same cut topk_kernel makes inside a row) - then the scores >= it number ~j rho +- sqrt(j) rho
+  const double mu = (double)k / rho;
+  int j = (int)(mu + 4.0 * sqrt(mu) + 8.0);
+  j = env_int("COCODR_SCORE_FILTER_J", j);  // (test hook: a rank too small hands every row back)
+  j = std::max(1, std::min(j, ns));
+  f.j = j;
+  const double expect = j * rho, dev = sqrt((double)j) * rho;
+  if (expect + 6.0 * dev > FCAP) return f;
+  f.lcap = expect + 6.0 * dev <= FCAP_SMALL ? FCAP_SMALL : FCAP;
+  f.ntn = sp.np_pad / 256;
+  const double per_tile = expect / f.ntn;
+  int capt = ((int)(2.0 * per_tile + 6.0 * sqrt(per_tile) + 16.0) + 1 + 7) / 8 * 8;  // entries + the header, whole 64-byte lines
+  capt = env_int("COCODR_SCORE_FILTER_CAPT", capt);  // (test hook: tiny blocks overflow)
+  f.capt = std::max(8, std::min(capt, 512)) / 8 * 8;
+  f.area = 2 * (size_t)sp.QC * sp.np_pad * 4;
+  long long qf = std::min<long long>({((long long)Nq + 255) / 256 * 256, (long long)(f.area / ((size_t)f.ntn * f.capt * 8)),
+                                      (long long)(f.area / ((size_t)ns * 4)), 16384ll});
+  qf = qf / 256 * 256;
+  if (qf < 256) return f;
+  f.QF = (int)qf;
+  f.FBR = (int)std::min<long long>(f.QF, (long long)(f.area / ((size_t)sp.np_pad * 4)) / 128 * 128);
+  if (f.FBR < 128) return f;
+  const size_t row_bytes = (size_t)sp.parts * sp.Hp * 2;
+  size_t o = sp.total;
+  f.off_ps = o; o = align256(o + (size_t)ns * row_bytes);
+  f.off_qfb = o; o = align256(o + (size_t)f.QF * row_bytes);
+  f.off_dt = o; o = align256(o + (size_t)f.QF * 4);
+  f.off_fb = o; o = align256(o + ((size_t)f.QF + 64) * 4);
+  f.total = o;
+  f.on = true;
+  return f;
+}
+
 int query_chunk(int nq, int np) {
   long long qc = (1ll << 28) / std::max(np, 1);  // two slabs of <= 1 GiB
   qc = std::max(128ll, std::min(qc, 8192ll));
@@ -497,9 +730,10 @@ size_t exact_bytes(int Nq, int Np) {
 }  // namespace
 
 extern "C" size_t cocodr_score_topk_workspace_bytes_dim(int Nq, int Np, int H, int k) {
-  (void)k;
   if (Nq <= 0 || Np <= 0 || H <= 0) return 0;
-  return score_mode() == 1 ? exact_bytes(Nq, Np) : std::max(exact_bytes(Nq, Np), split_plan(Nq, Np, H).total);  // (mode 2 needs less than mode 0)
+  if (score_mode() == 1) return exact_bytes(Nq, Np);
+  const SplitPlan sp = split_plan(Nq, Np, H);
+  return std::max(exact_bytes(Nq, Np), filter_plan(Nq, Np, k, sp).total);  // (mode 2 needs less than mode 0)
 }
 extern "C" size_t cocodr_score_topk_workspace_bytes(int Nq, int Np, int k) { return cocodr_score_topk_workspace_bytes_dim(Nq, Np, 1024, k); }
 extern "C" int cocodr_score_set_mode(int mode) {
@@ -507,6 +741,94 @@ extern "C" int cocodr_score_set_mode(int mode) {
   g_score_mode = mode;
   return COCODR_OK;
 }
+
+namespace {
+// passages per launch of the split-precision product: the GEMM addresses an operand with 32-bit byte offsets, so they go in column
+// blocks of < 4 GiB of half operands
+int passage_block(const SplitPlan& sp) {
+  int pblk = (int)std::min<long long>(sp.np_pad, ((1ll << 32) / ((long long)sp.parts * sp.Hp * 2) - 1) / 256 * 256);
+  if (const char* e = getenv("COCODR_SCORE_PBLK")) pblk = std::max(256, std::min(pblk, atoi(e) / 256 * 256));  // test hook: small column blocks
+  return pblk;
+}
+
+// The filtered search over the half operands Qc / Pc (split_f16_kernel's): per chunk of QF query rows
+//   scores of the passage sample -> per-row threshold (topk_kernel on the sample, its j-th best) -> the full product with the filter
+//   epilogue -> selection from the candidate blocks -> the exhaustive pass (device-gated: it costs three empty launches when, as
+//   usual, no row was handed back).  Everything on the caller's stream.  Exact: a row is answered from its candidates only when they
+//   provably contain its k best (>= k scores at or above the threshold, nothing overflowed); the order is topk_kernel's.
+int filtered_search(const _Float16* Qc, const _Float16* Pc, const int* exps, int Nq, int Np, int H, int k, long long id_offset, float* D,
+                    long long* I, char* wsb, const SplitPlan& sp, const FilterPlan& fp, hipStream_t st) {
+  const int K = sp.parts * sp.Hp;
+  _Float16* Ps = reinterpret_cast<_Float16*>(wsb + fp.off_ps);
+  _Float16* Qfb = reinterpret_cast<_Float16*>(wsb + fp.off_qfb);
+  float* Dt = reinterpret_cast<float*>(wsb + fp.off_dt);
+  int* fb_count = reinterpret_cast<int*>(wsb + fp.off_fb);
+  int* fb_rows = fb_count + 64;
+  float* area = reinterpret_cast<float*>(wsb + sp.off_slab);
+  const int pblk = passage_block(sp);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(fp.ns), dim3(256), 0, st, Pc, Ps, K, fp.stride, (const int*)nullptr, (const int*)nullptr, 0);
+  CK_LAUNCH("score_sample");
+  auto product = [&](const _Float16* A, int M, const _Float16* B, int N, float* C, long long ldc) {
+    cocodr_gemm_args g = {};
+    g.A = reinterpret_cast<const uint16_t*>(A);
+    g.B = reinterpret_cast<const uint16_t*>(B);
+    g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = g.ldb = K; g.ldc = (int)ldc;
+    g.out_f32 = 1; g.batch = 1; g.ab_f16 = 1;
+    return g;
+  };
+  for (int q0 = 0; q0 < Nq; q0 += fp.QF) {
+    const int nq = std::min(fp.QF, Nq - q0);
+    const _Float16* Aq = Qc + (size_t)q0 * K;
+    {
+      ProfScope prof(PROF_SCORE, st, 2.0 * nq * (double)Np * H);  // (the sample's product is overhead: its time counts, its FLOPs do not)
+      cocodr_gemm_args g = product(Aq, nq, Ps, fp.ns, area, fp.ns);
+      const int rc = cocodr_gemm(&g, (cocodr_stream_t)st);
+      if (rc != COCODR_OK) return rc;
+    }
+    hipLaunchKernelGGL(row_rank_kernel, dim3(nq), dim3(TOPK_THREADS), 0, st, area, (long long)fp.ns, fp.ns, fp.j, Dt);
+    CK_LAUNCH("score_thresholds");
+    if (hipMemsetAsync(fb_count, 0, 4, st) != hipSuccess) { cocodr_set_error("score_topk: memset failed"); return COCODR_ERR_LAUNCH; }
+    {
+      ProfScope prof(PROF_SCORE, st, 0.0);
+      for (int p0 = 0; p0 < sp.np_pad; p0 += pblk) {
+        const cocodr_gemm_args g = product(Aq, nq, Pc + (size_t)p0 * K, std::min(pblk, sp.np_pad - p0), nullptr, 0);
+        cocodr_score_filter f = {};
+        f.mode = 0;
+        f.thr = Dt; f.thr_stride = 1;
+        f.cand = reinterpret_cast<uint2*>(area);
+        f.capt = fp.capt; f.ntn_total = fp.ntn; f.tile0 = p0 / 256;
+        f.col0 = p0; f.n_valid = Np;
+        cocodr_gemm_pp_launch_filter(g, f, st);
+      }
+      CK_LAUNCH("score_filter_gemm");
+    }
+    if (fp.lcap <= FCAP_SMALL)
+      hipLaunchKernelGGL(filter_select_kernel<FCAP_SMALL>, dim3(nq), dim3(FSEL_THREADS), 0, st, reinterpret_cast<const uint2*>(area), fp.ntn, fp.capt, k,
+                         id_offset, D + (size_t)q0 * k, I + (size_t)q0 * k, exps, fb_count, fb_rows);
+    else
+      hipLaunchKernelGGL(filter_select_kernel<FCAP>, dim3(nq), dim3(FSEL_THREADS), 0, st, reinterpret_cast<const uint2*>(area), fp.ntn, fp.capt, k,
+                         id_offset, D + (size_t)q0 * k, I + (size_t)q0 * k, exps, fb_count, fb_rows);
+    CK_LAUNCH("score_filter_select");
+    for (int base = 0; base < nq; base += fp.FBR) {  // the rows handed back, FBR at a time (gated by the device-side count)
+      const int rows = std::min(fp.FBR, nq - base);
+      hipLaunchKernelGGL(copy_rows_kernel, dim3(rows), dim3(256), 0, st, Aq, Qfb, K, 0ll, (const int*)fb_rows, (const int*)fb_count, base);
+      for (int p0 = 0; p0 < sp.np_pad; p0 += pblk) {
+        const cocodr_gemm_args g = product(Qfb, rows, Pc + (size_t)p0 * K, std::min(pblk, sp.np_pad - p0), area + p0, sp.np_pad);
+        cocodr_score_filter f = {};
+        f.mode = 1;
+        f.m_dev = fb_count; f.m_base = base;
+        cocodr_gemm_pp_launch_filter(g, f, st);
+      }
+      hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(TOPK_THREADS), 0, st, area, (long long)sp.np_pad, Np, k, id_offset, D + (size_t)q0 * k,
+                         I + (size_t)q0 * k, exps, (const int*)fb_rows, (const int*)fb_count, base);
+      CK_LAUNCH("score_filter_fallback");
+    }
+  }
+  return COCODR_OK;
+}
+}  // namespace
 
 extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset, float* D,
                                  long long* I, void* workspace, size_t workspace_bytes, cocodr_stream_t stream) {
@@ -536,6 +858,8 @@ extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np,
     hipLaunchKernelGGL(split_f16_kernel, dim3(2048), dim3(256), 0, st, Q, Qc, Nq, Nq, H, sp.Hp, exps, 0, sp.parts);
     hipLaunchKernelGGL(split_f16_kernel, dim3(4096), dim3(256), 0, st, P, Pc, Np, sp.np_pad, H, sp.Hp, exps, 1, sp.parts);
     CK_LAUNCH("score_split");
+    const FilterPlan fp = filter_plan(Nq, Np, k, sp);
+    if (fp.on && workspace_bytes >= fp.total) return filtered_search(Qc, Pc, exps, Nq, Np, H, k, id_offset, D, I, wsb, sp, fp, st);
   }
   const int QC = split ? sp.QC : query_chunk(Nq, Np);
   const long long ld = split ? sp.np_pad : ((long long)Np + 3) / 4 * 4;
@@ -557,9 +881,7 @@ extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np,
     }
     if (split) {
       ProfScope prof(PROF_SCORE, st, 2.0 * nq * (double)Np * H);  // algorithmic FLOPs of the scores, whatever pipe produces them
-      // the GEMM addresses an operand with 32-bit byte offsets: passages go in column blocks of < 4 GiB of half operands
-      int pblk = (int)std::min<long long>(sp.np_pad, ((1ll << 32) / ((long long)sp.parts * sp.Hp * 2) - 1) / 256 * 256);
-      if (const char* e = getenv("COCODR_SCORE_PBLK")) pblk = std::max(256, std::min(pblk, atoi(e) / 256 * 256));  // test hook: small column blocks
+      const int pblk = passage_block(sp);
       for (int p0 = 0; p0 < sp.np_pad; p0 += pblk) {
         cocodr_gemm_args g = {};
         g.A = reinterpret_cast<const uint16_t*>(Qc + (size_t)q0 * sp.parts * sp.Hp);
