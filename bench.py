@@ -293,8 +293,18 @@ def eval_search(dev, nq: int = 10000, npass: int = 125000, dim: int = 1024, k: i
         dt, n_launch, ms, flops = timed(0)
         dte, ne, mse, flopse = timed(1)
         dth, _, _, _ = timed(2)
+        os.environ["COCODR_SCORE_NOFILTER"] = "1"  # the exhaustive route (score slab + radix select), for comparison
+        dtx, _, _, _ = timed(0)
     finally:
+        os.environ.pop("COCODR_SCORE_NOFILTER", None)
         ops.score_set_mode(0)
+    plan = ops.score_filter_plan(nq, npass, dim, k)
+    handed_back = None
+    if plan["filtered"]:
+        ops.score_topk(Q, P, k, workspace=ws)
+        torch.cuda.synchronize()
+        o = plan["handed_back_count_offset"]
+        handed_back = int(ws[o:o + 4].view(torch.int32).item())
     alg = 2.0 * nq * npass * dim
     dimp = (dim + 63) // 64 * 64
     executed = 3.0 * 2.0 * nq * npass * dimp  # ql.ph + qh.pl + qh.ph
@@ -302,10 +312,16 @@ def eval_search(dev, nq: int = 10000, npass: int = 125000, dim: int = 1024, k: i
            "workload": f"{nq} queries x {npass} passages x {dim} fp32, k={k}, split-precision scores (3 half-precision MFMA products per "
                        f"score, fp32 accumulate) + exact top-k, one GPU's shard of config 5",
            "algorithmic_tflops": round(alg / dt / 1e12, 1)}
+    out["selection"] = {"filtered": bool(plan["filtered"]), "plan": plan, "rows_handed_back_to_the_exhaustive_pass": handed_back,
+                        "exhaustive_route_ms": round(dtx * 1e3, 2), "exhaustive_route_dot_products_per_sec": round(nq * npass / dtx),
+                        "note": "filtered search (include/cocodr.h): per-row thresholds from a strided passage sample, the score GEMM's "
+                                "epilogue keeps the scores at or above them, the k best are selected from those candidates; identical "
+                                "D / I to the exhaustive route (COCODR_SCORE_NOFILTER=1: fp32 score slab + radix select), "
+                                "tests/test_gpu_search_filter.py"}
     out["roofline"] = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "dtype": "f16 operands, f32 accumulate",
                        "achieved": round(executed / dt / 1e12, 1), "frac": round(executed / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                        "algorithmic_achieved": round(alg / dt / 1e12, 1), "algorithmic_frac": round(alg / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                       "note": "whole search (operand split + score GEMM + selection) / wall time against the dense 16-bit MFMA peak: "
+                       "note": "whole search (operand split + sample and score GEMMs + selection) / wall time against the dense 16-bit MFMA peak: "
                                "`achieved` / `frac` count the EXECUTED half-precision MFMA FLOPs (3 per algorithmic FLOP: the price of fp32 "
                                "accuracy on the 16-bit pipe), `algorithmic_*` the 2 Nq Np H of the metric; the reference's own arithmetic "
                                "(fp32) is the exact_fp32_mfma_pipeline block, against the fp32-MFMA peak"}
@@ -802,6 +818,7 @@ def leg_summary(extras: dict) -> dict:
     s["corpus_encode_packed_seq_per_sec"] = g(extras, "corpus_encode", "packed_sequences_per_sec")
     s["search_dot_products_per_sec"] = g(extras, "eval_search", "dot_products_per_sec")
     s["search_half_precision_opt_in_dot_products_per_sec"] = g(extras, "eval_search", "half_precision_scores_opt_in", "dot_products_per_sec")
+    s["search_exhaustive_route_dot_products_per_sec"] = g(extras, "eval_search", "selection", "exhaustive_route_dot_products_per_sec")
     s["search_cpu_dot_products_per_sec"] = g(extras, "eval_search", "cpu_baseline", "value")
     s["config5_search_dot_products_per_sec"] = g(extras, "config5_end_to_end", "search_dot_products_per_sec")
     s["config5_encode_passages_per_sec"] = g(extras, "config5_end_to_end", "encode_passages_per_sec")

@@ -154,6 +154,7 @@ SIGNATURES = {
     "cocodr_score_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "cocodr_score_topk_workspace_bytes_dim": (c_size_t, [c_int, c_int, c_int, c_int]),
     "cocodr_score_set_mode": (c_int, [c_int]),
+    "cocodr_score_filter_plan": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "cocodr_score_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
     "cocodr_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_int, c_void_p]),

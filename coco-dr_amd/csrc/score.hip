@@ -384,6 +384,50 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
   }
 }
 
+// Bitonic sort (ascending) of a[0 .. n), n a power of two, in LDS by THREADS threads; ends behind a barrier.  A round trip through
+// LDS carries up to THREE consecutive strides of a merge: a thread loads the 8 elements that differ in those three index bits, runs
+// the three compare-exchange stages on registers and stores them back - 22 round trips instead of 55 single stages for n = 1024
+// (the plain network is bound by its LDS traffic: every stage reads and writes every key).
+template <int NST>
+__device__ __forceinline__ void bitonic_round(unsigned long long* a, int g, int low, int size) {
+  constexpr int E = 1 << NST;
+  const int lo_bits = g & (low - 1);
+  const int base = ((g - lo_bits) << NST) | lo_bits;
+  const bool up = (base & size) == 0;
+  unsigned long long v[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) v[j] = a[base + j * low];
+#pragma unroll
+  for (int st = NST - 1; st >= 0; --st)
+#pragma unroll
+    for (int j = 0; j < E; ++j)
+      if ((j & (1 << st)) == 0) {
+        const unsigned long long x = v[j], y = v[j | (1 << st)];
+        const bool sw = (x > y) == up;
+        v[j] = sw ? y : x;
+        v[j | (1 << st)] = sw ? x : y;
+      }
+#pragma unroll
+  for (int j = 0; j < E; ++j) a[base + j * low] = v[j];
+}
+template <int THREADS>
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* a, int n) {
+  const int tid = threadIdx.x;
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0;) {
+      const int nst = stride >= 4 ? 3 : (stride == 2 ? 2 : 1);
+      const int low = stride >> (nst - 1);
+      for (int g = tid; g < (n >> nst); g += THREADS) {
+        if (nst == 3) bitonic_round<3>(a, g, low, size);
+        else if (nst == 2) bitonic_round<2>(a, g, low, size);
+        else bitonic_round<1>(a, g, low, size);
+      }
+      __syncthreads();
+      stride >>= nst;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ filtered search: selection from the GEMM's candidate blocks
 // (score_filter.h).  One workgroup per query row: the row's hits of all column tiles are gathered into LDS as (key << 32) | column,
 // sorted (bitonic, ascending = score descending, position ascending on ties - the order of topk_kernel) and the first k leave.
@@ -400,39 +444,43 @@ __global__ __launch_bounds__(FSEL_THREADS) void filter_select_kernel(const uint2
                                                                      int* __restrict__ fb_rows) {
   __shared__ uint32_t hist[NBIN];
   __shared__ unsigned long long list[LCAP];   // (key << 32) | column : ascending = score descending, position ascending
-  __shared__ int sh[8 + FSEL_THREADS / 64];   // [0..2] radix-pass result, [3] winners taken, [5] hits, [6] overflow, [7] gather cursor
+  __shared__ int sh[8 + FSEL_THREADS / 64];   // [0..2] radix-pass result, [3] winners taken, [6] overflow, [7] hits (gather cursor)
   const int tid = threadIdx.x, row = blockIdx.x;
   const uint2* blocks = cand + (size_t)row * ntn * capt;
-  if (tid == 0) { sh[3] = 0; sh[5] = 0; sh[6] = 0; sh[7] = 0; }
+  if (tid == 0) { sh[3] = 0; sh[6] = 0; sh[7] = 0; }
   __syncthreads();
   {
-    int total = 0, over = 0;
+    // ONE trip over the row's blocks: a block's first 64-byte line is its header and its first seven entries (the usual block holds
+    // fewer), fetched as four independent 16-byte loads; entries go to the list at once (dropped, not written, past its end - the
+    // row is handed back in that case anyway)
+    int over = 0;
+#pragma unroll 2
     for (int t = tid; t < ntn; t += FSEL_THREADS) {
-      const int c = (int)blocks[(size_t)t * capt].x;
-      total += c;
-      over |= c > capt - 1;
+      const uint4* b4 = reinterpret_cast<const uint4*>(blocks + (size_t)t * capt);  // (capt % 8 == 0: blocks are 64-byte aligned)
+      const uint4 q0 = b4[0], q1 = b4[1], q2 = b4[2], q3 = b4[3];
+      const int c = (int)q0.x;
+      if (c > 0) {
+        over |= c > capt - 1;
+        const int at = atomicAdd(&sh[7], c);
+        const uint32_t ev[7] = {q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.z}, ei[7] = {q0.w, q1.y, q1.w, q2.y, q2.w, q3.y, q3.w};
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+          if (i < c && at + i < LCAP) list[at + i] = ((unsigned long long)desc_key(__uint_as_float(ev[i])) << 32) | ei[i];
+        const uint2* b = blocks + (size_t)t * capt;
+        for (int i = 7; i < min(c, capt - 1); ++i) {
+          const uint2 e = b[1 + i];
+          if (at + i < LCAP) list[at + i] = ((unsigned long long)desc_key(__uint_as_float(e.x)) << 32) | e.y;
+        }
+      }
     }
-    if (total) atomicAdd(&sh[5], total);
     if (over) sh[6] = 1;
   }
   __syncthreads();
-  const int n = sh[5];
+  const int n = sh[7];
   if (sh[6] != 0 || n < k || n > LCAP) {  // workgroup-uniform: not answerable from the candidates
     if (tid == 0) fb_rows[atomicAdd(fb_count, 1)] = row;
     return;
   }
-  for (int t = tid; t < ntn; t += FSEL_THREADS) {
-    const uint2* b = blocks + (size_t)t * capt;
-    const int c = (int)b[0].x;
-    if (c > 0) {
-      const int at = atomicAdd(&sh[7], c);
-      for (int i = 0; i < c; ++i) {
-        const uint2 e = b[1 + i];
-        list[at + i] = ((unsigned long long)desc_key(__uint_as_float(e.x)) << 32) | e.y;
-      }
-    }
-  }
-  __syncthreads();
   auto scan = [&](auto body) {
     for (int c = tid; c < n; c += FSEL_THREADS) {
       const unsigned long long e = list[c];
@@ -477,18 +525,10 @@ __global__ __launch_bounds__(FSEL_THREADS) void filter_select_kernel(const uint2
   __syncthreads();
   for (int i = k + tid; i < kpad; i += FSEL_THREADS) list[i] = ~0ull;  // (kpad <= KMAX <= LCAP)
   __syncthreads();
-  for (int size = 2; size <= kpad; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (kpad >> 1); t += FSEL_THREADS) {
-        const int lo = 2 * t - (t & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const unsigned long long a = list[lo], b = list[hi];
-        if ((a > b) == up) { list[lo] = b; list[hi] = a; }
-      }
-      __syncthreads();
-    }
-  }
+  // (measured and not kept: the network on registers + wave shuffles - element r * 256 + tid in register r, only strides 64 / 128
+  //  through the list - 374 us for 10 000 rows against 245 us for the plain LDS network: ds_bpermute costs what a 64-bit LDS access
+  //  costs, and four rows per CU hide the barriers already)
+  bitonic_sort_lds<FSEL_THREADS>(list, kpad);
   const float out_mul = unscale ? ldexpf(1.0f, -(unscale[0] + unscale[1])) : 1.0f;
   float* Drow = D + (size_t)row * k;
   long long* Irow = I + (size_t)row * k;
@@ -734,6 +774,14 @@ extern "C" size_t cocodr_score_topk_workspace_bytes_dim(int Nq, int Np, int H, i
   if (score_mode() == 1) return exact_bytes(Nq, Np);
   const SplitPlan sp = split_plan(Nq, Np, H);
   return std::max(exact_bytes(Nq, Np), filter_plan(Nq, Np, k, sp).total);  // (mode 2 needs less than mode 0)
+}
+extern "C" int cocodr_score_filter_plan(int Nq, int Np, int H, int k, long long out[8]) {
+  CK_ARG(out != nullptr && Nq > 0 && Np > 0 && H > 0 && k > 0, "score_filter_plan: bad argument");
+  const SplitPlan sp = split_plan(Nq, Np, H);
+  const FilterPlan f = filter_plan(Nq, Np, k, sp);
+  out[0] = f.on ? 1 : 0; out[1] = f.ns; out[2] = f.stride; out[3] = f.j; out[4] = f.capt; out[5] = f.QF; out[6] = f.FBR;
+  out[7] = (long long)f.off_fb;
+  return COCODR_OK;
 }
 extern "C" size_t cocodr_score_topk_workspace_bytes(int Nq, int Np, int k) { return cocodr_score_topk_workspace_bytes_dim(Nq, Np, 1024, k); }
 extern "C" int cocodr_score_set_mode(int mode) {

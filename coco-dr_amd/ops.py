@@ -388,6 +388,15 @@ def topk_merge(D: torch.Tensor, I: torch.Tensor, shard_offset: torch.Tensor, k_o
     return outD, outI
 
 
+def score_filter_plan(Nq: int, Np: int, H: int, k: int) -> dict:
+    """How cocodr_score_topk would search these sizes in the current score mode (include/cocodr.h: the filtered search)."""
+    out = (C.c_longlong * 8)()
+    check(lib().cocodr_score_filter_plan(int(Nq), int(Np), int(H), int(k), C.cast(out, C.c_void_p)), "score_filter_plan")
+    keys = ("filtered", "sample_passages", "sample_stride", "threshold_rank", "block_slots", "rows_per_pass", "rows_per_exhaustive_pass",
+            "handed_back_count_offset")
+    return {k_: int(v) for k_, v in zip(keys, out)}
+
+
 def score_set_mode(mode: int) -> None:
     """0 = split-precision scores on the 16-bit matrix pipe (default: fp32-accurate), 1 = exact fp32 MFMA scores, 2 = half-precision
     scores (opt-in: one product of the operands rounded to IEEE half, a third of mode 0's matrix work; include/cocodr.h)."""

@@ -358,9 +358,22 @@ int cocodr_gram_f32(const float* A, long long lda, int G, long long D, float* ou
  *    (worst case 1e-3): rankings differ from the fp32 ones only between near-ties; nDCG@10 / recall@1000 within 1e-3 of the exact
  *    search on the config-5 workload (tests/test_gpu_retrieval.py).  Identical passages still score bit-identically.
  * Embeddings with non-finite components get NaN scores on the split path (ranked last).
+ * Selection.  Small searches score a chunk of query rows into an fp32 slab and select from it (radix select per row).  On the
+ * 16-bit pipelines a search over >= 32 768 passages with 16 k <= Np is FILTERED instead (cocodr_score_filter_plan tells): every
+ * query row gets a threshold - the j-th best of its scores against a strided sample of ~Np / 32 passages, j a few deviations past
+ * the sample's share of the top k - the score GEMM's epilogue keeps only the scores at or above it (~2 k of a row) in fixed
+ * candidate blocks, and the k best are selected from those.  No [Nq, Np] score slab is written or read.  The result is the
+ * exhaustive search's, bit for bit and tie for tie: a row is answered from its candidates only if they number >= k and none of
+ * its blocks overflowed (then they provably contain its k best); any other row - thresholds that came out too high, heavy ties,
+ * clustered duplicates - is scored and selected exhaustively by a device-gated second pass.  COCODR_SCORE_NOFILTER=1: never filter.
  * workspace_bytes_dim: for embeddings of width H; workspace_bytes: the same for H = 1024 (enough for any H <= 1024).
  * The workspace must be 256-byte aligned. */
 size_t cocodr_score_topk_workspace_bytes_dim(int Nq, int Np, int H, int k);
+/* The filtered search's plan for these sizes in the current score mode: out[0] = 1 if cocodr_score_topk filters (given the
+ * workspace cocodr_score_topk_workspace_bytes_dim asks for), out[1] = sampled passages, [2] = their stride, [3] = j, [4] = slots per
+ * (row, 256-passage tile) block incl. its header, [5] = query rows per pass, [6] = rows per exhaustive pass, [7] = byte offset in
+ * the workspace of the int32 count of rows the LAST pass handed back to the exhaustive pass (diagnostics, tests). */
+int cocodr_score_filter_plan(int Nq, int Np, int H, int k, long long out[8]);
 size_t cocodr_score_topk_workspace_bytes(int Nq, int Np, int k);
 int cocodr_score_set_mode(int mode);
 int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset,

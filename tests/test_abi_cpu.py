@@ -62,6 +62,34 @@ def test_argument_validation_without_gpu(lib):
     assert lib.cocodr_score_topk_workspace_bytes(100, 1000, 10) >= 100 * 1000 * 4
 
 
+def test_filtered_search_plan_arithmetic(lib, monkeypatch):
+    """cocodr_score_filter_plan is host arithmetic (include/cocodr.h): which searches are filtered, and with what sample / rank /
+    block sizes; the workspace the library asks for grows by the plan's extra buffers and shrinks back with the switch."""
+    from cocodr_amd import ops
+    for h in ("COCODR_SCORE_NOFILTER", "COCODR_SCORE_FILTER_MIN_NP", "COCODR_SCORE_FILTER_J", "COCODR_SCORE_FILTER_CAPT"):
+        monkeypatch.delenv(h, raising=False)
+    p = ops.score_filter_plan(10000, 125000, 1024, 1000)  # one GPU's shard of config 5
+    assert p["filtered"] == 1 and p["sample_passages"] == 4096 and p["sample_stride"] == 30
+    mu = 1000 * 4096 / 125000
+    assert p["threshold_rank"] == int(mu + 4 * mu ** 0.5 + 8)
+    assert p["block_slots"] % 8 == 0 and 24 <= p["block_slots"] <= 64
+    assert p["rows_per_pass"] >= 10000 and p["rows_per_pass"] % 256 == 0 and p["rows_per_exhaustive_pass"] == 4096
+    assert ops.score_filter_plan(64, 1_000_000, 1024, 1000)["filtered"] == 1
+    for nq, npass, k in [(100, 20000, 100), (100, 40000, 4000), (100, 40000, 3000), (16, 8_000_000, 1000)]:
+        assert ops.score_filter_plan(nq, npass, 768, k)["filtered"] == 0  # few passages / k too large a share / candidates past the list
+    with_filter = lib.cocodr_score_topk_workspace_bytes_dim(10000, 125000, 1024, 1000)
+    monkeypatch.setenv("COCODR_SCORE_NOFILTER", "1")
+    assert ops.score_filter_plan(10000, 125000, 1024, 1000)["filtered"] == 0
+    without = lib.cocodr_score_topk_workspace_bytes_dim(10000, 125000, 1024, 1000)
+    monkeypatch.delenv("COCODR_SCORE_NOFILTER")
+    assert 0 < with_filter - without < 200 << 20
+    ops.score_set_mode(1)
+    try:
+        assert ops.score_filter_plan(10000, 125000, 1024, 1000)["filtered"] == 0  # the exact fp32 pipeline is never filtered
+    finally:
+        ops.score_set_mode(0)
+
+
 def test_ops_reject_cpu_tensors_and_model_refuses_cpu():
     from cocodr_amd import ops
     from cocodr_amd.modeling import CocoBertConfig, CocoBertModel

@@ -138,3 +138,27 @@ def test_more_rows_handed_back_than_one_exhaustive_pass_holds(monkeypatch):
     ref = search(Qd, Pd, 100, monkeypatch, NOFILTER=1)
     same(search(Qd, Pd, 100, monkeypatch, FILTER_J=1), ref)
     same(search(Qd, Pd, 100, monkeypatch), ref)
+
+
+def test_default_route_is_the_filter_and_hands_back_almost_nothing():
+    """At one GPU's shard of config 5 (10 000 x 125 000 x 1 024, k = 1 000) the plan filters, the thresholds leave every row between
+    k and the list's capacity in candidates: the count of rows handed back to the exhaustive pass (read from the workspace) is 0 or a
+    handful; with embedding-shaped data of a common offset (LayerNorm-like rows) as well."""
+    nq, npass, H, k = 10000, 125000, 1024, 1000
+    plan = ops.score_filter_plan(nq, npass, H, k)
+    assert plan["filtered"] == 1
+    g = torch.Generator().manual_seed(3)
+    for offset in (0.0, 0.05):
+        Q = (torch.randn(nq, H, generator=g) / H ** 0.5 + offset).to(DEV)
+        P = (torch.randn(npass, H, generator=g) / H ** 0.5 + offset).to(DEV)
+        ws = torch.empty(ops.lib().cocodr_score_topk_workspace_bytes_dim(nq, npass, H, k), dtype=torch.uint8, device=DEV)
+        D, I = ops.score_topk(Q, P, k, workspace=ws)
+        torch.cuda.synchronize()
+        handed_back = int(ws[plan["handed_back_count_offset"]:plan["handed_back_count_offset"] + 4].view(torch.int32).item())
+        assert handed_back <= 10, handed_back
+        rows = torch.randint(0, nq, (16,), generator=g)
+        S = Q[rows.to(DEV)].double() @ P.double().T
+        Dr, Ir = torch.topk(S, k, dim=1)
+        assert (I[rows.to(DEV)] == Ir).float().mean() > 0.995
+        torch.testing.assert_close(D[rows.to(DEV)].double(), Dr, rtol=1e-5, atol=1e-6)
+        del Q, P, ws, D, I, S
