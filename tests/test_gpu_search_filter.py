@@ -159,6 +159,7 @@ def test_default_route_is_the_filter_and_hands_back_almost_nothing():
         rows = torch.randint(0, nq, (16,), generator=g)
         S = Q[rows.to(DEV)].double() @ P.double().T
         Dr, Ir = torch.topk(S, k, dim=1)
-        assert (I[rows.to(DEV)] == Ir).float().mean() > 0.995
+        got_i, ref_i = I[rows.to(DEV)].cpu().numpy(), Ir.cpu().numpy()  # (fp32 round-off reorders near-ties against the fp64 product)
+        assert min(len(np.intersect1d(a, b)) for a, b in zip(got_i, ref_i)) >= 0.99 * k
         torch.testing.assert_close(D[rows.to(DEV)].double(), Dr, rtol=1e-5, atol=1e-6)
         del Q, P, ws, D, I, S
