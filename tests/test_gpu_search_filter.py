@@ -163,3 +163,13 @@ def test_default_route_is_the_filter_and_hands_back_almost_nothing():
         assert min(len(np.intersect1d(a, b)) for a, b in zip(got_i, ref_i)) >= 0.99 * k
         torch.testing.assert_close(D[rows.to(DEV)].double(), Dr, rtol=1e-5, atol=1e-6)
         del Q, P, ws, D, I, S
+
+
+def test_one_million_passages_in_several_query_passes(monkeypatch):
+    """3 000 queries x 1 000 000 passages: the candidate blocks of a pass (3 907 column tiles per row) fill the slab area after 2 560
+    rows, so the filtered search runs in two query passes; thresholds come from 31 488 sampled passages."""
+    plan = ops.score_filter_plan(3000, 1_000_000, 64, 100)
+    assert plan["filtered"] == 1 and plan["rows_per_pass"] < 3000 and plan["sample_passages"] == 31488
+    Q, P = data(3000, 1_000_000, 64, 21)
+    Qd, Pd = torch.from_numpy(Q).to(DEV), torch.from_numpy(P).to(DEV)
+    same(search(Qd, Pd, 100, monkeypatch), search(Qd, Pd, 100, monkeypatch, NOFILTER=1))
