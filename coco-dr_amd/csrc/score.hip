@@ -591,7 +591,14 @@ __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ X
     if (b < 0x7f800000u) m = max(m, b);  // finite magnitudes only (bit patterns of non-negative floats order like the floats)
   };
   const float4* X4 = reinterpret_cast<const float4*>(X);  // (16-byte aligned, n % 4 == 0: checked by the caller)
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)gridDim.x * 256) {
+  const size_t n4 = n / 4, step = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * step < n4; i += 4 * step) {  // four loads in flight per thread
+    const float4 a = X4[i], b = X4[i + step], c = X4[i + 2 * step], d = X4[i + 3 * step];
+    one(a.x); one(a.y); one(a.z); one(a.w); one(b.x); one(b.y); one(b.z); one(b.w);
+    one(c.x); one(c.y); one(c.z); one(c.w); one(d.x); one(d.y); one(d.z); one(d.w);
+  }
+  for (; i < n4; i += step) {
     const float4 v = X4[i];
     one(v.x); one(v.y); one(v.z); one(v.w);
   }
