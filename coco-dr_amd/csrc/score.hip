@@ -698,8 +698,11 @@ FilterPlan filter_plan(int Nq, int Np, int k, const SplitPlan& sp) {
   FilterPlan f;
   f.total = sp.total;
   if (score_mode() == 1 || env_int("COCODR_SCORE_NOFILTER", 0) != 0) return f;
-  const int min_np = env_int("COCODR_SCORE_FILTER_MIN_NP", 32768);  // (test hook: small searches through this path)
-  if (Np < min_np || k > KMAX || (long long)k * 16 > Np) return f;
+  // where it pays (tools/search_crossover.py, H = 768): the extra launches (sample product, thresholds, gated exhaustive pass: ~60 us)
+  // cost 2-22 % at <= 256 queries x <= 125 000 passages, level at 256 x 125 000 / 16 x 500 000, +6 ... +33 % from 2 000 queries up
+  const bool force = env_int("COCODR_SCORE_FILTER_FORCE", 0) != 0;  // (test hook: small searches through this path)
+  if (!force && (Np < 32768 || (long long)Nq * Np < (100ll << 20))) return f;
+  if (k > KMAX || (long long)k * 16 > Np) return f;
   // sample: every stride-th passage, ~Np / 32 of them (the sample's product is that fraction of extra matrix work)
   int ns = (Np / 32 + 255) / 256 * 256;
   ns = std::max(std::min(ns, 32768), std::min(4096, Np / 256 * 256));

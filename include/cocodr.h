@@ -359,7 +359,8 @@ int cocodr_gram_f32(const float* A, long long lda, int G, long long D, float* ou
  *    search on the config-5 workload (tests/test_gpu_retrieval.py).  Identical passages still score bit-identically.
  * Embeddings with non-finite components get NaN scores on the split path (ranked last).
  * Selection.  Small searches score a chunk of query rows into an fp32 slab and select from it (radix select per row).  On the
- * 16-bit pipelines a search over >= 32 768 passages with 16 k <= Np is FILTERED instead (cocodr_score_filter_plan tells): every
+ * 16-bit pipelines a search over >= 32 768 passages with Nq Np >= 100 Mi and 16 k <= Np is FILTERED instead
+ * (cocodr_score_filter_plan tells; the window is where it was measured to win, tools/search_crossover.py): every
  * query row gets a threshold - the j-th best of its scores against a strided sample of ~Np / 32 passages, j a few deviations past
  * the sample's share of the top k - the score GEMM's epilogue keeps only the scores at or above it (~2 k of a row) in fixed
  * candidate blocks, and the k best are selected from those.  No [Nq, Np] score slab is written or read.  The result is the

@@ -66,7 +66,7 @@ def test_filtered_search_plan_arithmetic(lib, monkeypatch):
     """cocodr_score_filter_plan is host arithmetic (include/cocodr.h): which searches are filtered, and with what sample / rank /
     block sizes; the workspace the library asks for grows by the plan's extra buffers and shrinks back with the switch."""
     from cocodr_amd import ops
-    for h in ("COCODR_SCORE_NOFILTER", "COCODR_SCORE_FILTER_MIN_NP", "COCODR_SCORE_FILTER_J", "COCODR_SCORE_FILTER_CAPT"):
+    for h in ("COCODR_SCORE_NOFILTER", "COCODR_SCORE_FILTER_FORCE", "COCODR_SCORE_FILTER_J", "COCODR_SCORE_FILTER_CAPT"):
         monkeypatch.delenv(h, raising=False)
     p = ops.score_filter_plan(10000, 125000, 1024, 1000)  # one GPU's shard of config 5
     assert p["filtered"] == 1 and p["sample_passages"] == 4096 and p["sample_stride"] == 30
@@ -74,9 +74,14 @@ def test_filtered_search_plan_arithmetic(lib, monkeypatch):
     assert p["threshold_rank"] == int(mu + 4 * mu ** 0.5 + 8)
     assert p["block_slots"] % 8 == 0 and 24 <= p["block_slots"] <= 64
     assert p["rows_per_pass"] >= 10000 and p["rows_per_pass"] % 256 == 0 and p["rows_per_exhaustive_pass"] == 4096
-    assert ops.score_filter_plan(64, 1_000_000, 1024, 1000)["filtered"] == 1
-    for nq, npass, k in [(100, 20000, 100), (100, 40000, 4000), (100, 40000, 3000), (16, 8_000_000, 1000)]:
-        assert ops.score_filter_plan(nq, npass, 768, k)["filtered"] == 0  # few passages / k too large a share / candidates past the list
+    assert ops.score_filter_plan(256, 1_000_000, 1024, 1000)["filtered"] == 1
+    # few passages / few scores in all (the extra launches do not pay) / k too large a share / candidates past the list
+    for nq, npass, k in [(5000, 20000, 100), (256, 125000, 100), (64, 1_000_000, 100), (3000, 40000, 4000), (3000, 40000, 3000), (16, 8_000_000, 1000)]:
+        assert ops.score_filter_plan(nq, npass, 768, k)["filtered"] == 0
+    monkeypatch.setenv("COCODR_SCORE_FILTER_FORCE", "1")
+    assert ops.score_filter_plan(256, 125000, 768, 100)["filtered"] == 1 and ops.score_filter_plan(70, 5003, 64, 10)["filtered"] == 1
+    assert ops.score_filter_plan(3000, 40000, 768, 3000)["filtered"] == 0  # (the statistical conditions are not a size rule)
+    monkeypatch.delenv("COCODR_SCORE_FILTER_FORCE")
     with_filter = lib.cocodr_score_topk_workspace_bytes_dim(10000, 125000, 1024, 1000)
     monkeypatch.setenv("COCODR_SCORE_NOFILTER", "1")
     assert ops.score_filter_plan(10000, 125000, 1024, 1000)["filtered"] == 0

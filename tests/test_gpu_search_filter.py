@@ -13,14 +13,18 @@ from cocodr_amd import ops  # noqa: E402
 import oracle as O  # noqa: E402
 
 DEV = "cuda"
-HOOKS = ("COCODR_SCORE_NOFILTER", "COCODR_SCORE_FILTER_MIN_NP", "COCODR_SCORE_FILTER_J", "COCODR_SCORE_FILTER_CAPT", "COCODR_SCORE_PBLK")
+HOOKS = ("COCODR_SCORE_NOFILTER", "COCODR_SCORE_FILTER_FORCE", "COCODR_SCORE_FILTER_J", "COCODR_SCORE_FILTER_CAPT", "COCODR_SCORE_PBLK")
 
 
 def search(Q, P, k, monkeypatch, id_offset=0, **env):
     for h in HOOKS:
         monkeypatch.delenv(h, raising=False)
+    if "NOFILTER" not in env:  # the filtered route whatever the size (the plan keeps small searches off it: it pays from ~1e8 scores)
+        env = dict(env, FILTER_FORCE=1)
     for name, v in env.items():
         monkeypatch.setenv("COCODR_SCORE_" + name, str(v))
+    if "NOFILTER" not in env:
+        assert ops.score_filter_plan(Q.shape[0], P.shape[0], Q.shape[1], k)["filtered"] == 1
     D, I = ops.score_topk(Q, P, k, id_offset=id_offset)
     torch.cuda.synchronize()
     for h in HOOKS:
@@ -55,7 +59,7 @@ def test_filtered_search_equals_exhaustive_search_and_oracle(nq, npass, H, k, mo
 
 @pytest.mark.parametrize("mode", [0, 2])
 def test_small_ragged_searches_through_the_filter(mode, monkeypatch):
-    """MIN_NP lowered: Np not a multiple of the 256-column tile (zero padding columns must never become candidates - every
+    """(forced onto the filtered route) Np not a multiple of the 256-column tile (zero padding columns must never become candidates - every
     true score here is negative), several passage column blocks, both 16-bit score modes."""
     Q, P = data(70, 5003, 64, 3)
     P -= 4.0 * Q[0] / np.sqrt((Q[0] ** 2).sum())  # row 0's scores ~ -4: far below the padding columns' zeros
@@ -63,8 +67,8 @@ def test_small_ragged_searches_through_the_filter(mode, monkeypatch):
     ops.score_set_mode(mode)
     try:
         ref = search(Qd, Pd, 10, monkeypatch, NOFILTER=1)
-        same(search(Qd, Pd, 10, monkeypatch, FILTER_MIN_NP=1024), ref)
-        same(search(Qd, Pd, 10, monkeypatch, FILTER_MIN_NP=1024, PBLK=512), ref)
+        same(search(Qd, Pd, 10, monkeypatch), ref)
+        same(search(Qd, Pd, 10, monkeypatch, PBLK=512), ref)
     finally:
         ops.score_set_mode(0)
     assert ref[0][0].max() < 0 and ref[1].max() < 5003
@@ -168,7 +172,7 @@ def test_default_route_is_the_filter_and_hands_back_almost_nothing():
 def test_one_million_passages_in_several_query_passes(monkeypatch):
     """3 000 queries x 1 000 000 passages: the candidate blocks of a pass (3 907 column tiles per row) fill the slab area after 2 560
     rows, so the filtered search runs in two query passes; thresholds come from 31 488 sampled passages."""
-    plan = ops.score_filter_plan(3000, 1_000_000, 64, 100)
+    plan = ops.score_filter_plan(3000, 1_000_000, 64, 100)  # (taken by default: 3e9 scores)
     assert plan["filtered"] == 1 and plan["rows_per_pass"] < 3000 and plan["sample_passages"] == 31488
     Q, P = data(3000, 1_000_000, 64, 21)
     Qd, Pd = torch.from_numpy(Q).to(DEV), torch.from_numpy(P).to(DEV)

@@ -1,77 +1,54 @@
-#!/usr/bin/env python3
-"""Probe (timing only, the overlapped variant races on the weights it reads): how much of the optimizer pass disappears when AdamW
-of step n runs on a side stream under the forward of step n + 1 - the upper bound of a range-by-range pipelined update.
-Usage: python tools/adamw_overlap_probe.py [base|large] [seqs]"""
-import os
-import sys
-import time
-
-import torch
-
+"""How much of the AdamW pass hides under the next step's forward?  (cocodr-base 64 x 128 packed, the headline step.)
+Times forward + optimizer pass back to back on one stream against the two on two streams without any dependency between them
+(an upper bound for an update that runs range by range ahead of the forward)."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import cocodr_amd  # noqa: E402,F401
-from bench import synth_batch  # noqa: E402
-from cocodr_amd.modeling import CocoBertConfig, CocoBertModel, _SimCEFn  # noqa: E402
-from cocodr_amd.optim import FlatAdamW, clip_grad_norm_  # noqa: E402
+import torch
+import cocodr_amd  # noqa: F401
+import bench
+from cocodr_amd.modeling import CoCondenserForPretraining, CocoBertConfig, CocoBertModel
+from cocodr_amd.optim import FlatAdamW, clip_grad_norm_
 
-name = sys.argv[1] if len(sys.argv) > 1 else "base"
-n_seq = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-dev = torch.device("cuda", 0)
-cfg = CocoBertConfig.base() if name == "base" else CocoBertConfig.large()
+dev = torch.device("cuda:0")
+cfg = CocoBertConfig.base()
 torch.manual_seed(0)
 bert = CocoBertModel(cfg).to(dev)
-bert.eval()
-opt = FlatAdamW.for_model(bert, lr=1e-4, weight_decay=0.01)
-pool = [synth_batch(10007 * i, n_seq, 128, cfg.vocab_size, dev) for i in range(8)]
-flats = bert.flat_parameters()
-side = torch.cuda.Stream(device=dev)
-
-
-def step_serial(i):
-    ids, mask = pool[i % 8]
+model = CoCondenserForPretraining(bert)
+opt = FlatAdamW.for_model(bert, lr=1e-5, weight_decay=0.01)
+ids, mask, lens = bench.synth_batch_lens(1, 64, 128, cfg.vocab_size, dev, False)
+batch = lambda: {"input_ids": ids, "attention_mask": mask}
+flats = [bert.flat_decay, bert.flat_nodecay]
+for _ in range(3):
     opt.zero_grad(set_to_none=True)
-    cls = bert.encode_cls(ids, mask)
-    loss, _ = _SimCEFn.apply(cls, 1, 0, cls.shape[0])
-    loss.backward()
+    loss = model(batch(), None); loss.backward()
     opt.step(clip=clip_grad_norm_(flats, 1.0))
-    return loss
+torch.cuda.synchronize()
+side = torch.cuda.Stream()
 
 
-def step_overlap(i):
-    ids, mask = pool[i % 8]
-    opt.zero_grad(set_to_none=True)
-    cls = bert.encode_cls(ids, mask)
-    loss, _ = _SimCEFn.apply(cls, 1, 0, cls.shape[0])
-    loss.backward()
-    clip = clip_grad_norm_(flats, 1.0)
-    main = torch.cuda.current_stream()
-    side.wait_stream(main)
-    for p in flats:
-        p.grad.record_stream(side)
-    clip.record_stream(side)
-    with torch.cuda.stream(side):
-        opt.step(clip=clip)
-    return loss
-
-
-def step_noopt(i):
-    ids, mask = pool[i % 8]
-    opt.zero_grad(set_to_none=True)
-    cls = bert.encode_cls(ids, mask)
-    loss, _ = _SimCEFn.apply(cls, 1, 0, cls.shape[0])
-    loss.backward()
-    clip_grad_norm_(flats, 1.0)
-    return loss
-
-
-for fn in (step_serial, step_overlap, step_noopt, step_serial, step_overlap, step_noopt):
-    for i in range(4):
-        loss = fn(i)
-    torch.cuda.synchronize()
+def t_ms(fn, n=20):
+    fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 16
-    for i in range(n):
-        loss = fn(i)
+    for _ in range(n):
+        fn()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
-    print(f"{name} {n_seq} {fn.__name__}: {dt * 1e3:.3f} ms/step  {n_seq / dt:.1f} seq/s", flush=True)
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+coef = clip_grad_norm_(flats, 1.0)
+torch.cuda.synchronize()
+def fwd():
+    with torch.no_grad():
+        bert.train()
+        return model(batch(), None)
+def step():
+    opt.step(clip=coef)
+def both_serial():
+    step(); fwd()
+def both_parallel():
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    fwd()
+    torch.cuda.current_stream().wait_stream(side)
+print(f"forward alone {t_ms(fwd):.3f} ms   optimizer pass alone {t_ms(step):.3f} ms   one stream {t_ms(both_serial):.3f} ms   two streams {t_ms(both_parallel):.3f} ms")
