@@ -841,7 +841,10 @@ int filtered_search(const _Float16* Qc, const _Float16* Pc, const int* exps, int
     const _Float16* Aq = Qc + (size_t)q0 * K;
     {
       ProfScope prof(PROF_SCORE, st, 2.0 * nq * (double)Np * H);  // (the sample's product is overhead: its time counts, its FLOPs do not)
-      cocodr_gemm_args g = product(Aq, nq, Ps, fp.ns, area, fp.ns);
+      // thresholds need no fp32 accuracy (they only steer the filter): the sample is scored by the product of the HIGH halves alone -
+      // columns [Hp, 2 Hp) of a query row [xl | xh | xh], [0, Hp) of a passage row [xh | xl | xh] - a third of the contraction
+      cocodr_gemm_args g = product(Aq + (sp.parts == 3 ? sp.Hp : 0), nq, Ps, fp.ns, area, fp.ns);
+      g.K = sp.Hp;
       const int rc = cocodr_gemm(&g, (cocodr_stream_t)st);
       if (rc != COCODR_OK) return rc;
     }
