@@ -1,15 +1,18 @@
 // Brute-force inner-product search  D, I = topk_k(Q P^T)  - the faiss.IndexFlatIP(dim).search of
 // evaluate/evaluation/evaluate_beir.py:220-224 and ANCE/drivers/run_ann_data_gen.py:310-317,390.
 //
-// Scores are exact fp32 (v_mfma_f32_32x32x2_f32 is bit-identical to an fmaf chain), so top-k ids
-// match an fp32 CPU search whenever the score gap exceeds fp32 round-off.  Selection is an exact,
-// deterministic radix select per query row (order: score descending, position ascending on ties)
-// followed by a bitonic sort of the k survivors in LDS.
+// Scores: fp32-accurate on the 16-bit matrix pipe (split precision, the default; further down) or exact fp32
+// (v_mfma_f32_32x32x2_f32 is bit-identical to an fmaf chain; mode 1), so top-k ids match an fp32 CPU search whenever the score gap
+// exceeds fp32 round-off.  Selection is exact and deterministic (order: score descending, position ascending on ties).
 //
-// Structure: a chunk of query rows is scored into a [QC, Np] fp32 slab in the caller's workspace, then selected.  The
-// workspace holds TWO such slabs: the selection of chunk c runs on a side stream while the score GEMM of chunk c + 1
-// runs on the caller's stream - the GEMM is bound by the fp32 matrix pipe and leaves the memory system and the LDS
-// atomics the selection lives on almost idle, so the selection (17 % of the search when serialised) hides under it.
+// Two routes to the k best of a row:
+//  * exhaustive (small searches, mode 1, and the rows the other route hands back): a chunk of query rows is scored into a
+//    [QC, Np] fp32 slab in the caller's workspace, then a radix select per row + bitonic sort of the k survivors.  The workspace
+//    holds TWO slabs: the selection of chunk c runs on a side stream while the score GEMM of chunk c + 1 runs on the caller's
+//    (measured in round 5: ~1 % - a CU holds a GEMM workgroup or selection workgroups, not both).
+//  * filtered (round 5; >= 100 Mi scores over >= 32 768 passages; score_filter.h, filtered_search below): per-row thresholds from
+//    a strided passage sample, the score GEMM's epilogue keeps only the scores at or above them, selection from those candidates.
+//    No slab.  Same D and I, tie for tie.
 #include <math.h>
 #include <stdlib.h>
 
