@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcocodr_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "loss.hip", "score.hip", "merge.hip", "encoder.hip", "collate.hip", "probe.hip", "comm.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_pp.hip", "gemm_a4.hip", "attention.hip", "rowops.hip", "loss.hip", "score.hip", "merge.hip", "encoder.hip", "collate.hip", "probe.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 FLAGS += os.environ.get("COCODR_EXTRA_FLAGS", "").split()  # measurement builds only (tools/gemm_ablate.py: -DCOCODR_ABL_*)
 
@@ -34,7 +34,7 @@ def _stale(out: str, deps) -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(BUILD, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cocodr.h"))
     jobs = []
     for src in SOURCES:

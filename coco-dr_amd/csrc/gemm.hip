@@ -589,6 +589,10 @@ size_t cocodr_gemm_pp_split_ws_floats();
 void cocodr_gemm_pp_launch_multi(const cocodr_gemm_args* a, int n, float* ws, size_t ws_floats, hipStream_t st);
 size_t cocodr_gemm_pp_multi_ws_floats();
 size_t cocodr_gemm_pp_multi_ws_floats_for(const cocodr_gemm_args* a, int n);
+bool cocodr_gemm_a4_ok(const cocodr_gemm_args& a);                              // gemm_a4.hip: one wave per SIMD, hand-scheduled K loop (NT form)
+void cocodr_gemm_a4_launch(const cocodr_gemm_args& a, hipStream_t st);
+bool cocodr_gemm_a4_walk_ok(const cocodr_gemm_args& a);                         // ... as a persistent walk with a register epilogue
+void cocodr_gemm_a4_walk_launch(const cocodr_gemm_args& a, hipStream_t st);
 
 namespace {
 
@@ -612,7 +616,7 @@ void launch(const cocodr_gemm_args& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 extern "C" int cocodr_gemm_set_impl(int impl) {
-  CK_ARG((impl >= 0 && impl <= 13) || impl == 18, "gemm_set_impl: impl must be in [0,13] or 18 (ping-pong with two fat phases per K-tile)");
+  CK_ARG((impl >= 0 && impl <= 15) || impl == 18, "gemm_set_impl: impl must be in [0,15] or 18 (ping-pong with two fat phases per K-tile)");
   g_gemm_impl = impl;
   return COCODR_OK;
 }
@@ -684,6 +688,8 @@ int select_impl(const cocodr_gemm_args& a) {
   if (impl == 11 && a.N % 256 != 0) impl = 5;  // the 256x256 tile needs N % 256 == 0
   if (impl == 12 && a.N % 96 != 0) impl = 9;   // the 256x96 tile needs N % 96 == 0
   if (impl >= 13 && a.N % 256 != 0) impl = 9;  // the ping-pong pipeline's 256x256 tile needs N % 256 == 0
+  if (impl == 15 && !cocodr_gemm_a4_walk_ok(a)) impl = 14;
+  if (impl == 14 && !cocodr_gemm_a4_ok(a)) impl = 13;  // the hand-scheduled kernel: NT form, K % 128 == 0, K >= 256
   return impl;
 }
 // row panels of the fused column sums for that pipeline (0: not fused there)
@@ -747,6 +753,8 @@ extern "C" int cocodr_gemm(const cocodr_gemm_args* args, cocodr_stream_t stream)
   if (cs_rows == 0) a.colsum_partial = nullptr;
   // (a pipeline forced through cocodr_gemm_set_impl takes any cut the plan allows - tests, sweeps; the automatic selection only the measured window)
   if (impl == 13 && (gemm_impl_override() != 0 || split_tail_wins(a)) && cocodr_gemm_pp_launch_split(a, st)) { /* whole rounds + a cut last round */ }
+  else if (impl == 15) cocodr_gemm_a4_walk_launch(a, st);
+  else if (impl == 14) cocodr_gemm_a4_launch(a, st);
   else if (impl >= 13) cocodr_gemm_pp_launch(a, impl == 18 ? 105 : 2, st);
   else if (impl == 12) launch_glds_any<256, 64, 2, 1, 4, 3>(a, st);
   else if (impl == 11) launch_glds_any<256, 32, 2, 4>(a, st);
