@@ -143,7 +143,7 @@ def _best_thread_count(n_seq: int, L: int) -> int:
     cands = sorted({t for t in (8, 16, 32, 64, phys) if t <= phys})
     best, best_t = cands[-1], float("inf")
     for t in cands:
-        r = cpu_baseline_torch(n_seq, L, warmup=1, steps=2, threads=t)
+        r = cpu_baseline_torch(n_seq, L, warmup=1, steps=1 if n_seq * L > 2048 else 2, threads=t)
         if r["s_per_step"] < best_t:
             best, best_t = t, r["s_per_step"]
     return best
@@ -193,12 +193,12 @@ def cpu_baseline():
     `port`: the numpy oracle."""
     out = {"kind": "port", "cpu": _cpu_model_name()}
     try:
-        thr = _best_thread_count(8, 64)
+        thr = _best_thread_count(SEQ_PER_GPU, SEQ_LEN)  # chosen ON the timed shape (64 x L128)
         # the headline's exact batch (64 sequences x L128) as a bounded sample: 1 warm-up + 5 timed steps (~25 s of CPU work)
         out.update(cpu_baseline_torch(SEQ_PER_GPU, SEQ_LEN, warmup=1, steps=5, threads=thr))
         out["eight_sequences"] = cpu_baseline_torch(8, SEQ_LEN, threads=thr)
         out["config1"] = cpu_baseline_torch(8, 64, threads=thr)
-        out["threads_tried"] = "fastest of 8 / 16 / 32 / 64 / all physical cores on the config-1 shape"
+        out["threads_tried"] = "fastest of 8 / 16 / 32 / 64 / all physical cores on the timed shape (64 sequences x L128, 1 warm-up + 1 step each)"
         out["port"] = cpu_baseline_numpy()
     except Exception as e:  # transformers missing on the box: the numpy port alone
         out.update(cpu_baseline_numpy())
@@ -735,9 +735,13 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
     attn_flops_per_step = float(np.mean([attention_train_flops(cfg, (extents_of(i) + 31) // 32 * 32) for i in range(steps)]))
     exec_info = {"rows_per_step": int(round(rows_per_step)), "rows_per_step_padded": seq_per_gpu * seq_len}
     if prof:
-        n_launch, gemm_ms, gemm_flops = ops.prof_end()
+        n_launch, gemm_ms_raw, gemm_flops = ops.prof_end()
+        # event-to-event time -> kernel time: one event pair adds a fixed ~2-3 us to the launch it brackets (measured on this box,
+        # on this stream, around an empty kernel); rocprofv3's per-kernel durations of the same command (profiles/) are the check
+        ev_us = ops.prof_event_overhead_us() if n_launch else 0.0
+        gemm_ms = gemm_ms_raw - n_launch * ev_us * 1e-3
         if n_launch and gemm_ms > 0:
-            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12  # FLOPs the bracketed launches carried out / their summed duration
+            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12  # FLOPs the bracketed launches carried out / their summed kernel time
             sampled = len(range(0, steps, PROF_EVERY))
             traffic, src = _traffic_for(model_name, seq_per_gpu, seq_len, packed)
             lps = n_launch // max(1, sampled)
@@ -754,6 +758,7 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
                     "launches_per_step": lps,
                     "sampled": f"every GEMM launch of every {PROF_EVERY}th timed step ({n_launch} launches)",
                     "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
+                    "event_overhead_us": round(ev_us, 2), "avg_launch_us_event_to_event": round(gemm_ms_raw * 1e3 / n_launch, 2),
                     "gemm_share_of_step": round(gemm_ms_step / (dt / steps * 1e3), 3),
                     "executed_gemm_flops_per_step": gemm_flops / sampled,
                     "flops": "achieved / frac: the FLOPs the timed launches EXECUTE (2 M N K of every launch: "
@@ -793,9 +798,12 @@ def whole_step_fracs(n_seq: int, steps: int, dt: float, cfg, seq_len: int, exec_
 def compact_roofline(roof: dict) -> dict:
     """The contract line's roofline block: numbers plus a short kernel name; the prose of the full block stays in bench_legs.json."""
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_per_step_bytes", "traffic_gbps", "algorithmic_achieved",
-            "algorithmic_frac", "launches_per_step", "avg_launch_us", "gemm_share_of_step", "rows_per_step", "rows_per_step_padded")
+            "algorithmic_frac", "launches_per_step", "avg_launch_us", "event_overhead_us", "gemm_share_of_step", "rows_per_step", "rows_per_step_padded")
     out = {k: roof[k] for k in keep if k in roof}
-    out["kernel"] = "bf16 MFMA GEMM class (gemm.hip + gemm_pp.hip), all launches of the step"
+    src = roof.get("traffic_source")
+    if isinstance(src, dict):  # the traffic figure is NOT taken in this run: file + commit of the PMC passes it was read from
+        out["traffic_source"] = {k: src.get(k) for k in ("file", "commit")}
+    out["kernel"] = "bf16 MFMA GEMM class (gemm.hip + gemm_pp.hip + gemm_a4.hip), all launches of the step"
     return out
 
 
@@ -822,7 +830,7 @@ def leg_summary(extras: dict) -> dict:
     s["search_cpu_dot_products_per_sec"] = g(extras, "eval_search", "cpu_baseline", "value")
     s["config5_search_dot_products_per_sec"] = g(extras, "config5_end_to_end", "search_dot_products_per_sec")
     s["config5_encode_passages_per_sec"] = g(extras, "config5_end_to_end", "encode_passages_per_sec")
-    s["same_per_gpu_batch_seq_per_sec"] = g(extras, "same_per_gpu_batch_as_n1", "sequences_per_sec")
+    s["config3_seq_per_sec"] = g(extras, "config3_global_batch_2048", "sequences_per_sec")
     s["sharded_search_dot_products_per_sec"] = g(extras, "multi_gpu", "sharded_search", "dot_products_per_sec")
     s["sharded_encode_seq_per_sec"] = g(extras, "multi_gpu", "sharded_corpus_encode", "sequences_per_sec")
     s["dp_ance_rows_per_sec"] = g(extras, "multi_gpu", "ance_triplet_step", "rows_per_sec")
@@ -864,8 +872,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="base", choices=["base", "large"])
     ap.add_argument("--seq-per-gpu", type=int, default=0,
-                    help="sequences per GPU and step; default 64 (BASELINE configs[1]), and 256 for cocodr-base at 8 GPUs = configs[2]'s "
-                         "global batch 2048 (COCO/README.md:55 NPROC x BATCH_SIZE)")
+                    help="sequences per GPU and step; default 64 (BASELINE configs[1]) at every --gpus N (weak scaling); at 8 GPUs "
+                         "configs[2]'s global batch 2048 (COCO/README.md:55 NPROC x BATCH_SIZE) runs as a side leg")
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
     ap.add_argument("--dense", action="store_true", help="every synthetic sequence fills seq_len (SURVEY 8d's roofline variant)")
     ap.add_argument("--padded", action="store_true",
@@ -887,9 +895,11 @@ def main():
         raise SystemExit(_self_launch(args))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    config3 = args.seq_per_gpu == 0 and world == 8 and args.model == "base"  # BASELINE configs[2]: global batch 2048 on 8 GPUs
+    # `value` keeps N = 1's per-GPU batch (64 sequences) at every N, so the driver's curve over --gpus 1 / 2 / 4 / 8 is a weak-scaling
+    # curve; BASELINE configs[2] (8 GPUs, global batch 2048 = 256 per GPU) runs as a side leg (summary.config3_seq_per_sec)
+    config3 = args.seq_per_gpu == 0 and world == 8 and args.model == "base"
     if args.seq_per_gpu == 0:
-        args.seq_per_gpu = 256 if config3 else SEQ_PER_GPU
+        args.seq_per_gpu = SEQ_PER_GPU
 
     import torch.distributed as dist
     import cocodr_amd  # noqa: F401
@@ -986,15 +996,15 @@ def main():
 
     dt = tmax(dt)
     if world > 1 and not args.no_full_step:
-        if config3:  # the weak-scaling point that keeps N = 1's per-GPU batch (the headline of this line is configs[2]'s 256 per GPU)
-            wdt, wloss, _, _, _, _ = contrastive_leg(args.model, SEQ_PER_GPU, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
+        if config3:  # BASELINE configs[2]: cocodr-base on 8 GPUs with RCCL all_gather negatives, global batch 2048 (COCO/README.md:55)
+            wdt, wloss, _, _, _, _ = contrastive_leg(args.model, 256, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
                                                   args.dp_chunks, False, args.dense, packed=packed, host_lengths=host_lengths)
             wdt = tmax(wdt)
-            extras["same_per_gpu_batch_as_n1"] = {"sequences_per_sec": round(SEQ_PER_GPU * world * args.steps / wdt, 2),
-                                                  "ms_per_step": round(wdt / args.steps * 1e3, 3), "global_batch": SEQ_PER_GPU * world,
-                                                  "loss": round(wloss, 4),
-                                                  "note": "64 sequences per GPU as at N = 1, 2, 4: the point to use for weak-scaling efficiency "
-                                                          "against those lines"}
+            extras["config3_global_batch_2048"] = {"sequences_per_sec": round(256 * world * args.steps / wdt, 2),
+                                                   "ms_per_step": round(wdt / args.steps * 1e3, 3), "global_batch": 256 * world,
+                                                   "loss": round(wloss, 4),
+                                                   "note": "256 sequences per GPU (BASELINE configs[2]); NOT comparable with the N = 1, 2, 4 "
+                                                           "lines' 64 per GPU - the headline `value` of this line is"}
         extras["multi_gpu"] = multi_gpu_legs(dev, rank, world, fence, tmax, shared, args.dp_chunks)
 
     if rank == 0:
@@ -1004,7 +1014,6 @@ def main():
         if world > 1:
             par += " + RCCL all_gather negatives" if backend == "nccl" else f" over gloo ({world} ranks sharing {n_dev} GPU(s): code-path check, not a scaling number)"
         which = ("BASELINE configs[1]" if args.model == "base" and world == 1 else
-                 "BASELINE configs[2] (8 GPUs, RCCL all_gather negatives, global batch 2048)" if config3 else
                  "BASELINE configs[1]'s batch per GPU, negatives all-gathered as in configs[2]" if args.model == "base" else
                  "north_star BERT-large target shape")
         boundary = ("{input_ids, attention_mask, lengths}: B lengths on the host" if host_lengths else

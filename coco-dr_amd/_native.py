@@ -178,6 +178,7 @@ SIGNATURES = {
     "cocodr_prof_begin": (c_int, [c_int]),
     "cocodr_prof_pause": (c_int, [c_int]),
     "cocodr_prof_end": (c_int, [C.POINTER(c_int), C.POINTER(c_double), C.POINTER(c_double)]),
+    "cocodr_prof_event_overhead_us": (c_int, [c_void_p, C.POINTER(c_double)]),
     "cocodr_probe_mfma32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "cocodr_probe_tr16": (c_int, [c_void_p, c_void_p, c_void_p]),
 }

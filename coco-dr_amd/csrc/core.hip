@@ -5,6 +5,7 @@
 
 #include "common.h"
 #include "prof.h"
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -75,6 +76,48 @@ extern "C" int cocodr_prof_end(int* launches, double* total_ms, double* total_fl
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = g_ps.flops;
   g_ps.used = 0;
+  return COCODR_OK;
+}
+
+// What a begin / end event pair adds to the duration of the kernel it brackets: the pair around an EMPTY one-workgroup kernel
+// (median of 33), minus that kernel's own ~1 us (rocprofv3 --kernel-trace reports 0.8-1.2 us for it).  The 33 pairs are enqueued
+// BEHIND a kernel that spins for ~1.5 ms, so that - as in a training step - the packets are already in the queue when the GPU
+// reaches them (with an idle queue the figure is the host's submission latency, ~5 us, not the events' cost).  bench.py subtracts
+// it per bracketed launch, so that roofline.frac prices kernel time, as rocprofv3's per-kernel durations do.
+__global__ void cocodr_prof_nop_kernel() {}
+__global__ void cocodr_prof_spin_kernel(unsigned long long ticks) {   // s_memrealtime: 100 MHz
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int cocodr_prof_event_overhead_us(cocodr_stream_t stream, double* overhead_us) {
+  CK_ARG(overhead_us != nullptr, "prof_event_overhead_us: null out");
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int N = 33;
+  hipEvent_t b[N], e[N];
+  for (int i = 0; i < N; ++i) {
+    hipEventCreate(&b[i]);
+    hipEventCreate(&e[i]);
+  }
+  hipLaunchKernelGGL(cocodr_prof_nop_kernel, dim3(1), dim3(64), 0, st);
+  hipLaunchKernelGGL(cocodr_prof_spin_kernel, dim3(1), dim3(64), 0, st, 150000ull);
+  for (int i = 0; i < N; ++i) {
+    hipEventRecord(b[i], st);
+    hipLaunchKernelGGL(cocodr_prof_nop_kernel, dim3(1), dim3(64), 0, st);
+    hipEventRecord(e[i], st);
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) {
+    cocodr_set_error("prof_event_overhead_us: stream synchronize failed");
+    return COCODR_ERR_LAUNCH;
+  }
+  float t[N];
+  for (int i = 0; i < N; ++i) {
+    hipEventElapsedTime(&t[i], b[i], e[i]);
+    hipEventDestroy(b[i]);
+    hipEventDestroy(e[i]);
+  }
+  std::sort(t, t + N);
+  const double med_us = (double)t[N / 2] * 1e3;
+  *overhead_us = med_us > 1.0 ? med_us - 1.0 : 0.0;
   return COCODR_OK;
 }
 

@@ -593,6 +593,7 @@ bool cocodr_gemm_a4_ok(const cocodr_gemm_args& a);                              
 void cocodr_gemm_a4_launch(const cocodr_gemm_args& a, hipStream_t st);
 bool cocodr_gemm_a4_walk_ok(const cocodr_gemm_args& a);                         // ... as a persistent walk with a register epilogue
 void cocodr_gemm_a4_walk_launch(const cocodr_gemm_args& a, hipStream_t st);
+void cocodr_gemm_a4_walk_launch_multi(const cocodr_gemm_args* a, int n, hipStream_t st);   // 2..4 weight-gradient problems in one walk
 
 namespace {
 
@@ -676,7 +677,21 @@ int select_impl(const cocodr_gemm_args& a) {
     // against 31-34; profiles/r04_gemm_impl_sweep_base.txt); the dgrad (NN) form is level at BERT-base sizes and 3-9 % ahead
     // at BERT-large ones (15 040 rows x 1024 x 4096 = 236 tiles: 110 us against 120; profiles/r04_gemm_impl_sweep_unaligned.txt)
     const bool pp_one_round = !nopp && !a.trans_a && batch == 1 && tilespp >= 176 && tilespp <= 256;
+    // hand-scheduled one-wave-per-SIMD kernel as a persistent walk (gemm_a4.hip; the forward NT form): ahead of every other pipeline
+    // when its 256 x 256 tiles fill one round of the CUs to >= 5/8 or several rounds to >= 80 % (profiles/r06_gemm_a4.md: 32 768 x
+    // 3072 x 1024 165 us against 207; 4 776 x 2304 x 768 25.2 against 28.6), behind the smaller tiles in between (276-384 tiles)
+    static const bool noa4 = getenv("COCODR_GEMM_NOA4") != nullptr;  // A/B switch of this rule
+    bool a4_wins = false;
+    if (!noa4 && cocodr_gemm_a4_walk_ok(a)) {   // (every form: NT, NN with the [K, N] operand and TN with both operands through transposing LDS reads)
+      const long long t = tilespp;
+      if (t <= 256) a4_wins = t >= (a.epi == COCODR_EPI_GELU ? 224 : 160);
+      else {
+        const long long rounds = (t + 255) / 256;
+        a4_wins = t * 100 >= rounds * 256 * 80;
+      }
+    }
     if (!(k_ok && small)) impl = 1;
+    else if (a4_wins) impl = 15;
     else if (pp_fills || pp_one_round) impl = 13;
     else if (fewer_rounds && !a.trans_a && tiles256 >= 128 && !a.colsum && !a.colsum_partial) impl = 12;
     else if (tiles256 >= 384 && !(a.trans_a && tiles256 < 800) && !(!a.trans_a && a.K >= 2048)) impl = 5;
@@ -830,6 +845,17 @@ extern "C" int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, float*
   bool ok = false;
   const long long tiles = multi_tiles(problems, n, &ok);
   for (int q = 0; q < n && ok; ++q) ok = problems[q].A && problems[q].B && problems[q].C;
+  static const bool noa4 = getenv("COCODR_GEMM_NOA4") != nullptr;  // A/B switch
+  bool a4 = ok && !noa4 && tiles >= multi_min_tiles() && tiles < (1ll << 30);
+  for (int q = 0; q < n && a4; ++q) a4 = cocodr_gemm_a4_walk_ok(problems[q]);
+  if (a4) {  // the hand-scheduled kernel walks the tiles of all problems (gemm_a4.hip): no partial last round to cut, no workspace
+    double flops = 0.0;
+    for (int q = 0; q < n; ++q) flops += 2.0 * problems[q].M * problems[q].N * (double)problems[q].K * (problems[q].batch > 0 ? problems[q].batch : 1);
+    ProfScope prof(PROF_GEMM, (hipStream_t)stream, flops);
+    cocodr_gemm_a4_walk_launch_multi(problems, n, (hipStream_t)stream);
+    CK_LAUNCH("gemm_multi(a4)");
+    return COCODR_OK;
+  }
   if (ok && tiles >= multi_min_tiles() && tiles < (1ll << 30)) {
     cocodr_gemm_args copy[4];
     double flops = 0.0;

@@ -1220,8 +1220,10 @@ __global__ __launch_bounds__(256) void lamb_apply_kernel(float* __restrict__ p, 
 // loads; each 8-byte half carries its own tag, so a torn read is recognised and repeated (MI355X_MICROARCH.md "Workgroup dispatch
 // ... visibility": data-tagged granules).  A release fence here would write back the XCD's whole L2 - tens of MB of freshly
 // streamed m / v lines - per workgroup and tensor (measured: 6.5x slower than the two-pass kernels).  The spin is bounded: a grid
-// that is not co-resident (it is sized from the occupancy query) raises *err and the step finishes with whatever arrived - wrong
-// numbers and a loud flag instead of a hung queue.
+// that is not co-resident (it is sized from the occupancy query, which knows nothing of CU masks, partitions or a second process)
+// raises *err; a workgroup that sees the flag applies NO step to its tensor (trust ratio 0) - a skipped update and a loud flag
+// instead of a hung queue or wrongly scaled weights.  FlatLamb.step reads the flag on its first step and every 64th and falls
+// back to the two-pass kernels for good when it is set.
 constexpr int LF_THREADS = 1024, LF_V = 4, LF_PER_CU = 1;  // ONE 1024-thread workgroup per CU (G = #CUs: a gather reads G granules - with 256-thread
                                                             // workgroups, 4 per CU, the G^2 granule reads were half of the tensors' own traffic); capacity G * 1024 * 16 floats
 typedef float lf4 __attribute__((ext_vector_type(4)));
@@ -1338,7 +1340,10 @@ __global__ __launch_bounds__(LF_THREADS, LF_PER_CU * LF_THREADS / 256) void lamb
     }
     block_sum2(sw, su);
     const float wn = fminf(sqrtf(sw), 10.0f), un = sqrtf(su);
-    const float tr = (wn == 0.f || un == 0.f) ? 1.0f : wn / un;
+    // a gather that gave up (this workgroup's or, as far as it is visible here, anybody's) holds partial norms: ratio 0 - the
+    // tensor keeps its weights (P - lr * 0 * U) instead of taking a wrongly scaled step; the host reads the flag (optim.py)
+    const bool failed = __builtin_nontemporal_load(a.err) != 0;
+    const float tr = failed ? 0.0f : ((wn == 0.f || un == 0.f) ? 1.0f : wn / un);
     if (s.e >= 0 && s.local == 0 && tid == 0) {
       const int si = a.seg_index[s.e];
       a.trust[si] = tr;

@@ -271,16 +271,19 @@ class _EncoderFn(torch.autograd.Function):
         ctx.ids, ctx.mask = ids, mask
         ctx.set_materialize_grads(False)
         if ctx.tail:  # the last layer ran on its [CLS] rows only: there is no last_hidden_state (and no hidden_states tuple)
-            model._last_hidden_states = None
-            return None, cls.clone()
-        model._last_hidden_states = hidden
+            return None, cls.clone(), None
+        # the third output is the [N + 1, B, L, H] stack of hidden states itself (not differentiable: a caller that wants gradients
+        # through an intermediate state asks for taps) - handed to THIS call's caller, not parked on the module, so that
+        # overlapping forwards of one module (side streams, BertDotNLL with merge_passes = False) cannot read each other's
+        stack = hidden.detach()
+        ctx.mark_non_differentiable(stack)
         last = hidden[NL]
         if taps and training:  # views of the saved activations (read-only for the caller, like any saved tensor)
-            return (last, cls.clone()) + tuple(hidden[l] for l in range(NL))
-        return last, cls.clone()
+            return (last, cls.clone(), stack) + tuple(hidden[l] for l in range(NL))
+        return last, cls.clone(), stack
 
     @staticmethod
-    def backward(ctx, d_last, d_cls, *d_taps):
+    def backward(ctx, d_last, d_cls, _d_stack, *d_taps):
         model = ctx.model
         if not ctx.training or ctx.arena is None:
             raise RuntimeError("encoder backward called but the forward ran without saved activations")
@@ -553,13 +556,13 @@ class _PackedEncoderFn(torch.autograd.Function):
         ctx.arena = arena if training else None
         ctx.set_materialize_grads(False)
         if ctx.tail:
-            model._last_hidden_states = None
-            return None, cls.clone()
-        model._last_hidden_states = hidden
-        return hidden[NL], cls.clone()  # the last layer stays packed [T, H]; PackedIndex.unpack (differentiable) pads it on demand
+            return None, cls.clone(), None
+        stack = hidden.detach()   # (see _EncoderFn.forward: the stack travels with the call)
+        ctx.mark_non_differentiable(stack)
+        return hidden[NL], cls.clone(), stack  # the last layer stays packed [T, H]; PackedIndex.unpack (differentiable) pads it on demand
 
     @staticmethod
-    def backward(ctx, d_last, d_cls):
+    def backward(ctx, d_last, d_cls, _d_stack=None):
         model, pk = ctx.model, ctx.pk
         if not ctx.training or ctx.arena is None:
             raise RuntimeError("encoder backward called but the forward ran without saved activations")
@@ -608,7 +611,6 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         self._shadow = None          # bf16 copy of the weight-matrix region
         self._shadow_version = -1
         self._extra_state: Dict[str, torch.Tensor] = {}  # checkpoint tensors outside the encoder (pooler, heads ...)
-        self._last_hidden_states = None
         self.dropout_seed: Optional[int] = None  # None: torch.initial_seed() at the first dropout forward
         self._dropout_calls = 0
         # store batches back to back (no padding rows beyond 32-token alignment) instead of padded to one length: same
@@ -1175,8 +1177,7 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         layer runs); ``last_hidden_state`` / ``hidden_states`` are None.
         ``lengths``: the B sequence lengths on the HOST (= attention_mask.sum(1); what a collator that pads on the CPU knows) -
         with ``pack_sequences`` the packed layout is then built without reading anything back from the device."""
-        if token_type_ids is not None and bool(token_type_ids.any()):
-            raise NotImplementedError("token_type_ids != 0: the reference never passes segment ids (COCO/data.py:140)")
+        self._check_token_types(token_type_ids)
         if position_ids is not None:
             raise NotImplementedError("custom position_ids are not on the reference path")
         if input_ids.dim() != 2:
@@ -1200,9 +1201,10 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
                 raise RuntimeError("CocoBertModel runs on an MI355X only: move it with .to('cuda') (there is no CPU fallback)")
             pk = self.pack(input_ids, attention_mask, lengths, lazy=True)  # None: not prefix masks -> padded
         cls_only = bool(cls_only and not output_hidden_states and self.cls_tail)
+        stack = None
         if pk is not None:
             try:
-                last, cls = _PackedEncoderFn.apply(*self._flat_leaves(), self, pk, torch.is_grad_enabled(), cls_only)
+                last, cls, stack = _PackedEncoderFn.apply(*self._flat_leaves(), self, pk, torch.is_grad_enabled(), cls_only)
             except NotPrefixMask:  # (a device-planned layout, resolved inside the forward: some mask has holes - run padded)
                 pk = None
         ids = mask = None
@@ -1212,7 +1214,7 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
                 attention_mask = (torch.arange(L, device=input_ids.device)[None] < lens_dev[:, None]).to(torch.int32)
             ids, mask, L = self._prep(input_ids, attention_mask)
             outs = _EncoderFn.apply(*self._flat_leaves(), ids, mask, self, torch.is_grad_enabled(), want_taps, cls_only)
-            last, cls, taps = outs[0], outs[1], outs[2:]
+            last, cls, stack, taps = outs[0], outs[1], outs[2], outs[3:]
         if last is None:  # [CLS] tail
             out = EncoderOutput(None, None, cls)
             return out if return_dict else (None, None)
@@ -1222,16 +1224,50 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
             last = (lambda: pk.unpack(last_packed)[:, :L])
             if output_hidden_states:
                 last = last()
-                hs = tuple(pk.unpack(h)[:, :L] for h in self._last_hidden_states[:-1].unbind(0)) + (last,)
+                hs = tuple(pk.unpack(h)[:, :L] for h in stack[:-1].unbind(0)) + (last,)
             out = EncoderOutput(last, hs, cls)
-            self._last_hidden_states = None
             return out if return_dict else (out.last_hidden_state, None)
         if output_hidden_states:  # in a training forward every entry is differentiable (a head may read any layer)
-            below = taps if taps else self._last_hidden_states[:-1].unbind(0)
+            below = taps if taps else stack[:-1].unbind(0)
             hs = tuple(h[:, :L] for h in below) + (last[:, :L],)
         out = EncoderOutput(last[:, :L], hs, cls)
-        self._last_hidden_states = None
         return out if return_dict else (out.last_hidden_state, None)
+
+    _TT_MSG = "token_type_ids != 0: the reference never passes segment ids (COCO/data.py:140)"
+
+    def _check_token_types(self, token_type_ids) -> None:
+        """A tokenizer's (all-zero) ``token_type_ids`` are accepted (README.md:101-116 passes them); non-zero ones are not on the
+        reference path.  A host tensor is checked on the spot.  A device tensor is checked WITHOUT stopping the host: its
+        "any non-zero" flag is copied to a pinned byte behind an event, and every later call (or ``check_inputs()``) raises for the
+        flags that have arrived - so a wrong batch is reported a call late instead of every call paying a device round trip."""
+        self._resolve_token_type_flags(block=False)
+        if token_type_ids is None:
+            return
+        if not token_type_ids.is_cuda:
+            if bool(token_type_ids.any()):
+                raise NotImplementedError(self._TT_MSG)
+            return
+        pend = self.__dict__.setdefault("_tt_pending", [])
+        if len(pend) >= 8:  # (a caller that never lets the device catch up: wait for the oldest)
+            self._resolve_token_type_flags(block=True)
+        host = torch.empty(1, dtype=torch.uint8).pin_memory()
+        host.copy_(token_type_ids.ne(0).any().reshape(1).to(torch.uint8), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pend.append((host, ev))
+
+    def _resolve_token_type_flags(self, block: bool) -> None:
+        pend = self.__dict__.get("_tt_pending")
+        while pend and (block or pend[0][1].query()):
+            host, ev = pend.pop(0)
+            ev.synchronize()
+            if int(host[0]):
+                pend.clear()
+                raise NotImplementedError(self._TT_MSG + " (seen in an earlier call: device tensors are checked a call late)")
+
+    def check_inputs(self) -> None:
+        """Waits for the deferred input checks of earlier forward calls (device-side ``token_type_ids``) and raises what they found."""
+        self._resolve_token_type_flags(block=True)
 
     def _flat_leaves(self):
         """The two tensors a forward attaches its autograd node to: the flat parameters - or, inside ``side_stream_aliases()``, views

@@ -418,6 +418,13 @@ def prof_end():
     return n.value, ms.value, fl.value
 
 
+def prof_event_overhead_us() -> float:
+    """microseconds one begin / end event pair adds to the launch it brackets (cocodr_prof_event_overhead_us, include/cocodr.h)"""
+    us = C.c_double(0.0)
+    check(lib().cocodr_prof_event_overhead_us(stream_ptr(), C.byref(us)), "prof_event_overhead_us")
+    return us.value
+
+
 def probe_mfma32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     out = torch.empty((32, 32), dtype=F32, device=a.device)
     check(lib().cocodr_probe_mfma32(ptr(a), ptr(b), ptr(out), stream_ptr()), "probe_mfma32")

@@ -225,9 +225,13 @@ class FlatLamb(torch.optim.Optimizer):
             self._plans[key] = (plan, fplan, keep, ws, stats, fws, 2 * len(arrs[0]))
         return self._plans[key]
 
+    #: steps between two read-backs of the one-pass kernel's error flag (the first step always checks)
+    one_pass_check_every = 64
+
     def one_pass_error(self) -> bool:
-        """True if a workgroup of the one-pass kernel ever gave up waiting for the others (a device that cannot hold its grid:
-        the numbers of that step are wrong).  Reads the flags back: a debugging / test call, not part of a step."""
+        """True if a workgroup of the one-pass kernel ever gave up waiting for the others (a device that cannot hold its grid -
+        CU mask, partition mode, a GPU shared with another process: the tensors concerned skipped that step).  Reads the flags
+        back (a device synchronisation): ``step`` calls it on its first step and every ``one_pass_check_every`` steps."""
         bad = False
         for (plan, fplan, _keep, _ws, _stats, fws, _t0) in self._plans.values():
             if fplan is not None:
@@ -275,4 +279,13 @@ class FlatLamb(torch.optim.Optimizer):
                 st["weight_norm"], st["adam_norm"] = stats[:, 0], stats[:, 1]
                 st["trust_ratio"] = ws[trust0:]
                 _after_native_update(p, m, shadow is not None)
+        if self.one_pass:
+            self._steps_taken = getattr(self, "_steps_taken", 0) + 1
+            if (self._steps_taken == 1 or self._steps_taken % self.one_pass_check_every == 0) and self.one_pass_error():
+                import warnings
+                self.one_pass = False  # (instance attribute: this optimizer stays on the two-pass kernels)
+                warnings.warn("FlatLamb: the one-pass LAMB kernel's workgroups were not co-resident on this device (CU mask, partition "
+                              "mode or a shared GPU); the weight matrices skipped their update in at most the last "
+                              f"{self.one_pass_check_every} steps. Falling back to the two-pass kernels for the rest of the run.",
+                              RuntimeWarning, stacklevel=2)
         return loss

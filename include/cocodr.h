@@ -138,6 +138,9 @@ int cocodr_gemm_multi(const cocodr_gemm_args* problems, int n, float* workspace,
  * direct-to-LDS <BM,BK,wave rows/32>: 2 = <128,64,2>, 3 = <256,64,2>, 4 = <128,32,2>, 5 = <256,32,2>, 6 = <256,32,4>, 7 = <256,64,4>, 8 = 128x192 tile,
  * 9 / 10 = 3 / 7 with four dedicated loader waves per workgroup, 11 = 256x256 tile, 12 = 256x96 tile (4x3 MFMA waves of
  * 64x32 + four loader waves; N % 96 == 0, makes the N = 768 GEMMs of 8192 tokens exactly one tile per CU)
+ *  * 13 = ping-pong pipeline (256x256 tile, eight waves), 18 = the same with two fat phases per K-tile,
+ * 14 = hand-scheduled one-wave-per-SIMD kernel (csrc/gemm_a4.hip: NT form, K % 128 == 0), 15 = the same as a persistent tile walk
+ * with a register epilogue
  * (also settable through the COCODR_GEMM_IMPL environment variable) */
 int cocodr_gemm_set_impl(int impl);
 
@@ -619,6 +622,10 @@ int cocodr_prof_begin(int kind);
 int cocodr_prof_pause(int paused);
 /* synchronises, returns launches / summed ms / summed algorithmic FLOPs, and disables profiling */
 int cocodr_prof_end(int* launches, double* total_ms, double* total_flops);
+/* what one begin / end event pair adds to the duration of the kernel it brackets, in microseconds: the pair around an empty
+ * one-workgroup kernel (median of 33) minus that kernel's own ~1 us; a bench subtracts it per bracketed launch so that its
+ * roofline prices kernel time (what rocprofv3 --kernel-trace reports), not event-to-event time */
+int cocodr_prof_event_overhead_us(cocodr_stream_t stream, double* overhead_us);
 
 /* Hardware probes used by the GPU tests to pin the MFMA / transposed-LDS-read lane layouts the
  * kernels rely on (out: fp32 / int32 device buffers, see tests/test_gpu_probe.py). */

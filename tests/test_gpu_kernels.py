@@ -49,7 +49,7 @@ def test_probe_ds_read_tr16_layout():
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18], ids=["regstage", "glds128x64", "glds256x64", "glds128x32", "glds256x32", "glds256x32w4", "glds256x64w4", "glds128x192", "glds256x64ld4", "glds256x64w4ld4", "glds256x256", "glds256x96ld4", "pingpong256x256", "pingpong256x256fat"], autouse=False)
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 14, 15], ids=["regstage", "glds128x64", "glds256x64", "glds128x32", "glds256x32", "glds256x32w4", "glds256x64w4", "glds128x192", "glds256x64ld4", "glds256x64w4ld4", "glds256x256", "glds256x96ld4", "pingpong256x256", "pingpong256x256fat", "onewave256x256", "onewave256x256walk"], autouse=False)
 def gemm_impl(request):
     ops.gemm_set_impl(request.param)
     yield request.param
@@ -406,6 +406,32 @@ def test_one_pass_lamb_equals_the_two_pass_kernels_and_the_oracle_on_matrix_size
     np.testing.assert_allclose(a[1].cpu().numpy(), np.asarray(trust), rtol=2e-4)
     for i, n in enumerate(sizes):
         np.testing.assert_allclose(a[0][offs[i]: offs[i] + n].cpu().numpy(), P[i], rtol=3e-4, atol=1e-7, err_msg=str(i))
+
+
+def test_one_pass_lamb_error_flag_skips_the_update_and_falls_back():
+    """a one-pass grid that is not co-resident must not leave wrongly scaled weights behind, and a training step must
+    notice.  The flag word is raised by hand here (a device that holds the grid never raises it): the one-pass tensors keep their
+    weights in that step (trust ratio 0), FlatLamb.step reads the flag on its first step, warns and stays on the two-pass kernels."""
+    import warnings
+    from cocodr_amd.optim import FlatLamb, LAMB_FUSED_MIN
+    n = 4 * LAMB_FUSED_MIN
+    p = torch.nn.Parameter((torch.randn(n + 64, generator=torch.Generator().manual_seed(1)) * 0.05).to(DEV))
+    opt = FlatLamb([p], [[0, n]], lr=1e-2, eps=1e-6)
+    assert opt.one_pass
+    plan, fplan, _keep, _ws, _stats, fws, _t0 = opt._plan(p, [0, n])
+    assert fplan is not None and fplan.nfused == 1
+    from cocodr_amd._native import lib
+    fws[int(lib().cocodr_lamb_fused_error_index(fplan.nfused))] = torch.tensor([1], dtype=torch.int32).view(torch.float32).item()
+    before = p.data.clone()
+    p.grad = torch.randn(n + 64, generator=torch.Generator().manual_seed(2)).to(DEV) * 1e-2
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        opt.step()
+    assert any("co-resident" in str(x.message) for x in w) and opt.one_pass is False
+    assert torch.equal(p.data[:n], before[:n])           # the one-pass tensor skipped its update
+    assert not torch.equal(p.data[n:], before[n:])       # the small tensor behind it went through the two-pass kernels
+    opt.step()                                           # two-pass from here on
+    assert not torch.equal(p.data[:n], before[:n])
 
 
 def test_one_pass_lamb_on_a_bert_base_width_model_equals_the_two_pass_step():
