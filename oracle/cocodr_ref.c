@@ -8,6 +8,10 @@
  *   cocodr_gemm_ref              hf nn.Linear forward / backward with the fused epilogues (modeling_bert.py:282-293, 325-351)
  *   cocodr_ln_fwd_ref            hf nn.LayerNorm (modeling_bert.py:288-292), eps inside the square root
  *   cocodr_attn_fwd_ref          hf eager_attention_forward (modeling_bert.py:111-203), key-padding mask, head_dim 64
+ *   cocodr_attn_bwd_ref          the autograd backward of the same function: dQ | dK | dV from dctx (+ the query-bias partial sums)
+ *   cocodr_ln_bwd_ref            the autograd backward of nn.LayerNorm (+ dgamma, dbeta, column sums of dy)
+ *   cocodr_embed_ln_fwd_ref      hf BertEmbeddings.forward (modeling_bert.py:68-108): LN(word[ids] + pos[0..L-1] + type[0])
+ *   cocodr_embed_ln_bwd_ref      its backward: scatter-add into the word table, position / type / LayerNorm gradients
  *   cocodr_simce_fwd_bwd_ref     COCO/modeling.py:244-248 compute_contrastive_loss, :172-177 co_target, .mean() at :229
  *   cocodr_triplet_nll_fwd_bwd_ref  ANCE/model/models.py:97-106, 260-261
  *   cocodr_score_topk_ref        faiss.IndexFlatIP(dim).search (evaluate/evaluation/evaluate_beir.py:220-224): exact inner
@@ -155,6 +159,183 @@ int cocodr_attn_fwd_ref(const uint16_t* qkv, const int32_t* mask, uint16_t* ctx,
         }
       }
   free(s);
+  return COCODR_OK;
+}
+
+/* backward of the attention above: P = softmax(S), dV = P^T dO, dP = dO V^T, dS = P o (dP - rowsum(dP o P)), dQ = dS K / 8,
+ * dK = dS^T Q / 8.  The device function recomputes P from the saved log-sum-exp; here it is recomputed from scratch (lse is not
+ * read).  qk_bias_partial [4 B, 2 H]: rows 4 b .. 4 b + 3 together hold the column sums of dQ | dK over sequence b - this twin
+ * writes the whole sum to row 4 b and zeros to the other three, and exact zeros for the dK half (the rows of dS sum to zero). */
+int cocodr_attn_bwd_ref(const uint16_t* qkv, const int32_t* mask, const uint16_t* ctx, const uint16_t* dctx, const float* lse,
+                        uint16_t* dqkv, float* qk_bias_partial, int B, int L, int heads, cocodr_stream_t stream) {
+  (void)stream; (void)ctx; (void)lse;
+  if (!qkv || !mask || !dctx || !dqkv || B <= 0 || L <= 0 || heads <= 0) return COCODR_ERR_INVALID;
+  const int H = heads * 64, ld = 3 * H;
+  double* P = (double*)malloc((size_t)L * L * sizeof(double));
+  double* dS = (double*)malloc((size_t)L * L * sizeof(double));
+  if (!P || !dS) { free(P); free(dS); return COCODR_ERR_INVALID; }
+  if (qk_bias_partial) memset(qk_bias_partial, 0, (size_t)4 * B * 2 * H * sizeof(float));
+  for (int b = 0; b < B; ++b) {
+    int any = 0;
+    for (int j = 0; j < L; ++j) any |= mask[b * L + j] != 0;
+    for (int h = 0; h < heads; ++h) {
+      const uint16_t* Q = qkv + (size_t)b * L * ld + h * 64;
+      const uint16_t* K = Q + H;
+      const uint16_t* V = Q + 2 * H;
+      const uint16_t* dO = dctx + (size_t)b * L * H + h * 64;
+      for (int i = 0; i < L; ++i) {
+        double mx = -INFINITY, sum = 0.0;
+        for (int j = 0; j < L; ++j) {
+          double d = 0.0;
+          for (int e = 0; e < 64; ++e) d += (double)bf2f(Q[(size_t)i * ld + e]) * (double)bf2f(K[(size_t)j * ld + e]);
+          P[(size_t)i * L + j] = (mask[b * L + j] != 0 || !any) ? d * 0.125 : -INFINITY;
+          if (P[(size_t)i * L + j] > mx) mx = P[(size_t)i * L + j];
+        }
+        for (int j = 0; j < L; ++j) { P[(size_t)i * L + j] = exp(P[(size_t)i * L + j] - mx); sum += P[(size_t)i * L + j]; }
+        double dot = 0.0;
+        for (int j = 0; j < L; ++j) {
+          P[(size_t)i * L + j] /= sum;
+          double dp = 0.0;
+          for (int e = 0; e < 64; ++e) dp += (double)bf2f(dO[(size_t)i * H + e]) * (double)bf2f(V[(size_t)j * ld + e]);
+          dS[(size_t)i * L + j] = dp;
+          dot += dp * P[(size_t)i * L + j];
+        }
+        for (int j = 0; j < L; ++j) dS[(size_t)i * L + j] = P[(size_t)i * L + j] * (dS[(size_t)i * L + j] - dot);
+      }
+      for (int i = 0; i < L; ++i)
+        for (int e = 0; e < 64; ++e) {
+          double dq = 0.0, dk = 0.0, dv = 0.0;
+          for (int j = 0; j < L; ++j) {
+            dq += dS[(size_t)i * L + j] * (double)bf2f(K[(size_t)j * ld + e]);
+            dk += dS[(size_t)j * L + i] * (double)bf2f(Q[(size_t)j * ld + e]);
+            dv += P[(size_t)j * L + i] * (double)bf2f(dO[(size_t)j * H + e]);
+          }
+          uint16_t* o = dqkv + (size_t)(b * L + i) * ld + h * 64 + e;
+          o[0] = f2bf((float)(dq * 0.125));
+          o[H] = f2bf((float)(dk * 0.125));
+          o[2 * H] = f2bf((float)dv);
+          if (qk_bias_partial) qk_bias_partial[(size_t)(4 * b) * 2 * H + h * 64 + e] += (float)(dq * 0.125);
+        }
+    }
+  }
+  free(P);
+  free(dS);
+  return COCODR_OK;
+}
+
+/* backward of out = (y - mean) rstd gamma + beta w.r.t. y, gamma, beta (mean / rstd as the forward saved them):
+ * xhat = (y - mean) rstd, g = dout gamma, dy = rstd (g - mean_h(g) - xhat mean_h(g xhat)); dy_colsum = column sums of dy
+ * (before its rounding to bf16) - the bias gradient of the Linear in front of the LayerNorm.  partial is device scratch: ignored. */
+int cocodr_ln_bwd_ref(const uint16_t* dout, const uint16_t* y, const float* gamma, const float* mean, const float* rstd, uint16_t* dy,
+                      float* dgamma, float* dbeta, float* dy_colsum, float* partial, int M, int H, cocodr_stream_t stream) {
+  (void)stream; (void)partial;
+  if (!dout || !y || !gamma || !mean || !rstd || !dy || M <= 0 || H <= 0) return COCODR_ERR_INVALID;
+  double* dg = (double*)calloc((size_t)3 * H, sizeof(double));
+  if (!dg) return COCODR_ERR_INVALID;
+  double *db = dg + H, *cs = dg + 2 * H;
+  for (int m = 0; m < M; ++m) {
+    const double mu = mean[m], rs = rstd[m];
+    double s1 = 0.0, s2 = 0.0;
+    for (int h = 0; h < H; ++h) {
+      const double xh = ((double)bf2f(y[(size_t)m * H + h]) - mu) * rs, d = (double)bf2f(dout[(size_t)m * H + h]);
+      const double g = d * (double)gamma[h];
+      s1 += g;
+      s2 += g * xh;
+      dg[h] += d * xh;
+      db[h] += d;
+    }
+    s1 /= H;
+    s2 /= H;
+    for (int h = 0; h < H; ++h) {
+      const double xh = ((double)bf2f(y[(size_t)m * H + h]) - mu) * rs;
+      const double g = (double)bf2f(dout[(size_t)m * H + h]) * (double)gamma[h];
+      const double v = rs * (g - s1 - xh * s2);
+      dy[(size_t)m * H + h] = f2bf((float)v);
+      cs[h] += v;   /* the device sums its fp32 values, not the rounded ones it stores */
+    }
+  }
+  for (int h = 0; h < H; ++h) {
+    if (dgamma) dgamma[h] = (float)dg[h];
+    if (dbeta) dbeta[h] = (float)db[h];
+    if (dy_colsum) dy_colsum[h] = (float)cs[h];
+  }
+  free(dg);
+  return COCODR_OK;
+}
+
+/* hf BertEmbeddings.forward: the reference never passes token_type_ids / position_ids (COCO/data.py:140,
+ * ANCE/model/models.py:226-227): segment row 0, positions 0 .. L - 1.  ids outside [0, vocab) are an error. */
+int cocodr_embed_ln_fwd_ref(const int32_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                            const float* beta, uint16_t* out, float* mean, float* rstd, int B, int L, int H, int vocab, float eps,
+                            cocodr_stream_t stream) {
+  (void)stream;
+  if (!ids || !word || !pos || !type0 || !gamma || !beta || !out || B <= 0 || L <= 0 || H <= 0) return COCODR_ERR_INVALID;
+  double* x = (double*)malloc((size_t)H * sizeof(double));
+  if (!x) return COCODR_ERR_INVALID;
+  for (int m = 0; m < B * L; ++m) {
+    const int id = ids[m], l = m % L;
+    if (id < 0 || id >= vocab) { free(x); return COCODR_ERR_INVALID; }
+    double mu = 0.0, var = 0.0;
+    for (int h = 0; h < H; ++h) {
+      x[h] = (double)word[(size_t)id * H + h] + (double)pos[(size_t)l * H + h] + (double)type0[h];
+      mu += x[h];
+    }
+    mu /= H;
+    for (int h = 0; h < H; ++h) var += (x[h] - mu) * (x[h] - mu);
+    const double rs = 1.0 / sqrt(var / H + (double)eps);
+    if (mean) mean[m] = (float)mu;
+    if (rstd) rstd[m] = (float)rs;
+    for (int h = 0; h < H; ++h) out[(size_t)m * H + h] = f2bf((float)((x[h] - mu) * rs * (double)gamma[h] + (double)beta[h]));
+  }
+  free(x);
+  return COCODR_OK;
+}
+
+size_t cocodr_embed_bwd_partial_floats_ref(int L, int H) { (void)L; (void)H; return 0; }
+
+/* backward of the above: dx = LayerNorm backward of dout at x = word[id] + pos[l] + type0 (recomputed), then dword[id] += dx
+ * (ACCUMULATED: the caller zeroes dword), dpos[l] = sum over the batch (overwritten, rows [0, L)), dtype0 = sum over all
+ * tokens, dgamma / dbeta as in cocodr_ln_bwd_ref.  partial is device scratch: ignored. */
+int cocodr_embed_ln_bwd_ref(const uint16_t* dout, const int32_t* ids, const float* word, const float* pos, const float* type0,
+                            const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos, float* dtype0,
+                            float* dgamma, float* dbeta, float* partial, int B, int L, int H, int vocab, cocodr_stream_t stream) {
+  (void)stream; (void)partial;
+  if (!dout || !ids || !word || !pos || !type0 || !gamma || !mean || !rstd || !dword || !dpos || !dtype0 || B <= 0 || L <= 0 || H <= 0)
+    return COCODR_ERR_INVALID;
+  double* acc = (double*)calloc((size_t)(L + 3) * H, sizeof(double));   /* dpos [L][H], dtype0, dgamma, dbeta */
+  if (!acc) return COCODR_ERR_INVALID;
+  double *dp = acc, *dt = acc + (size_t)L * H, *dg = dt + H, *db = dg + H;
+  for (int m = 0; m < B * L; ++m) {
+    const int id = ids[m], l = m % L;
+    if (id < 0 || id >= vocab) { free(acc); return COCODR_ERR_INVALID; }
+    const double mu = mean[m], rs = rstd[m];
+    double s1 = 0.0, s2 = 0.0;
+    for (int h = 0; h < H; ++h) {
+      const double x = (double)word[(size_t)id * H + h] + (double)pos[(size_t)l * H + h] + (double)type0[h];
+      const double xh = (x - mu) * rs, d = (double)bf2f(dout[(size_t)m * H + h]), g = d * (double)gamma[h];
+      s1 += g;
+      s2 += g * xh;
+      dg[h] += d * xh;
+      db[h] += d;
+    }
+    s1 /= H;
+    s2 /= H;
+    for (int h = 0; h < H; ++h) {
+      const double x = (double)word[(size_t)id * H + h] + (double)pos[(size_t)l * H + h] + (double)type0[h];
+      const double xh = (x - mu) * rs, g = (double)bf2f(dout[(size_t)m * H + h]) * (double)gamma[h];
+      const double dx = rs * (g - s1 - xh * s2);
+      dword[(size_t)id * H + h] += (float)dx;
+      dp[(size_t)l * H + h] += dx;
+      dt[h] += dx;
+    }
+  }
+  for (size_t i = 0; i < (size_t)L * H; ++i) dpos[i] = (float)dp[i];
+  for (int h = 0; h < H; ++h) {
+    dtype0[h] = (float)dt[h];
+    if (dgamma) dgamma[h] = (float)dg[h];
+    if (dbeta) dbeta[h] = (float)db[h];
+  }
+  free(acc);
   return COCODR_OK;
 }
 

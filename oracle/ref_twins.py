@@ -12,8 +12,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "cocodr_ref.c")
 LIB = os.path.join(HERE, "libcocodr_ref.so")
-TWINS = ["cocodr_gemm", "cocodr_ln_fwd", "cocodr_attn_fwd", "cocodr_simce_fwd_bwd", "cocodr_triplet_nll_fwd_bwd", "cocodr_score_topk",
-         "cocodr_topk_merge"]
+TWINS = ["cocodr_gemm", "cocodr_ln_fwd", "cocodr_ln_bwd", "cocodr_attn_fwd", "cocodr_attn_bwd", "cocodr_embed_ln_fwd", "cocodr_embed_ln_bwd",
+         "cocodr_simce_fwd_bwd", "cocodr_triplet_nll_fwd_bwd", "cocodr_score_topk", "cocodr_topk_merge"]
 _lib = None
 
 

@@ -151,3 +151,80 @@ def test_search_and_merge_device_vs_twin():
     oD, oI = np.zeros((Nq, k), np.float32), np.zeros((Nq, k), np.int64)
     assert tw.cocodr_topk_merge_ref(_hp(hDw), _hp(hIw), _hp(hoffs), 4, Nq, k, Nq * k, _hp(oD), _hp(oI), k, None) == 0
     assert np.array_equal(mI.cpu().numpy(), oI) and np.array_equal(mD.cpu().numpy(), oD)
+
+
+def test_backward_kernels_device_vs_twin():
+    """cocodr_ln_bwd / cocodr_attn_bwd / cocodr_embed_ln_fwd / cocodr_embed_ln_bwd against their C twins, one argument tuple per pair
+    (the backward kernels are the ones a maintainer most needs a host twin for)."""
+    rng = np.random.Generator(np.random.PCG64(21))
+    tw = ref_twins.lib()
+    dl = dev_lib()
+    sp = stream_ptr()
+
+    def dev(x):
+        return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+    # ---- LayerNorm backward (mean / rstd from the forward twin)
+    M, H = 160, 256
+    y, dout = _bits(_bf(rng.standard_normal((M, H)) * 1.3 + 0.1)), _bits(_bf(rng.standard_normal((M, H))))
+    gam, bet = rng.standard_normal(H).astype(np.float32), np.zeros(H, np.float32)
+    o_, mean, rstd = np.zeros((M, H), np.uint16), np.zeros(M, np.float32), np.zeros(M, np.float32)
+    assert tw.cocodr_ln_fwd_ref(_hp(y), _hp(gam), _hp(bet), _hp(o_), _hp(mean), _hp(rstd), None, 0, M, H, 1e-12, None) == 0
+    host = [np.zeros((M, H), np.uint16)] + [np.zeros(H, np.float32) for _ in range(3)]
+    assert tw.cocodr_ln_bwd_ref(_hp(dout), _hp(y), _hp(gam), _hp(mean), _hp(rstd), *[_hp(h) for h in host], None, M, H, None) == 0
+    d_in = [dev(x.view(np.int16)).view(torch.bfloat16) for x in (dout, y)] + [dev(gam), dev(mean), dev(rstd)]
+    d_out = [torch.empty((M, H), dtype=torch.bfloat16, device=DEV)] + [torch.empty(H, dtype=torch.float32, device=DEV) for _ in range(3)]
+    part = torch.empty(int(dl.cocodr_ln_bwd_partial_floats(M, H)), dtype=torch.float32, device=DEV)
+    assert dl.cocodr_ln_bwd(*[t.data_ptr() for t in d_in], *[t.data_ptr() for t in d_out], part.data_ptr(), M, H, sp) == 0
+    assert np.abs(_f32(_bits(d_out[0])) - _f32(host[0])).max() <= np.abs(_f32(host[0])).max() * 2 ** -7
+    for got, want in zip(d_out[1:], host[1:]):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=2e-2)   # fp32 sums of M bf16-derived terms, another order
+    # ---- attention backward
+    B, L, heads = 2, 64, 2
+    Hh = heads * 64
+    qkv, dctx = _bits(_bf(rng.standard_normal((B * L, 3 * Hh)) * 0.7)), _bits(_bf(rng.standard_normal((B * L, Hh)) * 0.5))
+    mask = np.ones((B, L), np.int32)
+    mask[1, 37:] = 0
+    hctx, hlse = np.zeros((B * L, Hh), np.uint16), np.zeros((B, heads, L), np.float32)
+    assert tw.cocodr_attn_fwd_ref(_hp(qkv), _hp(mask), _hp(hctx), _hp(hlse), B, L, heads, None) == 0
+    hdqkv, hqk = np.zeros((B * L, 3 * Hh), np.uint16), np.zeros((4 * B, 2 * Hh), np.float32)
+    assert tw.cocodr_attn_bwd_ref(_hp(qkv), _hp(mask), _hp(hctx), _hp(dctx), _hp(hlse), _hp(hdqkv), _hp(hqk), B, L, heads, None) == 0
+    dq_, dm_, dc_, dd_ = (dev(x.view(np.int16)).view(torch.bfloat16) if x.dtype == np.uint16 else dev(x) for x in (qkv, mask, hctx, dctx))
+    ctx_d, lse_d = ops.attn_fwd(dq_, dm_, B, L, heads)
+    ddqkv = torch.empty((B * L, 3 * Hh), dtype=torch.bfloat16, device=DEV)
+    dqk = torch.empty((4 * B, 2 * Hh), dtype=torch.float32, device=DEV)
+    assert dl.cocodr_attn_bwd(dq_.data_ptr(), dm_.data_ptr(), ctx_d.data_ptr(), dd_.data_ptr(), lse_d.data_ptr(), ddqkv.data_ptr(), dqk.data_ptr(),
+                              B, L, heads, sp) == 0
+    valid = np.repeat(mask.reshape(-1) != 0, 3 * Hh).reshape(B * L, 3 * Hh)
+    got, want = _f32(_bits(ddqkv)), _f32(hdqkv)
+    assert np.abs(got - want)[valid].max() <= np.abs(want).max() * 2 ** -5   # P recomputed from the bf16-rounded lse path: a few bf16 ulps
+    np.testing.assert_allclose(dqk.cpu().numpy().reshape(B, 4, 2 * Hh).sum(1), hqk.reshape(B, 4, 2 * Hh).sum(1), rtol=2e-2, atol=2e-2)
+    # ---- embeddings forward / backward
+    Bq, Lq, He, V = 4, 32, 128, 300
+    ids = rng.integers(0, V, (Bq, Lq)).astype(np.int32)
+    word = (rng.standard_normal((V, He)) * 0.5).astype(np.float32)
+    pos = (rng.standard_normal((64, He)) * 0.5).astype(np.float32)
+    typ, g_, b_ = ((rng.standard_normal(He) * 0.5).astype(np.float32) for _ in range(3))
+    hout, hmean, hrstd = np.zeros((Bq * Lq, He), np.uint16), np.zeros(Bq * Lq, np.float32), np.zeros(Bq * Lq, np.float32)
+    assert tw.cocodr_embed_ln_fwd_ref(_hp(ids), _hp(word), _hp(pos), _hp(typ), _hp(g_), _hp(b_), _hp(hout), _hp(hmean), _hp(hrstd), Bq, Lq, He, V,
+                                      1e-12, None) == 0
+    t = [dev(x) for x in (ids, word, pos, typ, g_, b_)]
+    dout_e = torch.empty((Bq * Lq, He), dtype=torch.bfloat16, device=DEV)
+    dmean, drstd = torch.empty(Bq * Lq, dtype=torch.float32, device=DEV), torch.empty(Bq * Lq, dtype=torch.float32, device=DEV)
+    assert dl.cocodr_embed_ln_fwd(*[x.data_ptr() for x in t], dout_e.data_ptr(), dmean.data_ptr(), drstd.data_ptr(), Bq, Lq, He, V, 1e-12, sp) == 0
+    assert np.abs(_f32(_bits(dout_e)) - _f32(hout)).max() <= np.abs(_f32(hout)).max() * 2 ** -7
+    assert np.allclose(dmean.cpu().numpy(), hmean, atol=1e-5) and np.allclose(drstd.cpu().numpy(), hrstd, rtol=1e-5)
+    dy = _bits(_bf(rng.standard_normal((Bq * Lq, He))))
+    hg = [np.zeros((V, He), np.float32), np.zeros((Lq, He), np.float32)] + [np.zeros(He, np.float32) for _ in range(3)]
+    assert tw.cocodr_embed_ln_bwd_ref(_hp(dy), _hp(ids), _hp(word), _hp(pos), _hp(typ), _hp(g_), _hp(hmean), _hp(hrstd), *[_hp(x) for x in hg], None,
+                                      Bq, Lq, He, V, None) == 0
+    dg = [torch.zeros((V, He), dtype=torch.float32, device=DEV), torch.zeros((64, He), dtype=torch.float32, device=DEV)] + \
+         [torch.empty(He, dtype=torch.float32, device=DEV) for _ in range(3)]
+    part = torch.empty(int(dl.cocodr_embed_bwd_partial_floats(Lq, He)), dtype=torch.float32, device=DEV)
+    assert dl.cocodr_embed_ln_bwd(dev(dy.view(np.int16)).view(torch.bfloat16).data_ptr(), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                  t[3].data_ptr(), t[4].data_ptr(), dmean.data_ptr(), drstd.data_ptr(), *[x.data_ptr() for x in dg], part.data_ptr(),
+                                  Bq, Lq, He, V, sp) == 0
+    np.testing.assert_allclose(dg[0].cpu().numpy(), hg[0], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(dg[1].cpu().numpy()[:Lq], hg[1], rtol=2e-3, atol=2e-3)
+    for got, want in zip(dg[2:], hg[2:]):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=2e-2)

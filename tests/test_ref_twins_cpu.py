@@ -104,6 +104,85 @@ def test_ln_and_attention_twins_match_the_oracle_layer(lib):
     assert np.abs(_f32(ctx) - want).max() <= np.abs(want).max() * 2 ** -7 and np.allclose(lse, want_lse, rtol=1e-5, atol=1e-5)
 
 
+def test_backward_twins_match_the_oracle(lib):
+    """cocodr_ln_bwd_ref / cocodr_attn_bwd_ref / cocodr_embed_ln_fwd_ref / cocodr_embed_ln_bwd_ref against the numpy oracle's
+    layer_norm_bwd, the attention part of layers_bwd and embeddings_fwd (hf modeling_bert.py:68-108, 111-203, 282-293)."""
+    rng = np.random.Generator(np.random.PCG64(15))
+    # ---- LayerNorm backward
+    M, H = 10, 128
+    y = _bf16(rng.standard_normal((M, H)) * 1.5 - 0.2)
+    dout = _bf16(rng.standard_normal((M, H)))
+    gam = rng.standard_normal(H).astype(np.float32)
+    yf = _f32(y).astype(np.float64)
+    _, xhat, rs = O.layer_norm_fwd(yf, gam.astype(np.float64), np.zeros(H))
+    mean = yf.mean(-1).astype(np.float32)
+    rstd = rs.ravel().astype(np.float32)
+    dy = np.zeros((M, H), np.uint16)
+    dg, db, cs = (np.zeros(H, np.float32) for _ in range(3))
+    assert lib.cocodr_ln_bwd_ref(_p(dout), _p(y), _p(gam), _p(mean), _p(rstd), _p(dy), _p(dg), _p(db), _p(cs), None, M, H, None) == 0
+    wdy, wdg, wdb = O.layer_norm_bwd(_f32(dout).astype(np.float64), xhat, rs, gam.astype(np.float64))
+    assert np.abs(_f32(dy) - wdy).max() <= np.abs(wdy).max() * 2 ** -7
+    np.testing.assert_allclose(dg, wdg, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db, wdb, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cs, wdy.sum(0), rtol=1e-5, atol=1e-5)
+    # ---- attention backward
+    B, L, heads = 2, 32, 2
+    Hh = heads * 64
+    qkv = _bf16(rng.standard_normal((B * L, 3 * Hh)) * 0.6)
+    dctx = _bf16(rng.standard_normal((B * L, Hh)) * 0.5)
+    mask = np.ones((B, L), np.int32)
+    mask[0, 25:] = 0
+    dqkv = np.zeros((B * L, 3 * Hh), np.uint16)
+    qkb = np.zeros((4 * B, 2 * Hh), np.float32)
+    assert lib.cocodr_attn_bwd_ref(_p(qkv), _p(mask), None, _p(dctx), None, _p(dqkv), _p(qkb), B, L, heads, None) == 0
+    x = _f32(qkv).astype(np.float64).reshape(B, L, 3, heads, 64)
+    q, k, v = (x[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(0, 1, 3, 2) / 8.0 + np.where(mask[:, None, None, :] != 0, 0.0, -1e30)
+    pr = np.exp(s - s.max(-1, keepdims=True))
+    pr /= pr.sum(-1, keepdims=True)
+    do = _f32(dctx).astype(np.float64).reshape(B, L, heads, 64).transpose(0, 2, 1, 3)
+    dv = pr.transpose(0, 1, 3, 2) @ do
+    dp = do @ v.transpose(0, 1, 3, 2)
+    ds = pr * (dp - (dp * pr).sum(-1, keepdims=True))
+    dq, dk = ds @ k / 8.0, ds.transpose(0, 1, 3, 2) @ q / 8.0
+    want = np.stack([t.transpose(0, 2, 1, 3).reshape(B * L, Hh) for t in (dq, dk, dv)], 1).reshape(B * L, 3 * Hh)
+    assert np.abs(_f32(dqkv) - want).max() <= np.abs(want).max() * 2 ** -7
+    got_q = qkb.reshape(B, 4, 2 * Hh).sum(1)
+    np.testing.assert_allclose(got_q[:, :Hh], dq.transpose(0, 2, 1, 3).reshape(B, L, Hh).sum(1), rtol=1e-4, atol=1e-5)
+    assert not got_q[:, Hh:].any()   # the key-bias gradient vanishes identically (include/cocodr.h, cocodr_attn_bwd)
+    # ---- embeddings forward / backward
+    ocfg = O.OracleConfig(vocab_size=50, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, max_position_embeddings=16)
+    P = O.make_params(ocfg, 3, dtype=np.float64, std=0.5)
+    Bq, Lq, He = 3, 8, 64
+    ids = rng.integers(0, 50, (Bq, Lq)).astype(np.int32)
+    f = lambda k_: np.ascontiguousarray(P[k_], np.float32)  # noqa: E731
+    word, pos, typ = f("embeddings.word_embeddings.weight"), f("embeddings.position_embeddings.weight"), f("embeddings.token_type_embeddings.weight")
+    g_, b_ = f("embeddings.LayerNorm.weight"), f("embeddings.LayerNorm.bias")
+    out = np.zeros((Bq * Lq, He), np.uint16)
+    mean, rstd = np.zeros(Bq * Lq, np.float32), np.zeros(Bq * Lq, np.float32)
+    assert lib.cocodr_embed_ln_fwd_ref(_p(ids), _p(word), _p(pos), _p(typ[0].copy()), _p(g_), _p(b_), _p(out), _p(mean), _p(rstd), Bq, Lq, He, 50,
+                                       1e-12, None) == 0
+    P32 = {k_: v_.astype(np.float32).astype(np.float64) for k_, v_ in P.items()}
+    cache = {}
+    want = O.embeddings_fwd(P32, ids.astype(np.int64), cache)
+    assert np.abs(_f32(out) - want.reshape(-1, He)).max() <= np.abs(want).max() * 2 ** -7
+    dout = _bf16(rng.standard_normal((Bq * Lq, He)))
+    dword = np.zeros_like(word)
+    dpos, dtyp = np.zeros((Lq, He), np.float32), np.zeros(He, np.float32)
+    dg, db = np.zeros(He, np.float32), np.zeros(He, np.float32)
+    assert lib.cocodr_embed_ln_bwd_ref(_p(dout), _p(ids), _p(word), _p(pos), _p(typ[0].copy()), _p(g_), _p(mean), _p(rstd), _p(dword), _p(dpos),
+                                       _p(dtyp), _p(dg), _p(db), None, Bq, Lq, He, 50, None) == 0
+    e = cache["emb"]
+    dx, wdg, wdb = O.layer_norm_bwd(_f32(dout).astype(np.float64).reshape(Bq, Lq, He), e["xhat"], e["rstd"], P32["embeddings.LayerNorm.weight"])
+    wword = np.zeros_like(word, dtype=np.float64)
+    np.add.at(wword, ids.astype(np.int64).ravel(), dx.reshape(-1, He))
+    np.testing.assert_allclose(dword, wword, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dpos, dx.sum(0), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dtyp, dx.sum((0, 1)), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dg, wdg, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(db, wdb, rtol=1e-5, atol=1e-5)
+
+
 def test_simce_twin_matches_the_reference_golden_and_the_oracle_gradient(lib):
     g = np.load(os.path.join(GOLD, "contrastive_loss.npz"))  # COCO/modeling.py:244-248 itself, at world sizes 1 / 2 / 8
     sizes = sorted(int(k[2:]) for k in g.files if k.startswith("E_"))
