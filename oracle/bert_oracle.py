@@ -22,6 +22,7 @@ __all__ = [
     "encoder_bwd", "cls_embedding", "co_target", "contrastive_loss",
     "contrastive_loss_grad", "contrastive_local_grad", "triplet_nll",
     "triplet_nll_grad", "gelu", "gelu_grad", "layer_norm_fwd", "layer_norm_bwd", "layers_bwd", "_layer_fwd",
+    "bf16_storage", "bf16_weights", "round_bf16",
 ]
 
 LN_EPS = 1e-12  # BertConfig.layer_norm_eps default (hf: BertEmbeddings / BertSelfOutput)
@@ -115,6 +116,44 @@ def gelu_grad(x: np.ndarray) -> np.ndarray:
     return (cdf + x * pdf).astype(x.dtype)
 
 
+# ---- optional "bf16 storage" mode (tests only): the device path keeps every activation it STORES between kernels - and the
+# probability / score-gradient operands of the attention MFMAs - in bfloat16 (fp32 accumulation inside the kernels, fp32 LayerNorm
+# statistics, fp32 master weights with a bf16 copy for the GEMMs).  Inside ``bf16_storage()`` the oracle rounds exactly those
+# tensors (round to nearest even), so that what remains between the two is summation order and the kernels' internal roundings -
+# the end-to-end comparison can then be held to ~1e-2 instead of the 6-8e-2 that fp32-vs-bf16 needs.
+_ROUND = None
+
+
+def round_bf16(x: np.ndarray) -> np.ndarray:
+    """round-to-nearest-even to bfloat16 precision, returned in x's dtype"""
+    f = np.ascontiguousarray(x, np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).reshape(f.shape).astype(x.dtype)
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _ROUND
+        self._old, _ROUND = _ROUND, round_bf16
+        return self
+
+    def __exit__(self, *exc):
+        global _ROUND
+        _ROUND = self._old
+        return False
+
+
+def _r(x):
+    return x if _ROUND is None else _ROUND(x)
+
+
+def bf16_weights(P: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """the parameters as the device's GEMMs see them: the weight MATRICES of the layers rounded to bf16 (the bf16 shadow of the
+    fp32 master copy); embedding tables, biases and LayerNorm parameters stay fp32"""
+    return {k: (round_bf16(v) if (k.endswith(".weight") and v.ndim == 2 and "embeddings" not in k) else v) for k, v in P.items()}
+
+
 def layer_norm_fwd(y: np.ndarray, g: np.ndarray, b: np.ndarray, eps: float = LN_EPS):
     """torch.nn.LayerNorm over the last axis, biased variance (hf: BertSelfOutput.LayerNorm)."""
     mu = y.mean(-1, keepdims=True)
@@ -160,6 +199,7 @@ def embeddings_fwd(P, input_ids: np.ndarray, cache: Optional[dict] = None, dropo
     te = P["embeddings.token_type_embeddings.weight"]
     y = we[input_ids] + pe[None, :L] + te[0][None, None]
     out, xhat, rstd = layer_norm_fwd(y, P["embeddings.LayerNorm.weight"], P["embeddings.LayerNorm.bias"])
+    out = _r(out)
     m = _drop_mult(dropout, out.shape, 0, 3, out.dtype.type)  # hf BertEmbeddings: dropout(LayerNorm(..))
     if m is not None:
         out = out * m
@@ -174,9 +214,9 @@ def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optio
     n = layer_names(i, stack)
     B, L, H = x.shape
     d = H // nh
-    q = x @ P[n["wq"]].T + P[n["bq"]]
-    k = x @ P[n["wk"]].T + P[n["bk"]]
-    v = x @ P[n["wv"]].T + P[n["bv"]]
+    q = _r(x @ P[n["wq"]].T + P[n["bq"]])
+    k = _r(x @ P[n["wk"]].T + P[n["bk"]])
+    v = _r(x @ P[n["wv"]].T + P[n["bv"]])
 
     def heads(t):
         return t.reshape(B, L, nh, d).transpose(0, 2, 1, 3)  # [B,nh,L,d]
@@ -192,19 +232,21 @@ def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optio
     t = x.dtype.type
     mp = _drop_mult(dropout, p.shape, i, 0, t)   # hf eager_attention_forward: dropout(softmax(..))
     pd = p if mp is None else p * mp
-    ctx = (pd @ vh).transpose(0, 2, 1, 3).reshape(B, L, H)
+    ctx = _r((_r(pd) @ vh).transpose(0, 2, 1, 3).reshape(B, L, H))
     a = ctx @ P[n["wo"]].T + P[n["bo"]]
     ma = _drop_mult(dropout, a.shape, i, 1, t)   # hf BertSelfOutput: LayerNorm(dropout(dense(..)) + input)
     if ma is not None:
         a = a * ma
-    x1, xhat1, rstd1 = layer_norm_fwd(a + x, P[n["g1"]], P[n["b1"]])
+    x1, xhat1, rstd1 = layer_norm_fwd(_r(a + x), P[n["g1"]], P[n["b1"]])
+    x1 = _r(x1)
     u = x1 @ P[n["w1"]].T + P[n["bi"]]
-    h = gelu(u)
+    h = _r(gelu(u))
     f = h @ P[n["w2"]].T + P[n["b2"]]
     mf = _drop_mult(dropout, f.shape, i, 2, t)   # hf BertOutput: LayerNorm(dropout(dense(..)) + input)
     if mf is not None:
         f = f * mf
-    x2, xhat2, rstd2 = layer_norm_fwd(f + x1, P[n["g2"]], P[n["be2"]])
+    x2, xhat2, rstd2 = layer_norm_fwd(_r(f + x1), P[n["g2"]], P[n["be2"]])
+    x2 = _r(x2)
     if cache is not None:
         cache[i] = dict(x=x, qh=qh, kh=kh, vh=vh, p=p, ctx=ctx, xhat1=xhat1, rstd1=rstd1, x1=x1,
                         u=u, h=h, xhat2=xhat2, rstd2=rstd2, mp=mp, ma=ma, mf=mf)
@@ -243,29 +285,31 @@ def layers_bwd(P, nh: int, cache: dict, layer_ids, dx: np.ndarray, G: Dict[str, 
         B, L, H = c["x"].shape
         d = H // nh
         dres2, G[n["g2"]], G[n["be2"]] = layer_norm_bwd(dx, c["xhat2"], c["rstd2"], P[n["g2"]])
+        dres2 = _r(dres2)
         dy2 = dres2 if c.get("mf") is None else dres2 * c["mf"]   # gradient of the dense output behind its dropout
         G[n["w2"]] = dy2.reshape(-1, H).T @ c["h"].reshape(-1, c["h"].shape[-1])
         G[n["b2"]] = dy2.reshape(-1, H).sum(0)
         dh = dy2 @ P[n["w2"]]
-        du = dh * gelu_grad(c["u"])
+        du = _r(dh * _r(gelu_grad(c["u"])))
         G[n["w1"]] = du.reshape(-1, du.shape[-1]).T @ c["x1"].reshape(-1, H)
         G[n["bi"]] = du.reshape(-1, du.shape[-1]).sum(0)
-        dx1 = du @ P[n["w1"]] + dres2
+        dx1 = _r(du @ P[n["w1"]] + dres2)
         dres1, G[n["g1"]], G[n["b1"]] = layer_norm_bwd(dx1, c["xhat1"], c["rstd1"], P[n["g1"]])
+        dres1 = _r(dres1)
         dy1 = dres1 if c.get("ma") is None else dres1 * c["ma"]
         G[n["wo"]] = dy1.reshape(-1, H).T @ c["ctx"].reshape(-1, H)
         G[n["bo"]] = dy1.reshape(-1, H).sum(0)
-        dctx = (dy1 @ P[n["wo"]]).reshape(B, L, nh, d).transpose(0, 2, 1, 3)
+        dctx = _r(dy1 @ P[n["wo"]]).reshape(B, L, nh, d).transpose(0, 2, 1, 3)
         p = c["p"]
         pd = p if c.get("mp") is None else p * c["mp"]
-        dv = pd.transpose(0, 1, 3, 2) @ dctx
+        dv = _r(_r(pd).transpose(0, 1, 3, 2) @ dctx)
         dp = dctx @ c["vh"].transpose(0, 1, 3, 2)
         if c.get("mp") is not None:
             dp = dp * c["mp"]
-        ds = p * (dp - (dp * p).sum(-1, keepdims=True))
+        ds = _r(p * (dp - (dp * p).sum(-1, keepdims=True)))
         scale = p.dtype.type(1.0 / np.sqrt(d))
-        dq = (ds @ c["kh"]) * scale
-        dk = (ds.transpose(0, 1, 3, 2) @ c["qh"]) * scale
+        dq = _r((ds @ c["kh"]) * scale)
+        dk = _r((ds.transpose(0, 1, 3, 2) @ c["qh"]) * scale)
 
         def merge(t):
             return t.transpose(0, 2, 1, 3).reshape(B, L, H)
@@ -278,7 +322,7 @@ def layers_bwd(P, nh: int, cache: dict, layer_ids, dx: np.ndarray, G: Dict[str, 
         G[n["bq"]] = dq.reshape(-1, H).sum(0)
         G[n["bk"]] = dk.reshape(-1, H).sum(0)
         G[n["bv"]] = dv.reshape(-1, H).sum(0)
-        dx = dq @ P[n["wq"]] + dk @ P[n["wk"]] + dv @ P[n["wv"]] + dres1
+        dx = _r(dq @ P[n["wq"]] + dk @ P[n["wk"]] + dv @ P[n["wv"]] + dres1)
         if extra is not None and i in extra:
             dx = dx + extra[i]
     return dx
