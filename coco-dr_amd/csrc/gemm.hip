@@ -240,7 +240,7 @@ struct Geom {
   static_assert(GA * NISSUE * 1024 == A_BYTES && GB * NISSUE * 1024 == B_BYTES, "operand tiles must split evenly over the issuing waves");
   static constexpr int NSTAGE = NS;  // ring depth: NS - 1 stages are in flight or landed ahead of the one being read.  Six 24-KiB
                                      // stages (BK = 32) instead of three 48-KiB ones measured 10-20 % SLOWER on every encoder shape
-                                     // (profiles/r01k_gemm_ring_depth.txt): a K-step costs ~0.17 us of hand-off however short it is
+                                     // (profiles/archive/r01k_gemm_ring_depth.txt): a K-step costs ~0.17 us of hand-off however short it is
   static constexpr int KS = BKv / 16;  // MFMA K-sub-steps per stage
   static constexpr int WG_PER_CU = (160 * 1024) / (NSTAGE * STAGE);
   static constexpr int MIN_WAVES_PER_SIMD = (WG_PER_CU * (NWAVES + NLOAD) + 3) / 4;
@@ -659,11 +659,11 @@ int select_impl(const cocodr_gemm_args& a) {
     // ping-pong pipeline (gemm_pp.hip, 256x256 tiles): wins once its tiles fill the 256 CUs for nearly whole rounds -
     // 2-12 % on the forward / dgrad forms from 400 tiles (BERT-large FFN1 at 8192 tokens, everything at 25600 tokens),
     // 3-7 % on the grouped weight gradients from ~1500 tiles; with 1.5 rounds or less it loses to the 256x128 tiles
-    // (profiles/r02_gemm_pp_vs_glds.txt)
+    // (profiles/archive/r02_gemm_pp_vs_glds.txt)
     const long long tilespp = a.N % 256 == 0 ? (long long)((a.M + 255) / 256) * (a.N / 256) * batch : 0;
     const long long roundspp = (tilespp + 255) / 256;
     static const bool nopp = getenv("COCODR_GEMM_NOPP") != nullptr;  // A/B switch of this rule
-    // (with two fat phases per K-tile the grouped weight gradients gain from ~400 tiles as well: profiles/r02_gemm_pp_fat.txt)
+    // (with two fat phases per K-tile the grouped weight gradients gain from ~400 tiles as well: profiles/archive/r02_gemm_pp_fat.txt)
     bool pp_fills = !nopp && tilespp >= 400 && tilespp * 100 >= roundspp * 256 * 78;
     // with a split workspace the last partial round can run as contraction slices (gemm_pp.hip launch_split).  Measured over
     // packed row counts 4 416 ... 26 016 (profiles/r04_gemm_tail_sweep.txt): it beats every other pipeline only where the

@@ -3,7 +3,7 @@
 //
 // Why a second pipeline: in gemm.hip's one-barrier-per-K-step loop all eight waves of a workgroup do the same thing at the
 // same time, so the MFMA pipe, the LDS and the address unit that feeds the LDS-DMA are each ~50 % busy and their times add
-// (profiles/r01f_*).  Here the waves with wr = 0 (one per SIMD) and the waves with wr = 1 (their SIMD partners) run the same
+// (profiles/archive/r01f_*).  Here the waves with wr = 0 (one per SIMD) and the waves with wr = 1 (their SIMD partners) run the same
 // program one barrier apart: while one group issues its 8 MFMAs of a phase (256 pipe cycles), the other group issues the LDS
 // fragment reads of ITS next phase and its share of the operand DMA.  The matrix pipe of a SIMD is handed from one wave to
 // the other at every barrier and never waits for a load.  (CDNA "8-phase" schedule; hardware facts in
@@ -137,7 +137,7 @@ __device__ __forceinline__ void pp_mfma(const FragSet<TA, 2> (&fa)[4], const Fra
 // VAR 0: four thin phases per K-tile (8 MFMAs each; the encoder).  VAR 5 (impl 18; the search's score GEMM): "fat" phases - two per K-tile of 16 MFMAs each, (A0: B0, B1) and (A1: B1, B0), i.e.
 // half the barriers per MFMA.  The fragment reads of a phase are retired (lgkmcnt) in FRONT of its first barrier, so that a
 // half-tile may be requested one phase after its last read even by the group that runs a barrier ahead.  Back to back in
-// tools/gemm_bench.py it is 3-9 % faster than VAR 0 on every shape (profiles/r02_gemm_pp_fat.txt), inside the BERT-large
+// tools/gemm_bench.py it is 3-9 % faster than VAR 0 on every shape (profiles/archive/r02_gemm_pp_fat.txt), inside the BERT-large
 // training step 0.8 % SLOWER (same box, two alternating runs each: 3 741 vs 3 771 sequences/s) - under the package power limit
 // a denser loop buys a lower clock, not time - so the encoder keeps VAR 0 and the long back-to-back launches of the search
 // (+2 %) take VAR 5.  F16: IEEE-half operands.
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // XCD walks a contiguous run of items' tiles, so the ~32 tiles its CUs hold at a time belong to one or two items and
   // form an 8 x 4 block of one item's output: 12 operand panel streams through the XCD's L2 for 32 tiles.  With the
   // remap per item (grid.y = item) an XCD held 4-6 tiles of each of 5-6 items at once, which share nothing: the grouped
-  // weight gradients fetched 3.5x their operands from the fabric (profiles/r02_gemm_pmc_large_200x128.json).
+  // weight gradients fetched 3.5x their operands from the fabric (profiles/archive/r02_gemm_pmc_large_200x128.json).
   int tile, z;
   if constexpr (MULTI) {
     const int per = ntm * ntn;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(const typename std
   // lands in was last read at phase p - 2 or earlier) and retires s = p + 2, which is first read at phase p + 1 or later: four
   // half-tiles (64 KiB per CU) stay in flight, five to six phases (~1.5 K-tiles) between request and first use.  With only
   // two half-tiles in flight the operand stream ran at ~50 GB/s per CU - the latency of a loaded L2 times the bytes in
-  // flight - and bounded the whole loop (DMA-only ablation, profiles/r02_gemm_pp_ablation.txt).
+  // flight - and bounded the whole loop (DMA-only ablation, profiles/archive/r02_gemm_pp_ablation.txt).
   // rem = K-tiles left including this one: the request exists while its K-tile does; the wait count shrinks with the queue.
   auto request = [&](auto jc, int t, int rem) {
     constexpr int j = decltype(jc)::value;

@@ -565,7 +565,7 @@ int launch_ln_bwd(const uint16_t* dout, const uint16_t* y, const float* gamma, c
   const cocodr_dropout_mask dmv = drop ? *dm : cocodr_dropout_mask{0, 0, 0, 1.0f};
   // The guard-free (FULL) instantiations looked good in isolation but spill at four waves per SIMD (23 VGPRs at H = 1024, 73 with
   // the dropout hash in the loop; the guarded ones 0 / 2): inside the training steps the guarded kernels are 0.1-1 % faster
-  // without dropout (profiles/r02x) and 1.5-2.3x per call with it.  COCODR_LN_FULL=1: A/B switch back to the guard-free ones.
+  // without dropout (profiles/archive/r02x) and 1.5-2.3x per call with it.  COCODR_LN_FULL=1: A/B switch back to the guard-free ones.
   static const bool full = getenv("COCODR_LN_FULL") != nullptr;
   auto kern = H <= 768 ? ln_bwd_kernel<3, true, false> : ln_bwd_kernel<MAXC, false, false>;
   if (drop) kern = H <= 768 ? ln_bwd_kernel<3, true, false, true> : ln_bwd_kernel<MAXC, false, false, true>;

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const _Float16* __restri
 // x 2^s = xh + xl + r with xh, xl IEEE half (11 significant bits each) and |r| <= 2^-22 |x|: the three partial products
 // ql.ph + qh.pl + qh.ph, every one exact in fp32 and accumulated in fp32 by v_mfma_f32_32x32x16_f16 in that order (small
 // terms first), reproduce q.p to better than a sequential fp32 dot product does - measured max error 0.5e-6 of the largest
-// score against 1.1e-6 for the fp32-MFMA / fmaf chain and 1.2e-6 for an fp32 BLAS product (profiles/r02_score_split_*) -
+// score against 1.1e-6 for the fp32-MFMA / fmaf chain and 1.2e-6 for an fp32 BLAS product (profiles/archive/r02_score_split_*) -
 // at 3/16 of the fp32 matrix pipe's time per score.  The power-of-two scale (per tensor, from its largest magnitude) keeps
 // xl out of the half subnormals for every element that matters; it is exact and undone exactly.
 __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ X, size_t n, uint32_t* __restrict__ out) {
