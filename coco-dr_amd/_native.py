@@ -157,6 +157,8 @@ SIGNATURES = {
     "cocodr_score_filter_plan": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "cocodr_score_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
+    "cocodr_score_topk_resident": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p,
+                                           c_size_t, c_int, c_void_p]),
     "cocodr_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_int, c_void_p]),
     "cocodr_encoder_layout": (c_int, [C.POINTER(Config), c_int, c_int, c_int, C.POINTER(EncoderLayout)]),
     "cocodr_encoder_bwd_layout": (c_int, [C.POINTER(Config), c_int, c_int, C.POINTER(EncoderBwdLayout)]),

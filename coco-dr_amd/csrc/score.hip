@@ -705,6 +705,9 @@ FilterPlan filter_plan(int Nq, int Np, int k, const SplitPlan& sp) {
   // cost 2-22 % at <= 256 queries x <= 125 000 passages, level at 256 x 125 000 / 16 x 500 000, +6 ... +33 % from 2 000 queries up
   const bool force = env_int("COCODR_SCORE_FILTER_FORCE", 0) != 0;  // (test hook: small searches through this path)
   if (!force && (Np < 32768 || (long long)Nq * Np < (100ll << 20))) return f;
+  // (measured up to ~1 M passages per call, tools/search_crossover.py; beyond ~2 M the fixed candidate blocks per row - Np / 256 of
+  //  them - outgrow what the selection reads comfortably: larger shards take the exhaustive route until that regime is measured)
+  if (!force && Np > (2 << 20)) return f;
   if (k > KMAX || (long long)k * 16 > Np) return f;
   // sample: every stride-th passage, ~Np / 32 of them (the sample's product is that fraction of extra matrix work)
   int ns = (Np / 32 + 255) / 256 * 256;
@@ -818,7 +821,7 @@ int passage_block(const SplitPlan& sp) {
 //   usual, no row was handed back).  Everything on the caller's stream.  Exact: a row is answered from its candidates only when they
 //   provably contain its k best (>= k scores at or above the threshold, nothing overflowed); the order is topk_kernel's.
 int filtered_search(const _Float16* Qc, const _Float16* Pc, const int* exps, int Nq, int Np, int H, int k, long long id_offset, float* D,
-                    long long* I, char* wsb, const SplitPlan& sp, const FilterPlan& fp, hipStream_t st) {
+                    long long* I, char* wsb, const SplitPlan& sp, const FilterPlan& fp, hipStream_t st, bool p_resident = false) {
   const int K = sp.parts * sp.Hp;
   _Float16* Ps = reinterpret_cast<_Float16*>(wsb + fp.off_ps);
   _Float16* Qfb = reinterpret_cast<_Float16*>(wsb + fp.off_qfb);
@@ -827,8 +830,10 @@ int filtered_search(const _Float16* Qc, const _Float16* Pc, const int* exps, int
   int* fb_rows = fb_count + 64;
   float* area = reinterpret_cast<float*>(wsb + sp.off_slab);
   const int pblk = passage_block(sp);
-  hipLaunchKernelGGL(copy_rows_kernel, dim3(fp.ns), dim3(256), 0, st, Pc, Ps, K, fp.stride, (const int*)nullptr, (const int*)nullptr, 0);
-  CK_LAUNCH("score_sample");
+  if (!p_resident) {  // (a resident index keeps its passage sample next to its half operands)
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(fp.ns), dim3(256), 0, st, Pc, Ps, K, fp.stride, (const int*)nullptr, (const int*)nullptr, 0);
+    CK_LAUNCH("score_sample");
+  }
   auto product = [&](const _Float16* A, int M, const _Float16* B, int N, float* C, long long ldc) {
     cocodr_gemm_args g = {};
     g.A = reinterpret_cast<const uint16_t*>(A);
@@ -894,8 +899,25 @@ int filtered_search(const _Float16* Qc, const _Float16* Pc, const int* exps, int
 }
 }  // namespace
 
+static int score_topk_impl(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset, float* D, long long* I,
+                           void* workspace, size_t workspace_bytes, bool p_resident, cocodr_stream_t stream);
+
 extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset, float* D,
                                  long long* I, void* workspace, size_t workspace_bytes, cocodr_stream_t stream) {
+  return score_topk_impl(Q, P, Nq, Np, H, k, id_offset, D, I, workspace, workspace_bytes, false, stream);
+}
+
+// faiss.IndexFlatIP: add(P) once, search(Q, k) many times (ANCE/drivers/run_ann_data_gen.py:310-317,390; evaluate_beir.py:220-224).
+// p_resident != 0: the caller vouches that `workspace` still holds what the previous cocodr_score_topk[_resident] call with the SAME
+// (P, Np, H, Nq, k, score mode) left there - the passages' scale, their half-precision split image and the filter's passage sample -
+// so none of it is rebuilt (3 of the search's launches and a pass over P).  The exact-fp32 mode has no passage image: flag ignored.
+extern "C" int cocodr_score_topk_resident(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset, float* D,
+                                          long long* I, void* workspace, size_t workspace_bytes, int p_resident, cocodr_stream_t stream) {
+  return score_topk_impl(Q, P, Nq, Np, H, k, id_offset, D, I, workspace, workspace_bytes, p_resident != 0, stream);
+}
+
+static int score_topk_impl(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset, float* D, long long* I,
+                           void* workspace, size_t workspace_bytes, bool p_resident, cocodr_stream_t stream) {
   CK_ARG(Q && P && D && I && workspace, "score_topk: null pointer");
   CK_ARG(Nq > 0 && Np > 0 && H > 0 && H % 4 == 0, "score_topk: bad shape Nq=%d Np=%d H=%d (H %% 4 == 0)", Nq, Np, H);
   CK_ARG(k > 0 && k <= KMAX, "score_topk: k=%d must be in [1,%d]", k, KMAX);
@@ -915,15 +937,16 @@ extern "C" int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np,
   uint32_t* maxbits = reinterpret_cast<uint32_t*>(wsb + sp.off_misc);
   int* exps = reinterpret_cast<int*>(wsb + sp.off_misc + 16);
   if (split) {
-    if (hipMemsetAsync(maxbits, 0, 32, st) != hipSuccess) { cocodr_set_error("score_topk: memset failed"); return COCODR_ERR_LAUNCH; }
+    // (resident passages: their maximum - maxbits[1] - and so their scale survive from the call that built the image)
+    if (hipMemsetAsync(maxbits, 0, p_resident ? 4 : 32, st) != hipSuccess) { cocodr_set_error("score_topk: memset failed"); return COCODR_ERR_LAUNCH; }
     hipLaunchKernelGGL(maxabs_kernel, dim3(1024), dim3(256), 0, st, Q, (size_t)Nq * H, maxbits);
-    hipLaunchKernelGGL(maxabs_kernel, dim3(2048), dim3(256), 0, st, P, (size_t)Np * H, maxbits + 1);
+    if (!p_resident) hipLaunchKernelGGL(maxabs_kernel, dim3(2048), dim3(256), 0, st, P, (size_t)Np * H, maxbits + 1);
     hipLaunchKernelGGL(scale_exp_kernel, dim3(1), dim3(64), 0, st, maxbits, exps);
     hipLaunchKernelGGL(split_f16_kernel, dim3(2048), dim3(256), 0, st, Q, Qc, Nq, Nq, H, sp.Hp, exps, 0, sp.parts);
-    hipLaunchKernelGGL(split_f16_kernel, dim3(4096), dim3(256), 0, st, P, Pc, Np, sp.np_pad, H, sp.Hp, exps, 1, sp.parts);
+    if (!p_resident) hipLaunchKernelGGL(split_f16_kernel, dim3(4096), dim3(256), 0, st, P, Pc, Np, sp.np_pad, H, sp.Hp, exps, 1, sp.parts);
     CK_LAUNCH("score_split");
     const FilterPlan fp = filter_plan(Nq, Np, k, sp);
-    if (fp.on && workspace_bytes >= fp.total) return filtered_search(Qc, Pc, exps, Nq, Np, H, k, id_offset, D, I, wsb, sp, fp, st);
+    if (fp.on && workspace_bytes >= fp.total) return filtered_search(Qc, Pc, exps, Nq, Np, H, k, id_offset, D, I, wsb, sp, fp, st, p_resident);
   }
   const int QC = split ? sp.QC : query_chunk(Nq, Np);
   const long long ld = split ? sp.np_pad : ((long long)Np + 3) / 4 * 4;

@@ -357,20 +357,24 @@ def triplet_nll_fwd_bwd(q, a, b, weights: Optional[torch.Tensor] = None):
 
 
 # ----------------------------------------------------------------------------------------------- search
-def score_topk(Q: torch.Tensor, P: torch.Tensor, k: int, id_offset: int = 0, workspace: Optional[torch.Tensor] = None):
-    """(D [Nq,k] fp32 descending, I [Nq,k] int64) = IndexFlatIP(P).search(Q, k)."""
+def score_topk(Q: torch.Tensor, P: torch.Tensor, k: int, id_offset: int = 0, workspace: Optional[torch.Tensor] = None,
+               p_resident: bool = False):
+    """(D [Nq,k] fp32 descending, I [Nq,k] int64) = IndexFlatIP(P).search(Q, k).  ``p_resident``: ``workspace`` still holds the
+    passage image of an identical earlier call (cocodr_score_topk_resident; ``retrieval.FlatIPIndex`` keeps that book)."""
     _req(Q, F32, "Q", 2); _req(P, F32, "P", 2)
     if Q.shape[1] != P.shape[1]:
         raise ValueError("score_topk: dim mismatch")
     Nq, H = Q.shape
     Np = P.shape[0]
     need = lib().cocodr_score_topk_workspace_bytes_dim(Nq, Np, H, k)
-    if workspace is None or workspace.numel() * workspace.element_size() < need:
+    if not p_resident and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.empty(need, dtype=torch.uint8, device=Q.device)
     D = torch.empty((Nq, k), dtype=F32, device=Q.device)
     I = torch.empty((Nq, k), dtype=I64, device=Q.device)
-    check(lib().cocodr_score_topk(ptr(Q), ptr(P), Nq, Np, H, k, id_offset, ptr(D), ptr(I), ptr(workspace),
-                                  workspace.numel() * workspace.element_size(), stream_ptr()), "score_topk")
+    if p_resident and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        raise ValueError("score_topk: p_resident needs the workspace of the earlier call")
+    check(lib().cocodr_score_topk_resident(ptr(Q), ptr(P), Nq, Np, H, k, id_offset, ptr(D), ptr(I), ptr(workspace),
+                                           workspace.numel() * workspace.element_size(), int(bool(p_resident)), stream_ptr()), "score_topk")
     return D, I
 
 

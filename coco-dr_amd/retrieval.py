@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import ops
+from ._native import lib
 
 __all__ = ["shard_indices", "merged_order", "encode_corpus", "search", "sharded_search", "merge_topk", "merge_shard_lists", "eval_dev_query",
            "EvalDevQuery", "generate_negatives", "ndcg_at_10", "map_at_10", "recall_at", "mrr_at_10", "build_ann_training_data"]
@@ -81,6 +82,51 @@ def encode_corpus(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, 
 def search(Q: torch.Tensor, P: torch.Tensor, k: int, id_offset: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """(D, I) = IndexFlatIP(P).search(Q, k) on one GPU."""
     return ops.score_topk(Q.contiguous(), P.contiguous(), k, id_offset)
+
+
+class FlatIPIndex:
+    """``faiss.IndexFlatIP(dim)`` as the reference uses it - ``add(P)`` once, ``search(Q, k)`` several times on the same index
+    (ANCE/drivers/run_ann_data_gen.py:310-317,390: the dev queries, then the training queries; evaluate/evaluation/
+    evaluate_beir.py:220-224) - with the passages resident in HBM.  The first search of a given (number of queries, k) builds the
+    passages' scale, half-precision split image and filter sample inside the index's workspace; later searches of that shape reuse
+    them (``cocodr_score_topk_resident``), which takes the pass over P and three launches out of every search.  Exact inner
+    products, (score descending, position ascending) - ``search``'s results, bit for bit."""
+
+    def __init__(self, dim: int):
+        self.d = int(dim)
+        self._P: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None
+        self._key = None
+
+    @property
+    def ntotal(self) -> int:
+        return 0 if self._P is None else int(self._P.shape[0])
+
+    def add(self, P: torch.Tensor) -> None:
+        P = torch.as_tensor(P)
+        if P.dim() != 2 or P.shape[1] != self.d:
+            raise ValueError(f"FlatIPIndex.add: expected [n, {self.d}], got {tuple(P.shape)}")
+        if not P.is_cuda:
+            raise RuntimeError("FlatIPIndex keeps its passages on the GPU: add a CUDA tensor (there is no CPU fallback)")
+        P = P.to(torch.float32).contiguous()
+        self._P = P if self._P is None else torch.cat([self._P, P])
+        self._key = None   # (the resident image describes the old passage set)
+
+    def reset(self) -> None:
+        self._P = self._ws = self._key = None
+
+    def search(self, Q: torch.Tensor, k: int, id_offset: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._P is None:
+            raise RuntimeError("FlatIPIndex.search: the index is empty")
+        Q = Q.to(torch.float32).contiguous()
+        Nq, Np, k = int(Q.shape[0]), self.ntotal, int(k)
+        need = int(lib().cocodr_score_topk_workspace_bytes_dim(Nq, Np, self.d, k))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws, self._key = torch.empty(need, dtype=torch.uint8, device=self._P.device), None
+        key = (Nq, k, need)   # the workspace layout (where the passage image sits) follows from (Nq, Np, H, k)
+        out = ops.score_topk(Q, self._P, k, id_offset, workspace=self._ws, p_resident=(key == self._key))
+        self._key = key
+        return out
 
 
 def merge_topk(D: torch.Tensor, I: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:

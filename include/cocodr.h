@@ -382,6 +382,13 @@ size_t cocodr_score_topk_workspace_bytes(int Nq, int Np, int k);
 int cocodr_score_set_mode(int mode);
 int cocodr_score_topk(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset,
                       float* D, long long* I, void* workspace, size_t workspace_bytes, cocodr_stream_t stream);
+/* faiss.IndexFlatIP: add(P) once, search(Q, k) many times (ANCE/drivers/run_ann_data_gen.py:310-317,390;
+ * evaluate/evaluation/evaluate_beir.py:220-224).  The same search with p_resident != 0: the caller vouches that `workspace` still
+ * holds what the previous cocodr_score_topk / cocodr_score_topk_resident call with the SAME (P, Np, H, Nq, k, score mode) left in it
+ * - the passages' scale, their half-precision split image and the filter's passage sample - and none of it is rebuilt (three
+ * launches and a pass over P less per search).  p_resident == 0 is cocodr_score_topk.  (Host side: cocodr_amd.retrieval.FlatIPIndex.) */
+int cocodr_score_topk_resident(const float* Q, const float* P, int Nq, int Np, int H, int k, long long id_offset, float* D,
+                               long long* I, void* workspace, size_t workspace_bytes, int p_resident, cocodr_stream_t stream);
 
 /* k-way merge of per-shard top-k lists into the list ONE search over the rank-major merged corpus would return - what
  * replaces the reference's gather-everything-then-search (ANCE/utils/util.py:117-155 barrier_array_merge +

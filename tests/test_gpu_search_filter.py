@@ -177,3 +177,38 @@ def test_one_million_passages_in_several_query_passes(monkeypatch):
     Q, P = data(3000, 1_000_000, 64, 21)
     Qd, Pd = torch.from_numpy(Q).to(DEV), torch.from_numpy(P).to(DEV)
     same(search(Qd, Pd, 100, monkeypatch), search(Qd, Pd, 100, monkeypatch, NOFILTER=1))
+
+
+def test_flat_ip_index_add_once_search_many_matches_search():
+    """retrieval.FlatIPIndex (faiss.IndexFlatIP as ANCE/drivers/run_ann_data_gen.py:310-317,390 uses it): the second and later
+    searches of a shape run cocodr_score_topk_resident on the passages' resident image - same D / I as a fresh search, bit for bit,
+    on the filtered route (forced: small sizes) and the exhaustive one; add() and a new shape invalidate the image."""
+    import os
+    from cocodr_amd import retrieval
+    g = torch.Generator().manual_seed(5)
+    Q1 = (torch.randn(300, 256, generator=g) / 16).to(DEV)
+    Q2 = (torch.randn(300, 256, generator=g) / 16).to(DEV)
+    P = (torch.randn(40000, 256, generator=g) / 16).to(DEV)
+    for force in ("1", None):
+        if force:
+            os.environ["COCODR_SCORE_FILTER_FORCE"] = force
+        else:
+            os.environ.pop("COCODR_SCORE_FILTER_FORCE", None)
+        try:
+            index = retrieval.FlatIPIndex(256)
+            index.add(P[:25000])
+            index.add(P[25000:])
+            assert index.ntotal == 40000
+            for Q in (Q1, Q2, Q1):   # first call builds the image, the next two reuse it
+                D, I = index.search(Q, 100)
+                Dr, Ir = retrieval.search(Q, P, 100)
+                assert torch.equal(I, Ir) and torch.equal(D, Dr)
+            D, I = index.search(Q1[:77], 50)           # another shape: rebuilt, not reused
+            Dr, Ir = retrieval.search(Q1[:77], P, 50)
+            assert torch.equal(I, Ir) and torch.equal(D, Dr)
+            index.add(P[:1000] * 2.0)                  # new passages: the image is stale
+            D, I = index.search(Q2, 100)
+            Dr, Ir = retrieval.search(Q2, torch.cat([P, P[:1000] * 2.0]), 100)
+            assert torch.equal(I, Ir) and torch.equal(D, Dr)
+        finally:
+            os.environ.pop("COCODR_SCORE_FILTER_FORCE", None)

@@ -42,10 +42,10 @@ buf = np.zeros(n * 8, np.uint64)
 assert L.cocodr_a4_timeline_read(buf.ctypes.data, n * 8) == 0
 t = buf.reshape(n, 8)[:, :5].astype(np.float64)
 t0 = t[:, 0].min()
-t = (t - t0) / 100.0  # s_memtime ticks at 100 MHz -> us
+t = (t - t0) / 100.0  # s_memtime = shader clocks: units of 100 clocks
 order = np.argsort(t[:, 0])
 t = t[order]
-print(f"{M}x{Nn}x{K} epi {epi}: {tiles} tiles; times in us relative to the first workgroup's entry (s_memtime, 100 MHz)")
+print(f"{M}x{Nn}x{K} epi {epi}: {tiles} tiles; durations in units of 100 shader clocks (s_memtime; the stamps of different XCDs are not synchronised)")
 print("  columns: entry, loop entry, loop exit, epilogue pass 0 done, epilogue pass 1 done")
 for q in (0, 1, 127, 255, 256, 257, 511, 512, 767, 1023, n - 1):
     if q < n:
