@@ -28,7 +28,10 @@ import sys
 import time
 import warnings
 
-warnings.filterwarnings("ignore")  # (nothing but the contract line may look like output; warnings are not results)
+# nothing but the contract line may look like output; the known noisy categories are silenced - NOT RuntimeWarning / our own
+# warnings (e.g. the DDP-adoption or LAMB fall-back messages of coco-dr_amd), which go to stderr and are worth reading
+for _cat in (UserWarning, FutureWarning, DeprecationWarning):
+    warnings.filterwarnings("ignore", category=_cat)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -134,6 +134,59 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& gp) {
   gp = fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
+// The same two functions for the 8 elements of an epilogue chunk, written stage by stage ACROSS the elements: element for element
+// the operations and their order are those of gelu_erf / gelu_erf_both (bit-identical results), but the eight dependency chains
+// (rcp, exp2, four fused multiply-adds, ...) sit side by side in the instruction stream instead of one after the other - with one
+// wave per SIMD (gemm_a4.hip) nothing else fills the issue slots a dependent chain leaves empty.  GELU8_STAGE makes a stage's
+// eight results opaque at once: hipcc must finish the stage for all elements before the next one starts (left alone - and even
+// with sched_barrier, which does not order pure arithmetic - it re-serialises the chains to save registers).
+#define GELU8_STAGE(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+__device__ __forceinline__ void gelu8_tail_terms(const float (&x)[8], float (&t)[8], float (&e)[8], float (&p)[8]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x[j]), 1.0f));
+  GELU8_STAGE(t);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(x[j] * x[j] * -0.72134752f);
+  GELU8_STAGE(e);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = fmaf(0.5307027145f, t[j], -0.7265760135f);
+  GELU8_STAGE(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = fmaf(p[j], t[j], 0.7107068705f);
+  GELU8_STAGE(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = fmaf(p[j], t[j], -0.142248368f);
+  GELU8_STAGE(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = fmaf(p[j], t[j], 0.127414796f);
+  GELU8_STAGE(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = p[j] * t[j] * e[j];   // q
+  GELU8_STAGE(p);
+}
+__device__ __forceinline__ void gelu_erf_both8(const float (&x)[8], float (&g)[8], float (&gp)[8]) {
+#pragma clang fp contract(off)
+  float t[8], e[8], q[8];
+  gelu8_tail_terms(x, t, e, q);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float cdf = x[j] >= 0.f ? 1.0f - q[j] : q[j];
+    g[j] = x[j] * cdf;
+    gp[j] = fmaf(x[j] * 0.3989422804014327f, e[j], cdf);
+  }
+}
+__device__ __forceinline__ void gelu_erf8(float (&x)[8]) {   // in place; the value of gelu_erf (see the note on contraction there)
+  float t[8], e[8], q[8];
+  gelu8_tail_terms(x, t, e, q);
+  {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = x[j] * (x[j] >= 0.f ? 1.0f - q[j] : q[j]);
+  }
+}
+#undef GELU8_STAGE
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a call site keeps one of these (static) and
 // raises the limit once per device it launches on (a bit per device ordinal; a second thread at worst repeats the idempotent call)
 #include <atomic>

@@ -177,12 +177,12 @@ __device__ __forceinline__ void epilogue_store8(const cocodr_gemm_args& p, int z
     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
   }
   if (p.epi == COCODR_EPI_GELU && p.C2 == nullptr) {  // inference: nobody needs the derivative
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+    gelu_erf8(v);
   } else if (p.epi == COCODR_EPI_GELU) {
-    float gp[8];
+    float gp[8], u[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) gelu_erf_both(v[j], v[j], gp[j]);
+    for (int j = 0; j < 8; ++j) u[j] = v[j];
+    gelu_erf_both8(u, v, gp);
     {  // GELU' is read by the backward only: streamed past the caches (non-temporal), so it does not evict the h tile FFN2 reads next
        // (same-box A/B of the two builds, round 5: GEMM class +0.4 % on the BERT-base step, +0.5 % at 256 padded BERT-large sequences)
       typedef uint32_t u4nt __attribute__((ext_vector_type(4)));

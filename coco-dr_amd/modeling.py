@@ -868,7 +868,8 @@ class CocoBertModel(FlatParamsMixin, nn.Module):
         if training:
             self._dp_note_forward()
         arena_drop = self._next_dropout(training)
-        assert (arena_drop is not None) == drops
+        if (arena_drop is not None) != drops:   # (a real check: `assert` disappears under python -O)
+            raise RuntimeError("internal: the dropout setting predicted for the arena does not match the one drawn for this forward")
         cfg = self._c_config(arena_drop, tail)
         lay = N.EncoderLayout()
         check(lib().cocodr_encoder_layout_packed(C.byref(cfg), pk.T, pk.B, int(training), C.byref(lay)), "encoder_layout_packed")

@@ -60,6 +60,17 @@ def encode_corpus(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, 
         raise ValueError("encode_corpus: give attention_mask or lengths")
     if lengths is not None and bert is None:
         raise ValueError("encode_corpus(lengths=): the model has no .bert encoder to hand the lengths to; pass attention_mask")
+    if lengths is not None:
+        # the lengths route reads the raw last-layer [CLS] straight from the encoder: only valid for a wrapper whose embedding IS that
+        # (BertDotNLL.query_emb / body_emb, ANCE/model/models.py:225-232) - a projection / norm head on top would be skipped silently
+        from .modeling import BertDotNLL
+        cls_ = type(model)
+        plain = (getattr(cls_, "query_emb", None) is getattr(BertDotNLL, "query_emb", None)
+                 and getattr(cls_, "body_emb", None) is getattr(BertDotNLL, "body_emb", None))
+        if not plain and not getattr(model, "embeddings_are_raw_cls", False):
+            raise ValueError("encode_corpus(lengths=) bypasses model.query_emb / body_emb (it reads the raw [CLS] rows): this model "
+                             "overrides them - pass attention_mask instead, or set model.embeddings_are_raw_cls = True if they are "
+                             "the raw last-layer [CLS]")
     if bert is not None:
         bert.pack_sequences = bool(pack)
     try:
