@@ -1017,7 +1017,15 @@ def main():
         return float(t)
 
     dt = tmax(dt)
+
+    def release():  # ranks that share a GPU (the one-GPU code-path check) also share its memory: hand the finished leg's cached blocks back
+        if shared:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+
     if world > 1 and not args.no_full_step:
+        release()
         if config3:  # BASELINE configs[2]: cocodr-base on 8 GPUs with RCCL all_gather negatives, global batch 2048 (COCO/README.md:55)
             wdt, wloss, _, _, _, _ = contrastive_leg(args.model, 256, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
                                                   args.dp_chunks, False, args.dense, packed=packed, host_lengths=host_lengths)
@@ -1027,6 +1035,7 @@ def main():
                                                    "loss": round(wloss, 4),
                                                    "note": "256 sequences per GPU (BASELINE configs[2]); NOT comparable with the N = 1, 2, 4 "
                                                            "lines' 64 per GPU - the headline `value` of this line is"}
+            release()
         extras["multi_gpu"] = multi_gpu_legs(dev, rank, world, fence, tmax, shared, args.dp_chunks)
 
     if rank == 0:

@@ -155,3 +155,44 @@ def test_state_dict_uses_hf_bert_names_and_flat_layout_is_uniform():
     # parameters() yields every HF tensor once, as nn.Parameter views of the two flats (tests/test_named_params_cpu.py)
     names = [n for n, _ in m.named_parameters()]
     assert sorted(names) == sorted(lo.names) and len(m.flat_parameters()) == 2
+
+
+def test_gemm_a4_build_keeps_the_accumulators_intact(tmp_path):
+    """csrc/gemm_a4.hip reads its 256 accumulator registers by NUMBER in the epilogue (inline asm); hipcc may use accumulator registers
+    as spill space wherever it believes them dead.  The loop statement declares them as outputs and every reading statement as pinned
+    inputs, which gives hipcc the right liveness - this audit of the generated assembly is the check: behind the
+    loop statement no kernel writes an accumulator register before the epilogue has read it, and only the two column-sum variants
+    (which carry 16 more live values through the epilogue) may touch scratch at all."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "coco-dr_amd", "csrc", "gemm_a4.hip")
+    out = tmp_path / "gemm_a4.o"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "coco-dr_amd", "csrc"), "-c", src, "-o", str(out), "-save-temps=obj"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = (tmp_path / "gemm_a4-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+    parts = re.split(r"\n(_ZN14cocodr_gemm_a4[^\n:]*):", text)
+    kernels = 0
+    for i in range(1, len(parts), 2):
+        name, body = parts[i], parts[i + 1].split("s_endpgm")[0]
+        if "walk_kernel" not in name:
+            continue
+        kernels += 1
+        lines = body.split("\n")
+        end = max(k for k, l in enumerate(lines) if "s_nop 15" in l)   # the loop statement ends with two of them
+        colsum = name.endswith("Lb1EEEvNS_7A4MultiE")                   # template argument COLSUM
+        if not colsum:
+            assert "scratch_" not in body, name
+        read = set()
+        for l in lines[end:]:
+            m = re.search(r"v_accvgpr_read_b32 v\d+, a\[(0x[0-9a-f]+|\d+)(?:\+(\d+))?\]", l)
+            if m:
+                read.add(int(m.group(1), 0) + int(m.group(2) or 0))
+            w = re.search(r"v_accvgpr_(?:write_b32|mov_b32) a(\d+)", l)
+            if w:
+                assert colsum and int(w.group(1)) in read, (name, l.strip())
+        assert len(read) == 256, (name, len(read))
+    assert kernels >= 20

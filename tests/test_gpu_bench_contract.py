@@ -20,7 +20,12 @@ def _run(*args, legs: bool = False):
     if os.path.exists(legs_path):
         os.remove(legs_path)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-2000:]
+    if p.returncode != 0:  # a failed rank's traceback sits far above torchrun's summary: show the first one, then the tail
+        at = p.stderr.find("Traceback")
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_contract_stderr.txt"), "w") as f:
+            f.write(p.stderr)
+        raise AssertionError((p.stderr[at:at + 3000] if at >= 0 else "") + "\n...\n" + p.stderr[-1500:])
     out = [l for l in p.stdout.splitlines() if l.strip()]
     # the driver's contract: the LAST stdout line is the one compact JSON object (< 4 KB; round 4's 20 KB line was not parsed), and no
     # other stdout line looks like JSON
@@ -125,6 +130,7 @@ def test_timed_step_receives_fresh_batches_and_packs_inside_the_step():
         finally:
             modeling.PackedIndex.build = staticmethod(orig)
         assert len(calls) == 4 and info["fresh_batches"] is True and info["rows_per_step"] < 16 * 128
+    torch.cuda.empty_cache()  # the multi-rank tests below start ranks that share this GPU with the test process
 
 
 def test_bench_multi_rank_path_on_one_gpu():

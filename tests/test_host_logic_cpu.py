@@ -59,7 +59,8 @@ def test_compact_roofline_keeps_numbers_and_one_short_name():
     r = bench.compact_roofline(_fake_roof())
     assert r["frac"] == 0.2441 and r["achieved"] == 610.2 and r["peak"] == 2500.0 and r["bound"] == "mfma" and r["traffic"] == 96008284
     assert all(not isinstance(v, str) or len(v) <= 100 for v in r.values()) and len(r["kernel"]) <= 100
-    assert "flops" not in r and "batches" not in r and "sampled" not in r and "traffic_source" not in r
+    assert "flops" not in r and "batches" not in r and "sampled" not in r
+    assert r["traffic_source"] == {"file": "f", "commit": "c"}                # where the PMC passes behind `traffic` live: stays in the line
 
 
 def test_leg_summary_and_side_file(tmp_path, monkeypatch, capsys):

@@ -61,7 +61,7 @@ new = (f"Last run\n(`profiles/{tag}_bench_line.json`, `profiles/{tag}_pytest_gpu
        f"sequences/s at 64 / 200 / 256 sequences packed (GEMM class {v('64_sequences')['roofline']['frac']:.2f} / {v('200_sequences')['roofline']['frac']:.2f} / {v('256_sequences')['roofline']['frac']:.2f} executed) and {v('64_sequences_padded')['sequences_per_sec']:.0f} / {v('200_sequences_padded')['sequences_per_sec']:.0f} / {v('256_sequences_padded')['sequences_per_sec']:.0f} padded ({v('64_sequences_padded')['roofline']['frac']:.2f} / {v('200_sequences_padded')['roofline']['frac']:.2f} /\n"
        f"{v('256_sequences_padded')['roofline']['frac']:.2f}; whole step {v('64_sequences_padded')['executed_whole_step_frac']:.2f} / {v('200_sequences_padded')['executed_whole_step_frac']:.2f} / {v('256_sequences_padded')['executed_whole_step_frac']:.3f}); full coCondenser step {fc['sequences_per_sec']:.0f} sequences/s ({fc['ms_per_step']:.2f} ms), ANCE {a['rows_per_sec']:.0f} rows/s, corpus encode {d['corpus_encode']['sequences_per_sec']:.0f}\n"
        f"passages/s, search {es['dot_products_per_sec'] / 1e9:.0f} G dot-products/s, 1 M-passage encode + 8-shard search end to end in {c['wall_s']:.0f} s on one GPU.  Also built and measured\n"
-       "late in the round: the fused decoder GEMM + cross entropy (`cocodr_decoder_ce`, parity-green, slower than the two-kernel form at this\n"
+       "late in the round: the fused decoder GEMM + cross entropy (parity-green, slower than the two-kernel form at this\n"
        "size: off by default), a row-split dispatch and side-stream weight gradients (`profiles/r04_gemm_dispatch_probes.md`, not adopted).  ")
 open(p, "w").write(s.replace(old, new))
 print("docs updated from", tag)
