@@ -13,8 +13,8 @@ import sys
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and ("gemm_glds_kernel" in r["Kernel_Name"] or "gemm_pp_kernel" in r["Kernel_Name"]):
-            name = re.sub(r"^void |cocodr_gemm_v2::|cocodr_gemm_pp::|\(.*$", "", r["Kernel_Name"])
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("gemm_glds_kernel", "gemm_pp_kernel", "gemm_a4_kernel", "gemm_a4_walk_kernel")):
+            name = re.sub(r"^void |cocodr_gemm_v2::|cocodr_gemm_pp::|cocodr_gemm_a4::|\(.*$", "", r["Kernel_Name"])
             acc[name].append(float(r["Counter_Value"]))
     return acc
 
@@ -29,7 +29,7 @@ def main(fetch_csv, write_csv, out, cmd="bench.py --steps 3 --warmup 1 --no-cpu-
         rows.append({"kernel": k, "launches": n, "fetch_bytes_corrected": fb, "write_bytes": wb})
         tot_b += (fb + wb) * n
         tot_n += n
-    json.dump({"kernel": "gemm_glds_kernel + gemm_pp_kernel (all instantiations)", "commit": commit, "launches": tot_n, "hbm_bytes_per_launch": tot_b / max(1, tot_n),
+    json.dump({"kernel": "gemm_glds_kernel + gemm_pp_kernel + gemm_a4_walk_kernel (all instantiations)", "commit": commit, "launches": tot_n, "hbm_bytes_per_launch": tot_b / max(1, tot_n),
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `" + cmd + "`;"
                          " bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                          "MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads on gfx950); Infinity-Cache hits are "
