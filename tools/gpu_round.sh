@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU visit: parity suite, the default bench line, kernel-trace stats and HBM-traffic PMC passes for the base and
 # large contrastive steps.  Usage (on the GPU box, from the repo root): tools/gpu_round.sh <tag> [commit] [stages]
-# stages: any of t (tests) b (bench) k (kernel stats) p (PMC traffic); default tbkp
+# stages: any of t (tests) b (bench) k (kernel stats) p (PMC traffic) e (corpus-encode kernel stats) m (clock + matrix-pipe PMC pass); default tbkp
 # The PMC stage writes gemm_pmc_<model>_<seq>x128[_packed].json; copy them to profiles/ (bench.py's roofline.traffic reads profiles/gemm_pmc_*.json
 # and reports the commit recorded inside).
 set -u
@@ -52,6 +52,21 @@ if [[ $stages == *k* ]]; then
     db=$(find $out/kt_$leg -name "*.db" | head -1)
     if [ -n "$db" ]; then python tools/rocpd_stats.py $db > $out/kernel_stats_$leg.md; fi
     tail -1 $out/kt_$leg.log > $out/kt_bench_$leg.json
+  done
+fi
+if [[ $stages == *e* ]]; then   # the forward-only path: corpus encode (cocodr-large, packed batches of 1024 x L128)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/kt_encode -o kt -- python $root/tools/encode_probe.py 16384 1024 > $out/kt_encode.log 2>&1)
+  db=$(find $out/kt_encode -name "*.db" | head -1)
+  if [ -n "$db" ]; then python tools/rocpd_stats.py $db > $out/kernel_stats_encode.md; fi
+  tail -1 $out/kt_encode.log
+fi
+if [[ $stages == *m* ]]; then   # effective clock and matrix-pipe busy per kernel (tools/pmc_clock.py), one pass per step shape
+  for cfg in "base 64 packed" "large 256 padded"; do
+    set -- $cfg; model=$1; nseq=$2; flag=""; if [ $3 = padded ]; then flag="--padded"; fi
+    name=${model}_${nseq}x128_$3
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_clock_$name -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-full-step $flag --model $model --seq-per-gpu $nseq > $out/pmc_clock_$name.log 2>&1)
+    f=$(find $out/pmc_clock_$name -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then python tools/pmc_clock.py $f > $out/clock_mfma_$name.md; fi
   done
 fi
 # keep the merged-back payload small (gpurun merges at most 64 MiB back): the summaries are written, drop every raw trace

@@ -22,7 +22,7 @@ def main(path, keep=""):
     for (_, name, grid), d in rows.items():
         if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["dur"] > 0:
             cyc = d["GRBM_GUI_ACTIVE"] / 8.0
-            name = re.sub(r"\(anonymous namespace\)::|^void |cocodr_gemm_pp::|cocodr_gemm_v2::|\(.*$", "", name)[:60]
+            name = re.sub(r"\(anonymous namespace\)::|^void |cocodr_gemm_pp::|cocodr_gemm_v2::|cocodr_gemm_a4::|\(.*$", "", name)[:60]
             agg[(name, grid)].append((d["dur"], cyc / d["dur"], d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc),
                                       d.get("SQ_WAIT_INST_ANY", 0) / max(d.get("SQ_WAVE_CYCLES", 1), 1), d.get("SQ_WAIT_ANY", 0) / max(d.get("SQ_WAVE_CYCLES", 1), 1)))
     print("| kernel | grid | launches | avg us | clock GHz | MFMA pipe busy (at that clock) | x clock / 2.4 = of nominal peak | issue-stalled | parked |")
