@@ -140,49 +140,69 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& gp) {
 // wave per SIMD (gemm_a4.hip) nothing else fills the issue slots a dependent chain leaves empty.  GELU8_STAGE makes a stage's
 // eight results opaque at once: hipcc must finish the stage for all elements before the next one starts (left alone - and even
 // with sched_barrier, which does not order pure arithmetic - it re-serialises the chains to save registers).
-#define GELU8_STAGE(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
-__device__ __forceinline__ void gelu8_tail_terms(const float (&x)[8], float (&t)[8], float (&e)[8], float (&p)[8]) {
+// The arithmetic of a stage runs on PAIRS of elements (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two IEEE single-precision
+// operations per instruction, the same roundings as the scalar forms - left to itself hipcc pairs some of the multiplications but
+// keeps the polynomial as scalar v_fmaak_f32 with literal constants); v_rcp / v_exp and the |x| modifier have no packed form.
+typedef float gelu_f2 __attribute__((ext_vector_type(2)));
+#define GELU8_STAGE(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+__device__ __forceinline__ gelu_f2 gelu_splat(float c) { return gelu_f2{c, c}; }
+__device__ __forceinline__ void gelu8_tail_terms(const float (&x)[8], gelu_f2 (&t)[4], gelu_f2 (&e)[4], gelu_f2 (&p)[4]) {
 #pragma clang fp contract(off)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) t[j] = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x[j]), 1.0f));
+  for (int j = 0; j < 4; ++j)
+    t[j] = gelu_f2{__builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x[2 * j]), 1.0f)), __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x[2 * j + 1]), 1.0f))};
   GELU8_STAGE(t);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(x[j] * x[j] * -0.72134752f);
+  for (int j = 0; j < 4; ++j) {
+    const gelu_f2 x2 = {x[2 * j], x[2 * j + 1]};
+    const gelu_f2 a = x2 * x2 * gelu_splat(-0.72134752f);
+    e[j] = gelu_f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  }
   GELU8_STAGE(e);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) p[j] = fmaf(0.5307027145f, t[j], -0.7265760135f);
+  for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(gelu_splat(0.5307027145f), t[j], gelu_splat(-0.7265760135f));
   GELU8_STAGE(p);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) p[j] = fmaf(p[j], t[j], 0.7107068705f);
+  for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], t[j], gelu_splat(0.7107068705f));
   GELU8_STAGE(p);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) p[j] = fmaf(p[j], t[j], -0.142248368f);
+  for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], t[j], gelu_splat(-0.142248368f));
   GELU8_STAGE(p);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) p[j] = fmaf(p[j], t[j], 0.127414796f);
+  for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], t[j], gelu_splat(0.127414796f));
   GELU8_STAGE(p);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) p[j] = p[j] * t[j] * e[j];   // q
+  for (int j = 0; j < 4; ++j) p[j] = p[j] * t[j] * e[j];   // q
   GELU8_STAGE(p);
 }
 __device__ __forceinline__ void gelu_erf_both8(const float (&x)[8], float (&g)[8], float (&gp)[8]) {
 #pragma clang fp contract(off)
-  float t[8], e[8], q[8];
+  gelu_f2 t[4], e[4], q[4];
   gelu8_tail_terms(x, t, e, q);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float cdf = x[j] >= 0.f ? 1.0f - q[j] : q[j];
-    g[j] = x[j] * cdf;
-    gp[j] = fmaf(x[j] * 0.3989422804014327f, e[j], cdf);
+  for (int j = 0; j < 4; ++j) {
+    const gelu_f2 x2 = {x[2 * j], x[2 * j + 1]};
+    const gelu_f2 up = gelu_splat(1.0f) - q[j];
+    const gelu_f2 cdf = {x2.x >= 0.f ? up.x : q[j].x, x2.y >= 0.f ? up.y : q[j].y};
+    const gelu_f2 g2 = x2 * cdf;
+    const gelu_f2 d2 = __builtin_elementwise_fma(x2 * gelu_splat(0.3989422804014327f), e[j], cdf);
+    g[2 * j] = g2.x; g[2 * j + 1] = g2.y;
+    gp[2 * j] = d2.x; gp[2 * j + 1] = d2.y;
   }
 }
 __device__ __forceinline__ void gelu_erf8(float (&x)[8]) {   // in place; the value of gelu_erf (see the note on contraction there)
-  float t[8], e[8], q[8];
+  gelu_f2 t[4], e[4], q[4];
   gelu8_tail_terms(x, t, e, q);
   {
 #pragma clang fp contract(off)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = x[j] * (x[j] >= 0.f ? 1.0f - q[j] : q[j]);
+    for (int j = 0; j < 4; ++j) {
+      const gelu_f2 x2 = {x[2 * j], x[2 * j + 1]};
+      const gelu_f2 up = gelu_splat(1.0f) - q[j];
+      const gelu_f2 cdf = {x2.x >= 0.f ? up.x : q[j].x, x2.y >= 0.f ? up.y : q[j].y};
+      const gelu_f2 g2 = x2 * cdf;
+      x[2 * j] = g2.x; x[2 * j + 1] = g2.y;
+    }
   }
 }
 #undef GELU8_STAGE
