@@ -161,8 +161,9 @@ def test_gemm_a4_build_keeps_the_accumulators_intact(tmp_path):
     """csrc/gemm_a4.hip reads its 256 accumulator registers by NUMBER in the epilogue (inline asm); hipcc may use accumulator registers
     as spill space wherever it believes them dead.  The loop statement declares them as outputs and every reading statement as pinned
     inputs, which gives hipcc the right liveness - this audit of the generated assembly is the check: behind the
-    loop statement no kernel writes an accumulator register before the epilogue has read it, and only the two column-sum variants
-    (which carry 16 more live values through the epilogue) may touch scratch at all."""
+    loop statement no kernel writes an accumulator register before the epilogue has read it, and NO variant touches scratch (the two
+    column-sum variants did until their 256 additions were pinned in program order: the spilled registers were the next tile's
+    fragments, and their reload waited for every store of the tile - 2.6 % of the BERT-large step's GEMM time)."""
     import re
     import shutil
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -183,9 +184,7 @@ def test_gemm_a4_build_keeps_the_accumulators_intact(tmp_path):
         kernels += 1
         lines = body.split("\n")
         end = max(k for k, l in enumerate(lines) if "s_nop 15" in l)   # the loop statement ends with two of them
-        colsum = name.endswith("Lb1EEEvNS_7A4MultiE")                   # template argument COLSUM
-        if not colsum:
-            assert "scratch_" not in body, name
+        assert "scratch_" not in body, name
         read = set()
         for l in lines[end:]:
             m = re.search(r"v_accvgpr_read_b32 v\d+, a\[(0x[0-9a-f]+|\d+)(?:\+(\d+))?\]", l)
@@ -193,6 +192,6 @@ def test_gemm_a4_build_keeps_the_accumulators_intact(tmp_path):
                 read.add(int(m.group(1), 0) + int(m.group(2) or 0))
             w = re.search(r"v_accvgpr_(?:write_b32|mov_b32) a(\d+)", l)
             if w:
-                assert colsum and int(w.group(1)) in read, (name, l.strip())
+                assert int(w.group(1)) in read, (name, l.strip())
         assert len(read) == 256, (name, len(read))
     assert kernels >= 20
