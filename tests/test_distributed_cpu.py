@@ -187,3 +187,39 @@ def test_dro_greedy_weight_update_aggregates_over_ranks():
             np.testing.assert_allclose(cc, st_r.count_cat, rtol=1e-6)
             np.testing.assert_allclose(gl_got, gl, rtol=1e-5, atol=1e-6)
         st = st_r  # both ranks hold the same global state
+
+
+# ---- the private torch API the DDP adoption leans on (CocoBertModel._dp_adopt_ddp_wrapper, modeling.py): checked against THIS torch
+class _SeesItsWrapper(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(4))
+        self.seen = []
+
+    def forward(self, x):
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        self.seen.append(DDP._active_ddp_module)
+        return (x * self.w).sum()
+
+
+def _ddp_publishes_its_wrapper(rank, world):
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    inner = _SeesItsWrapper()
+    wrapped = DDP(inner, find_unused_parameters=True)
+    wrapped(torch.ones(4)).backward()
+    inside = inner.seen[-1] is wrapped                       # published while the wrapped forward runs ...
+    outside = DDP._active_ddp_module is None                 # ... and withdrawn afterwards
+    # the switches the adoption flips / rebinds exist under these names
+    return bool(inside and outside and isinstance(wrapped.require_backward_grad_sync, bool) and callable(wrapped.no_sync)
+                and hasattr(wrapped, "process_group"))
+
+
+def test_torch_ddp_still_offers_what_the_adoption_of_a_ddp_wrapper_needs():
+    """`DistributedDataParallel._active_ddp_module`, `require_backward_grad_sync`, `no_sync` and `process_group` are what
+    `_dp_adopt_ddp_wrapper` uses to find the reference's DDP wrap line (ANCE/drivers/run_ann.py:177-184) and take over the gradient
+    reduction.  The first is private: a torch release that drops or renames it makes this test fail here, loudly, instead of leaving
+    the ranks of a wrapped model un-reduced behind a warning."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    assert hasattr(DDP, "_active_ddp_module"), "torch %s: DistributedDataParallel._active_ddp_module is gone" % torch.__version__
+    out = _run(_ddp_publishes_its_wrapper, 2)
+    assert out == {0: True, 1: True}
