@@ -775,7 +775,7 @@ def contrastive_leg(model_name: str, seq_per_gpu: int, seq_len: int, steps: int,
                     "traffic_gbps": None if traffic is None else round(traffic * lps / (gemm_ms_step * 1e-3) / 1e9, 1),
                     "traffic_source": src,
                     "algorithmic_achieved": round(alg, 1), "algorithmic_frac": round(alg / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "kernel": "bf16 MFMA GEMM class of coco-dr_amd/csrc/gemm.hip + gemm_pp.hip (all NT / NN / TN launches of the step)",
+                    "kernel": "bf16 MFMA GEMM class of coco-dr_amd/csrc/gemm.hip + gemm_pp.hip + gemm_a4.hip (all NT / NN / TN launches of the step)",
                     "launches_per_step": lps,
                     "sampled": f"every GEMM launch of every {PROF_EVERY}th timed step ({n_launch} launches)",
                     "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
@@ -949,7 +949,38 @@ def main():
                                                             world, use_dist, args.dp_chunks, not args.no_roofline, args.dense, packed=packed,
                                                             host_lengths=host_lengths)
     extras = {}
-    if solo and not args.no_full_step and rank == 0:
+    # ---- from here on the headline is measured: nothing a side leg does may cost the contract line.  A side leg that raises is
+    # recorded as "<leg>_error" (stderr + bench_legs.json); one that HANGS (a collective whose peer died on a multi-GPU node) is
+    # cut off by a watchdog: rank 0 prints the line with the legs finished so far and "side_legs_incomplete", every rank exits 0
+    state = {"emitted": False, "emit": None}
+    deadline = float(os.environ.get("COCODR_BENCH_SIDE_LEGS_DEADLINE_S", "1800" if world == 1 else "900"))
+
+    def watchdog():
+        import threading
+
+        def fire():
+            if rank == 0 and not state["emitted"] and state["emit"] is not None:
+                print(f"[bench] side legs exceeded {deadline:.0f} s: printing the headline without them", file=sys.stderr, flush=True)
+                try:
+                    state["emit"](incomplete=True)
+                except Exception as e:  # pragma: no cover
+                    print(f"[bench] watchdog emit failed: {e}", file=sys.stderr, flush=True)
+            os._exit(0)
+
+        t = threading.Timer(deadline + (0.0 if rank == 0 else 5.0), fire)
+        t.daemon = True
+        t.start()
+        return t
+
+    def side_leg(name, fn):
+        try:
+            extras[name] = fn()
+        except Exception as e:
+            import traceback
+            extras[name + "_error"] = f"{type(e).__name__}: {e}"[:300]
+            print(f"[bench] side leg {name} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+
+    def leg_north_star():
         # the north-star target shape (BASELINE.json north_star: ">= 50 % MFMA roofline on BERT-large seq128 contrastive step
         # at 1 GPU"): cocodr-large at this line's 64 sequences and at COCO/README.md:59-63's per-GPU batch for the large
         # model (100 documents = 200 spans), each with its own HIP-event roofline block
@@ -966,20 +997,22 @@ def main():
                 entry.update({"execution": "packed" if pk_ else "padded", "roofline": lroof})
                 large[f"{n_seq}_sequences" + ("" if pk_ else "_padded")] = entry
         large["workload"] = "cocodr-large (BERT-large, 24 x 1024) contrastive step, seq_len 128, bf16 + fp32 accumulate, clip_grad_norm_(1.0) + AdamW, 1 GPU"
-        extras["north_star_large_step"] = large
-        if packed:
-            # the same headline step with the batch in the OTHER boundary form: host-known lengths next to ids + mask (a collator that
-            # pads on the CPU has them; nothing is read back) when the headline takes the reference's batch unchanged, and vice versa
-            # (with the same roofline sampling as the headline leg - its event pairs cost ~1.5 % of the timed region - so that the
-            # two numbers differ by the boundary form alone)
-            hdt, hloss, _, _, _, _ = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
-                                                     args.dp_chunks, not args.no_roofline, args.dense, packed=True, host_lengths=not host_lengths)
-            hv = args.seq_per_gpu * args.steps / hdt
-            extras["reference_batch_contrastive_step" if host_lengths else "host_lengths_contrastive_step"] = {
-                "sequences_per_sec": round(hv, 1), "ms_per_step": round(hdt / args.steps * 1e3, 3), "loss": round(hloss, 4),
+        return large
+
+    def leg_other_boundary():
+        # the same headline step with the batch in the OTHER boundary form: host-known lengths next to ids + mask (a collator that
+        # pads on the CPU has them; nothing is read back) when the headline takes the reference's batch unchanged, and vice versa
+        # (with the same roofline sampling as the headline leg - its event pairs cost ~1.5 % of the timed region - so that the
+        # two numbers differ by the boundary form alone)
+        hdt, hloss, _, _, _, _ = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
+                                                 args.dp_chunks, not args.no_roofline, args.dense, packed=True, host_lengths=not host_lengths)
+        hv = args.seq_per_gpu * args.steps / hdt
+        return {"sequences_per_sec": round(hv, 1), "ms_per_step": round(hdt / args.steps * 1e3, 3), "loss": round(hloss, 4),
                 "headline_vs_this": round((args.seq_per_gpu * args.steps / dt) / hv, 4),
                 "batch": "{input_ids, attention_mask} only (COCO/data.py:150-154): layout planned on the device, 16 bytes read back" if host_lengths
                          else "{input_ids, attention_mask, lengths}: the B lengths on the host, nothing read back"}
+
+    def leg_other_execution():
         # the same headline step in the other execution: padded (every GEMM over all B x L rows, executed FLOPs = the dense count: the
         # line that is comparable kernel for kernel with rounds 1-2) when the headline is packed, and the other way round
         odt, oloss, oroof, _, _, oinfo = contrastive_leg(args.model, args.seq_per_gpu, args.seq_len, args.steps, args.warmup, dev, 0, 1, False,
@@ -993,16 +1026,28 @@ def main():
                               + ("here every kernel runs over all B x L rows, padding included, as the reference does "
                                  "(CocoBertModel.pack_sequences = False)" if packed else
                                  "here the sequences are stored back to back, every one on its own length (no work on padding rows)")})
-        extras["padded_contrastive_step" if packed else "packed_contrastive_step"] = other
-        if args.model == "base":
-            extras["full_coco_step"] = full_coco_step(cfg, dev, ids, mask, lens if host_lengths else None)  # second scope: what the reference's step really runs
-            extras["ance_triplet_step"] = ance_step(dev, host_lengths=host_lengths)
-        extras["corpus_encode"] = corpus_encode(cfg, dev, seq_len=args.seq_len)
-        extras["eval_search"] = eval_search(dev)
+        return other
+
+    def leg_search():
+        r_ = eval_search(dev)
         if not args.no_cpu_baseline:
-            extras["eval_search"]["cpu_baseline"] = search_cpu_baseline()
+            r_["cpu_baseline"] = search_cpu_baseline()
+        return r_
+
+    def solo_side_legs():
+        side_leg("north_star_large_step", leg_north_star)
+        if packed:
+            side_leg("reference_batch_contrastive_step" if host_lengths else "host_lengths_contrastive_step", leg_other_boundary)
+        side_leg("padded_contrastive_step" if packed else "packed_contrastive_step", leg_other_execution)
         if args.model == "base":
-            extras["config5_end_to_end"] = config5_end_to_end(dev)
+            # second scope: what the reference's step really runs
+            side_leg("full_coco_step", lambda: full_coco_step(cfg, dev, ids, mask, lens if host_lengths else None))
+            side_leg("ance_triplet_step", lambda: ance_step(dev, host_lengths=host_lengths))
+        side_leg("corpus_encode", lambda: corpus_encode(cfg, dev, seq_len=args.seq_len))
+        side_leg("eval_search", leg_search)
+        if args.model == "base":
+            side_leg("config5_end_to_end", lambda: config5_end_to_end(dev))
+
     def fence():
         torch.cuda.synchronize()
         if use_dist:
@@ -1024,21 +1069,25 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
 
-    if world > 1 and not args.no_full_step:
+    def multi_side_legs():
         release()
         if config3:  # BASELINE configs[2]: cocodr-base on 8 GPUs with RCCL all_gather negatives, global batch 2048 (COCO/README.md:55)
-            wdt, wloss, _, _, _, _ = contrastive_leg(args.model, 256, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
-                                                  args.dp_chunks, False, args.dense, packed=packed, host_lengths=host_lengths)
-            wdt = tmax(wdt)
-            extras["config3_global_batch_2048"] = {"sequences_per_sec": round(256 * world * args.steps / wdt, 2),
-                                                   "ms_per_step": round(wdt / args.steps * 1e3, 3), "global_batch": 256 * world,
-                                                   "loss": round(wloss, 4),
-                                                   "note": "256 sequences per GPU (BASELINE configs[2]); NOT comparable with the N = 1, 2, 4 "
-                                                           "lines' 64 per GPU - the headline `value` of this line is"}
+            def leg_config3():
+                wdt, wloss, _, _, _, _ = contrastive_leg(args.model, 256, args.seq_len, args.steps, args.warmup, dev, rank, world, use_dist,
+                                                      args.dp_chunks, False, args.dense, packed=packed, host_lengths=host_lengths)
+                wdt = tmax(wdt)
+                return {"sequences_per_sec": round(256 * world * args.steps / wdt, 2), "ms_per_step": round(wdt / args.steps * 1e3, 3),
+                        "global_batch": 256 * world, "loss": round(wloss, 4),
+                        "note": "256 sequences per GPU (BASELINE configs[2]); NOT comparable with the N = 1, 2, 4 "
+                                "lines' 64 per GPU - the headline `value` of this line is"}
+            side_leg("config3_global_batch_2048", leg_config3)
             release()
-        extras["multi_gpu"] = multi_gpu_legs(dev, rank, world, fence, tmax, shared, args.dp_chunks)
+        side_leg("multi_gpu", lambda: multi_gpu_legs(dev, rank, world, fence, tmax, shared, args.dp_chunks))
 
-    if rank == 0:
+    def emit(incomplete=False):
+        if rank != 0 or state["emitted"]:
+            return
+        state["emitted"] = True
         n_seq = args.seq_per_gpu * world * args.steps
         value = n_seq / dt
         par = f"dp{world}"
@@ -1064,10 +1113,13 @@ def main():
         if roof is not None:
             out["roofline"] = compact_roofline(roof)
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not incomplete:
             cpu = cpu_baseline()
             out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "cpu") if k in cpu}
         out["summary"] = leg_summary(extras)
+        failed = sorted(k[:-6] for k in extras if k.endswith("_error"))
+        if incomplete or failed:  # (absent from a normal line)
+            out["side_legs_incomplete"] = {"watchdog": bool(incomplete), "failed": failed}
         out["legs_file"] = "bench_legs.json"
         # ---- every leg in full: side file + stderr, never the contract line
         legs = {"headline": {**out, "roofline": roof, "cpu_baseline": cpu,
@@ -1087,9 +1139,18 @@ def main():
             line = json.dumps(out, separators=(",", ":"))
         sys.stderr.flush()
         print(line, flush=True)
+    state["emit"] = emit
+    dog = watchdog()
+    if not args.no_full_step:
+        if solo:
+            solo_side_legs()
+        else:
+            multi_side_legs()
+    emit()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    dog.cancel()
 
 
 if __name__ == "__main__":

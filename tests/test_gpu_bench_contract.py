@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*args, legs: bool = False):
+def _run(*args, legs: bool = False, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     legs_path = os.path.join(ROOT, "bench_legs.json")
@@ -160,3 +161,13 @@ def test_bench_eight_rank_path_keeps_the_per_gpu_batch_on_one_gpu():
     m = legs["multi_gpu"]
     assert m["sharded_corpus_encode"]["sequences_per_sec"] > 0 and m["sharded_search"]["result_rows"] == 2000
     assert m["ance_triplet_step"]["rows_per_sec"] > 0
+
+
+def test_a_side_leg_that_never_returns_cannot_cost_the_contract_line():
+    """The headline is measured first; the side legs run under a watchdog (bench.py main): past the deadline rank 0 prints the line with
+    the legs finished so far and every rank exits 0 - on a multi-GPU node a side-leg collective whose peer died would otherwise hang
+    the run and lose the measured headline.  Here: a 3 s deadline on the single-GPU run, whose side legs take minutes."""
+    d = _run("--steps", "4", "--warmup", "2", "--no-cpu-baseline", extra_env={"COCODR_BENCH_SIDE_LEGS_DEADLINE_S": "3"})
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["side_legs_incomplete"]["watchdog"] is True
+    assert "config5_encode_passages_per_sec" not in d.get("summary", {})
