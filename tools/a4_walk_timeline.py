@@ -14,7 +14,7 @@ sys.path.insert(0, root)
 import cocodr_amd  # noqa: E402,F401
 from cocodr_amd import _native as N  # noqa: E402
 
-N.LIB_PATH = os.path.join(root, "tools", "experiments", "_build", "lib_a4_timeline.so")
+N.LIB_PATH = os.path.join(root, "tools", "experiments", "_build", "lib_a4_timeline%s.so" % os.environ.get("A4_TL_TAG", ""))
 L = N.lib()
 sp = N.stream_ptr()
 L.cocodr_a4_timeline_read.restype = C.c_int
