@@ -208,6 +208,26 @@ def embeddings_fwd(P, input_ids: np.ndarray, cache: Optional[dict] = None, dropo
     return out
 
 
+def _attn_ctx_blocked(s: np.ndarray, vh: np.ndarray, block: int = 32) -> np.ndarray:
+    """softmax(s) @ vh the way a one-pass (online-softmax) kernel accumulates it; ``s`` [B, nh, L, L] are the masked scores MINUS
+    their row maximum (masked keys: -inf), so exp(s) <= 1.  Only used in bf16-storage mode (the rounding of the un-normalised
+    block probabilities is the point)."""
+    B, nh, L, _ = s.shape
+    m = np.full((B, nh, L), -np.inf)
+    l = np.zeros((B, nh, L))
+    o = np.zeros((B, nh, L, vh.shape[-1]))
+    for k0 in range(0, L, block):
+        sb = s[..., k0:k0 + block].astype(np.float64)
+        mnew = np.maximum(m, sb.max(-1))
+        safe = np.where(np.isfinite(mnew), mnew, 0.0)
+        alpha = np.where(np.isfinite(m), np.exp(m - safe), 0.0)
+        pb = np.exp(sb - safe[..., None])          # masked keys: exp(-inf) = 0
+        l = l * alpha + pb.sum(-1)
+        o = o * alpha[..., None] + round_bf16(pb.astype(np.float32)).astype(np.float64) @ vh[..., k0:k0 + block, :].astype(np.float64)
+        m = mnew
+    return (o / l[..., None]).astype(vh.dtype)
+
+
 def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optional[dict], stack: str = "encoder.layer.",
                dropout=None):
     """One BertLayer: hf BertSelfAttention (eager) + BertSelfOutput + BertIntermediate + BertOutput."""
@@ -232,7 +252,14 @@ def _layer_fwd(P, i: int, x: np.ndarray, mask: np.ndarray, nh: int, cache: Optio
     t = x.dtype.type
     mp = _drop_mult(dropout, p.shape, i, 0, t)   # hf eager_attention_forward: dropout(softmax(..))
     pd = p if mp is None else p * mp
-    ctx = _r((_r(pd) @ vh).transpose(0, 2, 1, 3).reshape(B, L, H))
+    if _ROUND is not None and mp is None:
+        # bf16-storage mode: the output as the device's one-pass kernel forms it (csrc/attention.hip attn_fwd_rows) - keys in blocks
+        # of 32, a running row maximum, the UN-normalised exp(s - max so far) rounded to bf16 for the product with V, fp32 running
+        # sum of the unrounded values, one division at the end.  Rounding the normalised probabilities instead (the line below) is
+        # the same noise in another realisation: ~20 % of the output's bf16 values come out one ulp apart
+        ctx = _r(_attn_ctx_blocked(s, vh).transpose(0, 2, 1, 3).reshape(B, L, H))
+    else:
+        ctx = _r((_r(pd) @ vh).transpose(0, 2, 1, 3).reshape(B, L, H))
     a = ctx @ P[n["wo"]].T + P[n["bo"]]
     ma = _drop_mult(dropout, a.shape, i, 1, t)   # hf BertSelfOutput: LayerNorm(dropout(dense(..)) + input)
     if ma is not None:
@@ -306,7 +333,16 @@ def layers_bwd(P, nh: int, cache: dict, layer_ids, dx: np.ndarray, G: Dict[str, 
         dp = dctx @ c["vh"].transpose(0, 1, 3, 2)
         if c.get("mp") is not None:
             dp = dp * c["mp"]
-        ds = _r(p * (dp - (dp * p).sum(-1, keepdims=True)))
+        if _ROUND is None:
+            delta = (dp * p).sum(-1, keepdims=True)
+        else:
+            # bf16-storage mode: the row term as the device forms it - delta = rowsum(dO * O) from the STORED (bf16) attention output
+            # (csrc/attention.hip: "delta = rowsum(dO * O)"), not from the probabilities.  Mathematically the same number; but the
+            # query / key gradients of a near-uniform attention are the small difference dP - delta, and the rounding of O moves delta
+            # by 2^-9 of itself - as large as that difference.  Formed the same way, the two sides make the same error.
+            oh = c["ctx"].reshape(B, L, nh, d).transpose(0, 2, 1, 3)
+            delta = (dctx * oh).sum(-1, keepdims=True)
+        ds = _r(p * (dp - delta))
         scale = p.dtype.type(1.0 / np.sqrt(d))
         dq = _r((ds @ c["kh"]) * scale)
         dk = _r((ds.transpose(0, 1, 3, 2) @ c["qh"]) * scale)
