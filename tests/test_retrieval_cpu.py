@@ -1,5 +1,6 @@
 """Host-side retrieval logic (product) against the oracle restatement on seeded synthetic runs.  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 import cocodr_amd
@@ -143,3 +144,43 @@ def test_mrr_matches_reference_golden():
     ranked = {q: [int(x) for x in row] for q, row in enumerate(g["ranked"])}
     relevant = {q: [int(x) for x in row if x >= 0] for q, row in enumerate(g["relevant"])}
     assert abs(R.mrr_at_10(relevant, ranked) - float(g["mrr10"])) < 1e-12
+
+
+def test_flat_ip_index_refuses_what_it_cannot_hold_without_touching_the_gpu():
+    """retrieval.FlatIPIndex (faiss.IndexFlatIP's add / search, ANCE/drivers/run_ann_data_gen.py:310-317): argument errors are host
+    logic - wrong width, host tensors (there is no CPU fallback), a search of the empty index."""
+    import torch
+    from cocodr_amd.retrieval import FlatIPIndex
+    index = FlatIPIndex(8)
+    assert index.ntotal == 0
+    with pytest.raises(ValueError):
+        index.add(torch.zeros(4, 7))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        index.add(torch.zeros(4, 8))
+    with pytest.raises(RuntimeError, match="empty"):
+        index.search(torch.zeros(2, 8), 1)
+    index.reset()
+    assert index.ntotal == 0
+
+
+def test_pmc_traffic_summary_counts_every_gemm_kernel_family(tmp_path):
+    """tools/pmc_traffic.py feeds bench.py's roofline.traffic: its kernel filter must cover all three GEMM translation units (the
+    hand-scheduled walk kernels were missing from it for part of round 6 - the figure silently covered 36 of 784 launches)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ["void cocodr_gemm_v2::gemm_glds_kernel<128, 64>(cocodr_gemm_args, int, int)", "void cocodr_gemm_pp::gemm_pp_kernel<2, 0>(X)",
+             "void cocodr_gemm_a4::gemm_a4_walk_kernel<0, 1, false, false, false, false>(cocodr_gemm_a4::A4Multi)", "void (anonymous namespace)::ln_fwd_kernel<3, true>(X)"]
+    for counter, path in (("FETCH_SIZE", tmp_path / "f.csv"), ("WRITE_SIZE", tmp_path / "w.csv")):
+        with open(path, "w") as f:
+            f.write("Counter_Name,Kernel_Name,Counter_Value\n")
+            for n in names:
+                f.write(f'{counter},"{n}",1024\n')
+    out = tmp_path / "o.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), str(tmp_path / "f.csv"), str(tmp_path / "w.csv"), str(out), "cmd", "abc"],
+                   check=True, capture_output=True)
+    d = json.load(open(out))
+    assert d["launches"] == 3 and d["commit"] == "abc"
+    assert abs(d["hbm_bytes_per_launch"] - (2 * 1024 + 1024) * 1024) < 1e-6
